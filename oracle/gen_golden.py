@@ -1,0 +1,317 @@
+#!/usr/bin/env python
+"""ORACLE tooling (test infrastructure): produce tests/golden/*.npz by running
+the REAL reference (imported from /root/reference, CPU) on seeded inputs.
+
+Runs only in the build container (the reference never travels).  Fixtures hold
+arrays only - inputs, weights and expected outputs; no reference source.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+Shims needed to import/run the reference on this CPU-only image:
+  * sys.modules stubs for h5py, transforms3d, torch.utils.tensorboard (absent,
+    not used by the hot path);
+  * torch.Tensor.cuda -> identity (capl.py:406, train.py harness call .cuda()).
+"""
+import io
+import os
+import random
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+for name in ("h5py", "transforms3d"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+tb = types.ModuleType("torch.utils.tensorboard")
+tb.SummaryWriter = object
+sys.modules.setdefault("torch.utils.tensorboard", tb)
+torch.Tensor.cuda = lambda self, *a, **k: self
+sys.path.insert(0, REF)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import model.dgcnn as ref_dgcnn          # noqa: E402
+    import model.capl as ref_capl            # noqa: E402
+    import runs.eval as ref_eval             # noqa: E402
+    import get_basis as ref_basis            # noqa: E402
+    import train as ref_train                # noqa: E402
+
+from oracle.ref_ops import synthetic_blocks  # noqa: E402  (input recipe only)
+
+
+def sd_np(sd, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def args_ns(k=20):
+    return types.SimpleNamespace(edgeconv_widths=[[64, 64], [64, 64], [64, 64]], dgcnn_mlp_widths=[512, 256],
+                                 pc_in_dim=9, dgcnn_k=k, base_widths=[128, 64], output_dim=64, eval_weight=1.2,
+                                 total_classes=13)
+
+
+class Quiet:
+    def cprint(self, *a, **k):
+        pass
+
+
+def randomise_bn(module, seed):
+    """Non-trivial BN affine + running stats so eval-mode parity is meaningful."""
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 1.5 - 0.4)   # includes negative gammas
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.5)
+
+
+# ---------------------------------------------------------------- (1) knn
+def g_knn():
+    k = 20
+    x9 = synthetic_blocks(2, 256, seed=0)
+    x64 = torch.randn(2, 64, 256, generator=torch.Generator().manual_seed(1))
+    xd = synthetic_blocks(1, 256, seed=2, dup_tail=32)
+    xf = synthetic_blocks(1, 2048, seed=3)
+    save("knn", k=np.int64(k),
+         x9=x9.numpy(), idx9=ref_dgcnn.knn(x9, k).numpy().astype(np.int16),
+         x64=x64.numpy(), idx64=ref_dgcnn.knn(x64, k).numpy().astype(np.int16),
+         xdup=xd.numpy(), idxdup=ref_dgcnn.knn(xd, k).numpy().astype(np.int16),
+         xfull_seed=np.int64(3), idxfull=ref_dgcnn.knn(xf, k).numpy().astype(np.int16))
+
+
+# ---------------------------------------------------------------- (2) edge feature
+def g_edge_feature():
+    x = torch.randn(2, 5, 40, generator=torch.Generator().manual_seed(4))
+    idx = ref_dgcnn.knn(x, 6)
+    save("edge_feature", x=x.numpy(), idx=idx.numpy(), out=ref_dgcnn.get_edge_feature(x, K=6, idx=idx).numpy(),
+         out_auto=ref_dgcnn.get_edge_feature(x, K=6).numpy())
+
+
+# ---------------------------------------------------------------- (3) DGCNN fwd/bwd
+def g_dgcnn():
+    a = args_ns()
+    torch.manual_seed(0)
+    net = ref_dgcnn.DGCNN(a.edgeconv_widths, a.dgcnn_mlp_widths, a.pc_in_dim, k=a.dgcnn_k, return_edgeconvs=True)
+    init_sd = sd_np(net.state_dict())
+    randomise_bn(net, 5)
+    sd = sd_np(net.state_dict())
+    x = synthetic_blocks(2, 256, seed=6)
+    net.eval()
+    with torch.no_grad():
+        ecs_e, out_e = net(x)
+    net.train()
+    xg = x.clone().requires_grad_(True)
+    ecs_t, out_t = net(xg)
+    g = torch.Generator().manual_seed(7)
+    cot = [torch.randn(e.shape, generator=g) for e in ecs_t] + [torch.randn(out_t.shape, generator=g)]
+    loss = sum((c * t).sum() for c, t in zip(cot, ecs_t + [out_t]))
+    loss.backward()
+    grads = {"grad." + n: p.grad.numpy() for n, p in net.named_parameters()}
+    after = {"after." + k: v for k, v in sd_np(net.state_dict()).items() if "running" in k or "num_batches" in k}
+    save("dgcnn", x=x.numpy(),
+         **{"init." + k: v for k, v in init_sd.items() if k.endswith("0.weight") and "edge_convs.0" in k},
+         **{"sd." + k: v for k, v in sd.items()},
+         ec0_eval=ecs_e[0].numpy(), ec1_eval=ecs_e[1].numpy(), ec2_eval=ecs_e[2].numpy(), out_eval=out_e.numpy(),
+         ec0_train=ecs_t[0].detach().numpy(), ec1_train=ecs_t[1].detach().numpy(), ec2_train=ecs_t[2].detach().numpy(),
+         out_train=out_t.detach().numpy(),
+         cot0=cot[0].numpy(), cot1=cot[1].numpy(), cot2=cot[2].numpy(), cot3=cot[3].numpy(),
+         grad_x=xg.grad.numpy(), **grads, **after)
+
+
+# ---------------------------------------------------------------- (4..11) CAPL model
+def make_capl(Kw, seed, classes=13, base_num=7, k=20):
+    a = args_ns(k)
+    gp = torch.randn(Kw, 192, generator=torch.Generator().manual_seed(2))
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref_capl.mpti_net_Point_GeoAsWeight_v2(classes=classes, criterion=nn.CrossEntropyLoss(ignore_index=255),
+                                                   args=a, base_num=base_num, gp=gp, energy=0.9)
+    return m, gp, a
+
+
+def g_capl():
+    m, gp, a = make_capl(200, 0)
+    init_keys = sorted(m.state_dict().keys())
+    init_proto = m.main_proto.detach().numpy().copy()
+    randomise_bn(m, 8)
+    sd = sd_np(m.state_dict())
+    B, N = 4, 256
+    x = synthetic_blocks(B, N, seed=9)
+    y = torch.randint(0, 8, (B, N), generator=torch.Generator().manual_seed(1))
+    out = {}
+    # (4) getFeatures eval, K_w = 200
+    m.eval()
+    with torch.no_grad():
+        pf, sem, oh = m.getFeatures(x)
+    out.update(gf_point=pf.numpy(), gf_sem=sem.numpy(), gf_word=oh.argmax(1).numpy().astype(np.int16))
+    # (5) get_pred
+    g = torch.Generator().manual_seed(10)
+    feat = torch.randn(3, 128, 50, generator=g)
+    p2 = torch.randn(13, 128, generator=g)
+    p3 = torch.randn(3, 13, 128, generator=g)
+    with torch.no_grad():
+        out.update(gp_feat=feat.numpy(), gp_p2=p2.numpy(), gp_p3=p3.numpy(),
+                   gp_2d=m.get_pred(feat, p2).numpy(), gp_2d_bg=m.get_pred(feat, p2, use_bg_proto=True).numpy(),
+                   gp_3d=m.get_pred(feat, p3).numpy(), gp_3d_bg=m.get_pred(feat, p3, use_bg_proto=True).numpy(),
+                   # (6) post_refine_proto_v2
+                   prp=m.post_refine_proto_v2(p2, feat, feat).numpy(),
+                   prp_bg=m.post_refine_proto_v2(p2, feat, feat, use_bg_proto=True).numpy())
+    # (7) get_gp_weight
+    coding = (torch.rand(13, 200, generator=g) > 0.7).float()
+    lab13 = torch.randint(0, 13, (B, N), generator=g)
+    lab8 = torch.randint(0, 8, (B, N), generator=g)
+    with torch.no_grad():
+        w_t, acc_t, nacc_t = m.get_gp_weight(coding, oh, gt_label=lab13, th=1.2)
+        w_tr, acc_tr, _ = m.get_gp_weight(coding[:7], oh, use_bg_weight=True, gt_label=lab8, th=1.5)
+        w_n, _, _ = m.get_gp_weight(coding, oh, th=2.0)
+    out.update(gw_coding=coding.numpy(), gw_lab13=lab13.numpy(), gw_lab8=lab8.numpy(),
+               gw_test=w_t.numpy(), gw_test_acc=np.float32(acc_t), gw_test_nacc=np.float32(nacc_t),
+               gw_train=w_tr.numpy(), gw_train_acc=np.float32(acc_tr), gw_nolabel=w_n.numpy())
+    # (8) forward eval
+    gened = torch.nn.functional.normalize(torch.randn(13, 128, generator=g), dim=1)
+    with torch.no_grad():
+        lg, acc, nacc = m(x, y=lab13, gened_proto=gened.unsqueeze(0), eval_model=True,
+                          base_class_coding=coding[:7], novel_class_coding=coding[7:])
+    out.update(fe_gened=gened.numpy(), fe_logits=lg.numpy(), fe_acc=np.float32(acc), fe_nacc=np.float32(nacc))
+    # (10) generate_fake_proto, explicit fake_novel
+    with torch.no_grad():
+        fp, _ = m.generate_fake_proto(x=pf[2:], y=y[2:], main_proto=m.main_proto.clone(),
+                                      fake_novel=[torch.tensor(2), torch.tensor(5)])
+    out.update(gfp_y=y.numpy(), gfp_proto=fp.numpy())
+    # (9) forward train: capture attention dropout mask + python-random choice
+    m.train()
+    masks = []
+
+    def hook(mod, inp, outp):
+        masks.append((outp != 0).numpy())
+    h = m.att_learner.dropout.register_forward_hook(hook)
+    random.seed(0)
+    torch.manual_seed(11)
+    xg = x.clone().requires_grad_(True)
+    pred, loss = m(xg, y=y)
+    loss.backward()
+    h.remove()
+    uniq = [int(u) for u in y[B // 2:].unique() if int(u) != 0]
+    random.seed(0)
+    chosen = [int(c) for c in random.sample(uniq, len(uniq) // 2)]
+    out.update(ft_mask=np.packbits(masks[0]), ft_mask_shape=np.array(masks[0].shape), ft_fake_novel=np.array(chosen),
+               ft_pred=pred.numpy().astype(np.int16), ft_loss=np.float32(loss.item()), ft_grad_x=xg.grad.numpy(),
+               **{"ft_grad." + n: p.grad.numpy() for n, p in m.named_parameters() if p.grad is not None},
+               **{"ft_after." + k: v for k, v in sd_np(m.state_dict()).items() if "running" in k})
+    # (11) hard coding (both copies)
+    cv = torch.rand(200, generator=g)
+    cv = cv / cv.sum()
+    m.energy = 0.9
+    hc_m = m.post_processing_hard_coding(cv.clone()).numpy()
+    hc_t = ref_train.post_processing_hard_coding(cv.clone(), 0.95).numpy()
+    out.update(hc_in=cv.numpy(), hc_model_090=hc_m, hc_train_095=hc_t)
+    save("capl", x=x.numpy(), y=y.numpy(), gp=gp.numpy(), init_main_proto=init_proto,
+         keys=np.array(init_keys), **{"sd." + k: v for k, v in sd.items()}, **out)
+
+    # (4b) K_w = 180, ScanNet class count, eval getFeatures only
+    m2, gp2, _ = make_capl(180, 1, classes=21, base_num=15)
+    randomise_bn(m2, 12)
+    m2.eval()
+    x2 = synthetic_blocks(2, 128, seed=13)
+    with torch.no_grad():
+        pf2, sem2, oh2 = m2.getFeatures(x2)
+    save("capl_scannet", x=x2.numpy(), gp=gp2.numpy(), **{"sd." + k: v for k, v in sd_np(m2.state_dict()).items()},
+         gf_point=pf2.numpy(), gf_sem=sem2.numpy(), gf_word=oh2.argmax(1).numpy().astype(np.int16))
+
+
+# ---------------------------------------------------------------- (12) get_basis numerics
+def g_basis():
+    from sklearn.cluster import KMeans
+    g = np.random.RandomState(0)
+    centers = g.randn(12, 192).astype(np.float32)
+    pts = (centers[g.randint(0, 12, 3000)] + 0.3 * g.randn(3000, 192)).astype(np.float32)
+    init = pts[g.choice(3000, 12, replace=False)].copy()
+    km = KMeans(n_clusters=12, init=init, n_init=1, max_iter=300, tol=0.0, algorithm="lloyd").fit(pts)
+    proto = ref_basis.Kmean2Proto(pts, km.labels_, 12)
+    with contextlib.redirect_stdout(io.StringIO()):
+        basis = ref_basis.compute_svd(proto)
+        p200 = g.randn(200, 192).astype(np.float32)
+        basis200 = ref_basis.compute_svd(p200)
+    save("basis", pts=pts, init=init, km_centers=km.cluster_centers_.astype(np.float32), km_labels=km.labels_.astype(np.int16),
+         km_inertia=np.float64(km.inertia_), km_iters=np.int64(km.n_iter_), proto=proto, basis=basis,
+         p200=p200, basis200=basis200)
+    # (14) DGCNNSeg(return_feat=True)
+    a = args_ns()
+    torch.manual_seed(3)
+    seg = ref_basis.DGCNNSeg(a, num_classes=8)
+    randomise_bn(seg, 14)
+    seg.eval()
+    x = synthetic_blocks(1, 256, seed=15)
+    with torch.no_grad():
+        logits, feat = seg(x, return_feat=True)
+    save("dgcnnseg", x=x.numpy(), **{"sd." + k: v for k, v in sd_np(seg.state_dict()).items()},
+         logits=logits.numpy(), feat=feat.numpy())
+
+
+# ---------------------------------------------------------------- (13) metric
+def g_metric():
+    g = np.random.RandomState(1)
+    order = [0, 1, 2, 6, 8, 10, 12, 7, 5, 4, 3, 11, 9]          # S3DIS S0 learning order (train.py:341-342)
+    novel = [7, 5, 4, 3, 11, 9]
+    gts = [g.randint(0, 13, (2, 300)) for _ in range(3)]
+    prs = [np.where(g.rand(2, 300) < 0.6, gt, g.randint(0, 13, (2, 300))) for gt in gts]
+    r = ref_eval.evaluate_metric_GFS(Quiet(), prs, gts, list(range(13)), novel, order, scannet=False)
+    order_sc = list(range(21))
+    g.shuffle(order_sc)
+    novel_sc = order_sc[15:]
+    gts2 = [g.randint(0, 21, (1, 500)) for _ in range(2)]
+    prs2 = [np.where(g.rand(1, 500) < 0.5, gt, g.randint(0, 21, (1, 500))) for gt in gts2]
+    r2 = ref_eval.evaluate_metric_GFS(Quiet(), prs2, gts2, list(range(21)), novel_sc, order_sc, scannet=True)
+    save("metric", order=np.array(order), novel=np.array(novel), gts=np.stack(gts), prs=np.stack(prs),
+         res=np.array(r[:4], dtype=np.float64), iou=r[4],
+         order_sc=np.array(order_sc), novel_sc=np.array(novel_sc), gts_sc=np.stack(gts2), prs_sc=np.stack(prs2),
+         res_sc=np.array(r2[:4], dtype=np.float64), iou_sc=r2[4])
+
+
+# ---------------------------------------------------------------- (15) train.py harness
+def g_harness():
+    m, gp, a = make_capl(200, 4)
+    randomise_bn(m, 16)
+    m.eval()
+    ref_train.args = a
+    ref_train.logger = Quiet()
+    N = 256
+    xs = synthetic_blocks(5, N, seed=17)
+    g = torch.Generator().manual_seed(18)
+    masks = (torch.rand(5, N, generator=g) > 0.6).long()
+    cls_ids = [7, 7, 8, 9, 9]
+    loader = [(xs[i:i + 1], masks[i:i + 1], torch.tensor([cls_ids[i]])) for i in range(5)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        gened, coding = ref_train.get_new_proto_Geo2SemProto(loader, m, base_num=7, novel_num=3, novel_class_list=[7, 8, 9],
+                                                             energy=0.9)
+    # collect_base_class_gp_coding_sum on a labelled stub loader
+    labels = torch.randint(0, 4, (5, N), generator=g)
+    tl = [(xs[i:i + 1], labels[i:i + 1], torch.zeros(1)) for i in range(5)]
+    random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        base_coding, bg_coding = ref_train.collect_base_class_gp_coding_sum(m, tl, train_class=np.arange(3), energy=0.9)
+    save("harness", x=xs.numpy(), masks=masks.numpy(), cls_ids=np.array(cls_ids), gp=gp.numpy(),
+         **{"sd." + k: v for k, v in sd_np(m.state_dict()).items()},
+         gened_proto=gened.numpy(), novel_coding=coding.numpy(), labels=labels.numpy(),
+         base_coding=base_coding.numpy(), bg_coding=bg_coding.numpy())
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["knn", "edge_feature", "dgcnn", "capl", "basis", "metric", "harness"]
+    for w in which:
+        globals()["g_" + w]()

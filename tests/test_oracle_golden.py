@@ -1,0 +1,201 @@
+"""Pins the oracle (oracle/ref_ops.py, oracle/knn_oracle.c) against golden
+vectors produced by the real reference (oracle/gen_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_from
+from oracle import c_oracle, ref_ops as R
+
+TOL = 1e-4   # north_star: features/logits/distances within 1e-4 fp32
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol, f"max abs err {err}"
+
+
+def knn_rows_ok(x, idx_a, idx_ref, k, gap_rel=1e-6):
+    """SURVEY 8(c) parity rule: per-row neighbour *sets* equal wherever the fp64
+    gap between rank k and rank k+1 exceeds gap_rel * scale."""
+    x64 = x.astype(np.float64)
+    bad = 0
+    for b in range(x.shape[0]):
+        d = -((x64[b][:, :, None] - x64[b][:, None, :]) ** 2).sum(0)
+        srt = np.sort(d, axis=1)[:, ::-1]
+        gap = srt[:, k - 1] - srt[:, k]
+        scale = np.abs(srt[:, k - 1]) + (x64[b] ** 2).sum(0).max()
+        for i in range(x.shape[2]):
+            if set(idx_a[b, i]) != set(int(v) for v in idx_ref[b, i]):
+                if gap[i] > gap_rel * scale[i]:
+                    bad += 1
+    return bad
+
+
+@pytest.mark.parametrize("key", ["9", "64", "dup"])
+def test_knn_c_oracle_vs_reference_sets(key):
+    g = load_golden("knn")
+    k = int(g["k"])
+    x = g["x" + key]
+    mine = c_oracle.knn(x, k)
+    assert knn_rows_ok(x, mine, g["idx" + key], k) == 0
+    # torch restatement is the same op sequence as the reference: identical
+    assert (R.knn(torch.from_numpy(x), k).numpy() == g["idx" + key]).all()
+
+
+def test_knn_c_oracle_full_block():
+    g = load_golden("knn")
+    k = int(g["k"])
+    x = R.synthetic_blocks(1, 2048, seed=int(g["xfull_seed"])).numpy()
+    mine = c_oracle.knn(x, k)
+    assert knn_rows_ok(x, mine, g["idxfull"], k) == 0
+    order_equal = (mine == g["idxfull"]).all(-1).mean()
+    assert order_equal > 0.99          # SURVEY: order differs on 0.02-0.13 % of rows
+
+
+def test_knn_c_equals_numpy_exact_order():
+    x = R.synthetic_blocks(1, 300, seed=5, dup_tail=40)
+    assert (c_oracle.knn(x.numpy(), 20) == R.knn_exact_order(x, 20).numpy()).all()
+    x = torch.randn(1, 64, 200, generator=torch.Generator().manual_seed(3))
+    assert (c_oracle.knn(x.numpy(), 7) == R.knn_exact_order(x, 7).numpy()).all()
+
+
+def test_knn_ties_lowest_index_first():
+    x = torch.zeros(1, 3, 16)            # all points identical: every distance ties
+    assert (c_oracle.knn(x.numpy(), 5)[0] == np.arange(5)[None, :]).all()
+
+
+def test_edge_feature():
+    g = load_golden("edge_feature")
+    x, idx = torch.from_numpy(g["x"]), torch.from_numpy(g["idx"])
+    assert (R.edge_feature(x, 6, idx).numpy() == g["out"]).all()
+    assert (R.edge_feature(x, 6).numpy() == g["out_auto"]).all()
+
+
+def test_dgcnn_eval_train_and_grads():
+    g = load_golden("dgcnn")
+    sd = state_dict_from(g)
+    x = torch.from_numpy(g["x"])
+    ecs, out = R.dgcnn_forward(sd, x, training=False)
+    for i in range(3):
+        close(ecs[i], g[f"ec{i}_eval"], 1e-5)
+    close(out, g["out_eval"], 1e-5)
+    # train mode + grads
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    xg = x.clone().requires_grad_(True)
+    stats = {}
+    ecs, out = R.dgcnn_forward(p, xg, training=True, new_stats=stats)
+    for i in range(3):
+        close(ecs[i].detach(), g[f"ec{i}_train"], 1e-5)
+    close(out.detach(), g["out_train"], 1e-5)
+    loss = sum((torch.from_numpy(g[f"cot{i}"]) * t).sum() for i, t in enumerate(ecs + [out]))
+    loss.backward()
+    gx = g["grad_x"]
+    close(xg.grad, gx, 1e-4 * np.abs(gx).max())
+    for k in g.files:
+        if k.startswith("grad.") and k != "grad_x":
+            ref = g[k]
+            close(p[k[5:]].grad, ref, 1e-4 * max(np.abs(ref).max(), 1e-6))
+        if k.startswith("after.") and "running" in k:
+            close(stats[k[6:]], g[k], 1e-5)
+
+
+def test_capl_get_features_and_heads():
+    g = load_golden("capl")
+    sd = state_dict_from(g)
+    gp = torch.from_numpy(g["gp"])
+    x = torch.from_numpy(g["x"])
+    pf, sem, oh = R.get_features(sd, gp, x)
+    close(pf, g["gf_point"]); close(sem, g["gf_sem"])
+    assert (oh.argmax(1).numpy() == g["gf_word"]).all()
+    feat, p2, p3 = (torch.from_numpy(g[k]) for k in ("gp_feat", "gp_p2", "gp_p3"))
+    bg = sd["bg_proto"]
+    close(R.get_pred(feat, p2), g["gp_2d"], 1e-5); close(R.get_pred(feat, p2, bg), g["gp_2d_bg"], 1e-5)
+    close(R.get_pred(feat, p3), g["gp_3d"], 1e-5); close(R.get_pred(feat, p3, bg), g["gp_3d_bg"], 1e-5)
+    close(R.post_refine_proto_v2(p2, feat, feat), g["prp"], 1e-5)
+    close(R.post_refine_proto_v2(p2, feat, feat, bg), g["prp_bg"], 1e-5)
+    coding = torch.from_numpy(g["gw_coding"])
+    w, acc, nacc = R.get_gp_weight(coding, oh, 7, 1.2, torch.from_numpy(g["gw_lab13"]))
+    close(w, g["gw_test"], 0); close(acc, g["gw_test_acc"], 1e-6); close(nacc, g["gw_test_nacc"], 1e-6)
+    w, acc, _ = R.get_gp_weight(coding[:7], oh, 7, 1.5, torch.from_numpy(g["gw_lab8"]), use_bg_weight=True)
+    close(w, g["gw_train"], 0); close(acc, g["gw_train_acc"], 1e-6)
+    w, _, _ = R.get_gp_weight(coding, oh, 7, 2.0)
+    close(w, g["gw_nolabel"], 0)
+
+
+def test_capl_forward_eval():
+    g = load_golden("capl")
+    sd = state_dict_from(g)
+    coding = torch.from_numpy(g["gw_coding"])
+    lg, acc, nacc = R.capl_forward_eval(sd, torch.from_numpy(g["gp"]), torch.from_numpy(g["x"]),
+                                        torch.from_numpy(g["gw_lab13"]), torch.from_numpy(g["fe_gened"]).unsqueeze(0),
+                                        coding[:7], coding[7:], base_num=7, eval_weight=1.2)
+    close(lg, g["fe_logits"]); close(acc, g["fe_acc"], 1e-6); close(nacc, g["fe_nacc"], 1e-6)
+
+
+def test_capl_generate_fake_proto_and_hard_coding():
+    g = load_golden("capl")
+    sd = state_dict_from(g)
+    pf = torch.from_numpy(g["gf_point"]); y = torch.from_numpy(g["gfp_y"])
+    fp, _ = R.generate_fake_proto(pf[2:], y[2:], sd["main_proto"].clone(), fake_novel=[2, 5])
+    close(fp, g["gfp_proto"], 1e-5)
+    cv = torch.from_numpy(g["hc_in"])
+    assert (R.hard_coding(cv, 0.9).numpy() == g["hc_model_090"]).all()
+    assert (R.hard_coding(cv, 0.95).numpy() == g["hc_train_095"]).all()
+
+
+def test_capl_forward_train_loss_and_grads():
+    g = load_golden("capl")
+    sd = state_dict_from(g)
+    p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    mask = np.unpackbits(g["ft_mask"])[: int(np.prod(g["ft_mask_shape"]))].reshape(g["ft_mask_shape"])
+    dm = torch.from_numpy(mask.astype(np.float32)) / 0.9
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    stats = {}
+    pred, loss, _ = R.capl_forward_train(p, torch.from_numpy(g["gp"]), x, torch.from_numpy(g["y"]), base_num=7,
+                                         fake_novel=[int(v) for v in g["ft_fake_novel"]], new_stats=stats, dropout_mask=dm)
+    assert abs(loss.item() - float(g["ft_loss"])) <= 1e-5 * abs(float(g["ft_loss"]))
+    assert (pred.numpy() == g["ft_pred"]).mean() > 0.999
+    loss.backward()
+    gx = g["ft_grad_x"]
+    close(x.grad, gx, 1e-4 * np.abs(gx).max())
+    for k in g.files:
+        if k.startswith("ft_grad."):
+            ref = g[k]
+            close(p[k[8:]].grad, ref, 1e-4 * max(np.abs(ref).max(), 1e-7))
+
+
+def test_capl_scannet_shapes():
+    g = load_golden("capl_scannet")
+    pf, sem, oh = R.get_features(state_dict_from(g), torch.from_numpy(g["gp"]), torch.from_numpy(g["x"]))
+    close(pf, g["gf_point"]); close(sem, g["gf_sem"])
+    assert (oh.argmax(1).numpy() == g["gf_word"]).all()
+
+
+def test_basis_numerics():
+    g = load_golden("basis")
+    c, lab, inertia = R.lloyd_kmeans(g["pts"], g["init"], int(g["km_iters"]) + 2)
+    close(c, g["km_centers"], 1e-4)
+    assert (lab == g["km_labels"]).all()
+    assert abs(inertia - float(g["km_inertia"])) <= 1e-5 * float(g["km_inertia"])
+    close(R.kmean2proto(g["pts"], g["km_labels"], 12), g["proto"], 1e-6)
+    close(R.svd_reconstruct(g["proto"]), g["basis"], 1e-5)
+    close(R.svd_reconstruct(g["p200"]), g["basis200"], 1e-4)
+
+
+def test_dgcnnseg_features():
+    g = load_golden("dgcnnseg")
+    close(R.dgcnnseg_features(state_dict_from(g), torch.from_numpy(g["x"])), g["feat"], 1e-5)
+
+
+def test_metric():
+    g = load_golden("metric")
+    r = R.evaluate_metric_gfs(list(g["prs"]), list(g["gts"]), list(range(13)), list(g["novel"]), list(g["order"]))
+    close(np.array(r[:4]), g["res"], 1e-12); close(r[4], g["iou"], 1e-12)
+    r = R.evaluate_metric_gfs(list(g["prs_sc"]), list(g["gts_sc"]), list(range(21)), list(g["novel_sc"]),
+                              list(g["order_sc"]), scannet=True)
+    close(np.array(r[:4]), g["res_sc"], 1e-12); close(r[4], g["iou_sc"], 1e-12)
