@@ -1,0 +1,323 @@
+// K3: point x prototype cosine matching on the gfx950 matrix cores, and the
+// k-means assignment step of get_basis.
+//
+// cos[b,w,n] = <g_w, f_n> / (max(|g_w|,eps) max(|f_n|,eps))   (F.normalize, eps 1e-12)
+//   * geometric words: softmax(10*cos) over words + arg-max one-hot (model/capl.py:344-353)
+//   * get_pred: 10*cos logits against (cls,c) or per-sample (b,cls,c) prototypes
+//     (model/capl.py:290-322)
+// This is a true dense (B*N) x C . C x K contraction, so it runs on MFMA:
+// v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate - an exact fp32 fma chain, the
+// only MFMA that meets the 1e-4 fp32 contract without splitting).
+//
+// Tiling: workgroup = 4 waves = 128 points; a wave owns 32 points (MFMA columns)
+// and ALL K prototype rows (NT row-tiles of 32), so the softmax / arg-max over
+// prototypes is an in-lane reduction over accumulator registers plus one
+// cross-half exchange - no LDS round trip for the scores.  Channels are
+// processed in chunks of 64: the prototype chunk [NT*32][64] is staged in LDS
+// (row stride 68 floats => conflict-free ds_read_b128 A-fragments), the point
+// chunk is read straight from the channel-first input (128-B coalesced rows).
+// Norms are accumulated on the fly and applied to the fp32 accumulators.
+#include "common.h"
+
+namespace gfs3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PR_CH = 64;     // channels per chunk
+constexpr int PR_LD = 68;     // LDS row stride (floats)
+constexpr float NORM_EPS = 1e-12f;
+
+enum { MODE_LOGITS = 0, MODE_SOFTMAX = 1 };
+
+// row (prototype) index inside a 32x32 accumulator tile for register r of lane-half h
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(256)
+proto_mfma_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
+                  const float *__restrict__ proto, int P, int K, float scale,
+                  float *__restrict__ out,        // LOGITS: (B,K,N) ; SOFTMAX: soft (B,K,N) or NULL
+                  int32_t *__restrict__ assign,   // SOFTMAX only, may be NULL
+                  float *__restrict__ onehot)     // SOFTMAX only, may be NULL
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *gs = smem;                          // [NT*32][PR_LD]
+    float *ginv = gs + NT * 32 * PR_LD;        // [NT*32] 1/max(|g|,eps)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * 128 + wv * 32;
+    const int n = n0 + j;
+    const int nc = min(n, N - 1);
+    const float *fb = feat + (size_t)b * feat_bstride;
+    const float *pb = proto + (P > 1 ? (size_t)b * K * C : 0);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float fsq = 0.f;        // partial |f_n|^2 (this lane-half's channels)
+    float gsq = 0.f;        // thread tid < NT*32 accumulates |g_tid|^2
+
+    for (int c0 = 0; c0 < C; c0 += PR_CH) {
+        __syncthreads();
+        // stage prototype chunk: gs[w][cc] = proto[w][c0+cc]  (zero padded)
+        for (int e = tid; e < NT * 32 * PR_CH; e += 256) {
+            const int w = e >> 6, cc = e & 63;
+            const float v = (w < K && c0 + cc < C) ? pb[(size_t)w * C + c0 + cc] : 0.f;
+            gs[w * PR_LD + cc] = v;
+        }
+        // this lane's point chunk: channels c0 + 8t + 4h + s
+        float f[32];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int c = c0 + 8 * t + 4 * h + s;
+                const float v = (c < C) ? fb[(size_t)c * N + nc] : 0.f;
+                f[4 * t + s] = v;
+                fsq = fmaf(v, v, fsq);
+            }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const float *row = gs + tid * PR_LD;
+#pragma unroll 8
+            for (int cc = 0; cc < PR_CH; ++cc) gsq = fmaf(row[cc], row[cc], gsq);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int wt = 0; wt < NT; ++wt) {
+                const float4 a = *reinterpret_cast<const float4 *>(gs + (wt * 32 + j) * PR_LD + 8 * t + 4 * h);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f[4 * t + 0], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f[4 * t + 1], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f[4 * t + 2], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f[4 * t + 3], acc[wt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NT * 32) ginv[tid] = 1.0f / fmaxf(sqrtf(gsq), NORM_EPS);
+    __syncthreads();
+    fsq += __shfl_xor(fsq, 32, 64);
+    const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
+
+    const bool nvalid = n < N;
+    if (MODE == MODE_LOGITS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                if (w < K && nvalid)
+                    out[((size_t)b * K + w) * N + n] = acc[t][r] * ginv[w] * finv * scale;
+            }
+    } else {
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                const float v = (w < K) ? acc[t][r] * ginv[w] * finv * scale : -__builtin_inff();
+                acc[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(acc[t][r] - mx);      // exp(-inf) = 0 for padded rows
+                acc[t][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        float best = -1.f;
+        int bw = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                const float p = acc[t][r] / sum;
+                acc[t][r] = p;
+                if (w < K && (p > best || (p == best && w < bw))) { best = p; bw = w; }
+            }
+        {   // combine the two lane halves: larger p wins, ties -> lower word index
+            const float ob = __shfl_xor(best, 32, 64);
+            const int ow = __shfl_xor(bw, 32, 64);
+            if (ob > best || (ob == best && ow < bw)) { best = ob; bw = ow; }
+        }
+        if (nvalid) {
+            if (assign && h == 0) assign[(size_t)b * N + n] = bw;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int w = t * 32 + acc_row(r, h);
+                    if (w < K) {
+                        const size_t o = ((size_t)b * K + w) * N + n;
+                        if (out) out[o] = acc[t][r];
+                        if (onehot) onehot[o] = (w == bw) ? 1.f : 0.f;
+                    }
+                }
+        }
+    }
+}
+
+template <int NT, int MODE>
+static int launch_proto(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
+                        float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
+{
+    const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(proto_mfma_kernel<NT, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+    }
+    dim3 grid((N + 127) / 128, B);
+    hipLaunchKernelGGL((proto_mfma_kernel<NT, MODE>), grid, dim3(256), lds, st, feat, bs, C, N, proto, P, K, scale,
+                       out, assign, onehot);
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
+template <int MODE>
+static int dispatch_proto(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
+                          float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
+{
+    const int nt = (K + 31) / 32;
+    if (nt <= 1) return launch_proto<1, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    if (nt <= 2) return launch_proto<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    if (nt <= 4) return launch_proto<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    return launch_proto<8, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+}
+
+// ---------------------------------------------------------------------------
+// k-means assignment (Lloyd step), first version: 64 points per workgroup in LDS,
+// centroids streamed through LDS in tiles of 64; thread (p, q) scores point p
+// against centroids q, q+4, ... of the tile.  sums/counts accumulate with float
+// atomics (256-B contiguous rows).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+kmeans_assign_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ cent, int K,
+                     int32_t *__restrict__ label, float *__restrict__ sums, float *__restrict__ counts,
+                     double *__restrict__ inertia)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = C + 1;
+    float *ps = smem;                 // [64][LD]
+    float *cs = ps + 64 * LD;         // [64][LD]
+    float *cn = cs + 64 * LD;         // [64] |c|^2
+    float *bd = cn + 64;              // [4][64] best distance per (q, p)
+    int *bi = reinterpret_cast<int *>(bd + 256);   // [4][64]
+    const int tid = threadIdx.x, p = tid & 63, q = tid >> 6;
+    const long long m0 = (long long)blockIdx.x * 64;
+    for (int e = tid; e < 64 * C; e += 256) {
+        const int pp = e / C, c = e - pp * C;
+        ps[pp * LD + c] = (m0 + pp < M) ? pts[(size_t)(m0 + pp) * C + c] : 0.f;
+    }
+    float best = __builtin_inff();
+    int bidx = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * C; e += 256) {
+            const int kk = e / C, c = e - kk * C;
+            cs[kk * LD + c] = (k0 + kk < K) ? cent[(size_t)(k0 + kk) * C + c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s = fmaf(cs[tid * LD + c], cs[tid * LD + c], s);
+            cn[tid] = s;
+        }
+        __syncthreads();
+        for (int kk = q; kk < 64 && k0 + kk < K; kk += 4) {
+            float dot = 0.f;
+            for (int c = 0; c < C; ++c) dot = fmaf(ps[p * LD + c], cs[kk * LD + c], dot);
+            const float d = cn[kk] - 2.f * dot;          // + |p|^2 (constant per point)
+            if (d < best) { best = d; bidx = k0 + kk; }
+        }
+    }
+    bd[q * 64 + p] = best;
+    bi[q * 64 + p] = bidx;
+    __syncthreads();
+    if (q == 0) {
+        for (int qq = 1; qq < 4; ++qq) {
+            const float d = bd[qq * 64 + p];
+            const int i = bi[qq * 64 + p];
+            if (d < best || (d == best && i < bidx)) { best = d; bidx = i; }
+        }
+        bi[p] = bidx;
+        float pn = 0.f;
+        for (int c = 0; c < C; ++c) pn = fmaf(ps[p * LD + c], ps[p * LD + c], pn);
+        bd[p] = best + pn;
+        if (m0 + p < M) {
+            label[m0 + p] = bidx;
+            atomicAdd(&counts[bidx], 1.0f);
+        }
+    }
+    __syncthreads();
+    // accumulate centroid sums: wave q handles points q, q+4, ...; lanes over channels
+    for (int pp = q; pp < 64 && m0 + pp < M; pp += 4) {
+        const int li = bi[pp];
+        for (int c = p; c < C; c += 64) atomicAdd(&sums[(size_t)li * C + c], ps[pp * LD + c]);
+    }
+    if (inertia && tid < 64) {
+        double v = (m0 + tid < M) ? (double)fmaxf(bd[tid], 0.f) : 0.0;
+        v = wave_sum(v);
+        if (tid == 0) atomicAdd(inertia, v);
+    }
+}
+
+}  // namespace gfs3d
+
+extern "C" int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                     const float *words, int Kw, float scale,
+                                     float *soft, int32_t *assign, float *onehot, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(feat && words, "gfs3d_word_assign_f32: NULL input");
+    GFS3D_REQUIRE(soft || assign || onehot, "gfs3d_word_assign_f32: no output requested");
+    GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, "gfs3d_word_assign_f32: bad shape B=%d C=%d N=%d", B, C, N);
+    GFS3D_REQUIRE(Kw >= 1 && Kw <= 256, "gfs3d_word_assign_f32: need 1 <= Kw <= 256, got %d", Kw);
+    GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "gfs3d_word_assign_f32: bad feat_bstride");
+    return dispatch_proto<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, words, 1, Kw, scale, soft, assign, onehot,
+                                        static_cast<hipStream_t>(stream), "gfs3d_word_assign_f32");
+}
+
+extern "C" int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                      const float *proto, int P, int K, float scale, float *out, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(feat && proto && out, "gfs3d_proto_cosine_f32: NULL pointer");
+    GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, "gfs3d_proto_cosine_f32: bad shape B=%d C=%d N=%d", B, C, N);
+    GFS3D_REQUIRE(K >= 1 && K <= 256, "gfs3d_proto_cosine_f32: need 1 <= K <= 256, got %d", K);
+    GFS3D_REQUIRE(P == 1 || P == B, "gfs3d_proto_cosine_f32: P must be 1 or B (got %d)", P);
+    GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "gfs3d_proto_cosine_f32: bad feat_bstride");
+    return dispatch_proto<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, out, nullptr, nullptr,
+                                       static_cast<hipStream_t>(stream), "gfs3d_proto_cosine_f32");
+}
+
+extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
+                                       int32_t *label, float *sums, float *counts, double *inertia, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(pts && cent && label && sums && counts, "gfs3d_kmeans_assign_f32: NULL pointer");
+    GFS3D_REQUIRE(M >= 1 && C >= 1 && C <= 256 && K >= 1, "gfs3d_kmeans_assign_f32: bad shape M=%lld C=%d K=%d", M, C, K);
+    const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("gfs3d_kmeans_assign_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+    }
+    const long long nblk = (M + 63) / 64;
+    GFS3D_REQUIRE(nblk < (1ll << 31), "gfs3d_kmeans_assign_f32: M too large");
+    hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)nblk), dim3(256), lds, static_cast<hipStream_t>(stream),
+                       pts, M, C, cent, K, label, sums, counts, inertia);
+    GFS3D_LAUNCH_CHECK("gfs3d_kmeans_assign_f32");
+    return GFS3D_OK;
+}

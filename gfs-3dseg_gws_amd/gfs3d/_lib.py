@@ -1,0 +1,108 @@
+"""ctypes binding of libgfs3d_hip.so (C ABI: include/gfs3d.h).
+
+The library is built in-tree by ``build_library()`` (hipcc, gfx950 only) and
+loaded lazily.  There is NO fallback: if the shared object is missing or a call
+fails, a RuntimeError is raised - the hot path is HIP or nothing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_CSRC = os.path.join(_PKG, "csrc")
+_SO = os.path.join(_PKG, "lib", "libgfs3d_hip.so")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip")
+_lib = None
+
+
+class EdgeConvArgs(Structure):
+    _fields_ = [
+        ("B", c_int), ("C", c_int), ("N", c_int), ("k", c_int),
+        ("training", c_int),
+        ("eps", c_float), ("momentum", c_float), ("slope", c_float),
+        ("x", c_void_p), ("idx", c_void_p), ("w1", c_void_p),
+        ("bn1_w", c_void_p), ("bn1_b", c_void_p), ("bn1_rm", c_void_p), ("bn1_rv", c_void_p),
+        ("w2", c_void_p),
+        ("bn2_w", c_void_p), ("bn2_b", c_void_p), ("bn2_rm", c_void_p), ("bn2_rv", c_void_p),
+        ("y_cf", c_void_p), ("y_cf_bstride", c_longlong), ("y_pm", c_void_p),
+        ("P", c_void_p), ("Q", c_void_p), ("SP", c_void_p), ("SQ", c_void_p), ("indeg", c_void_p),
+        ("stats", c_void_p), ("hsel", c_void_p), ("jsel", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+    ]
+
+
+class EdgeConvBwdArgs(Structure):
+    _fields_ = [
+        ("f", EdgeConvArgs),
+        ("dy_cf", c_void_p), ("dy_bstride", c_longlong),
+        ("dx", c_void_p),
+        ("dw1", c_void_p), ("dbn1_w", c_void_p), ("dbn1_b", c_void_p),
+        ("dw2", c_void_p), ("dbn2_w", c_void_p), ("dbn2_b", c_void_p),
+    ]
+
+
+# every symbol include/gfs3d.h declares: (restype, argtypes)
+SYMBOLS = {
+    "gfs3d_version": (c_int, []),
+    "gfs3d_last_error": (c_char_p, []),
+    "gfs3d_knn_topk_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),
+    "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),
+    "gfs3d_word_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                       c_void_p, c_void_p]),
+    "gfs3d_kmeans_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+}
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into lib/libgfs3d_hip.so (hipcc
+    cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, s) for s in _SOURCES]
+    deps = srcs + [os.path.join(_CSRC, "common.h"), os.path.join(_PKG, "..", "include", "gfs3d.h")]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-value", *srcs, "-o", _SO + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(_SO + ".tmp", _SO)
+    return _SO
+
+
+def lib():
+    """Load the shared object (after ``import torch`` so that the HIP runtime
+    torch already mapped - same SONAME libamdhip64.so.7 - is the one we bind to)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(
+                f"gfs3d: {_SO} is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+        import torch  # noqa: F401  (maps torch's libamdhip64 first)
+        L = ctypes.CDLL(_SO)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)      # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gfs3d_last_error()
+        raise RuntimeError(f"gfs3d: {what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,315 @@
+"""Host-side operators over the C ABI (include/gfs3d.h).
+
+torch is plumbing here: device memory (torch.empty), the current HIP stream
+and autograd bookkeeping.  All arithmetic of the hot path happens inside
+libgfs3d_hip.so.  Every operator insists on CUDA(HIP) fp32 tensors and raises
+otherwise - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EdgeConvArgs, EdgeConvBwdArgs
+
+EC_WIDTH = 64
+MAX_K = 32
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"gfs3d: `{name}` must be a HIP (cuda) tensor - the hot path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"gfs3d: `{name}` must be float32, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+_workspaces = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """One growing scratch buffer per device; all launches are on the current
+    stream, so consecutive calls reuse it safely."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# --------------------------------------------------------------------------
+# K1
+# --------------------------------------------------------------------------
+def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False):
+    """x (B,C,N) channel-first -> neighbour indices (B,N,k), nearest first.
+    Replaces knn() of model/dgcnn.py:17-23."""
+    _need_gpu(x, "x")
+    if x.dim() != 3:
+        raise RuntimeError("gfs3d.knn_topk: x must be (B,C,N)")
+    x = x.contiguous()
+    B, C, N = x.shape
+    i64 = torch.empty((B, N, k), dtype=torch.int64, device=x.device) if want_i64 else None
+    i32 = torch.empty((B, N, k), dtype=torch.int32, device=x.device) if want_i32 else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _stream())
+    _lib.check(rc, "gfs3d_knn_topk_f32")
+    if want_i64 and want_i32:
+        return i64, i32
+    return i64 if want_i64 else i32
+
+
+# --------------------------------------------------------------------------
+# K2
+# --------------------------------------------------------------------------
+class _EdgeConvCtx:
+    """Buffers one EdgeConv forward leaves behind for its backward."""
+    __slots__ = ("B", "C", "N", "k", "P", "Q", "SP", "SQ", "indeg", "stats", "hsel", "jsel", "y_pm", "idx")
+
+
+def _fill_args(a: EdgeConvArgs, x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope, c):
+    a.B, a.C, a.N, a.k = c.B, c.C, c.N, c.k
+    a.training = 1 if training else 0
+    a.eps, a.momentum, a.slope = eps, momentum, slope
+    a.x, a.idx, a.w1 = x.data_ptr(), idx.data_ptr(), w1.data_ptr()
+    a.bn1_w, a.bn1_b = g1.data_ptr(), b1.data_ptr()
+    a.bn1_rm = rm1.data_ptr() if rm1 is not None else None
+    a.bn1_rv = rv1.data_ptr() if rv1 is not None else None
+    a.w2 = w2.data_ptr()
+    a.bn2_w, a.bn2_b = g2.data_ptr(), b2.data_ptr()
+    a.bn2_rm = rm2.data_ptr() if rm2 is not None else None
+    a.bn2_rv = rv2.data_ptr() if rv2 is not None else None
+    a.P, a.Q = c.P.data_ptr(), c.Q.data_ptr()
+    a.SP = c.SP.data_ptr() if c.SP is not None else None
+    a.SQ = c.SQ.data_ptr() if c.SQ is not None else None
+    a.indeg = c.indeg.data_ptr() if c.indeg is not None else None
+    a.stats = c.stats.data_ptr()
+    a.hsel = c.hsel.data_ptr() if c.hsel is not None else None
+    a.jsel = c.jsel.data_ptr() if c.jsel is not None else None
+    a.y_pm = c.y_pm.data_ptr() if c.y_pm is not None else None
+    nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(c.B, c.C, c.N, c.k)
+    ws = _workspace(x.device, nbytes)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    return ws
+
+
+class EdgeConvFunction(torch.autograd.Function):
+    """y = max_k LReLU(BN2(W2 LReLU(BN1(W1 [x_j - x_i ; x_i]))))  for one block
+    (model/dgcnn.py:116-118), forward and backward in HIP."""
+
+    @staticmethod
+    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope):
+        for t, nme in ((x, "x"), (w1, "conv1.weight"), (w2, "conv2.weight")):
+            _need_gpu(t, nme)
+        x = x.contiguous()
+        B, C, N = x.shape
+        k = idx.shape[-1]
+        if idx.dtype != torch.int32 or not idx.is_contiguous():
+            raise RuntimeError("gfs3d.edgeconv: idx must be contiguous int32 (B,N,k)")
+        if w1.numel() != EC_WIDTH * 2 * C or w2.numel() != EC_WIDTH * EC_WIDTH:
+            raise NotImplementedError("gfs3d.edgeconv: only EdgeConv widths [64, 64] are implemented in HIP")
+        dev = x.device
+        c = _EdgeConvCtx()
+        c.B, c.C, c.N, c.k, c.idx = B, C, N, k, idx
+        f32 = dict(dtype=torch.float32, device=dev)
+        c.P = torch.empty((B, N, EC_WIDTH), **f32)
+        c.Q = torch.empty((B, N, EC_WIDTH), **f32)
+        c.stats = torch.empty((8, EC_WIDTH), **f32)
+        if training:
+            c.SP = torch.empty((B, N, EC_WIDTH), **f32)
+            c.SQ = torch.empty((B, N, EC_WIDTH), **f32)
+            c.indeg = torch.empty((B, N), **f32)
+            c.hsel = torch.empty((B, N, EC_WIDTH), **f32)
+            c.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
+            c.y_pm = torch.empty((B, N, EC_WIDTH), **f32)
+        else:
+            c.SP = c.SQ = c.indeg = c.hsel = c.jsel = c.y_pm = None
+        y = torch.empty((B, EC_WIDTH, N), **f32)
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        a = EdgeConvArgs()
+        ws = _fill_args(a, x, idx, w1c, g1, b1, rm1, rv1, w2c, g2, b2, rm2, rv2, training, eps, momentum, slope, c)
+        a.y_cf, a.y_cf_bstride = y.data_ptr(), EC_WIDTH * N
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gfs3d_edgeconv_forward_f32(ctypes.byref(a), _stream())
+        _lib.check(rc, "gfs3d_edgeconv_forward_f32")
+        del ws
+        if training:
+            ctx.c = c
+            ctx.scalars = (eps, momentum, slope)
+            ctx.save_for_backward(x, w1c, g1, b1, w2c, g2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not hasattr(ctx, "c"):
+            raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
+        x, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
+        c = ctx.c
+        eps, momentum, slope = ctx.scalars
+        dy = dy.contiguous()
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        dw1 = torch.empty_like(w1)
+        dw2 = torch.empty_like(w2)
+        dg1, db1, dg2, db2 = (torch.empty(EC_WIDTH, **f32) for _ in range(4))
+        ba = EdgeConvBwdArgs()
+        ws = _fill_args(ba.f, x, c.idx, w1, g1, b1, None, None, w2, g2, b2, None, None, True, eps, momentum, slope, c)
+        ba.dy_cf, ba.dy_bstride = dy.data_ptr(), EC_WIDTH * c.N
+        ba.dx = dx.data_ptr()
+        ba.dw1, ba.dbn1_w, ba.dbn1_b = dw1.data_ptr(), dg1.data_ptr(), db1.data_ptr()
+        ba.dw2, ba.dbn2_w, ba.dbn2_b = dw2.data_ptr(), dg2.data_ptr(), db2.data_ptr()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gfs3d_edgeconv_backward_f32(ctypes.byref(ba), _stream())
+        _lib.check(rc, "gfs3d_edgeconv_backward_f32")
+        del ws
+        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 8
+
+
+def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2):
+    """Run one EdgeConv block given the two conv weights and the two
+    nn.BatchNorm2d modules (their running stats are updated in place when
+    training, like nn.BatchNorm2d does)."""
+    if training:
+        for bn in (bn1, bn2):
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    mom = bn1.momentum if bn1.momentum is not None else 0.1
+    return EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
+                                  bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
+                                  bool(training), float(bn1.eps), float(mom), float(slope))
+
+
+# --------------------------------------------------------------------------
+# K3
+# --------------------------------------------------------------------------
+def _bstride(t: torch.Tensor) -> int:
+    """feat may be a channel slice of a bigger (B,Ctot,N) buffer: need unit
+    stride over N, N stride over C; batch stride is free."""
+    B, C, N = t.shape
+    if t.stride(2) != 1 or (C > 1 and t.stride(1) != N):
+        raise RuntimeError("gfs3d: feature tensor must be (B,C,N) with contiguous (C,N) planes")
+    return t.stride(0) if B > 1 else C * N
+
+
+def word_assign_raw(feat: torch.Tensor, words: torch.Tensor, scale: float = 10.0,
+                    want_soft: bool = True, want_onehot: bool = True):
+    """softmax(scale*cos(word, point)) over words, arg-max word and its one-hot
+    (model/capl.py:344-353).  No autograd here - see WordAssignFunction."""
+    _need_gpu(feat, "feat")
+    _need_gpu(words, "words")
+    B, C, N = feat.shape
+    Kw = words.shape[0]
+    words = words.contiguous()
+    dev = feat.device
+    soft = torch.empty((B, Kw, N), dtype=torch.float32, device=dev) if want_soft else None
+    onehot = torch.empty((B, Kw, N), dtype=torch.float32, device=dev) if want_onehot else None
+    assign = torch.empty((B, N), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gfs3d_word_assign_f32(_p(feat), _bstride(feat), B, C, N, _p(words), Kw, float(scale),
+                                              _p(soft), _p(assign), _p(onehot), _stream())
+    _lib.check(rc, "gfs3d_word_assign_f32")
+    return soft, assign, onehot
+
+
+def proto_cosine_raw(feat: torch.Tensor, proto: torch.Tensor, scale: float = 10.0) -> torch.Tensor:
+    """scale * cosine(point feature, prototype): proto (K,C) or (B,K,C) -> (B,K,N)
+    (get_pred, model/capl.py:290-322)."""
+    _need_gpu(feat, "feat")
+    _need_gpu(proto, "proto")
+    B, C, N = feat.shape
+    proto = proto.contiguous()
+    P = 1 if proto.dim() == 2 else proto.shape[0]
+    K = proto.shape[-2]
+    out = torch.empty((B, K, N), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.lib().gfs3d_proto_cosine_f32(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
+                                               _p(out), _stream())
+    _lib.check(rc, "gfs3d_proto_cosine_f32")
+    return out
+
+
+class WordAssignFunction(torch.autograd.Function):
+    """Differentiable wrt the point features (the words `gp` carry no grad,
+    capl.py:49-50).  Backward is the softmax/normalise chain rule as two device
+    matmuls on the saved soft assignment."""
+
+    @staticmethod
+    def forward(ctx, feat, words, scale):
+        soft, assign, onehot = word_assign_raw(feat, words, scale)
+        ctx.scale = scale
+        ctx.save_for_backward(feat, words, soft)
+        ctx.mark_non_differentiable(onehot, assign)
+        return soft, onehot, assign
+
+    @staticmethod
+    def backward(ctx, dsoft, _d1, _d2):
+        feat, words, soft = ctx.saved_tensors
+        # d(scale*cos) = soft * (dsoft - sum_w soft*dsoft)
+        dlog = soft * (dsoft - (soft * dsoft).sum(dim=1, keepdim=True)) * ctx.scale
+        gn = torch.nn.functional.normalize(words, p=2, dim=1)                  # (Kw,C)
+        fnorm = feat.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)           # (B,1,N)
+        fhat = feat / fnorm
+        dfhat = torch.matmul(gn.t().unsqueeze(0), dlog)                        # (B,C,N)
+        dfeat = (dfhat - fhat * (fhat * dfhat).sum(dim=1, keepdim=True)) / fnorm
+        return dfeat, None, None
+
+
+class ProtoCosineFunction(torch.autograd.Function):
+    """get_pred with gradients to both the point features and the prototypes."""
+
+    @staticmethod
+    def forward(ctx, feat, proto, scale):
+        out = proto_cosine_raw(feat, proto, scale)
+        ctx.scale = scale
+        ctx.save_for_backward(feat, proto)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, proto = ctx.saved_tensors
+        s = ctx.scale
+        fnorm = feat.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)
+        fhat = feat / fnorm                                                      # (B,C,N)
+        pnorm = proto.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-12)
+        phat = proto / pnorm                                                     # (K,C) | (B,K,C)
+        d = dout * s
+        if proto.dim() == 2:
+            dfhat = torch.matmul(phat.t().unsqueeze(0), d)                       # (B,C,N)
+            dphat = torch.einsum("bkn,bcn->kc", d, fhat)
+        else:
+            dfhat = torch.matmul(phat.transpose(1, 2), d)
+            dphat = torch.matmul(d, fhat.transpose(1, 2))                        # (B,K,C)
+        dfeat = (dfhat - fhat * (fhat * dfhat).sum(dim=1, keepdim=True)) / fnorm
+        dproto = (dphat - phat * (phat * dphat).sum(dim=-1, keepdim=True)) / pnorm
+        return dfeat, dproto, None
+
+
+def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor):
+    """One Lloyd assignment step on device: labels, per-centroid sums/counts and
+    inertia (get_basis.py:210 runs sklearn KMeans on the CPU)."""
+    _need_gpu(pts, "pts")
+    _need_gpu(cent, "cent")
+    pts, cent = pts.contiguous(), cent.contiguous()
+    M, C = pts.shape
+    K = cent.shape[0]
+    dev = pts.device
+    label = torch.empty(M, dtype=torch.int32, device=dev)
+    sums = torch.zeros((K, C), dtype=torch.float32, device=dev)
+    counts = torch.zeros(K, dtype=torch.float32, device=dev)
+    inertia = torch.zeros(1, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().gfs3d_kmeans_assign_f32(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts),
+                                                _p(inertia), _stream())
+    _lib.check(rc, "gfs3d_kmeans_assign_f32")
+    return label, sums, counts, inertia

@@ -1,0 +1,32 @@
+"""Self-attention head of the CAPL model - same constructor, parameter names
+(q_map/k_map/v_map.weight) and forward contract as the reference
+model/attention.py:10-48.  It is on the forward path but not one of the
+north-star kernels: it runs as device GEMMs
+through torch (rocBLAS) and never materialises more than one (B,N,N) tensor.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, in_channel, out_channel=None, attn_dropout=0.1):
+        super().__init__()
+        self.in_channel = in_channel
+        self.out_channel = in_channel if out_channel is None else out_channel
+        self.temperature = self.out_channel ** 0.5
+        for name in ("q_map", "k_map", "v_map"):          # registration order = reference order
+            setattr(self, name, nn.Conv1d(in_channel, self.out_channel, 1, bias=False))
+        self.dropout = nn.Dropout(attn_dropout)
+        self._forced_keep_mask = None      # tests: (B,N,N) bool, replaces the RNG draw of nn.Dropout
+
+    def forward(self, x):
+        """x (B, in_channel, N) -> (B, out_channel, N)."""
+        q, k, v = self.q_map(x), self.k_map(x), self.v_map(x)
+        attn = torch.bmm(q.transpose(1, 2) / self.temperature, k)
+        attn = F.softmax(attn, dim=-1)
+        if self._forced_keep_mask is not None and self.training:
+            attn = attn * (self._forced_keep_mask.to(attn.dtype) / (1.0 - self.dropout.p))
+        else:
+            attn = self.dropout(attn)
+        return torch.bmm(attn, v.transpose(1, 2)).transpose(1, 2)

@@ -1,0 +1,165 @@
+"""DGCNN backbone with the reference's module surface (model/dgcnn.py of
+Pixie8888/GFS-3DSeg_GWs): ``knn``, ``get_edge_feature``, ``conv2d``, ``conv1d``,
+``DGCNN``, ``BaseLearner``, ``DGCNNSeg_att`` - same constructor arguments,
+forward() contracts and state_dict keys (``edge_convs.{i}.layer.{0,1,3,4}.*``,
+``conv.layer.{0,1,3,4}.*``), so reference checkpoints load and train.py /
+get_basis.py can import it unchanged.
+
+What is different is everything underneath: kNN graph construction and each
+EdgeConv block run as hand-written HIP kernels (gfs3d.ops -> libgfs3d_hip.so);
+no (B,N,N) distance matrix and no (B,2C,N,k) / (B,64,N,k) edge tensor exists.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from gfs3d import ops
+from model.attention import SelfAttention
+
+_LRELU = 0.2
+
+
+def knn(x, k):
+    """(B,C,N) -> (B,N,k) int64 neighbour indices, nearest first (self included).
+    Reference: dgcnn.py:17-23.  Fused distance + top-k on the GPU."""
+    return ops.knn_topk(x, k, want_i64=True, want_i32=False)
+
+
+def get_edge_feature(x, K=20, idx=None):
+    """(B,C,N) -> (B,2C,N,K) = cat(x_j - x_i, x_i) (reference dgcnn.py:26-42).
+    Kept for API compatibility; DGCNN.forward below never materialises it."""
+    B, C, N = x.shape
+    if idx is None:
+        idx = knn(x, K)
+    nbr = torch.gather(x, 2, idx.reshape(B, 1, N * K).expand(B, C, N * K)).view(B, C, N, K)
+    ctr = x.unsqueeze(-1).expand(B, C, N, K)
+    return torch.cat((nbr - ctr, ctr), dim=1)
+
+
+def _pointwise_stack(conv_cls, bn_cls, in_feat, layer_dims, batch_norm, relu, bias):
+    mods, prev = [], in_feat
+    for width in layer_dims:
+        mods.append(conv_cls(prev, width, kernel_size=1, bias=bias))
+        if batch_norm:
+            mods.append(bn_cls(width))
+        if relu:
+            mods.append(nn.LeakyReLU(_LRELU))
+        prev = width
+    return nn.Sequential(*mods)
+
+
+class conv2d(nn.Module):
+    """[Conv2d 1x1 -> BatchNorm2d -> LeakyReLU(0.2)] per entry of layer_dims, held in
+    ``self.layer`` (reference dgcnn.py:45-61)."""
+
+    def __init__(self, in_feat, layer_dims, batch_norm=True, relu=True, bias=False):
+        super().__init__()
+        self.layer_dims = layer_dims
+        self.layer = _pointwise_stack(nn.Conv2d, nn.BatchNorm2d, in_feat, layer_dims, batch_norm, relu, bias)
+
+    def forward(self, x):
+        return self.layer(x)
+
+    def fused_parts(self):
+        """(conv1, bn1, conv2, bn2) when this block has the shape the HIP EdgeConv
+        kernel implements (two bias-free 1x1 convs to 64 channels with BN + LeakyReLU)."""
+        m = list(self.layer)
+        ok = (len(m) == 6 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d)
+              and isinstance(m[3], nn.Conv2d) and isinstance(m[4], nn.BatchNorm2d)
+              and m[0].bias is None and m[3].bias is None
+              and m[0].out_channels == ops.EC_WIDTH and m[3].out_channels == ops.EC_WIDTH
+              and m[1].track_running_stats and m[4].track_running_stats and m[1].affine and m[4].affine)
+        if not ok:
+            raise NotImplementedError(
+                "gfs3d: the HIP EdgeConv kernel implements edgeconv widths [64, 64] with BatchNorm + LeakyReLU "
+                f"(got layer_dims={self.layer_dims}); there is no unfused fallback")
+        return m[0], m[1], m[3], m[4]
+
+
+class conv1d(nn.Module):
+    """Point-wise MLP [Conv1d 1x1 -> BatchNorm1d -> LeakyReLU(0.2)] (reference dgcnn.py:64-80)."""
+
+    def __init__(self, in_feat, layer_dims, batch_norm=True, relu=True, bias=False):
+        super().__init__()
+        self.layer_dims = layer_dims
+        self.layer = _pointwise_stack(nn.Conv1d, nn.BatchNorm1d, in_feat, layer_dims, batch_norm, relu, bias)
+
+    def forward(self, x):
+        return self.layer(x)
+
+
+class DGCNN(nn.Module):
+    """Stacked EdgeConv blocks (kNN graph rebuilt on every block's features) followed by
+    a point-wise MLP on the concatenated block outputs (reference dgcnn.py:83-127)."""
+
+    def __init__(self, edgeconv_widths, mlp_widths, nfeat, k=20, return_edgeconvs=False):
+        super().__init__()
+        self.n_edgeconv = len(edgeconv_widths)
+        self.k = k
+        self.return_edgeconvs = return_edgeconvs
+        self.edge_convs = nn.ModuleList()
+        prev = nfeat
+        for widths in edgeconv_widths:
+            self.edge_convs.append(conv2d(2 * prev, widths))
+            prev = widths[-1]
+        self.conv = conv1d(sum(w[-1] for w in edgeconv_widths), mlp_widths)
+
+    def edgeconv_features(self, x):
+        """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv)."""
+        feats = []
+        for block in self.edge_convs:
+            c1, bn1, c2, bn2 = block.fused_parts()
+            idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True)
+            x = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU)
+            feats.append(x)
+        return feats
+
+    def forward(self, x):
+        feats = self.edgeconv_features(x)
+        out = self.conv(torch.cat(feats, dim=1))
+        if self.return_edgeconvs:
+            return feats, out
+        return feats[0], out
+
+
+class BaseLearner(nn.Module):
+    """Conv1d(bias) + BatchNorm1d stack with ReLU between (not after) the layers
+    (reference dgcnn.py:130-152); keys ``convs.{i}.{0,1}.*``."""
+
+    def __init__(self, in_channels, params):
+        super().__init__()
+        self.num_convs = len(params)
+        dims = [in_channels] + list(params)
+        self.convs = nn.ModuleList(
+            nn.Sequential(nn.Conv1d(dims[i], dims[i + 1], 1), nn.BatchNorm1d(dims[i + 1]))
+            for i in range(self.num_convs))
+
+    def forward(self, x):
+        last = self.num_convs - 1
+        for i, blk in enumerate(self.convs):
+            x = blk(x)
+            if i != last:
+                x = F.relu(x)
+        return x
+
+
+class DGCNNSeg_att(nn.Module):
+    """Pre-train style segmenter (reference dgcnn.py:155-202): encoder + base learner +
+    attention -> point-wise classifier."""
+
+    def __init__(self, args, num_classes):
+        super().__init__()
+        self.encoder = DGCNN(args.edgeconv_widths, args.dgcnn_mlp_widths, args.pc_in_dim, k=args.dgcnn_k)
+        self.base_learner = BaseLearner(args.dgcnn_mlp_widths[-1], args.base_widths)
+        self.att_learner = SelfAttention(args.dgcnn_mlp_widths[-1], args.output_dim)
+        self.feat_dim = args.edgeconv_widths[0][-1] + args.output_dim + args.base_widths[-1]
+        self.segmenter = nn.Sequential(
+            nn.Conv1d(self.feat_dim, 256, 1, bias=False), nn.BatchNorm1d(256), nn.LeakyReLU(_LRELU),
+            nn.Conv1d(256, 128, 1), nn.BatchNorm1d(128), nn.LeakyReLU(_LRELU),
+            nn.Dropout(0.3), nn.Conv1d(128, num_classes, 1))
+
+    def forward(self, pc, return_feat=False):
+        level1, level2 = self.encoder(pc)
+        feat = torch.cat((level1, self.att_learner(level2), self.base_learner(level2)), dim=1)
+        logits = self.segmenter(feat)
+        return (logits, level1) if return_feat else logits

@@ -1,0 +1,123 @@
+/* gfs3d.h - C ABI of libgfs3d_hip.so: the MI355X (gfx950) hot path of
+ * Pixie8888/GFS-3DSeg_GWs (DGCNN kNN graph + EdgeConv + geometric-word /
+ * prototype cosine matching).
+ *
+ * The reference has no FFI: its "interface" for this path is the set of Python
+ * functions below.  Each entry point names the reference
+ * code it replaces.  All pointers are DEVICE pointers unless stated; all
+ * tensors are dense fp32 in the layout given; `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).  No entry point allocates, frees or
+ * synchronises: callers hand in outputs and a workspace (graph-capture safe).
+ *
+ * Return value: 0 on success, non-zero error code otherwise;
+ * gfs3d_last_error() gives a thread-local human-readable message.  Nothing
+ * here ever falls back to a CPU path.
+ */
+#ifndef GFS3D_H
+#define GFS3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFS3D_OK 0
+#define GFS3D_ERR_INVALID 1      /* bad shape / null pointer / unsupported size */
+#define GFS3D_ERR_WORKSPACE 2    /* workspace too small */
+#define GFS3D_ERR_HIP 3          /* a HIP runtime call or launch failed */
+
+#define GFS3D_EC_WIDTH 64        /* EdgeConv block widths supported: [64, 64] */
+#define GFS3D_MAX_K 32           /* neighbours per point supported by the EdgeConv kernels */
+
+int gfs3d_version(void);
+const char *gfs3d_last_error(void);
+
+/* ------------------------------------------------------------------ K1 --
+ * Fused pairwise-distance + top-k.  Replaces knn(x, k), model/dgcnn.py:17-23
+ * (bmm + 3 elementwise (B,N,N) passes + topk).
+ *   x      (B, C, N) channel-first (the reference layout)
+ *   idx64  (B, N, k) int64, nearest first - what knn() returns; may be NULL
+ *   idx32  (B, N, k) int32 copy consumed by the EdgeConv kernels; may be NULL
+ * Numerics contract (oracle/knn_oracle.c): dot = fp32 fma chain over c,
+ * pd = fl(fl(2 dot - |xj|^2) - |xi|^2), ties -> lower index first.
+ * Requires 1 <= k <= min(N, 64), C >= 1. */
+int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
+                       int64_t *idx64, int32_t *idx32, void *stream);
+
+/* ------------------------------------------------------------------ K2 --
+ * One EdgeConv block = get_edge_feature (dgcnn.py:26-42) + conv2d block
+ * [1x1 conv -> BatchNorm2d -> LeakyReLU(0.2)] x2 (dgcnn.py:45-61) + max over
+ * k (dgcnn.py:118), widths [64, 64], never materialising (B,2C,N,k). */
+typedef struct gfs3d_edgeconv_args {
+    int B, C, N, k;               /* C = input channels of this block */
+    int training;                 /* 1: batch statistics over (B,N,k); 0: running statistics */
+    float eps, momentum, slope;   /* 1e-5, 0.1, 0.2 in the reference */
+    const float *x;               /* (B, C, N) channel-first */
+    const int32_t *idx;           /* (B, N, k) from gfs3d_knn_topk_f32 */
+    const float *w1;              /* (64, 2C)  edge_convs[i].layer[0].weight */
+    const float *bn1_w, *bn1_b;   /* (64)      edge_convs[i].layer[1] */
+    float *bn1_rm, *bn1_rv;       /* (64) running stats; updated in place when training */
+    const float *w2;              /* (64, 64)  edge_convs[i].layer[3].weight */
+    const float *bn2_w, *bn2_b;   /* (64)      edge_convs[i].layer[4] */
+    float *bn2_rm, *bn2_rv;
+    float *y_cf;                  /* out: (B, 64, N) channel-first; batch stride below */
+    long long y_cf_bstride;       /* elements between consecutive b in y_cf (>= 64*N) */
+    float *y_pm;                  /* out: (B, N, 64) point-major copy (input layout of the next block) */
+    /* saved for backward (outputs of forward, inputs of backward) */
+    float *P, *Q;                 /* (B, N, 64): Wa x_n and (Wb - Wa) x_n */
+    float *SP, *SQ;               /* (B, N, 64): sum_j P[idx[n,j]] and sum over in-edges of Q */
+    float *indeg;                 /* (B, N) in-degree of each point in the kNN graph (as float) */
+    float *stats;                 /* (8, 64): mean1 rstd1 scale1 shift1 mean2 rstd2 scale2 shift2 */
+    float *hsel;                  /* (B, N, 64) pre-BN2 value that won the max */
+    uint8_t *jsel;                /* (B, N, 64) neighbour slot j that won the max */
+    void *workspace;
+    size_t workspace_bytes;       /* >= gfs3d_edgeconv_workspace_bytes() */
+} gfs3d_edgeconv_args;
+
+size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);
+int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *stream);
+
+/* Backward of the block above (autograd of dgcnn.py:116-118 in the reference).
+ *   dy_cf  (B, 64, N) channel-first gradient of y, batch stride dy_bstride
+ * outputs: dx (B,C,N); dw1 (64,2C); dbn1_w/b (64); dw2 (64,64); dbn2_w/b (64).
+ * Uses (and overwrites) the workspace; P,Q,SP,SQ,indeg,stats,hsel,jsel,y_pm must
+ * be what forward produced for the same inputs. */
+typedef struct gfs3d_edgeconv_bwd_args {
+    gfs3d_edgeconv_args f;
+    const float *dy_cf;
+    long long dy_bstride;
+    float *dx;
+    float *dw1, *dbn1_w, *dbn1_b, *dw2, *dbn2_w, *dbn2_b;
+} gfs3d_edgeconv_bwd_args;
+
+int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *a, void *stream);
+
+/* ------------------------------------------------------------------ K3 --
+ * Point x prototype cosine matching on MFMA (fp32-in / fp32-acc).
+ *
+ * gfs3d_word_assign_f32: geometric-word assignment, model/capl.py:344-353
+ *   feat   (B, C, N) channel-first, batch stride feat_bstride
+ *   words  (Kw, C)   geometric words (NOT normalised; normalised on load)
+ *   soft   (B, Kw, N) softmax(scale * cos) over words   (may be NULL)
+ *   assign (B, N) int32 arg-max word                    (may be NULL)
+ *   onehot (B, Kw, N) float one-hot of assign           (may be NULL)
+ * gfs3d_proto_cosine_f32: scale * cosine logits, model/capl.py:290-322 (get_pred)
+ *   proto (P, K, C) with P == 1 (shared) or P == B (per-sample); out (B, K, N)
+ * gfs3d_kmeans_assign_f32: Lloyd assignment + centroid partial sums for
+ *   get_basis.py:210 (sklearn KMeans on CPU in the reference)
+ *   pts (M, C) row-major, cent (K, C); label (M) int32; sums (K, C) and counts (K)
+ *   are ACCUMULATED into (zero them first); inertia (1) double accumulated. */
+int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                          const float *words, int Kw, float scale,
+                          float *soft, int32_t *assign, float *onehot, void *stream);
+int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                           const float *proto, int P, int K, float scale, float *out, void *stream);
+int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
+                            int32_t *label, float *sums, float *counts, double *inertia, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFS3D_H */

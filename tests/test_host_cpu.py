@@ -1,0 +1,145 @@
+"""CPU-side checks of the product package: module surface / state_dict layout,
+host logic vs golden vectors, the C ABI loads and exports every declared symbol,
+and the hot path refuses CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, state_dict_from
+
+
+def _args():
+    return types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                                 base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+
+
+def test_library_exports_every_declared_symbol():
+    from gfs3d import _lib, build_library
+    so = build_library()
+    L = ctypes.CDLL(so)
+    header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
+    declared = set(re.findall(r"\b(gfs3d_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(L, name), name
+    L.gfs3d_version.restype = ctypes.c_int
+    assert L.gfs3d_version() >= 100
+
+
+def test_args_struct_matches_header_field_order():
+    from gfs3d._lib import EdgeConvArgs
+    header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
+    body = header.split("typedef struct gfs3d_edgeconv_args {")[1].split("} gfs3d_edgeconv_args;")[0]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.sub(r"[\s\*]", " ", part).split()[-1])
+    assert names == [f[0] for f in EdgeConvArgs._fields_]
+
+
+def test_dgcnn_state_dict_and_seeded_init_match_reference():
+    from model.dgcnn import DGCNN
+    g = load_golden("dgcnn")
+    torch.manual_seed(0)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True)
+    sd = net.state_dict()
+    assert sorted(sd) == sorted(k[3:] for k in g.files if k.startswith("sd."))
+    assert np.array_equal(sd["edge_convs.0.layer.0.weight"].numpy(), g["init.edge_convs.0.layer.0.weight"])
+    net.load_state_dict(state_dict_from(g))        # strict
+
+
+def test_capl_state_dict_and_seeded_init_match_reference():
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    g = load_golden("capl")
+    torch.manual_seed(0)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, args=_args(), base_num=7, gp=torch.from_numpy(g["gp"]), energy=0.9)
+    assert sorted(m.state_dict()) == sorted(str(k) for k in g["keys"])
+    assert np.array_equal(m.main_proto.detach().numpy(), g["init_main_proto"])
+    m.load_state_dict(state_dict_from(g))
+    for attr in ("encoder", "base_learner", "att_learner", "main_proto", "bg_proto", "fusion", "gp"):
+        assert hasattr(m, attr)
+
+
+def test_hot_path_refuses_cpu_tensors():
+    from gfs3d import ops
+    from model.dgcnn import DGCNN, knn
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        knn(torch.randn(1, 3, 32), 4)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.randn(1, 9, 32))
+    with pytest.raises(NotImplementedError):
+        DGCNN([[32, 32]], [64], 9, k=4).edge_convs[0].fused_parts()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.proto_cosine_raw(torch.randn(1, 8, 16), torch.randn(3, 8))
+
+
+def test_hard_coding_matches_reference():
+    from model.capl import hard_coding_mask
+    g = load_golden("capl")
+    cv = torch.from_numpy(g["hc_in"])
+    assert (hard_coding_mask(cv, 0.9).numpy() == g["hc_model_090"]).all()
+    assert (hard_coding_mask(cv, 0.95).numpy() == g["hc_train_095"]).all()
+
+
+def test_get_gp_weight_matches_reference():
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    import torch.nn.functional as F
+    g = load_golden("capl")
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, args=_args(), base_num=7, gp=torch.from_numpy(g["gp"]), energy=0.9)
+    oh = F.one_hot(torch.from_numpy(g["gf_word"].astype(np.int64)), 200).transpose(2, 1).float()
+    coding = torch.from_numpy(g["gw_coding"])
+    w, acc, nacc = m.get_gp_weight(coding, oh, gt_label=torch.from_numpy(g["gw_lab13"]), th=1.2)
+    assert np.array_equal(w.numpy(), g["gw_test"])
+    assert abs(float(acc) - float(g["gw_test_acc"])) < 1e-6 and abs(float(nacc) - float(g["gw_test_nacc"])) < 1e-6
+    w, acc, _ = m.get_gp_weight(coding[:7], oh, use_bg_weight=True, gt_label=torch.from_numpy(g["gw_lab8"]), th=1.5)
+    assert np.array_equal(w.numpy(), g["gw_train"]) and abs(float(acc) - float(g["gw_train_acc"])) < 1e-6
+    w, _, _ = m.get_gp_weight(coding, oh, th=2.0)
+    assert np.array_equal(w.numpy(), g["gw_nolabel"])
+
+
+def test_generate_fake_proto_matches_reference():
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    g = load_golden("capl")
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, args=_args(), base_num=7, gp=torch.from_numpy(g["gp"]), energy=0.9)
+    m.load_state_dict(state_dict_from(g))
+    pf, y = torch.from_numpy(g["gf_point"]), torch.from_numpy(g["gfp_y"])
+    fp, _ = m.generate_fake_proto(pf[2:], y[2:], m.main_proto.detach().clone(), fake_novel=[2, 5])
+    assert np.abs(fp.numpy() - g["gfp_proto"]).max() < 1e-5
+    import random
+    random.seed(0)
+    _, chosen = m.generate_fake_proto(pf[2:], y[2:], m.main_proto.detach().clone())
+    assert sorted(chosen) == sorted(int(v) for v in g["ft_fake_novel"])
+
+
+class _Log:
+    def cprint(self, *a):
+        pass
+
+
+def test_metric_matches_reference():
+    from runs.eval import evaluate_metric_GFS
+    g = load_golden("metric")
+    r = evaluate_metric_GFS(_Log(), [torch.from_numpy(p) for p in g["prs"]], list(g["gts"]), list(range(13)),
+                            list(g["novel"]), list(g["order"]))
+    assert np.allclose(r[:4], g["res"], rtol=0, atol=1e-12) and np.allclose(r[4], g["iou"], atol=1e-12)
+    r = evaluate_metric_GFS(_Log(), list(g["prs_sc"]), list(g["gts_sc"]), list(range(21)), list(g["novel_sc"]),
+                            list(g["order_sc"]), scannet=True)
+    assert np.allclose(r[:4], g["res_sc"], atol=1e-12) and np.allclose(r[4], g["iou_sc"], atol=1e-12)
+
+
+def test_basis_host_numerics_match_reference():
+    from get_basis import Kmean2Proto, compute_svd
+    g = load_golden("basis")
+    assert np.abs(Kmean2Proto(g["pts"], g["km_labels"], 12) - g["proto"]).max() < 1e-6
+    assert np.abs(compute_svd(g["proto"]) - g["basis"]).max() < 1e-5
+    assert np.abs(compute_svd(g["p200"]) - g["basis200"]).max() < 1e-4
