@@ -13,6 +13,15 @@ constexpr int WAVE = 64;
 
 void set_error(const char *fmt, ...);
 
+// measurement hooks (api.hip): no-ops unless gfs3d_profile_enable(1)
+int prof_begin(int kernel_id, hipStream_t st);
+void prof_end(int token, hipStream_t st);
+struct ProfScope {
+    int tok; hipStream_t st;
+    ProfScope(int id, hipStream_t s) : tok(prof_begin(id, s)), st(s) {}
+    ~ProfScope() { prof_end(tok, st); }
+};
+
 #define GFS3D_REQUIRE(cond, ...)                                                        \
     do {                                                                                \
         if (!(cond)) {                                                                  \

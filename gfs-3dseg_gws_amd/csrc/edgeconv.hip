@@ -719,6 +719,7 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
             set_error("gfs3d_edgeconv_forward_f32: hipMemsetAsync failed");
             return GFS3D_ERR_HIP;
         }
+        ProfScope prof(4, st);
         hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
                            a->SP, a->SQ, a->indeg, part);
         GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
@@ -730,6 +731,7 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
         const size_t lds = sizeof(float) * 8 * (size_t)a->k * EC;   // 40 KiB at k = 20
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ProfScope prof(1, st);
         hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_heavy), dim3(256), lds, st, a->P, a->Q, a->idx, a->w2, a->stats,
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, part);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
@@ -784,6 +786,7 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
         const size_t lds = sizeof(float) * (2 * EC * EC + EC + 4 * (2 * (size_t)a->k * EC + 2 * EC));
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ProfScope prof(2, st);
         hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_heavy), dim3(256), lds, st, a->P, a->Q, a->idx, a->w2, a->stats, coef,
                            g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
         GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");

@@ -197,6 +197,7 @@ static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64
         }
     }
     dim3 grid((N + 63) / 64, B);
+    ProfScope prof(0, st);
     hipLaunchKernelGGL(knn_topk_kernel<K>, grid, dim3(256), lds, st, x, C, N, k, idx64, idx32);
     GFS3D_LAUNCH_CHECK("gfs3d_knn_topk_f32");
     return GFS3D_OK;

@@ -179,6 +179,7 @@ static int launch_proto(const float *feat, long long bs, int B, int C, int N, co
         if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
     }
     dim3 grid((N + 127) / 128, B);
+    ProfScope prof(3, st);
     hipLaunchKernelGGL((proto_mfma_kernel<NT, MODE>), grid, dim3(256), lds, st, feat, bs, C, N, proto, P, K, scale,
                        out, assign, onehot);
     GFS3D_LAUNCH_CHECK(who);
@@ -316,6 +317,7 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
     }
     const long long nblk = (M + 63) / 64;
     GFS3D_REQUIRE(nblk < (1ll << 31), "gfs3d_kmeans_assign_f32: M too large");
+    ProfScope prof(5, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3((unsigned)nblk), dim3(256), lds, static_cast<hipStream_t>(stream),
                        pts, M, C, cent, K, label, sums, counts, inertia);
     GFS3D_LAUNCH_CHECK("gfs3d_kmeans_assign_f32");

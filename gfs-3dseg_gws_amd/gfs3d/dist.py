@@ -1,0 +1,78 @@
+"""Block-sharded data parallelism helpers (one process per GPU, RCCL over xGMI
+via torch.distributed backend 'nccl'; 'gloo' on CPU for the logic tests).
+
+The reference is single-device (no DP/DDP anywhere), so this
+is new functionality defined by BASELINE.json: blocks are independent units, so
+ranks own disjoint shards of the block batch and the only data-path exchange per
+training step is ONE flat-bucket all-reduce of the gradients (404,544 fp32 =
+1.6 MB for the CAPL model, 261,504 for the bare backbone): at that size a ring is
+latency-bound, so a single bucket (one collective per step) is the right shape
+for point-to-point xGMI links.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world() -> Tuple[int, int]:
+    return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
+
+
+def shard_range(n_items: int, rank: Optional[int] = None, world_size: Optional[int] = None) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n_items for this rank; shard sizes differ by at most 1."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class FlatGradBucket:
+    """All parameter gradients live in ONE flat fp32 buffer (p.grad are views into it), so the
+    data-parallel exchange is a single all-reduce with no packing copies."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradBucket: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def all_reduce_mean(self) -> None:
+        """SUM over ranks then divide by world size (mean over the global batch when every
+        rank's loss is a mean over its equally sized shard)."""
+        if not is_dist() or dist.get_world_size() == 1:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())
+
+
+def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:
+    """Integer counters (confusion counts for mIoU, word histograms): exact SUM over ranks."""
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def max_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if is_dist() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

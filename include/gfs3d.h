@@ -34,6 +34,15 @@ extern "C" {
 int gfs3d_version(void);
 const char *gfs3d_last_error(void);
 
+/* Measurement hooks (bench.py): when enabled, the launchers bracket the heavy kernels
+ * with hipEvents on the launch stream.  gfs3d_profile_read synchronises the recorded
+ * events of one kernel id, returns the summed device time in ms and the number of
+ * launches, and clears them.  Ids: 0 knn_topk, 1 ec_main_fwd, 2 ec_main_bwd,
+ * 3 proto_mfma (word assign / get_pred), 4 ec_stats1, 5 kmeans_assign. */
+#define GFS3D_PROF_KERNELS 6
+int gfs3d_profile_enable(int on);
+int gfs3d_profile_read(int kernel_id, double *total_ms, long long *launches);
+
 /* ------------------------------------------------------------------ K1 --
  * Fused pairwise-distance + top-k.  Replaces knn(x, k), model/dgcnn.py:17-23
  * (bmm + 3 elementwise (B,N,N) passes + topk).

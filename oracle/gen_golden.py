@@ -115,7 +115,12 @@ def g_dgcnn():
         ecs_e, out_e = net(x)
     net.train()
     xg = x.clone().requires_grad_(True)
+    route = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: route.append(o.max(dim=-1)[1].numpy().astype(np.uint8)))
+             for blk in net.edge_convs]
     ecs_t, out_t = net(xg)
+    for h in hooks:
+        h.remove()
     g = torch.Generator().manual_seed(7)
     cot = [torch.randn(e.shape, generator=g) for e in ecs_t] + [torch.randn(out_t.shape, generator=g)]
     loss = sum((c * t).sum() for c, t in zip(cot, ecs_t + [out_t]))
@@ -129,6 +134,7 @@ def g_dgcnn():
          ec0_train=ecs_t[0].detach().numpy(), ec1_train=ecs_t[1].detach().numpy(), ec2_train=ecs_t[2].detach().numpy(),
          out_train=out_t.detach().numpy(),
          cot0=cot[0].numpy(), cot1=cot[1].numpy(), cot2=cot[2].numpy(), cot3=cot[3].numpy(),
+         route0=route[0], route1=route[1], route2=route[2],
          grad_x=xg.grad.numpy(), **grads, **after)
 
 
@@ -199,12 +205,18 @@ def g_capl():
     def hook(mod, inp, outp):
         masks.append((outp != 0).numpy())
     h = m.att_learner.dropout.register_forward_hook(hook)
+    route = []
+    rhooks = [blk.register_forward_hook(lambda mm, i, o: route.append(o.max(dim=-1)[1].numpy().astype(np.uint8)))
+              for blk in m.encoder.edge_convs]
     random.seed(0)
     torch.manual_seed(11)
     xg = x.clone().requires_grad_(True)
     pred, loss = m(xg, y=y)
     loss.backward()
     h.remove()
+    for rh in rhooks:
+        rh.remove()
+    out.update(ft_route0=route[0], ft_route1=route[1], ft_route2=route[2])
     uniq = [int(u) for u in y[B // 2:].unique() if int(u) != 0]
     random.seed(0)
     chosen = [int(c) for c in random.sample(uniq, len(uniq) // 2)]

@@ -63,16 +63,16 @@ def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
 
 
 def test_knn_vs_reference_golden_sets(dev):
+    """vs the real reference: neighbour sets equal on every row whose fp64 gap between
+    rank k and k+1 exceeds 1e-6 relative (SURVEY 8c parity rule; exact twins tie)."""
     from model.dgcnn import knn
+    from test_oracle_golden import knn_rows_ok
     g = load_golden("knn")
     k = int(g["k"])
     for key in ("9", "64", "dup"):
-        x = torch.from_numpy(g["x" + key])
-        mine = knn(x.to(dev), k).cpu().numpy()
-        ref = g["idx" + key]
-        same_set = np.mean([set(mine[b, i]) == set(int(v) for v in ref[b, i])
-                            for b in range(x.shape[0]) for i in range(x.shape[2])])
-        assert same_set >= 0.995, (key, same_set)      # remaining rows are fp32 near-ties
+        x = g["x" + key]
+        mine = knn(torch.from_numpy(x).to(dev), k).cpu().numpy()
+        assert knn_rows_ok(x, mine, g["idx" + key], k) == 0, key
 
 
 def test_knn_full_size_properties(dev):
@@ -150,13 +150,14 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     pr = {kk: v.clone().requires_grad_("running" not in kk) for kk, v in p.items()}
     xr = x.clone().requires_grad_(True)
     stats = {}
-    yr = R.conv_stack(R.edge_feature(xr, k, idx), pr, "b", 2, training=True, new_stats=stats).max(dim=-1)[0]
+    yr, jr = R.conv_stack(R.edge_feature(xr, k, idx), pr, "b", 2, training=True, new_stats=stats).max(dim=-1)
     (yr * cot).sum().backward()
     # HIP
     blk = _make_block(p, C, dev).train()
     c1, bn1, c2, bn2 = blk.fused_parts()
     xg = x.to(dev).requires_grad_(True)
     y = ops.edgeconv_block(xg, idx.int().to(dev), c1.weight, bn1, c2.weight, bn2, True)
+    _force_routing(y, jr)
     (y * cot.to(dev)).sum().backward()
     assert maxerr(y, yr) < TOL
     for name, mod in (("b.layer.1", bn1), ("b.layer.4", bn2)):
@@ -170,6 +171,19 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     assert relerr(bn1.bias.grad, pr["b.layer.1.bias"].grad) < TOL
     assert relerr(bn2.weight.grad, pr["b.layer.4.weight"].grad) < TOL
     assert relerr(bn2.bias.grad, pr["b.layer.4.bias"].grad) < TOL
+
+
+def _force_routing(y, j_ref):
+    """The arg-max over the k neighbours is decided by fp32 rounding whenever the two best
+    values are within ~1e-6 (measured: 1-7 such (point, channel) pairs per layer in the golden
+    cases), and the loser/winner get different gradients.  To compare gradients with the
+    reference, route exactly as the reference did: overwrite the saved winner slot."""
+    ctx = y.grad_fn.c
+    j_ref = torch.as_tensor(np.asarray(j_ref)).to(ctx.jsel.device)
+    flips = int((ctx.jsel.long() != j_ref.permute(0, 2, 1).long()).sum())
+    assert flips <= 1e-3 * ctx.jsel.numel(), flips
+    ctx.jsel.copy_(j_ref.permute(0, 2, 1).to(torch.uint8))
+    return flips
 
 
 def _load_dgcnn(g, dev):
@@ -197,6 +211,8 @@ def test_dgcnn_train_fwd_bwd_vs_reference_golden(dev):
     for i in range(3):
         assert maxerr(feats[i], g[f"ec{i}_train"]) < TOL
     assert maxerr(out, g["out_train"]) < TOL
+    for i in range(3):
+        _force_routing(feats[i], g[f"route{i}"])
     loss = sum((torch.from_numpy(g[f"cot{i}"]).to(dev) * t).sum() for i, t in enumerate(feats + [out]))
     loss.backward()
     assert relerr(x.grad, g["grad_x"]) < TOL
@@ -218,8 +234,11 @@ def test_edgeconv_full_size_permutation_equivariance(dev):
     with torch.no_grad():
         f1, o1 = net(x)
         f2, o2 = net(x[:, :, perm])
-    assert maxerr(f1[2][:, :, perm], f2[2]) < TOL
-    assert maxerr(o1[:, :, perm], o2) < TOL
+    # exact fp32 distance ties at the k-th boundary are broken by index, which the permutation
+    # changes: allow a vanishing fraction of points to see a different neighbour set
+    assert maxerr(f1[0][:, :, perm], f2[0]) < TOL
+    for a, b in ((f1[2][:, :, perm], f2[2]), (o1[:, :, perm], o2)):
+        assert float(((a - b).abs() < TOL).float().mean()) > 0.9999
     assert bool(torch.isfinite(o1).all())
 
 
@@ -316,7 +335,17 @@ def test_capl_forward_train_vs_reference_golden(dev):
     m.att_learner._forced_keep_mask = torch.from_numpy(mask.astype(bool)).to(dev)
     x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
     random.seed(0)
+    captured = []
+    orig = m.encoder.edgeconv_features
+
+    def spy(inp):
+        feats = orig(inp)
+        captured.extend(feats)
+        return feats
+    m.encoder.edgeconv_features = spy
     pred, loss = m(x, y=torch.from_numpy(g["y"]).to(dev))
+    for i in range(3):
+        _force_routing(captured[i], g[f"ft_route{i}"])
     loss.backward()
     assert abs(float(loss) - float(g["ft_loss"])) <= 1e-4 * abs(float(g["ft_loss"]))
     assert float((pred.cpu().numpy() == g["ft_pred"]).mean()) > 0.999
