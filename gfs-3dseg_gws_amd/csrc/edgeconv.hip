@@ -25,6 +25,7 @@
 namespace gfs3d {
 
 constexpr int EC = GFS3D_EC_WIDTH;   // 64
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // stats rows
 enum { ST_MEAN1 = 0, ST_RSTD1, ST_SCALE1, ST_SHIFT1, ST_MEAN2, ST_RSTD2, ST_SCALE2, ST_SHIFT2 };
@@ -108,6 +109,31 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
         const int which = threadIdx.x >> 6;
         const double t = red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
         partial[((size_t)blockIdx.x * 2 + which) * EC + lane] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// R: out[e] = sum_p partial[p*width + e] in double.  block = 64 outputs x 16 part-groups
+// (the per-block partial sums are few thousand rows; a single thread walking them is a
+// 250 us latency chain, this is ~10 us).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024)
+reduce_parts_kernel(const T *__restrict__ partial, int nparts, int width, double *__restrict__ out)
+{
+    __shared__ double red[16][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    double s = 0.0;
+    if (e < width)
+        for (int p = grp; p < nparts; p += 16) s += (double)partial[(size_t)p * width + e];
+    red[grp][el] = s;
+    __syncthreads();
+    if (grp == 0 && e < width) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][el];
+        out[e] = t;
     }
 }
 
@@ -383,19 +409,26 @@ ec_main_bwd_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
                    float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LD = EC + 4;              // a1t row stride: per-lane row reads (dW2 term) hit distinct banks
     float *sW = smem;                       // [co][ci]
     float *sD = sW + EC * EC;               // dW2s accumulators
     float *sA1 = sD + EC * EC;              // [64] block sum of a1
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float *a1t = sA1 + EC + (size_t)wv * (2 * k * EC + 2 * EC);
-    float *Tt = a1t + k * EC;
-    float2 *cj = reinterpret_cast<float2 *>(Tt + k * EC);
+    float *a1t = sA1 + EC + (size_t)wv * (2 * k * LD + 2 * EC);
+    float *Tt = a1t + k * LD;
+    float2 *cj = reinterpret_cast<float2 *>(Tt + k * LD);
 
     for (int e = tid; e < EC * EC; e += 256) { sW[e] = w2[e]; sD[e] = 0.f; }
     if (tid < EC) sA1[tid] = 0.f;
-    float Mrow[EC], S[EC];
+    float Mrow[EC], D[EC];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) { Mrow[c] = coef[CF_M + lane * EC + c]; S[c] = 0.f; }
+    for (int c = 0; c < EC; ++c) { Mrow[c] = coef[CF_M + lane * EC + c]; D[c] = 0.f; }
+    // S = sum_e a1 a1^T lives on the (otherwise idle) matrix pipe: three 32x32 fp32 MFMA
+    // accumulators (lo-lo, lo-hi, hi-hi channel halves), two edges per MFMA step.
+    f32x16 S00, S01, S11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S00[r] = 0.f; S01[r] = 0.f; S11[r] = 0.f; }
+    const int mc = lane & 31, mh = lane >> 5;
     const float v0 = coef[CF_V0 + lane];
     const float Aco = coef[CF_A + lane];
     const float s1 = stats[ST_SCALE1 * EC + lane], t1 = stats[ST_SHIFT1 * EC + lane];
@@ -406,38 +439,74 @@ ec_main_bwd_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
         const int b = pt / N;
         const float q = Q[(size_t)pt * EC + lane];
         const int myidx = (lane < k) ? idx[(size_t)pt * k + lane] : 0;
+        const float mycoef = Aco * g_pm[(size_t)pt * EC + lane];      // lane = co for the routed terms
+        const int myj = (int)jsel[(size_t)pt * EC + lane];
         unsigned posmask = 0u;
-        for (int j = 0; j < k; ++j) {
-            const int m = __shfl(myidx, j, 64);
-            const float z = fmaf(P[((size_t)b * N + m) * EC + lane] + q, s1, t1);
-            posmask |= (z > 0.f ? 1u : 0u) << j;
-            const float a = lrelu(z, slope);
-            a1t[j * EC + lane] = a;
-            Tt[j * EC + lane] = 0.f;
-            sum_a1 += a;
+        for (int j0 = 0; j0 < k; j0 += 4) {           // 4 independent row gathers in flight
+            float pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = __shfl(myidx, min(j0 + u, k - 1), 64);
+                pv[u] = P[((size_t)b * N + m) * EC + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                if (j < k) {
+                    const float z = fmaf(pv[u] + q, s1, t1);
+                    posmask |= (z > 0.f ? 1u : 0u) << j;
+                    const float a = lrelu(z, slope);
+                    a1t[j * LD + lane] = a;
+                    Tt[j * LD + lane] = 0.f;
+                    sum_a1 += a;
+                }
+            }
         }
-        // routed (sparse) terms: lane = co here
-        cj[lane] = make_float2(Aco * g_pm[(size_t)pt * EC + lane], __int_as_float((int)jsel[(size_t)pt * EC + lane]));
+        cj[lane] = make_float2(mycoef, __int_as_float(myj));
         __builtin_amdgcn_wave_barrier();
+        for (int s = 0; s < k; s += 2) {
+            const int ej = s + mh;
+            const float alo = (ej < k) ? a1t[ej * LD + mc] : 0.f;
+            const float ahi = (ej < k) ? a1t[ej * LD + 32 + mc] : 0.f;
+            S00 = __builtin_amdgcn_mfma_f32_32x32x2f32(alo, alo, S00, 0, 0, 0);
+            S01 = __builtin_amdgcn_mfma_f32_32x32x2f32(alo, ahi, S01, 0, 0, 0);
+            S11 = __builtin_amdgcn_mfma_f32_32x32x2f32(ahi, ahi, S11, 0, 0, 0);
+        }
+        // routed term of dW2 (lane = co): D[ci] += coef[co] * a1[jsel[co]][ci]; every lane reads ITS winner's row
+        {
+            const float4 *row = reinterpret_cast<const float4 *>(a1t + myj * LD);
+#pragma unroll
+            for (int c4 = 0; c4 < EC / 4; ++c4) {
+                const float4 a = row[c4];
+                D[4 * c4 + 0] = fmaf(mycoef, a.x, D[4 * c4 + 0]);
+                D[4 * c4 + 1] = fmaf(mycoef, a.y, D[4 * c4 + 1]);
+                D[4 * c4 + 2] = fmaf(mycoef, a.z, D[4 * c4 + 2]);
+                D[4 * c4 + 3] = fmaf(mycoef, a.w, D[4 * c4 + 3]);
+                if ((c4 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // routed term of da1 (lane = ci): T[j][ci] += coef[co] W2[co][ci] at j = jsel[co].  Plain
+        // read-modify-write is safe: one wave, in-order LDS, lanes own distinct addresses
+        // (LDS float atomics measured ~190 cycles per wave-instruction here).
+#pragma unroll 4
         for (int co = 0; co < EC; ++co) {
             const float2 cv = cj[co];
             const int jj = __float_as_int(cv.y);
-            atomicAdd(&Tt[jj * EC + lane], cv.x * sW[co * EC + lane]);     // same wave: ordered ds_add
-            atomicAdd(&sD[co * EC + lane], cv.x * a1t[jj * EC + lane]);
+            Tt[jj * LD + lane] = fmaf(cv.x, sW[co * EC + lane], Tt[jj * LD + lane]);
         }
         __builtin_amdgcn_wave_barrier();
         float gq = 0.f;
         for (int j = 0; j < k; ++j) {
-            const float aown = a1t[j * EC + lane];
-            float acc = v0 + Tt[j * EC + lane];
-            const float4 *av = reinterpret_cast<const float4 *>(a1t + j * EC);
+            float acc = v0 + Tt[j * LD + lane];
+            const float4 *av = reinterpret_cast<const float4 *>(a1t + j * LD);
 #pragma unroll
             for (int c4 = 0; c4 < EC / 4; ++c4) {
                 const float4 a = av[c4];
-                acc = fmaf(Mrow[4 * c4 + 0], a.x, acc); S[4 * c4 + 0] = fmaf(a.x, aown, S[4 * c4 + 0]);
-                acc = fmaf(Mrow[4 * c4 + 1], a.y, acc); S[4 * c4 + 1] = fmaf(a.y, aown, S[4 * c4 + 1]);
-                acc = fmaf(Mrow[4 * c4 + 2], a.z, acc); S[4 * c4 + 2] = fmaf(a.z, aown, S[4 * c4 + 2]);
-                acc = fmaf(Mrow[4 * c4 + 3], a.w, acc); S[4 * c4 + 3] = fmaf(a.w, aown, S[4 * c4 + 3]);
+                acc = fmaf(Mrow[4 * c4 + 0], a.x, acc);
+                acc = fmaf(Mrow[4 * c4 + 1], a.y, acc);
+                acc = fmaf(Mrow[4 * c4 + 2], a.z, acc);
+                acc = fmaf(Mrow[4 * c4 + 3], a.w, acc);
+                if ((c4 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // cap the LDS prefetch window (register pressure)
             }
             const float dy1 = acc * (((posmask >> j) & 1u) ? 1.f : slope);
             gq += dy1;
@@ -448,42 +517,40 @@ ec_main_bwd_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
         __builtin_amdgcn_wave_barrier();
     }
     atomicAdd(&sA1[lane], sum_a1);
+#pragma unroll
+    for (int c = 0; c < EC; ++c) atomicAdd(&sD[c * EC + lane], D[c]);      // sD holds dW2s transposed: [ci][co]
     __syncthreads();
     // S: reduce the 4 waves through LDS (reuse sW), then write block partials
     for (int e = tid; e < EC * EC; e += 256) sW[e] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < EC; ++c) atomicAdd(&sW[c * EC + lane], S[c]);
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * mh;      // MFMA C/D layout: row from (reg, lane half), col = lane & 31
+        atomicAdd(&sW[row * EC + mc], S00[r]);
+        atomicAdd(&sW[row * EC + 32 + mc], S01[r]);
+        atomicAdd(&sW[(32 + mc) * EC + row], S01[r]);
+        atomicAdd(&sW[(32 + row) * EC + 32 + mc], S11[r]);
+    }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * BWD_PART;
-    for (int e = tid; e < EC * EC; e += 256) { out[e] = sW[e]; out[EC * EC + e] = sD[e]; }
+    for (int e = tid; e < EC * EC; e += 256) { out[e] = sW[e]; out[EC * EC + e] = sD[(e & 63) * EC + (e >> 6)]; }
     if (tid < EC) out[2 * EC * EC + tid] = sA1[tid];
 }
 
-// B4a: reduce block partials (double accumulation) -> red[BWD_PART] floats
-__global__ void __launch_bounds__(256)
-ec_bwd_reduce_kernel(const float *__restrict__ partial, int nparts, float *__restrict__ red)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= BWD_PART) return;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)partial[(size_t)p * BWD_PART + e];
-    red[e] = (float)s;
-}
 // B4b: dW2[co][c] = dW2s[co][c] + Bc[co] s_a1[c] + Cc[co] * sum_c' W2[co][c'] S[c'][c].  1 block x 256
 __global__ void __launch_bounds__(256)
-ec_bwd_dw2_kernel(const float *__restrict__ red, const float *__restrict__ w2, const float *__restrict__ coef,
+ec_bwd_dw2_kernel(const double *__restrict__ red, const float *__restrict__ w2, const float *__restrict__ coef,
                   float *__restrict__ dw2)
 {
     __shared__ float sS[EC][EC + 1];
     const int tid = threadIdx.x;
-    for (int e = tid; e < EC * EC; e += 256) sS[e >> 6][e & 63] = red[e];
+    for (int e = tid; e < EC * EC; e += 256) sS[e >> 6][e & 63] = (float)red[e];
     __syncthreads();
     for (int e = tid; e < EC * EC; e += 256) {
         const int co = e >> 6, c = e & 63;
         float acc = 0.f;
         for (int cc = 0; cc < EC; ++cc) acc = fmaf(w2[co * EC + cc], sS[cc][c], acc);
-        dw2[e] = red[EC * EC + e] + coef[CF_BC + co] * red[2 * EC * EC + c] + coef[CF_CC + co] * acc;
+        dw2[e] = (float)(red[EC * EC + e] + (double)coef[CF_BC + co] * red[2 * EC * EC + c] + (double)coef[CF_CC + co] * acc);
     }
 }
 
@@ -601,17 +668,13 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         out[EC * C + e] = ad;
     }
 }
-// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd     (double reduce over tiles)
+// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd     (red = tile partials summed in double)
 __global__ void __launch_bounds__(256)
-ec_bwd_dw1_kernel(const float *__restrict__ partial, int nparts, int C, float *__restrict__ dw1)
+ec_bwd_dw1_kernel(const double *__restrict__ red, int C, float *__restrict__ dw1)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= EC * C) return;
-    double a = 0.0, d = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        a += (double)partial[(size_t)p * 2 * EC * C + e];
-        d += (double)partial[(size_t)p * 2 * EC * C + EC * C + e];
-    }
+    const double a = red[e], d = red[EC * C + e];
     const int o = e / C, c = e - o * C;
     dw1[(size_t)o * 2 * C + c] = (float)(a - d);
     dw1[(size_t)o * 2 * C + C + c] = (float)d;
@@ -624,7 +687,8 @@ struct Plan {
     int g_heavy;        // blocks of the grid-stride heavy kernels
     int tiles;          // ceil(N/64) * B
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin;           // forward
-    size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_red, off_mu, off_wpart;   // backward
+    size_t off_dred;                                                     // reduced partials (doubles)
+    size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
     size_t total;
 };
 
@@ -641,6 +705,11 @@ static Plan make_plan(int B, int C, int N, int k)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     p.off_part = take(sizeof(double) * 2 * EC * (size_t)maxparts);
+    {
+        size_t w = BWD_PART;
+        if ((size_t)2 * EC * C > w) w = (size_t)2 * EC * C;
+        p.off_dred = take(sizeof(double) * w);
+    }
     p.off_hmax = take(sizeof(float) * BN * EC);
     p.off_hmin = take(sizeof(float) * BN * EC);
     p.off_jmax = take(BN * EC);
@@ -651,7 +720,6 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_GQ = take(sizeof(float) * BN * EC);
     p.off_coef = take(sizeof(float) * CF_TOTAL);
     p.off_bpart = take(sizeof(float) * (size_t)BWD_PART * g);
-    p.off_red = take(sizeof(float) * BWD_PART);
     p.off_mu = take(sizeof(float) * 2 * EC);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)C * p.tiles);
     p.total = o;
@@ -724,7 +792,12 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
                            a->SP, a->SQ, a->indeg, part);
         GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
     }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, part, p.g_heavy, count, a->bn1_w, a->bn1_b,
+    double *dred = reinterpret_cast<double *>(ws + p.off_dred);
+    if (a->training) {
+        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
+        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn1)");
+    }
+    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn1_w, a->bn1_b,
                        a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
     GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
     {   // F4
@@ -736,7 +809,11 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, part);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, part, p.g_heavy, count, a->bn2_w, a->bn2_b,
+    if (a->training) {
+        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
+        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn2)");
+    }
+    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn2_w, a->bn2_b,
                        a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN2);
     GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(2)");
     hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, a->stats, a->N, a->slope,
@@ -767,7 +844,7 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     float *GP = reinterpret_cast<float *>(ws + p.off_GP), *GQ = reinterpret_cast<float *>(ws + p.off_GQ);
     float *coef = reinterpret_cast<float *>(ws + p.off_coef);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
-    float *red = reinterpret_cast<float *>(ws + p.off_red);
+    double *dred = reinterpret_cast<double *>(ws + p.off_dred);
     float *mu = reinterpret_cast<float *>(ws + p.off_mu);
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
     dim3 tgrid((a->N + 63) / 64, a->B);
@@ -775,7 +852,9 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, a->y_pm, a->hsel, a->stats,
                        a->N, a->slope, g, part);
     GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
-    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(256), 0, st, part, p.tiles, count, a->w2, a->stats,
+    hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.tiles, 2 * EC, dred);
+    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(prep)");
+    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(256), 0, st, dred, 1, count, a->w2, a->stats,
                        ba->dbn2_w, ba->dbn2_b, coef);
     GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
     if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
@@ -783,7 +862,7 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
         return GFS3D_ERR_HIP;
     }
     {
-        const size_t lds = sizeof(float) * (2 * EC * EC + EC + 4 * (2 * (size_t)a->k * EC + 2 * EC));
+        const size_t lds = sizeof(float) * (2 * EC * EC + EC + 4 * (2 * (size_t)a->k * (EC + 4) + 2 * EC));
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         ProfScope prof(2, st);
@@ -791,13 +870,15 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
                            g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
         GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
     }
-    hipLaunchKernelGGL(ec_bwd_reduce_kernel, dim3((BWD_PART + 255) / 256), dim3(256), 0, st, bpart, p.g_heavy, red);
-    GFS3D_LAUNCH_CHECK("ec_bwd_reduce_kernel");
-    hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(1), dim3(256), 0, st, red, a->w2, coef, ba->dw2);
+    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_heavy, BWD_PART, dred);
+    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
+    hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(1), dim3(256), 0, st, dred, a->w2, coef, ba->dw2);
     GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
     hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, part);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
-    hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, part, p.g_heavy, count, ba->dbn1_w, ba->dbn1_b, mu);
+    hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
+    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn1 bwd)");
+    hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
     {
         const size_t lds = sizeof(float) * (2 * 64 * 65 + (size_t)a->C * 64 * 3);
@@ -807,7 +888,9 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
                            GP, GQ, a->stats, mu, a->C, a->N, a->k, ba->dx, wpart);
         GFS3D_LAUNCH_CHECK("ec_bwd_pq_kernel");
     }
-    hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, wpart, p.tiles, a->C, ba->dw1);
+    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((2 * EC * a->C + 63) / 64), dim3(1024), 0, st, wpart, p.tiles, 2 * EC * a->C, dred);
+    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(dw1)");
+    hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, dred, a->C, ba->dw1);
     GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
     return GFS3D_OK;
 }

@@ -13,7 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
-_SO = os.path.join(_PKG, "lib", "libgfs3d_hip.so")
+_SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
 _SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip")
 _lib = None
 

@@ -45,6 +45,35 @@ with contextlib.redirect_stdout(io.StringIO()):
 from oracle.ref_ops import synthetic_blocks  # noqa: E402  (input recipe only)
 
 
+class KnnTap:
+    """Records what the reference's knn() returns during a forward (get_edge_feature looks
+    the function up in the module namespace), so fixtures can name the WINNING NEIGHBOUR of
+    every max-over-k instead of its slot."""
+    def __enter__(self):
+        self.idx = []
+        self.orig = ref_dgcnn.knn
+
+        def tapped(x, k):
+            out = self.orig(x, k)
+            self.idx.append(out)
+            return out
+        ref_dgcnn.knn = tapped
+        return self
+
+    def __exit__(self, *a):
+        ref_dgcnn.knn = self.orig
+
+
+def winners(idx_list, arg_list):
+    """(B,N,k) neighbour ids + (B,64,N) arg-max slots -> (B,64,N) winning neighbour id."""
+    out = []
+    for idx, arg in zip(idx_list, arg_list):
+        B, N, k = idx.shape
+        m = torch.gather(idx.unsqueeze(1).expand(B, arg.shape[1], N, k), 3, arg.long().unsqueeze(-1)).squeeze(-1)
+        out.append(m.numpy().astype(np.int16))
+    return out
+
+
 def sd_np(sd, prefix=""):
     return {prefix + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
 
@@ -116,11 +145,13 @@ def g_dgcnn():
     net.train()
     xg = x.clone().requires_grad_(True)
     route = []
-    hooks = [blk.register_forward_hook(lambda m, i, o: route.append(o.max(dim=-1)[1].numpy().astype(np.uint8)))
+    hooks = [blk.register_forward_hook(lambda m, i, o: route.append(o.max(dim=-1)[1]))
              for blk in net.edge_convs]
-    ecs_t, out_t = net(xg)
+    with KnnTap() as tap:
+        ecs_t, out_t = net(xg)
     for h in hooks:
         h.remove()
+    route = winners(tap.idx, route)
     g = torch.Generator().manual_seed(7)
     cot = [torch.randn(e.shape, generator=g) for e in ecs_t] + [torch.randn(out_t.shape, generator=g)]
     loss = sum((c * t).sum() for c, t in zip(cot, ecs_t + [out_t]))
@@ -206,16 +237,18 @@ def g_capl():
         masks.append((outp != 0).numpy())
     h = m.att_learner.dropout.register_forward_hook(hook)
     route = []
-    rhooks = [blk.register_forward_hook(lambda mm, i, o: route.append(o.max(dim=-1)[1].numpy().astype(np.uint8)))
+    rhooks = [blk.register_forward_hook(lambda mm, i, o: route.append(o.max(dim=-1)[1]))
               for blk in m.encoder.edge_convs]
     random.seed(0)
     torch.manual_seed(11)
     xg = x.clone().requires_grad_(True)
-    pred, loss = m(xg, y=y)
+    with KnnTap() as tap:
+        pred, loss = m(xg, y=y)
     loss.backward()
     h.remove()
     for rh in rhooks:
         rh.remove()
+    route = winners(tap.idx, route)
     out.update(ft_route0=route[0], ft_route1=route[1], ft_route2=route[2])
     uniq = [int(u) for u in y[B // 2:].unique() if int(u) != 0]
     random.seed(0)

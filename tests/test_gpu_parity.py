@@ -157,7 +157,7 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     c1, bn1, c2, bn2 = blk.fused_parts()
     xg = x.to(dev).requires_grad_(True)
     y = ops.edgeconv_block(xg, idx.int().to(dev), c1.weight, bn1, c2.weight, bn2, True)
-    _force_routing(y, jr)
+    _force_routing(y, torch.gather(idx.unsqueeze(1).expand(B, 64, N, k), 3, jr.unsqueeze(-1)).squeeze(-1))
     (y * cot.to(dev)).sum().backward()
     assert maxerr(y, yr) < TOL
     for name, mod in (("b.layer.1", bn1), ("b.layer.4", bn2)):
@@ -173,16 +173,20 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     assert relerr(bn2.bias.grad, pr["b.layer.4.bias"].grad) < TOL
 
 
-def _force_routing(y, j_ref):
+def _force_routing(y, winner):
     """The arg-max over the k neighbours is decided by fp32 rounding whenever the two best
     values are within ~1e-6 (measured: 1-7 such (point, channel) pairs per layer in the golden
-    cases), and the loser/winner get different gradients.  To compare gradients with the
-    reference, route exactly as the reference did: overwrite the saved winner slot."""
+    cases), and winner and loser get different gradients.  To compare gradients with the
+    reference, route exactly as the reference did.  `winner` is (B,64,N): either the winning
+    neighbour's point id (fixtures; robust to a different neighbour order) or, with
+    by_slot semantics when it comes from the oracle on the same idx, the slot."""
     ctx = y.grad_fn.c
-    j_ref = torch.as_tensor(np.asarray(j_ref)).to(ctx.jsel.device)
-    flips = int((ctx.jsel.long() != j_ref.permute(0, 2, 1).long()).sum())
+    w = torch.as_tensor(np.asarray(winner)).to(ctx.jsel.device).long().permute(0, 2, 1)      # (B,N,64)
+    eq = ctx.idx.long()[:, :, None, :] == w[:, :, :, None]                                   # (B,N,64,k)
+    slot = torch.where(eq.any(-1), eq.float().argmax(-1), ctx.jsel.long())
+    flips = int((slot != ctx.jsel.long()).sum())
     assert flips <= 1e-3 * ctx.jsel.numel(), flips
-    ctx.jsel.copy_(j_ref.permute(0, 2, 1).to(torch.uint8))
+    ctx.jsel.copy_(slot.to(torch.uint8))
     return flips
 
 
@@ -223,23 +227,38 @@ def test_dgcnn_train_fwd_bwd_vs_reference_golden(dev):
             assert maxerr(buf, g["after." + name]) < 1e-5, name
 
 
-def test_edgeconv_full_size_permutation_equivariance(dev):
-    """BASELINE config 2 size (B=32 x 2048): permuting the points of every block permutes
-    the outputs (size-independent property; exercises the full-size launch geometry)."""
+@pytest.mark.parametrize("C", [9, 64])
+def test_edgeconv_full_size_vs_oracle(dev, C):
+    """BASELINE config 2 size (B=32 x 2048, k=20): one EdgeConv block, eval mode, on the HIP
+    kNN graph; the oracle materialises the (32,2C,2048,20) edge tensor on the host."""
+    from gfs3d import ops
+    B, N, k = 32, 2048, 20
+    p = _block_params(C, 300 + C)
+    x = R.synthetic_blocks(B, N, seed=5) if C == 9 else torch.randn(B, C, N, generator=torch.Generator().manual_seed(9))
+    idx = ops.knn_topk(x.to(dev), k, want_i64=True, want_i32=False)
+    blk = _make_block(p, C, dev).eval()
+    c1, bn1, c2, bn2 = blk.fused_parts()
+    with torch.no_grad():
+        y = ops.edgeconv_block(x.to(dev), idx.int(), c1.weight, bn1, c2.weight, bn2, False)
+        ref = R.conv_stack(R.edge_feature(x, k, idx.cpu()), p, "b", 2, training=False).max(dim=-1)[0]
+    assert maxerr(y, ref) < TOL
+
+
+def test_dgcnn_full_size_train_step_is_finite_and_deterministic_forward(dev):
+    """Full-size train-mode forward twice on the same input gives identical features (no
+    atomics on the forward value path) and finite gradients."""
     from model.dgcnn import DGCNN
     torch.manual_seed(0)
-    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev).eval()
-    x = R.synthetic_blocks(32, 2048, seed=1).to(dev)
-    perm = torch.randperm(2048, generator=torch.Generator().manual_seed(3)).to(dev)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev).train()
+    x = R.synthetic_blocks(32, 2048, seed=1).to(dev).requires_grad_(True)
+    f1, o1 = net(x)
     with torch.no_grad():
-        f1, o1 = net(x)
-        f2, o2 = net(x[:, :, perm])
-    # exact fp32 distance ties at the k-th boundary are broken by index, which the permutation
-    # changes: allow a vanishing fraction of points to see a different neighbour set
-    assert maxerr(f1[0][:, :, perm], f2[0]) < TOL
-    for a, b in ((f1[2][:, :, perm], f2[2]), (o1[:, :, perm], o2)):
-        assert float(((a - b).abs() < TOL).float().mean()) > 0.9999
-    assert bool(torch.isfinite(o1).all())
+        f2, _ = net(x)
+    for a, b in zip(f1, f2):
+        assert bool((a == b).all())
+    o1.mean().backward()
+    assert bool(torch.isfinite(x.grad).all())
+    assert all(bool(torch.isfinite(q.grad).all()) for q in net.parameters())
 
 
 # ------------------------------------------------------------------ K3
@@ -350,8 +369,15 @@ def test_capl_forward_train_vs_reference_golden(dev):
     assert abs(float(loss) - float(g["ft_loss"])) <= 1e-4 * abs(float(g["ft_loss"]))
     assert float((pred.cpu().numpy() == g["ft_pred"]).mean()) > 0.999
     assert relerr(x.grad, g["ft_grad_x"]) < 5e-4
-    worst = max(relerr(p.grad, g["ft_grad." + n]) for n, p in m.named_parameters() if p.grad is not None)
-    assert worst < 5e-4, worst
+    zero_grad = {"base_learner.convs.0.0.bias", "base_learner.convs.1.0.bias", "base_learner.convs.1.1.bias",
+                 "fusion.0.bias"}   # per-channel constants removed by the next BatchNorm: analytically zero
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        if n in zero_grad:
+            assert float(p.grad.abs().max()) < 1e-5, n
+        else:
+            assert relerr(p.grad, g["ft_grad." + n]) < 5e-4, n
 
 
 def test_kmeans_assign_vs_oracle(dev):
