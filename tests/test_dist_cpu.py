@@ -1,0 +1,75 @@
+"""Data-parallel host logic on CPU: world_size-2 gloo processes (127.0.0.1)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Log:
+    def cprint(self, *a):
+        pass
+
+
+def _worker(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "gfs-3dseg_gws_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfs3d import dist as gd
+    from runs.eval import evaluate_metric_GFS
+    res = {}
+    # 1. shards are disjoint and cover everything
+    res["shard"] = gd.shard_range(37)
+    # 2. flat-bucket gradient all-reduce = mean over ranks, grads stay views of the bucket
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    bucket = gd.FlatGradBucket(lin.parameters())
+    x = torch.full((4, 5), float(rank + 1))
+    bucket.zero()
+    lin(x).sum().backward()
+    local = bucket.flat.clone()
+    bucket.all_reduce_mean()
+    res["local_grad"], res["mean_grad"] = local.numpy(), bucket.flat.numpy().copy()
+    res["views"] = all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in lin.parameters())
+    # 3. metric: every rank evaluates its shard of the batches, counters are all-reduced
+    g = np.load(os.path.join(here, "golden", "metric.npz"))
+    lo, hi = gd.shard_range(len(g["prs"]))
+    r = evaluate_metric_GFS(_Log(), list(g["prs"][lo:hi]), list(g["gts"][lo:hi]), list(range(13)), list(g["novel"]),
+                            list(g["order"]))
+    res["metric"] = np.array(r[:4])
+    res["max"] = gd.max_over_ranks(float(rank), "cpu")
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_helpers_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    a, b = out[0], out[1]
+    assert a["shard"] == (0, 19) and b["shard"] == (19, 37)
+    mean = (a["local_grad"] + b["local_grad"]) / 2
+    assert np.allclose(a["mean_grad"], mean, atol=1e-6) and np.allclose(b["mean_grad"], mean, atol=1e-6)
+    assert a["views"] and b["views"]
+    ref = load_golden("metric")["res"]
+    assert np.allclose(a["metric"], ref, atol=1e-12) and np.allclose(b["metric"], ref, atol=1e-12)
+    assert a["max"] == 1.0 and b["max"] == 1.0
