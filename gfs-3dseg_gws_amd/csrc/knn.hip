@@ -179,6 +179,172 @@ knn_topk_kernel(const float *__restrict__ x, int C, int N, int k,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// MFMA variant (C <= 2*CS): the dot products run on the matrix pipe.
+//   v_mfma_f32_32x32x2_f32, A = 32 candidates (rows), B = 32 queries (columns), two channels
+//   per step in ascending order: the accumulator is bit-for-bit the c-ordered fp32 fma chain
+//   of the oracle (checked by the bit-exact tests), and the VALU is left to the selection.
+// A wave owns 32 queries and scans ALL candidates (no cross-wave merge); lane (j, h) sees, for
+// query j, the 16 candidate rows (r&3)+8(r>>2)+4h of every 32-candidate tile, in increasing
+// index order, and keeps its own top-K; the h=1 list is merged into the h=0 list at the end
+// with the full (value desc, index asc) comparator.  Operands are read straight from the
+// channel-first input (one 128-B row per half-wave and channel), next tile prefetched.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int K>
+struct TopListOrd : TopList<K> {
+    // insert keeping (value desc, index asc) order - needed when lists from interleaved
+    // candidate subsets are merged
+    __device__ __forceinline__ void insert_ordered(float val, int id) {
+        auto before = [](float a, int ai, float b, int bi) { return a > b || (a == b && ai < bi); };
+#pragma unroll
+        for (int t = K - 1; t >= 1; --t) {
+            const bool sh = before(val, id, this->v[t - 1], this->i[t - 1]);
+            const bool here = before(val, id, this->v[t], this->i[t]);
+            this->i[t] = sh ? this->i[t - 1] : (here ? id : this->i[t]);
+            this->v[t] = sh ? this->v[t - 1] : (here ? val : this->v[t]);
+        }
+        const bool h0 = before(val, id, this->v[0], this->i[0]);
+        this->i[0] = h0 ? id : this->i[0];
+        this->v[0] = h0 ? val : this->v[0];
+    }
+};
+
+// |x|^2 of the point whose even channels sit in the h=0 lane and odd channels in the h=1 lane:
+// sequential c = 0,1,2,... sum of rounded squares (oracle order), identical in both lanes.
+template <int CS>
+__device__ __forceinline__ float sqnorm_split(const float (&v)[CS], int h)
+{
+    float sq = 0.f;
+#pragma unroll
+    for (int s = 0; s < CS; ++s) {
+        const float other = __shfl_xor(v[s], 32, 64);
+        const float even = h ? other : v[s];
+        const float odd = h ? v[s] : other;
+        sq = __fadd_rn(sq, __fmul_rn(even, even));
+        sq = __fadd_rn(sq, __fmul_rn(odd, odd));      // zero-padded channel adds +0 exactly
+    }
+    return sq;
+}
+
+template <int CS, int K>
+__global__ void __launch_bounds__(256, 2)
+knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
+                int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
+{
+    constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    if (q0 >= N) return;                               // whole wave out of range (wave-uniform)
+    const int per_wave = 32 + 2 * QS * 64;
+    float *sqs = smem + (size_t)w * per_wave;          // [32] candidate |x|^2 of the current tile
+    float *qv = sqs + 32;
+    int *qid = reinterpret_cast<int *>(qv + QS * 64);
+    const float *xb = x + (size_t)b * C * N;
+
+    float qb[CS];
+    {
+        const int qi = min(q0 + j, N - 1);
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const int c = 2 * s + h;
+            qb[s] = (c < C) ? xb[(size_t)c * N + qi] : 0.f;
+        }
+    }
+    const float sqq = sqnorm_split<CS>(qb, h);
+
+    TopListOrd<K> best;
+    best.init();
+    float thr = -__builtin_inff();
+    int cnt = 0;
+
+    float a[CS];
+    auto load_tile = [&](float (&dst)[CS], int j0) {
+        const int ci = min(j0 + j, N - 1);
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const int c = 2 * s + h;
+            dst[s] = (c < C) ? xb[(size_t)c * N + ci] : 0.f;
+        }
+    };
+    load_tile(a, 0);
+    for (int j0 = 0; j0 < N; j0 += 32) {
+        const float sqc = sqnorm_split<CS>(a, h);
+        if (h == 0) sqs[j] = sqc;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qb[s], acc, 0, 0, 0);
+        // the MFMAs have consumed a[]: refill it with the next tile while the selection below runs
+        if (j0 + 32 < N) load_tile(a, j0 + 32);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int cand = j0 + row;
+            const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqs[row]), sqq);
+            if (pd > thr && cand < N) {
+                qv[cnt * 64 + lane] = pd;
+                qid[cnt * 64 + lane] = cand;
+                ++cnt;
+            }
+        }
+        if (__any(cnt > QS - 16)) {
+            const int mx = wave_max(cnt);
+            for (int s = 0; s < mx; ++s)
+                if (s < cnt) best.insert(qv[s * 64 + lane], qid[s * 64 + lane]);
+            cnt = 0;
+            thr = best.v[K - 1];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    {
+        const int mx = wave_max(cnt);
+        for (int s = 0; s < mx; ++s)
+            if (s < cnt) best.insert(qv[s * 64 + lane], qid[s * 64 + lane]);
+    }
+    // merge the h=1 half-list into h=0 (interleaved candidate subsets -> full comparator)
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+        const float ov = __shfl(best.v[t], lane + 32, 64);
+        const int oi = __shfl(best.i[t], lane + 32, 64);
+        if (h == 0) best.insert_ordered(ov, oi);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int *outl = qid;                                   // [K][32]
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) outl[t * 32 + j] = best.i[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nvalid = min(32, N - q0);
+    const size_t obase = ((size_t)b * N + q0) * k;
+    for (int e = lane; e < nvalid * k; e += 64) {
+        const int q = e / k, t = e - q * k;
+        const int v = outl[t * 32 + q];
+        if (idx64) idx64[obase + e] = (int64_t)v;
+        if (idx32) idx32[obase + e] = v;
+    }
+}
+
+template <int CS, int K>
+static int launch_knn_mfma(const float *x, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
+{
+    constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
+    const size_t lds = sizeof(float) * 4 * (size_t)(32 + 2 * QS * 64);
+    dim3 grid((N + 127) / 128, B);
+    ProfScope prof(0, st);
+    hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, C, N, k, idx64, idx32);
+    GFS3D_LAUNCH_CHECK("gfs3d_knn_topk_f32(mfma)");
+    return GFS3D_OK;
+}
+
 template <int K>
 static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
 {
@@ -216,6 +382,10 @@ extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
     GFS3D_REQUIRE(B <= 65535, "gfs3d_knn_topk_f32: B=%d exceeds grid.y", B);
     if (B == 0) return GFS3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, B, C, N, k, idx64, idx32, st);
+    if (k <= 20 && C <= 64) return launch_knn_mfma<32, 20>(x, B, C, N, k, idx64, idx32, st);
+    if (k <= 32 && C <= 64) return launch_knn_mfma<32, 32>(x, B, C, N, k, idx64, idx32, st);
+    // generic shapes: VALU kernel (any C that fits LDS, k <= 64)
     if (k <= 20) return launch_knn<20>(x, B, C, N, k, idx64, idx32, st);
     if (k <= 32) return launch_knn<32>(x, B, C, N, k, idx64, idx32, st);
     return launch_knn<64>(x, B, C, N, k, idx64, idx32, st);
