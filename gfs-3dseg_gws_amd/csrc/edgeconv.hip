@@ -178,95 +178,147 @@ __global__ void ec_bn_finalize_kernel(const double *__restrict__ partial, int np
 }
 
 // ---------------------------------------------------------------------------
-// F4: the heavy forward pass.  A wave owns two points at a time (one per
-// half-wave); lane hl of a half owns output channels hl and hl+32 with the two
-// W2 rows in 128 VGPRs; a1 vectors are broadcast through LDS (one ds_read_b128
-// feeds 8 FMAs).  Tracks max/min/arg over j of the pre-BN2 conv2 output and the
-// BN2 batch-statistics partial sums.
+// F3b: fold BN1 into the projections: P' = P*scale1, Q' = Q*scale1 + shift1, so that the
+// heavy kernels form a1 = LReLU(P'[m] + Q'[n]) with one add per element and no per-channel
+// constants in registers.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-ec_main_fwd_kernel(const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ idx,
-                   const float *__restrict__ w2, const float *__restrict__ stats,
+__global__ void __launch_bounds__(256)
+ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, const float *__restrict__ stats,
+                   size_t total, float *__restrict__ Pp, float *__restrict__ Qp)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e & 63);
+    const float s = stats[ST_SCALE1 * EC + c], t = stats[ST_SHIFT1 * EC + c];
+    Pp[e] = P[e] * s;
+    Qp[e] = fmaf(Q[e], s, t);
+}
+
+// ---------------------------------------------------------------------------
+// F4: the heavy forward pass on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32).
+//
+//   H2[edge][c_out] = sum_c a1[edge][c] * W2[c_out][c]      A = a1 rows, B = W2^T
+//
+// A wave walks "super-tiles" of 8 points.  Row i of the 32-row MFMA tile t is the edge
+//   point p = 4*((i>>2)&1) + (i>>3),  neighbour slot j = 4*t + (i&3)
+// so that in the C/D layout (lane = column c_out, register r <-> row (r&3)+8(r>>2)+4h) lane
+// half h owns points 4h..4h+3 and register group q = r>>2 is ONE point: the max / min / arg
+// over the k neighbours and the BN2 statistics are in-lane reductions over accumulator
+// registers - no LDS, no shuffles.  k <= 32 (8 tiles); slots j >= k are masked.
+// A-operand: lane (i, h) gathers the 128-B half row P'[m][32h..32h+31] of ITS edge (8 x
+// dwordx4 from the L2-resident projection), adds Q'[n], applies LeakyReLU.  B-operand: both
+// 32-column halves of W2^T live in 64 VGPRs for the whole kernel.  Channel order inside the
+// fma chain is (32h+s) for step s: k=0 -> channel s, k=1 -> channel 32+s.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
+                   const float *__restrict__ w2,
                    int BN, int N, int k, float slope, int want_stats,
                    float *__restrict__ hmax, float *__restrict__ hmin,
                    uint8_t *__restrict__ jmax, uint8_t *__restrict__ jmin,
                    double *__restrict__ partial)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ double red[4][2][2][EC / 2 * 2];   // [wave][half][s|ss][64]
+    __shared__ double red[4][2][2][EC];   // [wave][half][s|ss][64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int half = lane >> 5, hl = lane & 31;
-    float *a1t = smem + (size_t)(wv * 2 + half) * k * EC;   // [k][64] per half-wave
+    const int i = lane & 31, h = lane >> 5;
 
-    float wa[EC], wb[EC];
+    float wB0[32], wB1[32];
 #pragma unroll
-    for (int c = 0; c < EC; ++c) {
-        wa[c] = w2[(size_t)hl * EC + c];
-        wb[c] = w2[(size_t)(hl + 32) * EC + c];
+    for (int s = 0; s < 32; ++s) {
+        wB0[s] = w2[(size_t)i * EC + 32 * h + s];
+        wB1[s] = w2[(size_t)(32 + i) * EC + 32 * h + s];
     }
-    const float s1a = stats[ST_SCALE1 * EC + hl], s1b = stats[ST_SCALE1 * EC + hl + 32];
-    const float t1a = stats[ST_SHIFT1 * EC + hl], t1b = stats[ST_SHIFT1 * EC + hl + 32];
+    const int pA = 4 * ((i >> 2) & 1) + (i >> 3);       // point (0..7) of this lane's A rows
+    const int jjA = i & 3;
+    const int T = (k + 3) >> 2;
+    double sd0 = 0.0, ssd0 = 0.0, sd1 = 0.0, ssd1 = 0.0;
 
-    double sa = 0.0, ssa = 0.0, sb = 0.0, ssb = 0.0;
-    const int npairs = (BN + 1) / 2;
-    for (int pr = blockIdx.x * 4 + wv; pr < npairs; pr += gridDim.x * 4) {
-        const int pt = pr * 2 + half;
-        const bool valid = pt < BN;
-        const int ptc = valid ? pt : BN - 1;
-        const int b = ptc / N;
-        const float qa = Q[(size_t)ptc * EC + hl], qb = Q[(size_t)ptc * EC + hl + 32];
-        const int myidx = (hl < k) ? idx[(size_t)ptc * k + hl] : 0;
-        for (int j = 0; j < k; ++j) {
-            const int m = __shfl(myidx, j, 32);
-            const size_t row = ((size_t)b * N + m) * EC;
-            const float za = fmaf(P[row + hl] + qa, s1a, t1a);
-            const float zb = fmaf(P[row + hl + 32] + qb, s1b, t1b);
-            a1t[j * EC + hl] = lrelu(za, slope);
-            a1t[j * EC + hl + 32] = lrelu(zb, slope);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float mxa = -__builtin_inff(), mna = __builtin_inff(), mxb = -__builtin_inff(), mnb = __builtin_inff();
-        int jxa = 0, jna = 0, jxb = 0, jnb = 0;
-        float pa = 0.f, ppa = 0.f, pb = 0.f, ppb = 0.f;
-        for (int j = 0; j < k; ++j) {
-            const float4 *av = reinterpret_cast<const float4 *>(a1t + j * EC);
-            float ha = 0.f, hb = 0.f;
+    const int nst = (BN + 7) >> 3;
+    for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
+        const int n0 = st * 8;
+        const int ptA = min(n0 + pA, BN - 1);
+        const int bA = ptA / N;
+        float qA[32];
+        {
+            const float4 *q4 = reinterpret_cast<const float4 *>(Qp + (size_t)ptA * EC + 32 * h);
 #pragma unroll
-            for (int c4 = 0; c4 < EC / 4; ++c4) {
-                const float4 a = av[c4];
-                ha = fmaf(wa[4 * c4 + 0], a.x, ha); hb = fmaf(wb[4 * c4 + 0], a.x, hb);
-                ha = fmaf(wa[4 * c4 + 1], a.y, ha); hb = fmaf(wb[4 * c4 + 1], a.y, hb);
-                ha = fmaf(wa[4 * c4 + 2], a.z, ha); hb = fmaf(wb[4 * c4 + 2], a.z, hb);
-                ha = fmaf(wa[4 * c4 + 3], a.w, ha); hb = fmaf(wb[4 * c4 + 3], a.w, hb);
+            for (int v = 0; v < 8; ++v) {
+                const float4 t4 = q4[v];
+                qA[4 * v + 0] = t4.x; qA[4 * v + 1] = t4.y; qA[4 * v + 2] = t4.z; qA[4 * v + 3] = t4.w;
             }
-            if (ha > mxa) { mxa = ha; jxa = j; }
-            if (ha < mna) { mna = ha; jna = j; }
-            if (hb > mxb) { mxb = hb; jxb = j; }
-            if (hb < mnb) { mnb = hb; jnb = j; }
-            pa += ha; ppa = fmaf(ha, ha, ppa);
-            pb += hb; ppb = fmaf(hb, hb, ppb);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const size_t o = (size_t)pt * EC;
-            hmax[o + hl] = mxa; hmax[o + hl + 32] = mxb;
-            hmin[o + hl] = mna; hmin[o + hl + 32] = mnb;
-            jmax[o + hl] = (uint8_t)jxa; jmax[o + hl + 32] = (uint8_t)jxb;
-            jmin[o + hl] = (uint8_t)jna; jmin[o + hl + 32] = (uint8_t)jnb;
-            sa += (double)pa; ssa += (double)ppa;
-            sb += (double)pb; ssb += (double)ppb;
+        float mx0[4], mn0[4], mx1[4], mn1[4];
+        int jx0[4], jn0[4], jx1[4], jn1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mx0[q] = mx1[q] = -__builtin_inff();
+            mn0[q] = mn1[q] = __builtin_inff();
+            jx0[q] = jn0[q] = jx1[q] = jn1[q] = 0;
         }
+        float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const int jA = min(4 * t + jjA, k - 1);
+            const int m = idx[(size_t)ptA * k + jA];
+            const float4 *p4 = reinterpret_cast<const float4 *>(Pp + ((size_t)bA * N + m) * EC + 32 * h);
+            float a[32];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const float4 t4 = p4[v];
+                a[4 * v + 0] = t4.x; a[4 * v + 1] = t4.y; a[4 * v + 2] = t4.z; a[4 * v + 3] = t4.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float z = a[s] + qA[s];
+                a[s] = fmaxf(z, z * slope);               // LeakyReLU, 0 < slope < 1
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wB0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wB1[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = r >> 2;
+                const int j = 4 * t + (r & 3);
+                const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                const float v0 = acc0[r], v1 = acc1[r];
+                if (ok) {
+                    if (v0 > mx0[q]) { mx0[q] = v0; jx0[q] = j; }
+                    if (v0 < mn0[q]) { mn0[q] = v0; jn0[q] = j; }
+                    if (v1 > mx1[q]) { mx1[q] = v1; jx1[q] = j; }
+                    if (v1 < mn1[q]) { mn1[q] = v1; jn1[q] = j; }
+                    s0 += v0; ss0 = fmaf(v0, v0, ss0);
+                    s1 += v1; ss1 = fmaf(v1, v1, ss1);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pt = n0 + 4 * h + q;
+            if (pt < BN) {
+                const size_t o = (size_t)pt * EC + i;
+                hmax[o] = mx0[q]; hmax[o + 32] = mx1[q];
+                hmin[o] = mn0[q]; hmin[o + 32] = mn1[q];
+                jmax[o] = (uint8_t)jx0[q]; jmax[o + 32] = (uint8_t)jx1[q];
+                jmin[o] = (uint8_t)jn0[q]; jmin[o + 32] = (uint8_t)jn1[q];
+            }
+        }
+        sd0 += (double)s0; ssd0 += (double)ss0;
+        sd1 += (double)s1; ssd1 += (double)ss1;
     }
     if (want_stats) {
-        red[wv][half][0][hl] = sa;  red[wv][half][0][hl + 32] = sb;
-        red[wv][half][1][hl] = ssa; red[wv][half][1][hl + 32] = ssb;
+        red[wv][h][0][i] = sd0;  red[wv][h][0][i + 32] = sd1;
+        red[wv][h][1][i] = ssd0; red[wv][h][1][i + 32] = ssd1;
         __syncthreads();
         if (tid < 128) {
             const int which = tid >> 6, c = tid & 63;
-            double t = 0.0;
+            double tsum = 0.0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) t += red[w][0][which][c] + red[w][1][which][c];
-            partial[((size_t)blockIdx.x * 2 + which) * EC + c] = t;
+            for (int w = 0; w < 4; ++w) tsum += red[w][0][which][c] + red[w][1][which][c];
+            partial[((size_t)blockIdx.x * 2 + which) * EC + c] = tsum;
         }
     }
 }
@@ -610,8 +662,8 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *dPt = smem;                  // [64 pts][65]
     float *dQt = dPt + 64 * 65;         // [64 pts][65]
-    float *xs = dQt + 64 * 65;          // [C][64 pts]
-    float *wa = xs + C * 64;            // [C][64 co]
+    float *xs = dQt + 64 * 65;          // [C][65] (padded: lanes vary c in the weight-gradient loop)
+    float *wa = xs + C * 65;            // [C][64 co]
     float *wd = wa + C * EC;            // [C][64 co]
     const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
     const int co = tid & 63, wv = tid >> 6;
@@ -624,7 +676,7 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     const float *xb = x + (size_t)b * C * N;
     for (int e = tid; e < C * 64; e += 256) {
         const int c = e >> 6, p = e & 63;
-        xs[e] = (n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
+        xs[c * 65 + p] = (n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
     }
     const float A1 = stats[ST_SCALE1 * EC + co], mean1 = stats[ST_MEAN1 * EC + co], rstd1 = stats[ST_RSTD1 * EC + co];
     const float mu_dy = mu[co], mu_dyx = mu[EC + co];
@@ -660,7 +712,7 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         const int o = e / C, c = e - o * C;
         float aa = 0.f, ad = 0.f;
         for (int p = 0; p < 64; ++p) {
-            const float xv = xs[c * 64 + p];
+            const float xv = xs[c * 65 + p];
             aa = fmaf(dPt[p * 65 + o], xv, aa);
             ad = fmaf(dQt[p * 65 + o], xv, ad);
         }
@@ -685,8 +737,9 @@ ec_bwd_dw1_kernel(const double *__restrict__ red, int C, float *__restrict__ dw1
 // ---------------------------------------------------------------------------
 struct Plan {
     int g_heavy;        // blocks of the grid-stride heavy kernels
+    int g_mfma;         // blocks of the MFMA kernels (4 waves each, a wave walks super-tiles of 8 points)
     int tiles;          // ceil(N/64) * B
-    size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin;           // forward
+    size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
     size_t total;
@@ -701,7 +754,14 @@ static Plan make_plan(int B, int C, int N, int k)
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     p.g_heavy = g;
-    const int maxparts = p.tiles > g ? p.tiles : g;
+    {
+        int gm = (int)((BN + 31) / 32);          // one super-tile per wave at least
+        if (gm > 512) gm = 512;                  // 2 resident workgroups per CU
+        if (gm < 1) gm = 1;
+        p.g_mfma = gm;
+    }
+    int maxparts = p.tiles > g ? p.tiles : g;
+    if (p.g_mfma > maxparts) maxparts = p.g_mfma;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     p.off_part = take(sizeof(double) * 2 * EC * (size_t)maxparts);
@@ -714,6 +774,8 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_hmin = take(sizeof(float) * BN * EC);
     p.off_jmax = take(BN * EC);
     p.off_jmin = take(BN * EC);
+    p.off_Pp = take(sizeof(float) * BN * EC);
+    p.off_Qp = take(sizeof(float) * BN * EC);
     // backward reuses hmax/hmin/jmax/jmin space? keep separate: simpler, memory is plentiful
     p.off_g = take(sizeof(float) * BN * EC);
     p.off_GP = take(sizeof(float) * BN * EC);
@@ -800,17 +862,18 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
     hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn1_w, a->bn1_b,
                        a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
     GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
-    {   // F4
-        const size_t lds = sizeof(float) * 8 * (size_t)a->k * EC;   // 40 KiB at k = 20
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
+    {   // F3b + F4
+        const size_t total = (size_t)BN * EC;
+        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
+        GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         ProfScope prof(1, st);
-        hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_heavy), dim3(256), lds, st, a->P, a->Q, a->idx, a->w2, a->stats,
+        hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, part);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     }
     if (a->training) {
-        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
+        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_mfma, 2 * EC, dred);
         GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn2)");
     }
     hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn2_w, a->bn2_b,
@@ -881,7 +944,7 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
     {
-        const size_t lds = sizeof(float) * (2 * 64 * 65 + (size_t)a->C * 64 * 3);
+        const size_t lds = sizeof(float) * (2 * 64 * 65 + (size_t)a->C * (65 + 2 * 64));
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_bwd_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(ec_bwd_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
