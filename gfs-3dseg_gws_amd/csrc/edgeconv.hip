@@ -402,208 +402,232 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
     }
 }
 
-// coefficient block (floats): A[64] Bc[64] Cc[64] v0[64] M[64*64] (row ci, col c)
-enum { CF_A = 0, CF_BC = 64, CF_CC = 128, CF_V0 = 192, CF_M = 256, CF_TOTAL = 256 + 64 * 64 };
+// coefficient block (floats): A[64] Bc[64] Cc[64]
+enum { CF_A = 0, CF_BC = 64, CF_CC = 128, CF_TOTAL = 192 };
 
-// B2: finalize dgamma2/dbeta2, A/Bc/Cc, M = W2^T diag(Cc) W2, v0 = W2^T Bc.  1 block x 256.
-__global__ void __launch_bounds__(256)
-ec_bwd_coef_kernel(const double *__restrict__ partial, int nparts, double count,
-                   const float *__restrict__ w2, const float *__restrict__ stats,
+// B2: finalize dgamma2 / dbeta2 and the per-channel constants of the BN2 backward:
+//     dh2 = A*route + Bc + Cc*h2   with  A = gamma2*rstd2 (= scale2),
+//     Bc = -A (m1 - mean2 rstd2 m2),  Cc = -A rstd2 m2,  m1 = mean(dy2), m2 = mean(dy2 xhat2).
+__global__ void __launch_bounds__(64)
+ec_bwd_coef_kernel(const double *__restrict__ red, double count, const float *__restrict__ stats,
                    float *__restrict__ dbn2_w, float *__restrict__ dbn2_b, float *__restrict__ coef)
 {
-    __shared__ float sW[EC][EC + 1];
-    __shared__ float sB[EC], sC[EC];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < EC * EC; e += 256) sW[e >> 6][e & 63] = w2[e];
-    if (tid < EC) {
-        double s = 0.0, sx = 0.0;
-        for (int p = 0; p < nparts; ++p) {
-            s += partial[((size_t)p * 2 + 0) * EC + tid];
-            sx += partial[((size_t)p * 2 + 1) * EC + tid];
-        }
-        dbn2_b[tid] = (float)s;
-        dbn2_w[tid] = (float)sx;
-        const double m1 = s / count, m2 = sx / count;
-        const double A = stats[ST_SCALE2 * EC + tid];
-        const double mean2 = stats[ST_MEAN2 * EC + tid], rstd2 = stats[ST_RSTD2 * EC + tid];
-        const float Bc = (float)(-A * (m1 - mean2 * rstd2 * m2));
-        const float Cc = (float)(-A * rstd2 * m2);
-        coef[CF_A + tid] = (float)A;
-        coef[CF_BC + tid] = Bc;
-        coef[CF_CC + tid] = Cc;
-        sB[tid] = Bc;
-        sC[tid] = Cc;
-    }
-    __syncthreads();
-    for (int e = tid; e < EC * EC; e += 256) {
-        const int ci = e >> 6, c = e & 63;
-        float acc = 0.f;
-        for (int co = 0; co < EC; ++co) acc = fmaf(sW[co][ci] * sC[co], sW[co][c], acc);
-        coef[CF_M + e] = acc;
-    }
-    if (tid < EC) {
-        float acc = 0.f;
-        for (int co = 0; co < EC; ++co) acc = fmaf(sW[co][tid], sB[co], acc);
-        coef[CF_V0 + tid] = acc;
-    }
+    const int c = threadIdx.x;
+    const double s = red[c], sx = red[EC + c];
+    dbn2_b[c] = (float)s;
+    dbn2_w[c] = (float)sx;
+    const double m1 = s / count, m2 = sx / count;
+    const double A = stats[ST_SCALE2 * EC + c];
+    const double mean2 = stats[ST_MEAN2 * EC + c], rstd2 = stats[ST_RSTD2 * EC + c];
+    coef[CF_A + c] = (float)A;
+    coef[CF_BC + c] = (float)(-A * (m1 - mean2 * rstd2 * m2));
+    coef[CF_CC + c] = (float)(-A * rstd2 * m2);
 }
 
-// B3: heavy backward pass.  wave per point, lane = input channel ci of conv2.
-// LDS per block: W2 [co][ci] (16 KiB) | dW2s accumulators [co][ci] (16 KiB) |
-// per wave: a1t[k][64], T[k][64], cj[64] (coef, jsel pairs)
-// partial outputs per block: S[64][64] | dW2s[64][64] | s_a1[64] | (unused)[64]
-constexpr int BWD_PART = 2 * EC * EC + 2 * EC;
+// ---------------------------------------------------------------------------
+// B3: heavy backward pass on the matrix pipe (direct form, three fp32 MFMA products per
+// 32-edge tile, same super-tile row mapping as ec_main_fwd_kernel):
+//   (1) H2  = A1 W2^T                       A-layout a1 (lane = edge) x W2 from LDS
+//   (2) dW2 += dH2^T A1                     both operands in C/D layout (lane = channel,
+//                                           register = edge): the accumulator of (1), turned
+//                                           into dH2 in place, IS the A operand
+//   (3) dA1 = dH2 W2                        dH2 transposed to A-layout through LDS
+// dH2 = Cc*H2 + Bc + [slot == winner] A*g is elementwise in the C/D layout (the routed term is
+// one compare per register); a1 in C/D layout comes from the same LDS transpose buffer (no
+// second gather); dy1 = dA1 * LReLU'(z1) (sign of a1); G_Q in-lane, G_P as 2x128-B atomic rows.
+// LDS: W2 [64][68] (block) + one [32][68] transpose tile and 32 neighbour ids per wave.
+// ---------------------------------------------------------------------------
+constexpr int BWD_PART = EC * EC;
+constexpr int TLD = EC + 4;
+__device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
 __global__ void __launch_bounds__(256, 2)
-ec_main_bwd_kernel(const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ idx,
-                   const float *__restrict__ w2, const float *__restrict__ stats, const float *__restrict__ coef,
+ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
+                   const float *__restrict__ w2, const float *__restrict__ coef,
                    const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
                    int BN, int N, int k, float slope,
                    float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LD = EC + 4;              // a1t row stride: per-lane row reads (dW2 term) hit distinct banks
-    float *sW = smem;                       // [co][ci]
-    float *sD = sW + EC * EC;               // dW2s accumulators
-    float *sA1 = sD + EC * EC;              // [64] block sum of a1
+    float *sW = smem;                                   // [64][TLD]  W2[co][ci]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    float *a1t = sA1 + EC + (size_t)wv * (2 * k * LD + 2 * EC);
-    float *Tt = a1t + k * LD;
-    float2 *cj = reinterpret_cast<float2 *>(Tt + k * LD);
+    const int i = lane & 31, h = lane >> 5;
+    float *tr = sW + EC * TLD + (size_t)wv * (32 * TLD + 32);   // [32][TLD] transpose tile
+    int *mrow = reinterpret_cast<int *>(tr + 32 * TLD);         // [32] neighbour id of each tile row
 
-    for (int e = tid; e < EC * EC; e += 256) { sW[e] = w2[e]; sD[e] = 0.f; }
-    if (tid < EC) sA1[tid] = 0.f;
-    float Mrow[EC], D[EC];
+    for (int e = tid; e < EC * EC; e += 256) sW[(e >> 6) * TLD + (e & 63)] = w2[e];
+    const float A0 = coef[CF_A + i], A1 = coef[CF_A + 32 + i];
+    const float Bc0 = coef[CF_BC + i], Bc1 = coef[CF_BC + 32 + i];
+    const float Cc0 = coef[CF_CC + i], Cc1 = coef[CF_CC + 32 + i];
+    f32x16 dW00, dW01, dW10, dW11;
 #pragma unroll
-    for (int c = 0; c < EC; ++c) { Mrow[c] = coef[CF_M + lane * EC + c]; D[c] = 0.f; }
-    // S = sum_e a1 a1^T lives on the (otherwise idle) matrix pipe: three 32x32 fp32 MFMA
-    // accumulators (lo-lo, lo-hi, hi-hi channel halves), two edges per MFMA step.
-    f32x16 S00, S01, S11;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { S00[r] = 0.f; S01[r] = 0.f; S11[r] = 0.f; }
-    const int mc = lane & 31, mh = lane >> 5;
-    const float v0 = coef[CF_V0 + lane];
-    const float Aco = coef[CF_A + lane];
-    const float s1 = stats[ST_SCALE1 * EC + lane], t1 = stats[ST_SHIFT1 * EC + lane];
-    float sum_a1 = 0.f;
+    for (int r = 0; r < 16; ++r) { dW00[r] = 0.f; dW01[r] = 0.f; dW10[r] = 0.f; dW11[r] = 0.f; }
+    const int pA = 4 * ((i >> 2) & 1) + (i >> 3);
+    const int jjA = i & 3;
+    const int T = (k + 3) >> 2;
     __syncthreads();
 
-    for (int pt = blockIdx.x * 4 + wv; pt < BN; pt += gridDim.x * 4) {
-        const int b = pt / N;
-        const float q = Q[(size_t)pt * EC + lane];
-        const int myidx = (lane < k) ? idx[(size_t)pt * k + lane] : 0;
-        const float mycoef = Aco * g_pm[(size_t)pt * EC + lane];      // lane = co for the routed terms
-        const int myj = (int)jsel[(size_t)pt * EC + lane];
-        unsigned posmask = 0u;
-        for (int j0 = 0; j0 < k; j0 += 4) {           // 4 independent row gathers in flight
-            float pv[4];
+    const int nst = (BN + 7) >> 3;
+    for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
+        const int n0 = st * 8;
+        const int ptA = min(n0 + pA, BN - 1);
+        const int bA = ptA / N;
+        float Ag0[4], Ag1[4], gq0[4], gq1[4];
+        int js0[4], js1[4];
+        size_t gbase[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = __shfl(myidx, min(j0 + u, k - 1), 64);
-                pv[u] = P[((size_t)b * N + m) * EC + lane];
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int pt = n0 + 4 * h + q;
+            const bool ok = pt < BN;
+            const size_t o = (size_t)min(pt, BN - 1) * EC + i;
+            Ag0[q] = ok ? A0 * g_pm[o] : 0.f;
+            Ag1[q] = ok ? A1 * g_pm[o + 32] : 0.f;
+            js0[q] = ok ? (int)jsel[o] : 255;
+            js1[q] = ok ? (int)jsel[o + 32] : 255;
+            gq0[q] = 0.f; gq1[q] = 0.f;
+            gbase[q] = (size_t)(min(pt, BN - 1) / N) * N;
+        }
+        for (int t = 0; t < T; ++t) {
+            const int jA = min(4 * t + jjA, k - 1);
+            const int mA = idx[(size_t)ptA * k + jA];
+            if (h == 0) mrow[i] = mA;
+            float a[32];
+            {
+                const float4 *p4 = reinterpret_cast<const float4 *>(Pp + ((size_t)bA * N + mA) * EC + 32 * h);
+                const float4 *q4 = reinterpret_cast<const float4 *>(Qp + (size_t)ptA * EC + 32 * h);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                if (j < k) {
-                    const float z = fmaf(pv[u] + q, s1, t1);
-                    posmask |= (z > 0.f ? 1u : 0u) << j;
-                    const float a = lrelu(z, slope);
-                    a1t[j * LD + lane] = a;
-                    Tt[j * LD + lane] = 0.f;
-                    sum_a1 += a;
+                for (int v = 0; v < 8; ++v) {
+                    const float4 pv = p4[v], qv = q4[v];
+                    float z;
+                    z = pv.x + qv.x; a[4 * v + 0] = fmaxf(z, z * slope);
+                    z = pv.y + qv.y; a[4 * v + 1] = fmaxf(z, z * slope);
+                    z = pv.z + qv.z; a[4 * v + 2] = fmaxf(z, z * slope);
+                    z = pv.w + qv.w; a[4 * v + 3] = fmaxf(z, z * slope);
                 }
             }
-        }
-        cj[lane] = make_float2(mycoef, __int_as_float(myj));
-        __builtin_amdgcn_wave_barrier();
-        for (int s = 0; s < k; s += 2) {
-            const int ej = s + mh;
-            const float alo = (ej < k) ? a1t[ej * LD + mc] : 0.f;
-            const float ahi = (ej < k) ? a1t[ej * LD + 32 + mc] : 0.f;
-            S00 = __builtin_amdgcn_mfma_f32_32x32x2f32(alo, alo, S00, 0, 0, 0);
-            S01 = __builtin_amdgcn_mfma_f32_32x32x2f32(alo, ahi, S01, 0, 0, 0);
-            S11 = __builtin_amdgcn_mfma_f32_32x32x2f32(ahi, ahi, S11, 0, 0, 0);
-        }
-        // routed term of dW2 (lane = co): D[ci] += coef[co] * a1[jsel[co]][ci]; every lane reads ITS winner's row
-        {
-            const float4 *row = reinterpret_cast<const float4 *>(a1t + myj * LD);
+            // (1) H2 = A1 W2^T
+            f32x16 acc0, acc1;
 #pragma unroll
-            for (int c4 = 0; c4 < EC / 4; ++c4) {
-                const float4 a = row[c4];
-                D[4 * c4 + 0] = fmaf(mycoef, a.x, D[4 * c4 + 0]);
-                D[4 * c4 + 1] = fmaf(mycoef, a.y, D[4 * c4 + 1]);
-                D[4 * c4 + 2] = fmaf(mycoef, a.z, D[4 * c4 + 2]);
-                D[4 * c4 + 3] = fmaf(mycoef, a.w, D[4 * c4 + 3]);
-                if ((c4 & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(sW + i * TLD + 32 * h + 4 * v);
+                const float4 w1 = *reinterpret_cast<const float4 *>(sW + (32 + i) * TLD + 32 * h + 4 * v);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w1.w, acc1, 0, 0, 0);
+            }
+            // a1: A-layout -> C/D layout through the transpose tile
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                *reinterpret_cast<float4 *>(tr + i * TLD + 32 * h + 4 * v) =
+                    make_float4(a[4 * v + 0], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
+            __builtin_amdgcn_wave_barrier();
+            float aD0[16], aD1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aD0[r] = tr[drow(r, h) * TLD + i];
+                aD1[r] = tr[drow(r, h) * TLD + 32 + i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // dH2 in place (C/D layout): Cc*h2 + Bc + routed term; masked rows -> 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = r >> 2;
+                const int j = 4 * t + (r & 3);
+                const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                const float d0 = fmaf(Cc0, acc0[r], Bc0) + (js0[q] == j ? Ag0[q] : 0.f);
+                const float d1 = fmaf(Cc1, acc1[r], Bc1) + (js1[q] == j ? Ag1[q] : 0.f);
+                acc0[r] = ok ? d0 : 0.f;
+                acc1[r] = ok ? d1 : 0.f;
+            }
+            // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]   (register r <-> the same edge in both operands)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dW00 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc0[r], aD0[r], dW00, 0, 0, 0);
+                dW01 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc0[r], aD1[r], dW01, 0, 0, 0);
+                dW10 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD0[r], dW10, 0, 0, 0);
+                dW11 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD1[r], dW11, 0, 0, 0);
+            }
+            // dH2: C/D layout -> A-layout through the transpose tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tr[drow(r, h) * TLD + i] = acc0[r];
+                tr[drow(r, h) * TLD + 32 + i] = acc1[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const float4 d4 = *reinterpret_cast<const float4 *>(tr + i * TLD + 32 * h + 4 * v);
+                a[4 * v + 0] = d4.x; a[4 * v + 1] = d4.y; a[4 * v + 2] = d4.z; a[4 * v + 3] = d4.w;
+            }
+            // (3) dA1 = dH2 W2 :  B[k = co = 32h+s][j = ci]
+            f32x16 e0, e1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float b0 = sW[(32 * h + s) * TLD + i];
+                const float b1 = sW[(32 * h + s) * TLD + 32 + i];
+                e0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0, e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1, e1, 0, 0, 0);
+            }
+            // dy1 = dA1 * LReLU'(z1); G_Q (in-lane), G_P (atomic 128-B half rows)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = r >> 2;
+                const int j = 4 * t + (r & 3);
+                const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                if (ok) {
+                    const float dy0 = e0[r] * (aD0[r] > 0.f ? 1.f : slope);
+                    const float dy1 = e1[r] * (aD1[r] > 0.f ? 1.f : slope);
+                    gq0[q] += dy0;
+                    gq1[q] += dy1;
+                    const size_t row = (gbase[q] + (size_t)mrow[drow(r, h)]) * EC + i;
+                    atomicAdd(&GP[row], dy0);
+                    atomicAdd(&GP[row + 32], dy1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pt = n0 + 4 * h + q;
+            if (pt < BN) {
+                GQ[(size_t)pt * EC + i] = gq0[q];
+                GQ[(size_t)pt * EC + 32 + i] = gq1[q];
             }
         }
-        // routed term of da1 (lane = ci): T[j][ci] += coef[co] W2[co][ci] at j = jsel[co].  Plain
-        // read-modify-write is safe: one wave, in-order LDS, lanes own distinct addresses
-        // (LDS float atomics measured ~190 cycles per wave-instruction here).
-#pragma unroll 4
-        for (int co = 0; co < EC; ++co) {
-            const float2 cv = cj[co];
-            const int jj = __float_as_int(cv.y);
-            Tt[jj * LD + lane] = fmaf(cv.x, sW[co * EC + lane], Tt[jj * LD + lane]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float gq = 0.f;
-        for (int j = 0; j < k; ++j) {
-            float acc = v0 + Tt[j * LD + lane];
-            const float4 *av = reinterpret_cast<const float4 *>(a1t + j * LD);
-#pragma unroll
-            for (int c4 = 0; c4 < EC / 4; ++c4) {
-                const float4 a = av[c4];
-                acc = fmaf(Mrow[4 * c4 + 0], a.x, acc);
-                acc = fmaf(Mrow[4 * c4 + 1], a.y, acc);
-                acc = fmaf(Mrow[4 * c4 + 2], a.z, acc);
-                acc = fmaf(Mrow[4 * c4 + 3], a.w, acc);
-                if ((c4 & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // cap the LDS prefetch window (register pressure)
-            }
-            const float dy1 = acc * (((posmask >> j) & 1u) ? 1.f : slope);
-            gq += dy1;
-            const int m = __shfl(myidx, j, 64);
-            atomicAdd(&GP[((size_t)b * N + m) * EC + lane], dy1);
-        }
-        GQ[(size_t)pt * EC + lane] = gq;
-        __builtin_amdgcn_wave_barrier();
     }
-    atomicAdd(&sA1[lane], sum_a1);
-#pragma unroll
-    for (int c = 0; c < EC; ++c) atomicAdd(&sD[c * EC + lane], D[c]);      // sD holds dW2s transposed: [ci][co]
+    // block-level sum of the four waves' dW2 accumulators, then one partial per block
     __syncthreads();
-    // S: reduce the 4 waves through LDS (reuse sW), then write block partials
-    for (int e = tid; e < EC * EC; e += 256) sW[e] = 0.f;
+    float *sD = smem;                                   // reuse: [64][64]
+    for (int e = tid; e < EC * EC; e += 256) sD[e] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * mh;      // MFMA C/D layout: row from (reg, lane half), col = lane & 31
-        atomicAdd(&sW[row * EC + mc], S00[r]);
-        atomicAdd(&sW[row * EC + 32 + mc], S01[r]);
-        atomicAdd(&sW[(32 + mc) * EC + row], S01[r]);
-        atomicAdd(&sW[(32 + row) * EC + 32 + mc], S11[r]);
+        const int row = drow(r, h);                     // C/D layout: row = co (within half), col = ci = i
+        atomicAdd(&sD[row * EC + i], dW00[r]);
+        atomicAdd(&sD[row * EC + 32 + i], dW01[r]);
+        atomicAdd(&sD[(32 + row) * EC + i], dW10[r]);
+        atomicAdd(&sD[(32 + row) * EC + 32 + i], dW11[r]);
     }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * BWD_PART;
-    for (int e = tid; e < EC * EC; e += 256) { out[e] = sW[e]; out[EC * EC + e] = sD[(e & 63) * EC + (e >> 6)]; }
-    if (tid < EC) out[2 * EC * EC + tid] = sA1[tid];
+    for (int e = tid; e < EC * EC; e += 256) out[e] = sD[e];
 }
 
-// B4b: dW2[co][c] = dW2s[co][c] + Bc[co] s_a1[c] + Cc[co] * sum_c' W2[co][c'] S[c'][c].  1 block x 256
+// B4: dW2 = block partials summed in double
 __global__ void __launch_bounds__(256)
-ec_bwd_dw2_kernel(const double *__restrict__ red, const float *__restrict__ w2, const float *__restrict__ coef,
-                  float *__restrict__ dw2)
+ec_bwd_dw2_kernel(const double *__restrict__ red, float *__restrict__ dw2)
 {
-    __shared__ float sS[EC][EC + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < EC * EC; e += 256) sS[e >> 6][e & 63] = (float)red[e];
-    __syncthreads();
-    for (int e = tid; e < EC * EC; e += 256) {
-        const int co = e >> 6, c = e & 63;
-        float acc = 0.f;
-        for (int cc = 0; cc < EC; ++cc) acc = fmaf(w2[co * EC + cc], sS[cc][c], acc);
-        dw2[e] = (float)(red[EC * EC + e] + (double)coef[CF_BC + co] * red[2 * EC * EC + c] + (double)coef[CF_CC + co] * acc);
-    }
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < EC * EC) dw2[e] = (float)red[e];
 }
 
 // B5: BN1 backward reductions: sum_n GQ (= sum_e dy1) and
@@ -781,7 +805,7 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_GP = take(sizeof(float) * BN * EC);
     p.off_GQ = take(sizeof(float) * BN * EC);
     p.off_coef = take(sizeof(float) * CF_TOTAL);
-    p.off_bpart = take(sizeof(float) * (size_t)BWD_PART * g);
+    p.off_bpart = take(sizeof(float) * (size_t)BWD_PART * p.g_mfma);
     p.off_mu = take(sizeof(float) * 2 * EC);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)C * p.tiles);
     p.total = o;
@@ -917,25 +941,26 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
     hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.tiles, 2 * EC, dred);
     GFS3D_LAUNCH_CHECK("reduce_parts_kernel(prep)");
-    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(256), 0, st, dred, 1, count, a->w2, a->stats,
-                       ba->dbn2_w, ba->dbn2_b, coef);
+    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, dred, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
     GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
     if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
         set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
         return GFS3D_ERR_HIP;
     }
+    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
     {
-        const size_t lds = sizeof(float) * (2 * EC * EC + EC + 4 * (2 * (size_t)a->k * (EC + 4) + 2 * EC));
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const size_t total = (size_t)BN * EC;
+        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
+        GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+        const size_t lds = sizeof(float) * (EC * TLD + 4 * (32 * TLD + 32));
         ProfScope prof(2, st);
-        hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_heavy), dim3(256), lds, st, a->P, a->Q, a->idx, a->w2, a->stats, coef,
+        hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_mfma), dim3(256), lds, st, Pp, Qp, a->idx, a->w2, coef,
                            g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
         GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
     }
-    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_heavy, BWD_PART, dred);
+    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_mfma, BWD_PART, dred);
     GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
-    hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(1), dim3(256), 0, st, dred, a->w2, coef, ba->dw2);
+    hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
     GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
     hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, part);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
