@@ -71,13 +71,12 @@ ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, i
 }
 
 // ---------------------------------------------------------------------------
-// F2: BN1 batch statistics of h1 = P[idx] + Q over all edges; SP, SQ, indeg.
+// F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ idx,
-                 int BN, int N, int k, float *__restrict__ SP, float *__restrict__ SQ,
-                 float *__restrict__ indeg, double *__restrict__ partial)
+                 int BN, int N, int k, float *__restrict__ SP, double *__restrict__ partial)
 {
     __shared__ double red[4][2][EC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -87,16 +86,22 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
         const float q = Q[(size_t)pt * EC + lane];
         const int myidx = (lane < k) ? idx[(size_t)pt * k + lane] : 0;
         float sp = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int j = 0; j < k; ++j) {
-            const int m = __shfl(myidx, j, 64);
-            const size_t row = ((size_t)b * N + m) * EC;
-            const float p = P[row + lane];
-            const float h = p + q;
-            sp += p;
-            s1 += h;
-            s2 = fmaf(h, h, s2);
-            atomicAdd(&SQ[row + lane], q);
-            if (lane == 0) atomicAdd(&indeg[(size_t)b * N + m], 1.0f);
+        for (int j0 = 0; j0 < k; j0 += 4) {               // 4 independent row gathers in flight
+            float pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = __shfl(myidx, min(j0 + u, k - 1), 64);
+                pv[u] = P[((size_t)b * N + m) * EC + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j0 + u < k) {
+                    const float h = pv[u] + q;
+                    sp += pv[u];
+                    s1 += h;
+                    s2 = fmaf(h, h, s2);
+                }
+            }
         }
         SP[(size_t)pt * EC + lane] = sp;
         s += (double)s1;
@@ -109,6 +114,86 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
         const int which = threadIdx.x >> 6;
         const double t = red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
         partial[((size_t)blockIdx.x * 2 + which) * EC + lane] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Reverse kNN graph (CSR of in-edges), built in the backward pass: SQ[m] = sum over in-edges
+// (n -> m) of Q[n] and the in-degree are what BN1's backward needs per target point.  Integer
+// atomics only (count, slot claim); the float sums are plain gathers of 256-B rows.  (A float
+// atomic scatter of Q costs 0.37 ms per layer, the four kernels below ~0.1 ms.)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rev_count_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, int *__restrict__ deg)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nedges) return;
+    const size_t pt = e / k;
+    const size_t b = pt / N;
+    atomicAdd(&deg[b * N + idx[e]], 1);
+}
+// one workgroup per block b: exclusive scan of deg[b][0..N) -> ptr[b][0..N)
+__global__ void __launch_bounds__(256)
+rev_scan_kernel(const int *__restrict__ deg, int N, int *__restrict__ ptr)
+{
+    __shared__ int part[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int per = (N + 255) / 256;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    int s = 0;
+    for (int n = lo; n < hi; ++n) s += deg[(size_t)b * N + n];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int n = lo; n < hi; ++n) {
+        ptr[(size_t)b * N + n] = run;
+        run += deg[(size_t)b * N + n];
+    }
+}
+__global__ void __launch_bounds__(256)
+rev_fill_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, const int *__restrict__ ptr,
+                int *__restrict__ cursor, int *__restrict__ src)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nedges) return;
+    const size_t pt = e / k;
+    const size_t b = pt / N;
+    const size_t tm = b * N + idx[e];
+    const int pos = ptr[tm] + atomicAdd(&cursor[tm], 1);
+    src[b * N * k + pos] = (int)(pt - b * N);
+}
+// wave per target point, lane = channel
+__global__ void __launch_bounds__(256)
+rev_gather_kernel(const float *__restrict__ Q, const int *__restrict__ ptr, const int *__restrict__ deg,
+                  const int *__restrict__ src, int BN, int N, int k, float *__restrict__ SQ, float *__restrict__ indeg)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int tm = blockIdx.x * 4 + wv; tm < BN; tm += gridDim.x * 4) {
+        const int b = tm / N;
+        const int d = deg[tm];
+        const int *lst = src + (size_t)b * N * k + ptr[tm];
+        float acc = 0.f;
+        for (int s0 = 0; s0 < d; s0 += 64) {
+            const int mine = (s0 + lane < d) ? lst[s0 + lane] : 0;
+            const int cnt = min(64, d - s0);
+            int s = 0;
+            for (; s + 4 <= cnt; s += 4) {
+                const float v0 = Q[((size_t)b * N + __shfl(mine, s + 0, 64)) * EC + lane];
+                const float v1 = Q[((size_t)b * N + __shfl(mine, s + 1, 64)) * EC + lane];
+                const float v2 = Q[((size_t)b * N + __shfl(mine, s + 2, 64)) * EC + lane];
+                const float v3 = Q[((size_t)b * N + __shfl(mine, s + 3, 64)) * EC + lane];
+                acc += (v0 + v1) + (v2 + v3);
+            }
+            for (; s < cnt; ++s) acc += Q[((size_t)b * N + __shfl(mine, s, 64)) * EC + lane];
+        }
+        SQ[(size_t)tm * EC + lane] = acc;
+        if (lane == 0) indeg[tm] = (float)d;
     }
 }
 
@@ -766,6 +851,7 @@ struct Plan {
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
+    size_t off_deg, off_ptr, off_src;                                        // reverse graph (deg and cursor adjacent)
     size_t total;
 };
 
@@ -807,6 +893,9 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_coef = take(sizeof(float) * CF_TOTAL);
     p.off_bpart = take(sizeof(float) * (size_t)BWD_PART * p.g_mfma);
     p.off_mu = take(sizeof(float) * 2 * EC);
+    p.off_deg = take(sizeof(int) * 2 * BN);            // deg | cursor
+    p.off_ptr = take(sizeof(int) * BN);
+    p.off_src = take(sizeof(int) * BN * (size_t)k);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)C * p.tiles);
     p.total = o;
     return p;
@@ -868,14 +957,9 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
         GFS3D_LAUNCH_CHECK("ec_pq_kernel");
     }
     if (a->training) {
-        if (hipMemsetAsync(a->SQ, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess ||
-            hipMemsetAsync(a->indeg, 0, sizeof(float) * (size_t)BN, st) != hipSuccess) {
-            set_error("gfs3d_edgeconv_forward_f32: hipMemsetAsync failed");
-            return GFS3D_ERR_HIP;
-        }
         ProfScope prof(4, st);
         hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
-                           a->SP, a->SQ, a->indeg, part);
+                           a->SP, part);
         GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
     }
     double *dred = reinterpret_cast<double *>(ws + p.off_dred);
@@ -962,6 +1046,24 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
     hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
     GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
+    {   // reverse graph -> SQ, indeg
+        int *deg = reinterpret_cast<int *>(ws + p.off_deg), *cursor = deg + BN;
+        int *ptr = reinterpret_cast<int *>(ws + p.off_ptr), *src = reinterpret_cast<int *>(ws + p.off_src);
+        const size_t nedges = (size_t)BN * a->k;
+        if (hipMemsetAsync(deg, 0, sizeof(int) * 2 * (size_t)BN, st) != hipSuccess) {
+            set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
+            return GFS3D_ERR_HIP;
+        }
+        const unsigned eb = (unsigned)((nedges + 255) / 256);
+        hipLaunchKernelGGL(rev_count_kernel, dim3(eb), dim3(256), 0, st, a->idx, nedges, a->N, a->k, deg);
+        GFS3D_LAUNCH_CHECK("rev_count_kernel");
+        hipLaunchKernelGGL(rev_scan_kernel, dim3(a->B), dim3(256), 0, st, deg, a->N, ptr);
+        GFS3D_LAUNCH_CHECK("rev_scan_kernel");
+        hipLaunchKernelGGL(rev_fill_kernel, dim3(eb), dim3(256), 0, st, a->idx, nedges, a->N, a->k, ptr, cursor, src);
+        GFS3D_LAUNCH_CHECK("rev_fill_kernel");
+        hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->Q, ptr, deg, src, BN, a->N, a->k, a->SQ, a->indeg);
+        GFS3D_LAUNCH_CHECK("rev_gather_kernel");
+    }
     hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, part);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
     hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);

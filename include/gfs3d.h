@@ -76,8 +76,9 @@ typedef struct gfs3d_edgeconv_args {
     float *y_pm;                  /* out: (B, N, 64) point-major copy (input layout of the next block) */
     /* saved for backward (outputs of forward, inputs of backward) */
     float *P, *Q;                 /* (B, N, 64): Wa x_n and (Wb - Wa) x_n */
-    float *SP, *SQ;               /* (B, N, 64): sum_j P[idx[n,j]] and sum over in-edges of Q */
-    float *indeg;                 /* (B, N) in-degree of each point in the kNN graph (as float) */
+    float *SP;                    /* (B, N, 64): sum_j P[idx[n,j]] (written by forward) */
+    float *SQ;                    /* (B, N, 64) scratch of backward: sum over in-edges of Q */
+    float *indeg;                 /* (B, N) scratch of backward: in-degree in the kNN graph (as float) */
     float *stats;                 /* (8, 64): mean1 rstd1 scale1 shift1 mean2 rstd2 scale2 shift2 */
     float *hsel;                  /* (B, N, 64) pre-BN2 value that won the max */
     uint8_t *jsel;                /* (B, N, 64) neighbour slot j that won the max */
