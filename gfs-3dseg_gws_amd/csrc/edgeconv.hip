@@ -295,7 +295,7 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 // 32-column halves of W2^T live in 64 VGPRs for the whole kernel.  Channel order inside the
 // fma chain is (32h+s) for step s: k=0 -> channel s, k=1 -> channel 32+s.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2,
                    int BN, int N, int k, float slope, int want_stats,
@@ -303,26 +303,28 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    uint8_t *__restrict__ jmax, uint8_t *__restrict__ jmin,
                    double *__restrict__ partial)
 {
-    __shared__ double red[4][2][2][EC];   // [wave][half][s|ss][64]
+    constexpr int WLD = EC + 4;                         // padded W2 rows: conflict-free ds_read_b128 fragments
+    __shared__ __attribute__((aligned(16))) float sW[EC * WLD];
+    __shared__ double red[4][2][2][EC];                 // [wave][half][s|ss][64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    for (int e = tid; e < EC * EC; e += 256) sW[(e >> 6) * WLD + (e & 63)] = w2[e];
+    __syncthreads();
 
-    float wB0[32], wB1[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        wB0[s] = w2[(size_t)i * EC + 32 * h + s];
-        wB1[s] = w2[(size_t)(32 + i) * EC + 32 * h + s];
-    }
     const int pA = 4 * ((i >> 2) & 1) + (i >> 3);       // point (0..7) of this lane's A rows
     const int jjA = i & 3;
     const int T = (k + 3) >> 2;
     double sd0 = 0.0, ssd0 = 0.0, sd1 = 0.0, ssd1 = 0.0;
+    const float4 *wrow0 = reinterpret_cast<const float4 *>(sW + i * WLD + 32 * h);
+    const float4 *wrow1 = reinterpret_cast<const float4 *>(sW + (32 + i) * WLD + 32 * h);
 
     const int nst = (BN + 7) >> 3;
     for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
         const int n0 = st * 8;
         const int ptA = min(n0 + pA, BN - 1);
         const int bA = ptA / N;
+        const int32_t *myidx = idx + (size_t)ptA * k;
+        const float *prow_base = Pp + (size_t)bA * N * EC + 32 * h;
         float qA[32];
         {
             const float4 *q4 = reinterpret_cast<const float4 *>(Qp + (size_t)ptA * EC + 32 * h);
@@ -341,43 +343,62 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             jx0[q] = jn0[q] = jx1[q] = jn1[q] = 0;
         }
         float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+        // software pipeline: rows of tile t+1 and the neighbour id of tile t+2 are in flight while
+        // tile t runs on the matrix pipe (no dependent idx -> row load chain inside the loop)
+        float4 pf[8];
+        int m_next = myidx[min(4 + jjA, k - 1)];
+        {
+            const float4 *p4 = reinterpret_cast<const float4 *>(prow_base + (size_t)myidx[min(jjA, k - 1)] * EC);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) pf[v] = p4[v];
+        }
         for (int t = 0; t < T; ++t) {
-            const int jA = min(4 * t + jjA, k - 1);
-            const int m = idx[(size_t)ptA * k + jA];
-            const float4 *p4 = reinterpret_cast<const float4 *>(Pp + ((size_t)bA * N + m) * EC + 32 * h);
             float a[32];
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
-                const float4 t4 = p4[v];
-                a[4 * v + 0] = t4.x; a[4 * v + 1] = t4.y; a[4 * v + 2] = t4.z; a[4 * v + 3] = t4.w;
+                float z;
+                z = pf[v].x + qA[4 * v + 0]; a[4 * v + 0] = fmaxf(z, z * slope);   // LeakyReLU, 0 < slope < 1
+                z = pf[v].y + qA[4 * v + 1]; a[4 * v + 1] = fmaxf(z, z * slope);
+                z = pf[v].z + qA[4 * v + 2]; a[4 * v + 2] = fmaxf(z, z * slope);
+                z = pf[v].w + qA[4 * v + 3]; a[4 * v + 3] = fmaxf(z, z * slope);
             }
+            {
+                const float4 *p4 = reinterpret_cast<const float4 *>(prow_base + (size_t)m_next * EC);
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float z = a[s] + qA[s];
-                a[s] = fmaxf(z, z * slope);               // LeakyReLU, 0 < slope < 1
+                for (int v = 0; v < 8; ++v) pf[v] = p4[v];      // (harmless re-read of the last row after the last tile)
+                m_next = myidx[min(4 * (t + 2) + jjA, k - 1)];
             }
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wB0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wB1[s], acc1, 0, 0, 0);
+            for (int v = 0; v < 8; ++v) {
+                const float4 w0 = wrow0[v], w1 = wrow1[v];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w1.w, acc1, 0, 0, 0);
             }
+            // branch-free epilogue: masked rows look like -inf / +inf / 0 to the reductions
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = r >> 2;
                 const int j = 4 * t + (r & 3);
                 const bool ok = (j < k) && (n0 + 4 * h + q < BN);
                 const float v0 = acc0[r], v1 = acc1[r];
-                if (ok) {
-                    if (v0 > mx0[q]) { mx0[q] = v0; jx0[q] = j; }
-                    if (v0 < mn0[q]) { mn0[q] = v0; jn0[q] = j; }
-                    if (v1 > mx1[q]) { mx1[q] = v1; jx1[q] = j; }
-                    if (v1 < mn1[q]) { mn1[q] = v1; jn1[q] = j; }
-                    s0 += v0; ss0 = fmaf(v0, v0, ss0);
-                    s1 += v1; ss1 = fmaf(v1, v1, ss1);
-                }
+                const bool gx0 = ok && v0 > mx0[q], gn0 = ok && v0 < mn0[q];
+                const bool gx1 = ok && v1 > mx1[q], gn1 = ok && v1 < mn1[q];
+                mx0[q] = gx0 ? v0 : mx0[q]; jx0[q] = gx0 ? j : jx0[q];
+                mn0[q] = gn0 ? v0 : mn0[q]; jn0[q] = gn0 ? j : jn0[q];
+                mx1[q] = gx1 ? v1 : mx1[q]; jx1[q] = gx1 ? j : jx1[q];
+                mn1[q] = gn1 ? v1 : mn1[q]; jn1[q] = gn1 ? j : jn1[q];
+                const float u0 = ok ? v0 : 0.f, u1 = ok ? v1 : 0.f;
+                s0 += u0; ss0 = fmaf(u0, u0, ss0);
+                s1 += u1; ss1 = fmaf(u1, u1, ss1);
             }
         }
 #pragma unroll
