@@ -778,86 +778,138 @@ __global__ void ec_bwd_bn1_final_kernel(const double *__restrict__ partial, int 
     mu[EC + c] = (float)(sx / count);
 }
 
-// B6: dP, dQ per point, then dx = Wa^T dP + Wd^T dQ (channel-first) and the
-// weight-gradient partials  dWa = sum dP x^T, dWd = sum dQ x^T.
-// block = 256 threads, tile of 64 points.  partial: [nblocks][2][64][C]
+// B6: dP, dQ per point (BN1 backward, elementwise), then on the matrix pipe
+//        dx[c][p]  = sum_o Wa[o][c] dP[p][o] + Wd[o][c] dQ[p][o]          (K = 128: dP half | dQ half)
+//        dWa[o][c] += sum_p dP[p][o] x[c][p],  dWd[o][c] += sum_p dQ[p][o] x[c][p]   (K = 64 points)
+// A workgroup walks tiles of 64 points (grid-stride) and keeps its share of the weight-gradient
+// tiles in MFMA accumulators across tiles: one partial per workgroup.  MFMA tile tasks are dealt
+// round-robin to the 4 waves.  LDS rows are padded to 68 floats (conflict-free b128 / b32 reads).
+// partial: [gridDim.x][2][64][CP]  (CP = C rounded up to 32)
+constexpr int PQ_LD = EC + 4;
 __global__ void __launch_bounds__(256)
 ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
                  const float *__restrict__ P, const float *__restrict__ Q,
                  const float *__restrict__ SP, const float *__restrict__ SQ, const float *__restrict__ indeg,
                  const float *__restrict__ GP, const float *__restrict__ GQ,
                  const float *__restrict__ stats, const float *__restrict__ mu,
-                 int C, int N, int k, float *__restrict__ dx, float *__restrict__ partial)
+                 int C, int N, int k, int tiles_per_b, int ntiles, float *__restrict__ dx, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *dPt = smem;                  // [64 pts][65]
-    float *dQt = dPt + 64 * 65;         // [64 pts][65]
-    float *xs = dQt + 64 * 65;          // [C][65] (padded: lanes vary c in the weight-gradient loop)
-    float *wa = xs + C * 65;            // [C][64 co]
-    float *wd = wa + C * EC;            // [C][64 co]
-    const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
-    const int co = tid & 63, wv = tid >> 6;
-    for (int e = tid; e < C * EC; e += 256) {
+    const int CT = (C + 31) >> 5, CP = CT * 32;
+    const int XLD = CP + 1;
+    float *dPt = smem;                          // [64 pts][PQ_LD]
+    float *dQt = dPt + 64 * PQ_LD;              // [64 pts][PQ_LD]
+    float *wa = dQt + 64 * PQ_LD;               // [CP][PQ_LD]   wa[c][o] = Wa[o][c]
+    float *wd = wa + CP * PQ_LD;                // [CP][PQ_LD]
+    float *xT = wd + CP * PQ_LD;                // [64 pts][XLD] xT[p][c]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int co = tid & 63;
+    for (int e = tid; e < CP * EC; e += 256) {
         const int c = e >> 6, o = e & 63;
-        const float a = w1[(size_t)o * 2 * C + c];
-        wa[e] = a;
-        wd[e] = w1[(size_t)o * 2 * C + C + c] - a;
-    }
-    const float *xb = x + (size_t)b * C * N;
-    for (int e = tid; e < C * 64; e += 256) {
-        const int c = e >> 6, p = e & 63;
-        xs[c * 65 + p] = (n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
+        const float a = (c < C) ? w1[(size_t)o * 2 * C + c] : 0.f;
+        const float bb = (c < C) ? w1[(size_t)o * 2 * C + C + c] : 0.f;
+        wa[c * PQ_LD + o] = a;
+        wd[c * PQ_LD + o] = bb - a;
     }
     const float A1 = stats[ST_SCALE1 * EC + co], mean1 = stats[ST_MEAN1 * EC + co], rstd1 = stats[ST_RSTD1 * EC + co];
     const float mu_dy = mu[co], mu_dyx = mu[EC + co];
     const float kf = (float)k;
-    for (int p = wv; p < 64; p += 4) {
-        const int n = n0 + p;
-        float dp = 0.f, dq = 0.f;
-        if (n < N) {
-            const size_t o = ((size_t)b * N + n) * EC + co;
-            const float deg = indeg[(size_t)b * N + n];
-            const float pv = P[o], qv = Q[o];
-            dq = A1 * (GQ[o] - kf * mu_dy - mu_dyx * rstd1 * (SP[o] + kf * (qv - mean1)));
-            dp = A1 * (GP[o] - deg * mu_dy - mu_dyx * rstd1 * (deg * (pv - mean1) + SQ[o]));
+
+    // weight-gradient tasks: (which in {dP,dQ}) x (o tile in {0,1}) x (c tile < CT); wave w owns tasks w, w+4, ...
+    const int n_wtasks = 4 * CT;
+    f32x16 wacc[4];                              // CT <= 4  ->  at most 4 tasks per wave
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[u][r] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
+        __syncthreads();                         // previous tile's MFMA reads of LDS are done
+        const float *xb = x + (size_t)b * C * N;
+        for (int e = tid; e < CP * 64; e += 256) {
+            const int c = e >> 6, p = e & 63;
+            xT[p * XLD + c] = (c < C && n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
         }
-        dPt[p * 65 + co] = dp;
-        dQt[p * 65 + co] = dq;
+        for (int p = wv; p < 64; p += 4) {
+            const int n = n0 + p;
+            float dp = 0.f, dq = 0.f;
+            if (n < N) {
+                const size_t o = ((size_t)b * N + n) * EC + co;
+                const float deg = indeg[(size_t)b * N + n];
+                const float pv = P[o], qv = Q[o];
+                dq = A1 * (GQ[o] - kf * mu_dy - mu_dyx * rstd1 * (SP[o] + kf * (qv - mean1)));
+                dp = A1 * (GP[o] - deg * mu_dy - mu_dyx * rstd1 * (deg * (pv - mean1) + SQ[o]));
+            }
+            dPt[p * PQ_LD + co] = dp;
+            dQt[p * PQ_LD + co] = dq;
+        }
+        __syncthreads();
+        // ---- dx tiles: (c tile rt < CT) x (point tile ct < 2); K = 128 (lane half h = 0: dP part, 1: dQ part)
+        for (int task = wv; task < 2 * CT; task += 4) {
+            const int rt = task >> 1, ct = task & 1;
+            const float *arow = (h ? wd : wa) + (rt * 32 + i) * PQ_LD;
+            const float *brow = (h ? dQt : dPt) + (ct * 32 + i) * PQ_LD;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * v);
+                const float4 b4 = *reinterpret_cast<const float4 *>(brow + 4 * v);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+            // C/D layout: column = point ct*32+i, row = channel rt*32 + drow(r,h)
+            const int n = n0 + ct * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = rt * 32 + drow(r, h);
+                if (c < C && n < N) dx[(size_t)b * C * N + (size_t)c * N + n] = acc[r];
+            }
+        }
+        // ---- weight-gradient tiles, accumulated across point tiles
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int task = wv + 4 * u;
+            if (task < n_wtasks) {
+                const int which = task / (2 * CT), rem = task - which * 2 * CT;
+                const int ot = rem / CT, cc = rem - ot * CT;
+                const float *src = which ? dQt : dPt;
+#pragma unroll 8
+                for (int s = 0; s < 32; ++s) {
+                    const float av = src[(2 * s + h) * PQ_LD + ot * 32 + i];      // A[i = o][k = point]
+                    const float bv = xT[(2 * s + h) * XLD + cc * 32 + i];         // B[k = point][j = c]
+                    wacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, wacc[u], 0, 0, 0);
+                }
+            }
+        }
     }
-    __syncthreads();
-    // dx[c][p] = sum_co wa[c][co] dP[p][co] + wd[c][co] dQ[p][co]
-    for (int e = tid; e < C * 64; e += 256) {
-        const int c = e >> 6, p = e & 63;
-        if (n0 + p >= N) continue;
-        float acc = 0.f;
-        for (int o = 0; o < EC; ++o) {
-            acc = fmaf(wa[c * EC + o], dPt[p * 65 + o], acc);
-            acc = fmaf(wd[c * EC + o], dQt[p * 65 + o], acc);
+    // one partial per workgroup: [2][64][CP]
+    float *out = partial + (size_t)blockIdx.x * 2 * EC * CP;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int task = wv + 4 * u;
+        if (task < n_wtasks) {
+            const int which = task / (2 * CT), rem = task - which * 2 * CT;
+            const int ot = rem / CT, cc = rem - ot * CT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[((size_t)which * EC + ot * 32 + drow(r, h)) * CP + cc * 32 + i] = wacc[u][r];
         }
-        dx[(size_t)b * C * N + (size_t)c * N + n0 + p] = acc;
-    }
-    // weight-gradient partials for this tile: [2][64 co][C]
-    float *out = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * EC * C;
-    for (int e = tid; e < EC * C; e += 256) {
-        const int o = e / C, c = e - o * C;
-        float aa = 0.f, ad = 0.f;
-        for (int p = 0; p < 64; ++p) {
-            const float xv = xs[c * 65 + p];
-            aa = fmaf(dPt[p * 65 + o], xv, aa);
-            ad = fmaf(dQt[p * 65 + o], xv, ad);
-        }
-        out[e] = aa;
-        out[EC * C + e] = ad;
     }
 }
-// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd     (red = tile partials summed in double)
+// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd     (red = workgroup partials summed in double, [2][64][CP])
 __global__ void __launch_bounds__(256)
-ec_bwd_dw1_kernel(const double *__restrict__ red, int C, float *__restrict__ dw1)
+ec_bwd_dw1_kernel(const double *__restrict__ red, int C, int CP, float *__restrict__ dw1)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= EC * C) return;
-    const double a = red[e], d = red[EC * C + e];
     const int o = e / C, c = e - o * C;
+    const double a = red[(size_t)o * CP + c], d = red[(size_t)(EC + o) * CP + c];
     dw1[(size_t)o * 2 * C + c] = (float)(a - d);
     dw1[(size_t)o * 2 * C + C + c] = (float)d;
 }
@@ -867,6 +919,7 @@ ec_bwd_dw1_kernel(const double *__restrict__ red, int C, float *__restrict__ dw1
 // ---------------------------------------------------------------------------
 struct Plan {
     int g_heavy;        // blocks of the grid-stride heavy kernels
+    int g_pq;           // workgroups of ec_bwd_pq_kernel (one weight-gradient partial each)
     int g_mfma;         // blocks of the MFMA kernels (4 waves each, a wave walks super-tiles of 8 points)
     int tiles;          // ceil(N/64) * B
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
@@ -885,6 +938,7 @@ static Plan make_plan(int B, int C, int N, int k)
     if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     p.g_heavy = g;
+    p.g_pq = p.tiles < 256 ? p.tiles : 256;
     {
         int gm = (int)((BN + 31) / 32);          // one super-tile per wave at least
         if (gm > 512) gm = 512;                  // 2 resident workgroups per CU
@@ -898,7 +952,8 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_part = take(sizeof(double) * 2 * EC * (size_t)maxparts);
     {
         size_t w = BWD_PART;
-        if ((size_t)2 * EC * C > w) w = (size_t)2 * EC * C;
+        const size_t CPp = (size_t)((C + 31) / 32) * 32;
+        if ((size_t)2 * EC * CPp > w) w = (size_t)2 * EC * CPp;
         p.off_dred = take(sizeof(double) * w);
     }
     p.off_hmax = take(sizeof(float) * BN * EC);
@@ -917,7 +972,7 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_deg = take(sizeof(int) * 2 * BN);            // deg | cursor
     p.off_ptr = take(sizeof(int) * BN);
     p.off_src = take(sizeof(int) * BN * (size_t)k);
-    p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)C * p.tiles);
+    p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)(((C + 31) / 32) * 32) * p.g_pq);
     p.total = o;
     return p;
 }
@@ -1092,16 +1147,18 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
     {
-        const size_t lds = sizeof(float) * (2 * 64 * 65 + (size_t)a->C * (65 + 2 * 64));
+        const int CP = ((a->C + 31) / 32) * 32;
+        const size_t lds = sizeof(float) * (2 * 64 * PQ_LD + 2 * (size_t)CP * PQ_LD + 64 * (size_t)(CP + 1));
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_bwd_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ec_bwd_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
-                           GP, GQ, a->stats, mu, a->C, a->N, a->k, ba->dx, wpart);
+        const int tiles_per_b = (a->N + 63) / 64;
+        hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
+                           GP, GQ, a->stats, mu, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);
         GFS3D_LAUNCH_CHECK("ec_bwd_pq_kernel");
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((2 * EC * CP + 63) / 64), dim3(1024), 0, st, wpart, p.g_pq, 2 * EC * CP, dred);
+        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(dw1)");
+        hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, dred, a->C, CP, ba->dw1);
+        GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
     }
-    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((2 * EC * a->C + 63) / 64), dim3(1024), 0, st, wpart, p.tiles, 2 * EC * a->C, dred);
-    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(dw1)");
-    hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, dred, a->C, ba->dw1);
-    GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
     return GFS3D_OK;
 }
