@@ -229,9 +229,24 @@ __device__ __forceinline__ float sqnorm_split(const float (&v)[CS], int h)
     return sq;
 }
 
+// |x_j|^2 for every point, once per call, in the oracle's order (sequential c, rounded squares)
+__global__ void __launch_bounds__(256)
+knn_sqnorm_kernel(const float *__restrict__ x, int C, int N, float *__restrict__ sq)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (n >= N) return;
+    const float *xb = x + (size_t)b * C * N + n;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = xb[(size_t)c * N];
+        s = __fadd_rn(s, __fmul_rn(v, v));
+    }
+    sq[(size_t)b * N + n] = s;
+}
+
 template <int CS, int K>
 __global__ void __launch_bounds__(256, 2)
-knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
+knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int C, int N, int k,
                 int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
 {
     constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
@@ -241,9 +256,8 @@ knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
     const int b = blockIdx.y;
     const int q0 = blockIdx.x * 128 + w * 32;
     if (q0 >= N) return;                               // whole wave out of range (wave-uniform)
-    const int per_wave = 32 + 2 * QS * 64;
-    float *sqs = smem + (size_t)w * per_wave;          // [32] candidate |x|^2 of the current tile
-    float *qv = sqs + 32;
+    const int per_wave = 2 * QS * 64;
+    float *qv = smem + (size_t)w * per_wave;
     int *qid = reinterpret_cast<int *>(qv + QS * 64);
     const float *xb = x + (size_t)b * C * N;
 
@@ -256,7 +270,8 @@ knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
             qb[s] = (c < C) ? xb[(size_t)c * N + qi] : 0.f;
         }
     }
-    const float sqq = sqnorm_split<CS>(qb, h);
+    const float sqq = sqg[(size_t)b * N + min(q0 + j, N - 1)];
+    const float *sqb = sqg + (size_t)b * N;
 
     TopListOrd<K> best;
     best.init();
@@ -272,10 +287,15 @@ knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
             dst[s] = (c < C) ? xb[(size_t)c * N + ci] : 0.f;
         }
     };
+    // norms of the 16 candidate rows this lane sees in a tile: rows 4h + 8g + {0..3}, g = 0..3
+    float sqc[16];
+    auto load_sq = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sqc[r] = sqb[min(j0 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
+    };
     load_tile(a, 0);
     for (int j0 = 0; j0 < N; j0 += 32) {
-        const float sqc = sqnorm_split<CS>(a, h);
-        if (h == 0) sqs[j] = sqc;
+        load_sq(j0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -288,7 +308,7 @@ knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int cand = j0 + row;
-            const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqs[row]), sqq);
+            const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
             if (pd > thr && cand < N) {
                 qv[cnt * 64 + lane] = pd;
                 qid[cnt * 64 + lane] = cand;
@@ -334,13 +354,15 @@ knn_mfma_kernel(const float *__restrict__ x, int C, int N, int k,
 }
 
 template <int CS, int K>
-static int launch_knn_mfma(const float *x, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
+static int launch_knn_mfma(const float *x, float *sq, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
 {
     constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
-    const size_t lds = sizeof(float) * 4 * (size_t)(32 + 2 * QS * 64);
+    const size_t lds = sizeof(float) * 4 * (size_t)(2 * QS * 64);
     dim3 grid((N + 127) / 128, B);
     ProfScope prof(0, st);
-    hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, C, N, k, idx64, idx32);
+    hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
+    GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
+    hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, sq, C, N, k, idx64, idx32);
     GFS3D_LAUNCH_CHECK("gfs3d_knn_topk_f32(mfma)");
     return GFS3D_OK;
 }
@@ -371,8 +393,14 @@ static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64
 
 }  // namespace gfs3d
 
+extern "C" size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k)
+{
+    (void)C; (void)k;
+    return (B < 1 || N < 1) ? 0 : sizeof(float) * (size_t)B * N;
+}
+
 extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
-                                  int64_t *idx64, int32_t *idx32, void *stream)
+                                  int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(x != nullptr, "gfs3d_knn_topk_f32: x is NULL");
@@ -382,9 +410,17 @@ extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
     GFS3D_REQUIRE(B <= 65535, "gfs3d_knn_topk_f32: B=%d exceeds grid.y", B);
     if (B == 0) return GFS3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, B, C, N, k, idx64, idx32, st);
-    if (k <= 20 && C <= 64) return launch_knn_mfma<32, 20>(x, B, C, N, k, idx64, idx32, st);
-    if (k <= 32 && C <= 64) return launch_knn_mfma<32, 32>(x, B, C, N, k, idx64, idx32, st);
+    if (C <= 64 && k <= 32) {          // MFMA path; needs B*N floats of workspace for the point norms
+        GFS3D_REQUIRE(workspace != nullptr, "gfs3d_knn_topk_f32: NULL workspace");
+        if (workspace_bytes < sizeof(float) * (size_t)B * N) {
+            set_error("gfs3d_knn_topk_f32: workspace %zu < required %zu", workspace_bytes, sizeof(float) * (size_t)B * N);
+            return GFS3D_ERR_WORKSPACE;
+        }
+        float *sq = static_cast<float *>(workspace);
+        if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, B, C, N, k, idx64, idx32, st);
+        if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, B, C, N, k, idx64, idx32, st);
+        return launch_knn_mfma<32, 32>(x, sq, B, C, N, k, idx64, idx32, st);
+    }
     // generic shapes: VALU kernel (any C that fits LDS, k <= 64)
     if (k <= 20) return launch_knn<20>(x, B, C, N, k, idx64, idx32, st);
     if (k <= 32) return launch_knn<32>(x, B, C, N, k, idx64, idx32, st);

@@ -62,7 +62,9 @@ def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = Fa
     i64 = torch.empty((B, N, k), dtype=torch.int64, device=x.device) if want_i64 else None
     i32 = torch.empty((B, N, k), dtype=torch.int32, device=x.device) if want_i32 else None
     with torch.cuda.device(x.device):
-        rc = _lib.lib().gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _stream())
+        L = _lib.lib()
+        ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
+        rc = L.gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "gfs3d_knn_topk_f32")
     if want_i64 and want_i32:
         return i64, i32

@@ -51,9 +51,11 @@ int gfs3d_profile_read(int kernel_id, double *total_ms, long long *launches);
  *   idx32  (B, N, k) int32 copy consumed by the EdgeConv kernels; may be NULL
  * Numerics contract (oracle/knn_oracle.c): dot = fp32 fma chain over c,
  * pd = fl(fl(2 dot - |xj|^2) - |xi|^2), ties -> lower index first.
- * Requires 1 <= k <= min(N, 64), C >= 1. */
+ * Requires 1 <= k <= min(N, 64), C >= 1.  workspace: gfs3d_knn_workspace_bytes() bytes of
+ * device scratch (the per-point squared norms). */
+size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k);
 int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
-                       int64_t *idx64, int32_t *idx32, void *stream);
+                       int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ K2 --
  * One EdgeConv block = get_edge_feature (dgcnn.py:26-42) + conv2d block
