@@ -118,82 +118,64 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
 }
 
 // ---------------------------------------------------------------------------
-// Reverse kNN graph (CSR of in-edges), built in the backward pass: SQ[m] = sum over in-edges
-// (n -> m) of Q[n] and the in-degree are what BN1's backward needs per target point.  Integer
-// atomics only (count, slot claim); the float sums are plain gathers of 256-B rows.  (A float
-// atomic scatter of Q costs 0.37 ms per layer, the four kernels below ~0.1 ms.)
+// Reverse kNN graph, built in the backward pass: SQ[m] = sum over in-edges (n -> m) of Q[n] and
+// the in-degree are what BN1's backward needs per target point.  One pass claims a slot per
+// in-edge in a fixed-capacity table (integer atomics only; in-degrees above the capacity - hubs
+// in high-dimensional feature space - go to an overflow list), then the float sums are plain
+// gathers of 256-B rows.  (A float-atomic scatter of Q costs 0.37 ms per layer, this ~0.1 ms.)
 // ---------------------------------------------------------------------------
+constexpr int REV_CAP = 64;
 __global__ void __launch_bounds__(256)
-rev_count_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, int *__restrict__ deg)
-{
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nedges) return;
-    const size_t pt = e / k;
-    const size_t b = pt / N;
-    atomicAdd(&deg[b * N + idx[e]], 1);
-}
-// one workgroup per block b: exclusive scan of deg[b][0..N) -> ptr[b][0..N)
-__global__ void __launch_bounds__(256)
-rev_scan_kernel(const int *__restrict__ deg, int N, int *__restrict__ ptr)
-{
-    __shared__ int part[256];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int per = (N + 255) / 256;
-    const int lo = min(tid * per, N), hi = min(lo + per, N);
-    int s = 0;
-    for (int n = lo; n < hi; ++n) s += deg[(size_t)b * N + n];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - s;
-    for (int n = lo; n < hi; ++n) {
-        ptr[(size_t)b * N + n] = run;
-        run += deg[(size_t)b * N + n];
-    }
-}
-__global__ void __launch_bounds__(256)
-rev_fill_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, const int *__restrict__ ptr,
-                int *__restrict__ cursor, int *__restrict__ src)
+rev_slot_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, int *__restrict__ cnt,
+                int *__restrict__ slot, int *__restrict__ ovf_cnt, int2 *__restrict__ ovf)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= nedges) return;
     const size_t pt = e / k;
     const size_t b = pt / N;
     const size_t tm = b * N + idx[e];
-    const int pos = ptr[tm] + atomicAdd(&cursor[tm], 1);
-    src[b * N * k + pos] = (int)(pt - b * N);
+    const int pos = atomicAdd(&cnt[tm], 1);
+    if (pos < REV_CAP) {
+        slot[tm * REV_CAP + pos] = (int)pt;
+    } else {
+        const int o = atomicAdd(ovf_cnt, 1);
+        ovf[o] = make_int2((int)tm, (int)pt);
+    }
 }
 // wave per target point, lane = channel
 __global__ void __launch_bounds__(256)
-rev_gather_kernel(const float *__restrict__ Q, const int *__restrict__ ptr, const int *__restrict__ deg,
-                  const int *__restrict__ src, int BN, int N, int k, float *__restrict__ SQ, float *__restrict__ indeg)
+rev_gather_kernel(const float *__restrict__ Q, const int *__restrict__ cnt, const int *__restrict__ slot,
+                  int BN, float *__restrict__ SQ, float *__restrict__ indeg)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int tm = blockIdx.x * 4 + wv; tm < BN; tm += gridDim.x * 4) {
-        const int b = tm / N;
-        const int d = deg[tm];
-        const int *lst = src + (size_t)b * N * k + ptr[tm];
+        const int d = cnt[tm];
+        const int dd = min(d, REV_CAP);
+        const int mine = (lane < dd) ? slot[(size_t)tm * REV_CAP + lane] : 0;
         float acc = 0.f;
-        for (int s0 = 0; s0 < d; s0 += 64) {
-            const int mine = (s0 + lane < d) ? lst[s0 + lane] : 0;
-            const int cnt = min(64, d - s0);
-            int s = 0;
-            for (; s + 4 <= cnt; s += 4) {
-                const float v0 = Q[((size_t)b * N + __shfl(mine, s + 0, 64)) * EC + lane];
-                const float v1 = Q[((size_t)b * N + __shfl(mine, s + 1, 64)) * EC + lane];
-                const float v2 = Q[((size_t)b * N + __shfl(mine, s + 2, 64)) * EC + lane];
-                const float v3 = Q[((size_t)b * N + __shfl(mine, s + 3, 64)) * EC + lane];
-                acc += (v0 + v1) + (v2 + v3);
-            }
-            for (; s < cnt; ++s) acc += Q[((size_t)b * N + __shfl(mine, s, 64)) * EC + lane];
+        int s = 0;
+        for (; s + 4 <= dd; s += 4) {
+            const float v0 = Q[(size_t)__shfl(mine, s + 0, 64) * EC + lane];
+            const float v1 = Q[(size_t)__shfl(mine, s + 1, 64) * EC + lane];
+            const float v2 = Q[(size_t)__shfl(mine, s + 2, 64) * EC + lane];
+            const float v3 = Q[(size_t)__shfl(mine, s + 3, 64) * EC + lane];
+            acc += (v0 + v1) + (v2 + v3);
         }
+        for (; s < dd; ++s) acc += Q[(size_t)__shfl(mine, s, 64) * EC + lane];
         SQ[(size_t)tm * EC + lane] = acc;
         if (lane == 0) indeg[tm] = (float)d;
+    }
+}
+// in-edges beyond REV_CAP (rare): wave per overflow entry, float atomics
+__global__ void __launch_bounds__(256)
+rev_overflow_kernel(const float *__restrict__ Q, const int *__restrict__ ovf_cnt, const int2 *__restrict__ ovf,
+                    float *__restrict__ SQ)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = *ovf_cnt;
+    for (int o = blockIdx.x * 4 + wv; o < n; o += gridDim.x * 4) {
+        const int2 en = ovf[o];
+        atomicAdd(&SQ[(size_t)en.x * EC + lane], Q[(size_t)en.y * EC + lane]);
     }
 }
 
@@ -925,7 +907,7 @@ struct Plan {
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
-    size_t off_deg, off_ptr, off_src;                                        // reverse graph (deg and cursor adjacent)
+    size_t off_cnt, off_slot, off_ovf;                                       // reverse graph (cnt[BN] | ovf_cnt)
     size_t total;
 };
 
@@ -969,9 +951,9 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_coef = take(sizeof(float) * CF_TOTAL);
     p.off_bpart = take(sizeof(float) * (size_t)BWD_PART * p.g_mfma);
     p.off_mu = take(sizeof(float) * 2 * EC);
-    p.off_deg = take(sizeof(int) * 2 * BN);            // deg | cursor
-    p.off_ptr = take(sizeof(int) * BN);
-    p.off_src = take(sizeof(int) * BN * (size_t)k);
+    p.off_cnt = take(sizeof(int) * (BN + 4));
+    p.off_slot = take(sizeof(int) * BN * (size_t)REV_CAP);
+    p.off_ovf = take(sizeof(int2) * BN * (size_t)k);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)(((C + 31) / 32) * 32) * p.g_pq);
     p.total = o;
     return p;
@@ -1123,22 +1105,21 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
     GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
     {   // reverse graph -> SQ, indeg
-        int *deg = reinterpret_cast<int *>(ws + p.off_deg), *cursor = deg + BN;
-        int *ptr = reinterpret_cast<int *>(ws + p.off_ptr), *src = reinterpret_cast<int *>(ws + p.off_src);
+        int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
+        int *slot = reinterpret_cast<int *>(ws + p.off_slot);
+        int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
         const size_t nedges = (size_t)BN * a->k;
-        if (hipMemsetAsync(deg, 0, sizeof(int) * 2 * (size_t)BN, st) != hipSuccess) {
+        if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), st) != hipSuccess) {
             set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
             return GFS3D_ERR_HIP;
         }
-        const unsigned eb = (unsigned)((nedges + 255) / 256);
-        hipLaunchKernelGGL(rev_count_kernel, dim3(eb), dim3(256), 0, st, a->idx, nedges, a->N, a->k, deg);
-        GFS3D_LAUNCH_CHECK("rev_count_kernel");
-        hipLaunchKernelGGL(rev_scan_kernel, dim3(a->B), dim3(256), 0, st, deg, a->N, ptr);
-        GFS3D_LAUNCH_CHECK("rev_scan_kernel");
-        hipLaunchKernelGGL(rev_fill_kernel, dim3(eb), dim3(256), 0, st, a->idx, nedges, a->N, a->k, ptr, cursor, src);
-        GFS3D_LAUNCH_CHECK("rev_fill_kernel");
-        hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->Q, ptr, deg, src, BN, a->N, a->k, a->SQ, a->indeg);
+        hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, st, a->idx, nedges, a->N, a->k,
+                           cnt, slot, ovf_cnt, ovf);
+        GFS3D_LAUNCH_CHECK("rev_slot_kernel");
+        hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->Q, cnt, slot, BN, a->SQ, a->indeg);
         GFS3D_LAUNCH_CHECK("rev_gather_kernel");
+        hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, st, a->Q, ovf_cnt, ovf, a->SQ);
+        GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
     }
     hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, part);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");

@@ -173,6 +173,34 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     assert relerr(bn2.bias.grad, pr["b.layer.4.bias"].grad) < TOL
 
 
+def test_edgeconv_backward_hub_point_overflows_slot_table(dev):
+    """A hub: one point is a neighbour of every other point (in-degree N-1 > the 64-entry slot
+    table of the reverse graph), so the overflow path of the backward runs."""
+    from gfs3d import ops
+    B, C, N, k = 1, 3, 256, 5
+    g = torch.Generator().manual_seed(11)
+    x = torch.nn.functional.normalize(torch.randn(B, C, N, generator=g), dim=1) * 10.0
+    x[:, :, 0] = 0.0
+    cot = torch.randn(B, 64, N, generator=g)
+    idx = torch.from_numpy(c_oracle.knn(x.numpy(), k))
+    assert int((idx == 0).any(-1).sum()) > 200
+    p = _block_params(C, 77)
+    pr = {kk: v.clone().requires_grad_("running" not in kk) for kk, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr, jr = R.conv_stack(R.edge_feature(xr, k, idx), pr, "b", 2, training=True, new_stats={}).max(dim=-1)
+    (yr * cot).sum().backward()
+    blk = _make_block(p, C, dev).train()
+    c1, bn1, c2, bn2 = blk.fused_parts()
+    xg = x.to(dev).requires_grad_(True)
+    y = ops.edgeconv_block(xg, idx.int().to(dev), c1.weight, bn1, c2.weight, bn2, True)
+    _force_routing(y, torch.gather(idx.unsqueeze(1).expand(B, 64, N, k), 3, jr.unsqueeze(-1)).squeeze(-1))
+    (y * cot.to(dev)).sum().backward()
+    assert maxerr(y, yr) < TOL
+    assert relerr(xg.grad, xr.grad) < TOL
+    assert relerr(c1.weight.grad, pr["b.layer.0.weight"].grad) < TOL
+    assert relerr(bn1.weight.grad, pr["b.layer.1.weight"].grad) < TOL
+
+
 def _force_routing(y, winner):
     """The arg-max over the k neighbours is decided by fp32 rounding whenever the two best
     values are within ~1e-6 (measured: 1-7 such (point, channel) pairs per layer in the golden
