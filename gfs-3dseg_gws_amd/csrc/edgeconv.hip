@@ -113,7 +113,7 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6;
         const double t = red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
-        partial[((size_t)blockIdx.x * 2 + which) * EC + lane] = t;
+        atomicAdd(&partial[which * EC + lane], t);          // 128 fp64 accumulators (zeroed by the launcher)
     }
 }
 
@@ -406,7 +406,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             double tsum = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) tsum += red[w][0][which][c] + red[w][1][which][c];
-            partial[((size_t)blockIdx.x * 2 + which) * EC + c] = tsum;
+            atomicAdd(&partial[which * EC + c], tsum);
         }
     }
 }
@@ -485,8 +485,7 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
     if (tid < 128) {
         const int which = tid >> 6;
         const double t = red[0][which][co] + red[1][which][co] + red[2][which][co] + red[3][which][co];
-        const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-        partial[(blk * 2 + which) * EC + co] = t;
+        atomicAdd(&partial[which * EC + co], t);
     }
 }
 
@@ -740,8 +739,8 @@ ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ 
     __syncthreads();
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6;
-        partial[((size_t)blockIdx.x * 2 + which) * EC + lane] =
-            red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
+        atomicAdd(&partial[which * EC + lane],
+                  red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
     }
 }
 // finalize: dbn1_b, dbn1_w, mu_dy, mu_dyx -> mu[2][64]
@@ -906,6 +905,7 @@ struct Plan {
     int tiles;          // ceil(N/64) * B
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
+    size_t off_acc;                                                      // 4 x 64 fp64 atomic accumulators (BN sums)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
     size_t off_cnt, off_slot, off_ovf;                                       // reverse graph (cnt[BN] | ovf_cnt)
     size_t total;
@@ -938,6 +938,7 @@ static Plan make_plan(int B, int C, int N, int k)
         if ((size_t)2 * EC * CPp > w) w = (size_t)2 * EC * CPp;
         p.off_dred = take(sizeof(double) * w);
     }
+    p.off_acc = take(sizeof(double) * 4 * EC);
     p.off_hmax = take(sizeof(float) * BN * EC);
     p.off_hmin = take(sizeof(float) * BN * EC);
     p.off_jmax = take(BN * EC);
@@ -1014,18 +1015,18 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
         hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
         GFS3D_LAUNCH_CHECK("ec_pq_kernel");
     }
+    double *acc1 = reinterpret_cast<double *>(ws + p.off_acc), *acc2 = acc1 + 2 * EC;
     if (a->training) {
+        if (hipMemsetAsync(acc1, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+            set_error("gfs3d_edgeconv_forward_f32: hipMemsetAsync failed");
+            return GFS3D_ERR_HIP;
+        }
         ProfScope prof(4, st);
         hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
-                           a->SP, part);
+                           a->SP, acc1);
         GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
     }
-    double *dred = reinterpret_cast<double *>(ws + p.off_dred);
-    if (a->training) {
-        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
-        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn1)");
-    }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn1_w, a->bn1_b,
+    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc1, 1, count, a->bn1_w, a->bn1_b,
                        a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
     GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
     float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
@@ -1035,14 +1036,10 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
         GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         ProfScope prof(1, st);
         hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
-                           BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, part);
+                           BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, acc2);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     }
-    if (a->training) {
-        hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_mfma, 2 * EC, dred);
-        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn2)");
-    }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, a->bn2_w, a->bn2_b,
+    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, a->bn2_w, a->bn2_b,
                        a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN2);
     GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(2)");
     hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, a->stats, a->N, a->slope,
@@ -1078,12 +1075,15 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
     dim3 tgrid((a->N + 63) / 64, a->B);
 
+    double *acc1 = reinterpret_cast<double *>(ws + p.off_acc), *acc2 = acc1 + 2 * EC;
+    if (hipMemsetAsync(acc1, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+        set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
+        return GFS3D_ERR_HIP;
+    }
     hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, a->y_pm, a->hsel, a->stats,
-                       a->N, a->slope, g, part);
+                       a->N, a->slope, g, acc1);
     GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
-    hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.tiles, 2 * EC, dred);
-    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(prep)");
-    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, dred, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
+    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, acc1, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
     GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
     if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
         set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
@@ -1121,11 +1121,9 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
         hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, st, a->Q, ovf_cnt, ovf, a->SQ);
         GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
     }
-    hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, part);
+    hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
-    hipLaunchKernelGGL(reduce_parts_kernel<double>, dim3(2), dim3(1024), 0, st, part, p.g_heavy, 2 * EC, dred);
-    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bn1 bwd)");
-    hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, dred, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
+    hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
     GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
     {
         const int CP = ((a->C + 31) / 32) * 32;
