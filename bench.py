@@ -46,6 +46,16 @@ def algorithmic_flops(kid, B):
     return 0, 0
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r01_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("traffic_bytes_per_launch")
+    except OSError:
+        return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (torch-CPU restatement of model/dgcnn.py, kind='port') timed on this
     host's cores on a bounded sample: B=8 blocks of the same workload, fwd+bwd."""
@@ -143,9 +153,14 @@ def main():
         avg_ms = ms / n
         achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": hbm_traffic(KERNELS[dom]),
                 "avg_launch_ms": round(avg_ms, 4), "launches": n,
                 "per_kernel_ms_per_step": {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}}
+        if 0 in prof:       # "kNN HBM GB/s" of the metric: algorithmic bytes 4CN + 8Nk per block and layer
+            kb = B_PER_GPU * sum(4 * C * NPTS + 8 * NPTS * KNN for C in (CIN, 64, 64))
+            kms = prof[0][0] / args.steps
+            roof["knn"] = {"ms_per_step": round(kms, 4), "algorithmic_GBps": round(kb / (kms * 1e-3) / 1e9, 2),
+                           "algorithmic_TFLOPps": round(algorithmic_flops(0, B_PER_GPU)[0] / (kms * 1e-3) / 1e12, 2)}
         ms_step = elapsed / args.steps * 1e3
         line = {
             "metric": "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd", "value": round(world * B_PER_GPU / (elapsed / args.steps), 2),
