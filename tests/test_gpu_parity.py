@@ -421,3 +421,25 @@ def test_kmeans_assign_vs_oracle(dev):
     cent, lab, inert, _ = device_kmeans(pts, 12, init=init, max_iter=300, tol=0.0)
     assert maxerr(cent, g["km_centers"]) < 1e-4
     assert np.array_equal(lab.cpu().numpy(), g["km_labels"].astype(np.int64))
+
+
+def test_harness_vs_reference_golden(dev):
+    """the batched device harness reproduces what the reference's B=1 loops in
+    train.py produce (golden 15): novel prototypes, novel / base / background word codings."""
+    from gfs3d import harness
+    g = load_golden("harness")
+    m = _capl(g, dev).eval()
+    xs = torch.from_numpy(g["x"]).to(dev)
+    masks = torch.from_numpy(g["masks"]).to(dev)
+    cls_ids = [int(c) for c in g["cls_ids"]]
+    supp = [(xs[i:i + 1], masks[i:i + 1], torch.tensor([cls_ids[i]])) for i in range(len(cls_ids))]
+    gened, coding = harness.get_new_proto_Geo2SemProto(supp, m, base_num=7, novel_num=3, novel_class_list=[7, 8, 9],
+                                                       energy=0.9, batch=2)
+    assert maxerr(gened, g["gened_proto"]) < TOL
+    assert float((coding.cpu().numpy() == g["novel_coding"]).mean()) >= 0.99
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    loader = [(xs[0:2], labels[0:2], None), (xs[2:5], labels[2:5], None)]          # two batches instead of five B=1 items
+    random.seed(0)
+    base, bg = harness.collect_base_class_gp_coding_sum(m, loader, train_class=np.arange(3), energy=0.9)
+    assert float((base.cpu().numpy() == g["base_coding"]).mean()) >= 0.99
+    assert maxerr(bg, g["bg_coding"]) < 1e-5
