@@ -443,3 +443,42 @@ def test_harness_vs_reference_golden(dev):
     base, bg = harness.collect_base_class_gp_coding_sum(m, loader, train_class=np.arange(3), energy=0.9)
     assert float((base.cpu().numpy() == g["base_coding"]).mean()) >= 0.99
     assert maxerr(bg, g["bg_coding"]) < 1e-5
+
+
+def test_get_edge_feature_vs_reference_golden(dev):
+    from model.dgcnn import get_edge_feature
+    g = load_golden("edge_feature")
+    x, idx = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["idx"]).to(dev)
+    assert maxerr(get_edge_feature(x, K=6, idx=idx), g["out"]) == 0.0
+    auto = get_edge_feature(x, K=6)                       # kNN from the HIP kernel
+    assert auto.shape == g["out_auto"].shape and maxerr(auto, g["out_auto"]) < 1e-6
+
+
+def test_dgcnnseg_features_vs_reference_golden(dev):
+    """get_basis.DGCNNSeg(return_feat=True) - golden (14)."""
+    from get_basis import DGCNNSeg
+    g = load_golden("dgcnnseg")
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20)
+    seg = DGCNNSeg(a, num_classes=8)
+    seg.load_state_dict(state_dict_from(g))
+    seg = seg.to(dev).eval()
+    with torch.no_grad():
+        logits, feat = seg(torch.from_numpy(g["x"]).to(dev), return_feat=True)
+    assert maxerr(feat, g["feat"]) < TOL
+    assert maxerr(logits, g["logits"]) < 1e-3
+
+
+def test_extract_geometric_words_end_to_end(dev):
+    """get_basis pipeline on synthetic blocks: features -> device k-means -> per-cluster means ->
+    SVD reconstruction; the words must be finite, of the right shape and reproduce themselves
+    when re-run (fixed seeds)."""
+    from get_basis import DGCNNSeg, extract_geometric_words
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20)
+    torch.manual_seed(0)
+    seg = DGCNNSeg(a, num_classes=4).to(dev)
+    blocks = R.synthetic_blocks(6, 512, seed=21)
+    labels = torch.randint(0, 4, (6, 512), generator=torch.Generator().manual_seed(2))
+    w1 = extract_geometric_words(seg, blocks, labels, num_classes=4, num_cnt=16, max_per_class=600, batch=4, seed=0, max_iter=20)
+    w2 = extract_geometric_words(seg, blocks, labels, num_classes=4, num_cnt=16, max_per_class=600, batch=4, seed=0, max_iter=20)
+    assert w1.shape == (16, 192) and np.isfinite(w1).all()
+    assert np.abs(w1 - w2).max() < 1e-3
