@@ -83,6 +83,10 @@ def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0)
     n_iter = 0
     for n_iter in range(1, max_iter + 1):
         _, sums, counts, _ = ops.kmeans_assign(points, cent)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # points sharded over ranks: one all-reduce of (K x D sums, K counts) per Lloyd iteration
+            torch.distributed.all_reduce(sums)
+            torch.distributed.all_reduce(counts)
         new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
         shift = float(((new - cent) ** 2).sum())
         cent = new

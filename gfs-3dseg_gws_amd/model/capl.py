@@ -173,15 +173,30 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         of the batch as 'fake novel' (python RNG, as the reference) and replace their
         prototype by the L2-normalised masked feature mean.  Returns (proto, fake_novel)."""
         labels = y.unsqueeze(1)
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
         if fake_novel is None:
-            present = [int(v) for v in labels.unique().tolist() if int(v) != 0]
+            if dp:
+                # block-sharded batch: the class set is the union over ranks (one MAX all-reduce of a
+                # presence vector); every rank then draws the SAME sample (python RNG seeded alike
+                # on all ranks, as train.py does)
+                seen = torch.zeros(main_proto.size(0) + 1, dtype=torch.int32, device=y.device)
+                seen[labels.unique().long().clamp_max(main_proto.size(0))] = 1
+                torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
+                present = [int(v) for v in torch.nonzero(seen).flatten().tolist() if int(v) != 0]
+            else:
+                present = [int(v) for v in labels.unique().tolist() if int(v) != 0]
             fake_novel = random.sample(present, len(present) // 2)
         proto = _unit(main_proto, 1)
         feat = _unit(x, 1)
         for cls in fake_novel:
             cls = int(cls)
             m = (labels == cls).to(feat.dtype)
-            mean = (feat * m).sum(0).sum(-1) / (m.sum(0).sum(-1) + _EPS)
+            num, den = (feat * m).sum(0).sum(-1), m.sum(0).sum(-1)
+            if dp:   # masked mean over the GLOBAL support half: differentiable SUM all-reduce of (sum, count)
+                from torch.distributed.nn.functional import all_reduce as _ar
+                num, den = _ar(num), _ar(den)
+            mean = num / (den + _EPS)
             if post_processing:
                 mean = self.post_processing_hard_coding(mean)
             pick = torch.zeros(proto.size(0), 1, dtype=proto.dtype, device=proto.device)

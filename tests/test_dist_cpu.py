@@ -55,6 +55,22 @@ def _worker(rank, world, port, out):
                             list(g["order"]))
     res["metric"] = np.array(r[:4])
     res["max"] = gd.max_over_ranks(float(rank), "cpu")
+    # 4. generate_fake_proto on a block-sharded support half == the single-process result on the whole half
+    import random, types
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    gc = np.load(os.path.join(here, "golden", "capl.npz"))
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                              base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(0)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, args=a, base_num=7, gp=torch.from_numpy(gc["gp"]), energy=0.9)
+    pf = torch.from_numpy(gc["gf_point"]).clone().requires_grad_(True)      # (4,128,256)
+    yy = torch.from_numpy(gc["gfp_y"])
+    lo, hi = gd.shard_range(4)
+    random.seed(0)
+    proto, chosen = m.generate_fake_proto(pf[lo:hi], yy[lo:hi], m.main_proto.detach().clone())
+    proto.sum().backward()
+    res["fake_proto"], res["fake_chosen"] = proto.detach().numpy(), sorted(int(c) for c in chosen)
+    res["fake_grad"] = pf.grad.numpy().copy()
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -73,3 +89,22 @@ def test_dp_helpers_world2_gloo():
     ref = load_golden("metric")["res"]
     assert np.allclose(a["metric"], ref, atol=1e-12) and np.allclose(b["metric"], ref, atol=1e-12)
     assert a["max"] == 1.0 and b["max"] == 1.0
+    # single-process reference for (4)
+    import random, types, sys
+    from conftest import PKG
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    gc = load_golden("capl")
+    ar = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                               base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(0)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, args=ar, base_num=7, gp=torch.from_numpy(gc["gp"]), energy=0.9)
+    pf = torch.from_numpy(gc["gf_point"]).clone().requires_grad_(True)
+    random.seed(0)
+    proto, chosen = m.generate_fake_proto(pf, torch.from_numpy(gc["gfp_y"]), m.main_proto.detach().clone())
+    proto.sum().backward()
+    assert a["fake_chosen"] == b["fake_chosen"] == sorted(int(c) for c in chosen)
+    assert np.abs(a["fake_proto"] - proto.detach().numpy()).max() < 1e-6
+    assert np.abs(b["fake_proto"] - proto.detach().numpy()).max() < 1e-6
+    # every rank back-propagates the same global prototype: summed shard gradients = 2x the single-process one
+    full = a["fake_grad"] + b["fake_grad"]
+    assert np.abs(full - 2 * pf.grad.numpy()).max() < 1e-5 * max(1.0, np.abs(pf.grad.numpy()).max())
