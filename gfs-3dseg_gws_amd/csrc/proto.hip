@@ -274,6 +274,169 @@ kmeans_assign_kernel(const float *__restrict__ pts, long long M, int C, const fl
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// k-means on the matrix pipe (K <= 256 centroids).
+//   assign:  D[k][m] = <c_k, p_m>  exactly like the prototype kernel (A = centroid rows from the
+//            padded LDS chunk, B = points; points are ROW-major here, so a lane reads 16-B pieces of
+//            its own row); epilogue: arg-min_k (|c_k|^2 - 2 D), label, count, inertia.
+//   sums:    S[k][c] = sum_m [label_m == k] p_m[c]  as a one-hot GEMM: A[k][m] is built on the fly
+//            from the labels (LDS), B[m][c] are 128-B coalesced row pieces; every workgroup owns one
+//            32-channel column tile and 4096 points, 2 centroid row-tiles per wave; partial tiles are
+//            added to the global sums with 128-B float-atomic rows.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256)
+kmeans_assign_mfma_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ cent, int K,
+                          int32_t *__restrict__ label, float *__restrict__ counts, double *__restrict__ inertia)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *gs = smem;                          // [NT*32][PR_LD]
+    float *cn = gs + NT * 32 * PR_LD;          // [NT*32] |c_k|^2
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m = (long long)blockIdx.x * 128 + wv * 32 + j;
+    const long long mc = m < M ? m : M - 1;
+    const float *prow = pts + (size_t)mc * C;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float psq = 0.f, csq = 0.f;
+    for (int c0 = 0; c0 < C; c0 += PR_CH) {
+        __syncthreads();
+        for (int e = tid; e < NT * 32 * PR_CH; e += 256) {
+            const int w = e >> 6, cc = e & 63;
+            gs[w * PR_LD + cc] = (w < K && c0 + cc < C) ? cent[(size_t)w * C + c0 + cc] : 0.f;
+        }
+        float f[32];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int c = c0 + 8 * t + 4 * h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = (c + u < C) ? prow[c + u] : 0.f;
+                f[4 * t + u] = v;
+                psq = fmaf(v, v, psq);
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 32) {
+            const float *row = gs + tid * PR_LD;
+#pragma unroll 8
+            for (int cc = 0; cc < PR_CH; ++cc) csq = fmaf(row[cc], row[cc], csq);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+#pragma unroll
+            for (int wt = 0; wt < NT; ++wt) {
+                const float4 a = *reinterpret_cast<const float4 *>(gs + (wt * 32 + j) * PR_LD + 8 * t + 4 * h);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f[4 * t + 0], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f[4 * t + 1], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f[4 * t + 2], acc[wt], 0, 0, 0);
+                acc[wt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f[4 * t + 3], acc[wt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NT * 32) cn[tid] = csq;
+    __syncthreads();
+    psq += __shfl_xor(psq, 32, 64);
+    float best = __builtin_inff();
+    int bk = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            const float d = cn[w] - 2.f * acc[t][r];            // + |p|^2, constant per point
+            if (w < K && (d < best || (d == best && w < bk))) { best = d; bk = w; }
+        }
+    {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int ok = __shfl_xor(bk, 32, 64);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+    }
+    double contrib = 0.0;
+    if (h == 0 && m < M) {
+        label[m] = bk;
+        atomicAdd(&counts[bk], 1.0f);
+        contrib = (double)fmaxf(best + psq, 0.f);
+    }
+    if (inertia) {
+        contrib = wave_sum(contrib);
+        if (lane == 0) atomicAdd(inertia, contrib);
+    }
+}
+
+constexpr int KM_CHUNK = 4096;     // points per workgroup of the sums kernel
+__global__ void __launch_bounds__(256)
+kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K, const int32_t *__restrict__ label,
+                        float *__restrict__ sums)
+{
+    __shared__ int slab[KM_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * KM_CHUNK;
+    const int c = blockIdx.y * 32 + j;                     // this lane's output channel
+    const int cc = min(c, C - 1);
+    for (int e = tid; e < KM_CHUNK; e += 256) slab[e] = (m0 + e < M) ? label[m0 + e] : -1;
+    __syncthreads();
+    const int k0 = wv * 32 + j, k1 = (wv + 4) * 32 + j;    // centroid rows of this lane in the wave's two row tiles
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const bool two = (wv + 4) * 32 < K;                    // second row tile in range (wave-uniform)
+    const int nsteps = (int)((M - m0 < KM_CHUNK ? M - m0 : KM_CHUNK) + 1) / 2;
+    for (int s0 = 0; s0 < nsteps; s0 += 8) {
+        float bv[8];
+        int lb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = 2 * (s0 + u) + h;
+            const long long mm = m0 + e;
+            bv[u] = pts[(size_t)(mm < M ? mm : M - 1) * C + cc];
+            lb[u] = slab[e < KM_CHUNK ? e : KM_CHUNK - 1];
+            if (e >= KM_CHUNK || s0 + u >= nsteps) lb[u] = -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lb[u] == k0 ? 1.f : 0.f, bv[u], acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lb[u] == k1 ? 1.f : 0.f, bv[u], acc1, 0, 0, 0);
+        }
+    }
+    if (c < C) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ka = wv * 32 + acc_row(r, h), kb = (wv + 4) * 32 + acc_row(r, h);
+            if (ka < K && acc0[r] != 0.f) atomicAdd(&sums[(size_t)ka * C + c], acc0[r]);
+            if (two && kb < K && acc1[r] != 0.f) atomicAdd(&sums[(size_t)kb * C + c], acc1[r]);
+        }
+    }
+}
+
+template <int NT>
+static int launch_kmeans(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums,
+                         float *counts, double *inertia, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_mfma_kernel<NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("gfs3d_kmeans_assign_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+    }
+    ProfScope prof(5, st);
+    hipLaunchKernelGGL((kmeans_assign_mfma_kernel<NT>), dim3((unsigned)((M + 127) / 128)), dim3(256), lds, st,
+                       pts, M, C, cent, K, label, counts, inertia);
+    GFS3D_LAUNCH_CHECK("kmeans_assign_mfma_kernel");
+    hipLaunchKernelGGL(kmeans_sums_mfma_kernel, dim3((unsigned)((M + KM_CHUNK - 1) / KM_CHUNK), (C + 31) / 32), dim3(256), 0, st,
+                       pts, M, C, K, label, sums);
+    GFS3D_LAUNCH_CHECK("kmeans_sums_mfma_kernel");
+    return GFS3D_OK;
+}
+
 }  // namespace gfs3d
 
 extern "C" int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, int B, int C, int N,
@@ -308,7 +471,15 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(pts && cent && label && sums && counts, "gfs3d_kmeans_assign_f32: NULL pointer");
-    GFS3D_REQUIRE(M >= 1 && C >= 1 && C <= 256 && K >= 1, "gfs3d_kmeans_assign_f32: bad shape M=%lld C=%d K=%d", M, C, K);
+    GFS3D_REQUIRE(M >= 1 && C >= 1 && K >= 1 && (K <= 256 || C <= 256), "gfs3d_kmeans_assign_f32: bad shape M=%lld C=%d K=%d", M, C, K);
+    if (K <= 256 && (M + 127) / 128 < (1ll << 31)) {           // matrix-pipe path
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int nt = (K + 31) / 32;
+        if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st);
+        if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st);
+        if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st);
+        return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st);
+    }
     const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_kernel),

@@ -482,3 +482,28 @@ def test_extract_geometric_words_end_to_end(dev):
     w2 = extract_geometric_words(seg, blocks, labels, num_classes=4, num_cnt=16, max_per_class=600, batch=4, seed=0, max_iter=20)
     assert w1.shape == (16, 192) and np.isfinite(w1).all()
     assert np.abs(w1 - w2).max() < 1e-3
+
+
+@pytest.mark.parametrize("M,C,K", [(5000, 192, 200), (4097, 64, 33), (130, 7, 3), (70000, 192, 256)])
+def test_kmeans_assign_mfma_vs_fp64(dev, M, C, K):
+    """Lloyd step on the matrix pipe: labels vs an fp64 arg-min (identical wherever the best two
+    centroids are separated by more than fp32 rounding), sums / counts / inertia consistent with the
+    labels the kernel itself produced."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(M + K)
+    cent = torch.randn(K, C, generator=g)
+    pts = cent[torch.randint(0, K, (M,), generator=g)] + 0.5 * torch.randn(M, C, generator=g)
+    label, sums, counts, inertia = ops.kmeans_assign(pts.to(dev), cent.to(dev))
+    d = torch.cdist(pts.double(), cent.double()) ** 2
+    ref = d.argmin(1)
+    lab = label.cpu().long()
+    top2 = torch.topk(d, 2, dim=1, largest=False)[0]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]
+    assert bool((lab[clear] == ref[clear]).all())
+    assert float((lab == ref).float().mean()) > 0.999
+    exp_sums = torch.zeros(K, C, dtype=torch.float64).index_add_(0, lab, pts.double())
+    exp_cnt = torch.bincount(lab, minlength=K).double()
+    assert maxerr(counts, exp_cnt) == 0.0
+    assert maxerr(sums, exp_sums) < 1e-3 * max(1.0, float(exp_sums.abs().max()))
+    exp_inertia = float(d[torch.arange(M), lab].sum())
+    assert abs(float(inertia) - exp_inertia) < 1e-3 * exp_inertia
