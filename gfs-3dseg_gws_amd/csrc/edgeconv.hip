@@ -496,13 +496,16 @@ enum { CF_A = 0, CF_BC = 64, CF_CC = 128, CF_TOTAL = 192 };
 //     dh2 = A*route + Bc + Cc*h2   with  A = gamma2*rstd2 (= scale2),
 //     Bc = -A (m1 - mean2 rstd2 m2),  Cc = -A rstd2 m2,  m1 = mean(dy2), m2 = mean(dy2 xhat2).
 __global__ void __launch_bounds__(64)
-ec_bwd_coef_kernel(const double *__restrict__ red, double count, const float *__restrict__ stats,
+ec_bwd_coef_kernel(const double *__restrict__ red, const double *__restrict__ red_local, double count,
+                   const float *__restrict__ stats,
                    float *__restrict__ dbn2_w, float *__restrict__ dbn2_b, float *__restrict__ coef)
 {
+    // red = sums over the WHOLE (possibly multi-rank) batch -> the means of the BN backward;
+    // red_local = this rank's sums -> this rank's share of dgamma/dbeta (summed later by the gradient all-reduce)
     const int c = threadIdx.x;
     const double s = red[c], sx = red[EC + c];
-    dbn2_b[c] = (float)s;
-    dbn2_w[c] = (float)sx;
+    dbn2_b[c] = (float)red_local[c];
+    dbn2_w[c] = (float)red_local[EC + c];
     const double m1 = s / count, m2 = sx / count;
     const double A = stats[ST_SCALE2 * EC + c];
     const double mean2 = stats[ST_MEAN2 * EC + c], rstd2 = stats[ST_RSTD2 * EC + c];
@@ -744,17 +747,13 @@ ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ 
     }
 }
 // finalize: dbn1_b, dbn1_w, mu_dy, mu_dyx -> mu[2][64]
-__global__ void ec_bwd_bn1_final_kernel(const double *__restrict__ partial, int nparts, double count,
+__global__ void ec_bwd_bn1_final_kernel(const double *__restrict__ partial, const double *__restrict__ local, double count,
                                         float *__restrict__ dbn1_w, float *__restrict__ dbn1_b, float *__restrict__ mu)
 {
     const int c = threadIdx.x;
-    double s = 0.0, sx = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        s += partial[((size_t)p * 2 + 0) * EC + c];
-        sx += partial[((size_t)p * 2 + 1) * EC + c];
-    }
-    dbn1_b[c] = (float)s;
-    dbn1_w[c] = (float)sx;
+    const double s = partial[c], sx = partial[EC + c];      // whole-batch sums (see ec_bwd_coef_kernel)
+    dbn1_b[c] = (float)local[c];
+    dbn1_w[c] = (float)local[EC + c];
     mu[c] = (float)(s / count);
     mu[EC + c] = (float)(sx / count);
 }
@@ -938,7 +937,7 @@ static Plan make_plan(int B, int C, int N, int k)
         if ((size_t)2 * EC * CPp > w) w = (size_t)2 * EC * CPp;
         p.off_dred = take(sizeof(double) * w);
     }
-    p.off_acc = take(sizeof(double) * 4 * EC);
+    p.off_acc = take(sizeof(double) * 8 * EC);
     p.off_hmax = take(sizeof(float) * BN * EC);
     p.off_hmin = take(sizeof(float) * BN * EC);
     p.off_jmax = take(BN * EC);
@@ -986,51 +985,44 @@ extern "C" size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k)
     return gfs3d::make_plan(B, C, N, k).total;
 }
 
-extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *stream)
+namespace gfs3d {
+// accumulator block (fp64): [0:128] stage-A sums, [128:256] stage-B sums, [256:384] / [384:512] this
+// rank's copies of A / B taken before the caller all-reduces A / B across ranks (synchronised BN)
+constexpr int ACC_DOUBLES = 8 * EC;
+
+static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_user, double stat_count, hipStream_t st)
 {
-    using namespace gfs3d;
-    int rc = check_args(a, "gfs3d_edgeconv_forward_f32");
-    if (rc) return rc;
-    GFS3D_REQUIRE(a->y_cf || a->y_pm, "gfs3d_edgeconv_forward_f32: no output buffer");
-    GFS3D_REQUIRE(a->training || (a->bn1_rm && a->bn1_rv && a->bn2_rm && a->bn2_rv),
-                  "gfs3d_edgeconv_forward_f32: eval mode needs running statistics");
-    if (a->training)
-        GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm,
-                      "gfs3d_edgeconv_forward_f32: training mode needs SP/SQ/indeg/hsel/jsel/y_pm buffers");
-    GFS3D_REQUIRE(!a->y_cf || a->y_cf_bstride >= (long long)EC * a->N, "gfs3d_edgeconv_forward_f32: bad y_cf_bstride");
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    const char *who = "gfs3d_edgeconv_forward_f32";
     const Plan p = make_plan(a->B, a->C, a->N, a->k);
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
-    const double count = (double)BN * a->k;
-    double *part = reinterpret_cast<double *>(ws + p.off_part);
+    const double count = stat_count > 0.0 ? stat_count : (double)BN * a->k;
     float *hmax = reinterpret_cast<float *>(ws + p.off_hmax), *hmin = reinterpret_cast<float *>(ws + p.off_hmin);
     uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax), *jmin = reinterpret_cast<uint8_t *>(ws + p.off_jmin);
+    double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
+    double *acc1 = acc, *acc2 = acc + 2 * EC;
+    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
-
-    {   // F1
+    if (phase == 0) {
         const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
         GFS3D_LAUNCH_CHECK("ec_pq_kernel");
-    }
-    double *acc1 = reinterpret_cast<double *>(ws + p.off_acc), *acc2 = acc1 + 2 * EC;
-    if (a->training) {
-        if (hipMemsetAsync(acc1, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
-            set_error("gfs3d_edgeconv_forward_f32: hipMemsetAsync failed");
-            return GFS3D_ERR_HIP;
+        if (a->training) {
+            if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+                set_error("%s: hipMemsetAsync failed", who);
+                return GFS3D_ERR_HIP;
+            }
+            ProfScope prof(4, st);
+            hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
+                               a->SP, acc1);
+            GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
         }
-        ProfScope prof(4, st);
-        hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
-                           a->SP, acc1);
-        GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
-    }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc1, 1, count, a->bn1_w, a->bn1_b,
-                       a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
-    GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
-    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
-    {   // F3b + F4
+    } else if (phase == 1) {
+        hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc1, 1, count, a->bn1_w, a->bn1_b,
+                           a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
+        GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
         const size_t total = (size_t)BN * EC;
         hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
         GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
@@ -1038,34 +1030,25 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
         hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, acc2);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
+    } else {
+        hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, a->bn2_w, a->bn2_b,
+                           a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN2);
+        GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(2)");
+        hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, a->stats, a->N, a->slope,
+                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel);
+        GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
     }
-    hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, a->bn2_w, a->bn2_b,
-                       a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN2);
-    GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(2)");
-    hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, a->stats, a->N, a->slope,
-                       a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel);
-    GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
     return GFS3D_OK;
 }
 
-extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, void *stream)
+static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *acc_user, double stat_count, hipStream_t st)
 {
-    using namespace gfs3d;
-    GFS3D_REQUIRE(ba != nullptr, "gfs3d_edgeconv_backward_f32: args is NULL");
+    const char *who = "gfs3d_edgeconv_backward_f32";
     const gfs3d_edgeconv_args *a = &ba->f;
-    int rc = check_args(a, "gfs3d_edgeconv_backward_f32");
-    if (rc) return rc;
-    GFS3D_REQUIRE(a->training, "gfs3d_edgeconv_backward_f32: only the training-mode (batch statistics) backward exists");
-    GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm, "gfs3d_edgeconv_backward_f32: NULL saved buffer");
-    GFS3D_REQUIRE(ba->dy_cf && ba->dx && ba->dw1 && ba->dbn1_w && ba->dbn1_b && ba->dw2 && ba->dbn2_w && ba->dbn2_b,
-                  "gfs3d_edgeconv_backward_f32: NULL gradient buffer");
-    GFS3D_REQUIRE(ba->dy_bstride >= (long long)EC * a->N, "gfs3d_edgeconv_backward_f32: bad dy_bstride");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const Plan p = make_plan(a->B, a->C, a->N, a->k);
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
-    const double count = (double)BN * a->k;
-    double *part = reinterpret_cast<double *>(ws + p.off_part);
+    const double count = stat_count > 0.0 ? stat_count : (double)BN * a->k;
     float *g = reinterpret_cast<float *>(ws + p.off_g);
     float *GP = reinterpret_cast<float *>(ws + p.off_GP), *GQ = reinterpret_cast<float *>(ws + p.off_GQ);
     float *coef = reinterpret_cast<float *>(ws + p.off_coef);
@@ -1073,59 +1056,69 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
     double *dred = reinterpret_cast<double *>(ws + p.off_dred);
     float *mu = reinterpret_cast<float *>(ws + p.off_mu);
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
+    double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
+    double *acc1 = acc, *acc2 = acc + 2 * EC, *loc1 = acc + 4 * EC, *loc2 = acc + 6 * EC;
     dim3 tgrid((a->N + 63) / 64, a->B);
-
-    double *acc1 = reinterpret_cast<double *>(ws + p.off_acc), *acc2 = acc1 + 2 * EC;
-    if (hipMemsetAsync(acc1, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
-        set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
-        return GFS3D_ERR_HIP;
-    }
-    hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, a->y_pm, a->hsel, a->stats,
-                       a->N, a->slope, g, acc1);
-    GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
-    hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, acc1, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
-    GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
-    if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
-        set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
-        return GFS3D_ERR_HIP;
-    }
-    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
-    {
-        const size_t total = (size_t)BN * EC;
-        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
-        GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
-        const size_t lds = sizeof(float) * (EC * TLD + 4 * (32 * TLD + 32));
-        ProfScope prof(2, st);
-        hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_mfma), dim3(256), lds, st, Pp, Qp, a->idx, a->w2, coef,
-                           g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
-        GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
-    }
-    hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_mfma, BWD_PART, dred);
-    GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
-    hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
-    GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
-    {   // reverse graph -> SQ, indeg
-        int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
-        int *slot = reinterpret_cast<int *>(ws + p.off_slot);
-        int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
-        const size_t nedges = (size_t)BN * a->k;
-        if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), st) != hipSuccess) {
-            set_error("gfs3d_edgeconv_backward_f32: hipMemsetAsync failed");
+    if (phase == 0) {
+        if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
-        hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, st, a->idx, nedges, a->N, a->k,
-                           cnt, slot, ovf_cnt, ovf);
-        GFS3D_LAUNCH_CHECK("rev_slot_kernel");
-        hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->Q, cnt, slot, BN, a->SQ, a->indeg);
-        GFS3D_LAUNCH_CHECK("rev_gather_kernel");
-        hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, st, a->Q, ovf_cnt, ovf, a->SQ);
-        GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
-    }
-    hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
-    GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
-    hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, ba->dbn1_w, ba->dbn1_b, mu);
-    GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
-    {
+        hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, a->y_pm, a->hsel, a->stats,
+                           a->N, a->slope, g, acc1);
+        GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
+        if (hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("%s: hipMemcpyAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+    } else if (phase == 1) {
+        hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, acc1, loc1, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
+        GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
+        if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+        float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
+        {
+            const size_t total = (size_t)BN * EC;
+            hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
+            GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+            const size_t lds = sizeof(float) * (EC * TLD + 4 * (32 * TLD + 32));
+            ProfScope prof(2, st);
+            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_mfma), dim3(256), lds, st, Pp, Qp, a->idx, a->w2, coef,
+                               g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
+            GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
+        }
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_mfma, BWD_PART, dred);
+        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
+        hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
+        GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
+        {   // reverse graph -> SQ, indeg
+            int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
+            int *slot = reinterpret_cast<int *>(ws + p.off_slot);
+            int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
+            const size_t nedges = (size_t)BN * a->k;
+            if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), st) != hipSuccess) {
+                set_error("%s: hipMemsetAsync failed", who);
+                return GFS3D_ERR_HIP;
+            }
+            hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, st, a->idx, nedges, a->N, a->k,
+                               cnt, slot, ovf_cnt, ovf);
+            GFS3D_LAUNCH_CHECK("rev_slot_kernel");
+            hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->Q, cnt, slot, BN, a->SQ, a->indeg);
+            GFS3D_LAUNCH_CHECK("rev_gather_kernel");
+            hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, st, a->Q, ovf_cnt, ovf, a->SQ);
+            GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
+        }
+        hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
+        GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
+        if (hipMemcpyAsync(loc2, acc2, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("%s: hipMemcpyAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+    } else {
+        hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, acc2, loc2, count, ba->dbn1_w, ba->dbn1_b, mu);
+        GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
         const int CP = ((a->C + 31) / 32) * 32;
         const size_t lds = sizeof(float) * (2 * 64 * PQ_LD + 2 * (size_t)CP * PQ_LD + 64 * (size_t)(CP + 1));
         if (lds > 64 * 1024)
@@ -1140,4 +1133,66 @@ extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, vo
         GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
     }
     return GFS3D_OK;
+}
+
+static int check_fwd(const gfs3d_edgeconv_args *a, const char *who)
+{
+    int rc = check_args(a, who);
+    if (rc) return rc;
+    GFS3D_REQUIRE(a->y_cf || a->y_pm, "%s: no output buffer", who);
+    GFS3D_REQUIRE(a->training || (a->bn1_rm && a->bn1_rv && a->bn2_rm && a->bn2_rv), "%s: eval mode needs running statistics", who);
+    if (a->training)
+        GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm,
+                      "%s: training mode needs SP/SQ/indeg/hsel/jsel/y_pm buffers", who);
+    GFS3D_REQUIRE(!a->y_cf || a->y_cf_bstride >= (long long)EC * a->N, "%s: bad y_cf_bstride", who);
+    return GFS3D_OK;
+}
+
+static int check_bwd(const gfs3d_edgeconv_bwd_args *ba, const char *who)
+{
+    GFS3D_REQUIRE(ba != nullptr, "%s: args is NULL", who);
+    const gfs3d_edgeconv_args *a = &ba->f;
+    int rc = check_args(a, who);
+    if (rc) return rc;
+    GFS3D_REQUIRE(a->training, "%s: only the training-mode (batch statistics) backward exists", who);
+    GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm, "%s: NULL saved buffer", who);
+    GFS3D_REQUIRE(ba->dy_cf && ba->dx && ba->dw1 && ba->dbn1_w && ba->dbn1_b && ba->dw2 && ba->dbn2_w && ba->dbn2_b,
+                  "%s: NULL gradient buffer", who);
+    GFS3D_REQUIRE(ba->dy_bstride >= (long long)EC * a->N, "%s: bad dy_bstride", who);
+    return GFS3D_OK;
+}
+}  // namespace gfs3d
+
+extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *stream)
+{
+    using namespace gfs3d;
+    int rc = check_fwd(a, "gfs3d_edgeconv_forward_f32");
+    for (int ph = 0; ph < 3 && !rc; ++ph) rc = forward_phase(a, ph, nullptr, 0.0, static_cast<hipStream_t>(stream));
+    return rc;
+}
+
+extern "C" int gfs3d_edgeconv_forward_phase_f32(const gfs3d_edgeconv_args *a, int phase, double *acc, double stat_count, void *stream)
+{
+    using namespace gfs3d;
+    int rc = check_fwd(a, "gfs3d_edgeconv_forward_phase_f32");
+    if (rc) return rc;
+    GFS3D_REQUIRE(phase >= 0 && phase <= 2, "gfs3d_edgeconv_forward_phase_f32: phase must be 0, 1 or 2");
+    return forward_phase(a, phase, acc, stat_count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, void *stream)
+{
+    using namespace gfs3d;
+    int rc = check_bwd(ba, "gfs3d_edgeconv_backward_f32");
+    for (int ph = 0; ph < 3 && !rc; ++ph) rc = backward_phase(ba, ph, nullptr, 0.0, static_cast<hipStream_t>(stream));
+    return rc;
+}
+
+extern "C" int gfs3d_edgeconv_backward_phase_f32(const gfs3d_edgeconv_bwd_args *ba, int phase, double *acc, double stat_count, void *stream)
+{
+    using namespace gfs3d;
+    int rc = check_bwd(ba, "gfs3d_edgeconv_backward_phase_f32");
+    if (rc) return rc;
+    GFS3D_REQUIRE(phase >= 0 && phase <= 2, "gfs3d_edgeconv_backward_phase_f32: phase must be 0, 1 or 2");
+    return backward_phase(ba, phase, acc, stat_count, static_cast<hipStream_t>(stream));
 }

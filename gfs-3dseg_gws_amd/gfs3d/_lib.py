@@ -55,6 +55,8 @@ SYMBOLS = {
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),
     "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),
+    "gfs3d_edgeconv_forward_phase_f32": (c_int, [POINTER(EdgeConvArgs), c_int, c_void_p, c_double, c_void_p]),
+    "gfs3d_edgeconv_backward_phase_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_int, c_void_p, c_double, c_void_p]),
     "gfs3d_word_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,

@@ -76,3 +76,17 @@ def max_over_ranks(value: float, device) -> float:
     if is_dist() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def enable_sync_batchnorm(model: torch.nn.Module, group=None) -> torch.nn.Module:
+    """Whole-batch BatchNorm statistics under block-sharded DP (what the single-device reference
+    computes): the EdgeConv kernels exchange their fp64 sums between phases (gfs3d.ops.BNSync), the
+    BatchNorm1d layers of the point-wise heads become torch SyncBatchNorm.  Returns the model."""
+    from . import ops
+    from model.dgcnn import DGCNN
+    sync = ops.BNSync.from_group(group)
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model, process_group=group)
+    for m in model.modules():
+        if isinstance(m, DGCNN):
+            m.bn_sync = sync
+    return model

@@ -74,35 +74,152 @@ def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = Fa
 # --------------------------------------------------------------------------
 # K2
 # --------------------------------------------------------------------------
-class _EdgeConvCtx:
-    """Buffers one EdgeConv forward leaves behind for its backward."""
-    __slots__ = ("B", "C", "N", "k", "P", "Q", "SP", "SQ", "indeg", "stats", "hsel", "jsel", "y_pm", "idx")
+class BNSync:
+    """How BatchNorm statistics are shared between the ranks of a block-sharded batch: `all_reduce`
+    sums a (128,) float64 device tensor in place over the ranks, `world_size` scales the sample
+    count (equal shards).  `BNSync.from_group()` wraps torch.distributed (RCCL)."""
+
+    def __init__(self, all_reduce, world_size: int):
+        self.all_reduce, self.world_size = all_reduce, int(world_size)
+
+    @staticmethod
+    def from_group(group=None):
+        import torch.distributed as dist
+        return BNSync(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group), dist.get_world_size(group))
 
 
-def _fill_args(a: EdgeConvArgs, x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope, c):
-    a.B, a.C, a.N, a.k = c.B, c.C, c.N, c.k
-    a.training = 1 if training else 0
-    a.eps, a.momentum, a.slope = eps, momentum, slope
-    a.x, a.idx, a.w1 = x.data_ptr(), idx.data_ptr(), w1.data_ptr()
-    a.bn1_w, a.bn1_b = g1.data_ptr(), b1.data_ptr()
-    a.bn1_rm = rm1.data_ptr() if rm1 is not None else None
-    a.bn1_rv = rv1.data_ptr() if rv1 is not None else None
-    a.w2 = w2.data_ptr()
-    a.bn2_w, a.bn2_b = g2.data_ptr(), b2.data_ptr()
-    a.bn2_rm = rm2.data_ptr() if rm2 is not None else None
-    a.bn2_rv = rv2.data_ptr() if rv2 is not None else None
-    a.P, a.Q = c.P.data_ptr(), c.Q.data_ptr()
-    a.SP = c.SP.data_ptr() if c.SP is not None else None
-    a.SQ = c.SQ.data_ptr() if c.SQ is not None else None
-    a.indeg = c.indeg.data_ptr() if c.indeg is not None else None
-    a.stats = c.stats.data_ptr()
-    a.hsel = c.hsel.data_ptr() if c.hsel is not None else None
-    a.jsel = c.jsel.data_ptr() if c.jsel is not None else None
-    a.y_pm = c.y_pm.data_ptr() if c.y_pm is not None else None
-    nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(c.B, c.C, c.N, c.k)
-    ws = _workspace(x.device, nbytes)
-    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    return ws
+class EdgeConvRun:
+    """One EdgeConv block invocation: owns the buffers the forward leaves for the backward and drives
+    the C ABI either monolithically or phase by phase (synchronised BatchNorm)."""
+
+    def __init__(self, x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope,
+                 private_workspace: bool = False):
+        for t, nme in ((x, "x"), (w1, "conv1.weight"), (w2, "conv2.weight")):
+            _need_gpu(t, nme)
+        self.x = x.contiguous()
+        B, C, N = self.x.shape
+        k = idx.shape[-1]
+        if idx.dtype != torch.int32 or not idx.is_contiguous():
+            raise RuntimeError("gfs3d.edgeconv: idx must be contiguous int32 (B,N,k)")
+        if w1.numel() != EC_WIDTH * 2 * C or w2.numel() != EC_WIDTH * EC_WIDTH:
+            raise NotImplementedError("gfs3d.edgeconv: only EdgeConv widths [64, 64] are implemented in HIP")
+        self.B, self.C, self.N, self.k, self.idx = B, C, N, k, idx
+        self.training = bool(training)
+        self.scalars = (float(eps), float(momentum), float(slope))
+        self.w1, self.w2 = w1.contiguous(), w2.contiguous()
+        self.g1, self.b1, self.g2, self.b2 = g1, b1, g2, b2
+        self.rm = (rm1, rv1, rm2, rv2)
+        dev = self.x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.P = torch.empty((B, N, EC_WIDTH), **f32)
+        self.Q = torch.empty((B, N, EC_WIDTH), **f32)
+        self.stats = torch.empty((8, EC_WIDTH), **f32)
+        if self.training:
+            self.SP = torch.empty((B, N, EC_WIDTH), **f32)
+            self.SQ = torch.empty((B, N, EC_WIDTH), **f32)
+            self.indeg = torch.empty((B, N), **f32)
+            self.hsel = torch.empty((B, N, EC_WIDTH), **f32)
+            self.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
+            self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)
+        else:
+            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.y_pm = None
+        self.y = torch.empty((B, EC_WIDTH, N), **f32)
+        nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(B, C, N, k)
+        self._private_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
+        self._nbytes = nbytes
+
+    # -- argument structs -------------------------------------------------
+    def _args(self, a: EdgeConvArgs, with_running: bool):
+        eps, momentum, slope = self.scalars
+        a.B, a.C, a.N, a.k = self.B, self.C, self.N, self.k
+        a.training = 1 if self.training else 0
+        a.eps, a.momentum, a.slope = eps, momentum, slope
+        a.x, a.idx, a.w1 = self.x.data_ptr(), self.idx.data_ptr(), self.w1.data_ptr()
+        a.bn1_w, a.bn1_b = self.g1.data_ptr(), self.b1.data_ptr()
+        a.w2 = self.w2.data_ptr()
+        a.bn2_w, a.bn2_b = self.g2.data_ptr(), self.b2.data_ptr()
+        rm1, rv1, rm2, rv2 = self.rm if with_running else (None,) * 4
+        a.bn1_rm = rm1.data_ptr() if rm1 is not None else None
+        a.bn1_rv = rv1.data_ptr() if rv1 is not None else None
+        a.bn2_rm = rm2.data_ptr() if rm2 is not None else None
+        a.bn2_rv = rv2.data_ptr() if rv2 is not None else None
+        a.P, a.Q, a.stats = self.P.data_ptr(), self.Q.data_ptr(), self.stats.data_ptr()
+        for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm"):
+            t = getattr(self, name)
+            setattr(a, name, t.data_ptr() if t is not None else None)
+        a.y_cf, a.y_cf_bstride = self.y.data_ptr(), EC_WIDTH * self.N
+        ws = self._private_ws if self._private_ws is not None else _workspace(self.x.device, self._nbytes)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        return ws
+
+    def _bwd_args(self, dy):
+        dev = self.x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.dy = dy.contiguous()
+        self.dx = torch.empty_like(self.x)
+        self.dw1, self.dw2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
+        self.dg1, self.db1, self.dg2, self.db2 = (torch.empty(EC_WIDTH, **f32) for _ in range(4))
+        ba = EdgeConvBwdArgs()
+        ws = self._args(ba.f, with_running=False)
+        ba.dy_cf, ba.dy_bstride = self.dy.data_ptr(), EC_WIDTH * self.N
+        ba.dx = self.dx.data_ptr()
+        ba.dw1, ba.dbn1_w, ba.dbn1_b = self.dw1.data_ptr(), self.dg1.data_ptr(), self.db1.data_ptr()
+        ba.dw2, ba.dbn2_w, ba.dbn2_b = self.dw2.data_ptr(), self.dg2.data_ptr(), self.db2.data_ptr()
+        return ba, ws
+
+    # -- execution --------------------------------------------------------
+    def forward_phase(self, phase: int, acc: torch.Tensor, stat_count: float):
+        a = EdgeConvArgs()
+        ws = self._args(a, with_running=True)
+        with torch.cuda.device(self.x.device):
+            rc = _lib.lib().gfs3d_edgeconv_forward_phase_f32(ctypes.byref(a), phase, _p(acc), float(stat_count), _stream())
+        _lib.check(rc, "gfs3d_edgeconv_forward_phase_f32")
+        del ws
+
+    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None):
+        if phase == 0:
+            self._ba = self._bwd_args(dy)
+        ba, ws = self._ba
+        with torch.cuda.device(self.x.device):
+            rc = _lib.lib().gfs3d_edgeconv_backward_phase_f32(ctypes.byref(ba), phase, _p(acc), float(stat_count), _stream())
+        _lib.check(rc, "gfs3d_edgeconv_backward_phase_f32")
+        if phase == 2:
+            del self._ba
+
+    def forward(self, sync: Optional[BNSync] = None):
+        if sync is None or not self.training:
+            a = EdgeConvArgs()
+            ws = self._args(a, with_running=True)
+            with torch.cuda.device(self.x.device):
+                rc = _lib.lib().gfs3d_edgeconv_forward_f32(ctypes.byref(a), _stream())
+            _lib.check(rc, "gfs3d_edgeconv_forward_f32")
+            del ws
+            return self.y
+        acc = torch.zeros(512, dtype=torch.float64, device=self.x.device)
+        count = float(self.B) * self.N * self.k * sync.world_size
+        self.forward_phase(0, acc, count)
+        sync.all_reduce(acc[0:128])
+        self.forward_phase(1, acc, count)
+        sync.all_reduce(acc[128:256])
+        self.forward_phase(2, acc, count)
+        return self.y
+
+    def backward(self, dy, sync: Optional[BNSync] = None):
+        if sync is None:
+            ba, ws = self._bwd_args(dy)
+            with torch.cuda.device(self.x.device):
+                rc = _lib.lib().gfs3d_edgeconv_backward_f32(ctypes.byref(ba), _stream())
+            _lib.check(rc, "gfs3d_edgeconv_backward_f32")
+            del ws
+        else:
+            acc = torch.zeros(512, dtype=torch.float64, device=self.x.device)
+            count = float(self.B) * self.N * self.k * sync.world_size
+            self.backward_phase(0, acc, count, dy)
+            sync.all_reduce(acc[0:128])
+            self.backward_phase(1, acc, count)
+            sync.all_reduce(acc[128:256])
+            self.backward_phase(2, acc, count)
+        return self.dx, self.dw1, self.dg1, self.db1, self.dw2, self.dg2, self.db2
 
 
 class EdgeConvFunction(torch.autograd.Function):
@@ -110,78 +227,28 @@ class EdgeConvFunction(torch.autograd.Function):
     (model/dgcnn.py:116-118), forward and backward in HIP."""
 
     @staticmethod
-    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope):
-        for t, nme in ((x, "x"), (w1, "conv1.weight"), (w2, "conv2.weight")):
-            _need_gpu(t, nme)
-        x = x.contiguous()
-        B, C, N = x.shape
-        k = idx.shape[-1]
-        if idx.dtype != torch.int32 or not idx.is_contiguous():
-            raise RuntimeError("gfs3d.edgeconv: idx must be contiguous int32 (B,N,k)")
-        if w1.numel() != EC_WIDTH * 2 * C or w2.numel() != EC_WIDTH * EC_WIDTH:
-            raise NotImplementedError("gfs3d.edgeconv: only EdgeConv widths [64, 64] are implemented in HIP")
-        dev = x.device
-        c = _EdgeConvCtx()
-        c.B, c.C, c.N, c.k, c.idx = B, C, N, k, idx
-        f32 = dict(dtype=torch.float32, device=dev)
-        c.P = torch.empty((B, N, EC_WIDTH), **f32)
-        c.Q = torch.empty((B, N, EC_WIDTH), **f32)
-        c.stats = torch.empty((8, EC_WIDTH), **f32)
+    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync):
+        run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope)
+        y = run.forward(sync)
         if training:
-            c.SP = torch.empty((B, N, EC_WIDTH), **f32)
-            c.SQ = torch.empty((B, N, EC_WIDTH), **f32)
-            c.indeg = torch.empty((B, N), **f32)
-            c.hsel = torch.empty((B, N, EC_WIDTH), **f32)
-            c.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
-            c.y_pm = torch.empty((B, N, EC_WIDTH), **f32)
-        else:
-            c.SP = c.SQ = c.indeg = c.hsel = c.jsel = c.y_pm = None
-        y = torch.empty((B, EC_WIDTH, N), **f32)
-        w1c, w2c = w1.contiguous(), w2.contiguous()
-        a = EdgeConvArgs()
-        ws = _fill_args(a, x, idx, w1c, g1, b1, rm1, rv1, w2c, g2, b2, rm2, rv2, training, eps, momentum, slope, c)
-        a.y_cf, a.y_cf_bstride = y.data_ptr(), EC_WIDTH * N
-        with torch.cuda.device(dev):
-            rc = _lib.lib().gfs3d_edgeconv_forward_f32(ctypes.byref(a), _stream())
-        _lib.check(rc, "gfs3d_edgeconv_forward_f32")
-        del ws
-        if training:
-            ctx.c = c
-            ctx.scalars = (eps, momentum, slope)
-            ctx.save_for_backward(x, w1c, g1, b1, w2c, g2, b2)
+            ctx.c = run
+            ctx.sync = sync
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
-        x, w1, g1, b1, w2, g2, b2 = ctx.saved_tensors
-        c = ctx.c
-        eps, momentum, slope = ctx.scalars
-        dy = dy.contiguous()
-        dev = x.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        dx = torch.empty_like(x)
-        dw1 = torch.empty_like(w1)
-        dw2 = torch.empty_like(w2)
-        dg1, db1, dg2, db2 = (torch.empty(EC_WIDTH, **f32) for _ in range(4))
-        ba = EdgeConvBwdArgs()
-        ws = _fill_args(ba.f, x, c.idx, w1, g1, b1, None, None, w2, g2, b2, None, None, True, eps, momentum, slope, c)
-        ba.dy_cf, ba.dy_bstride = dy.data_ptr(), EC_WIDTH * c.N
-        ba.dx = dx.data_ptr()
-        ba.dw1, ba.dbn1_w, ba.dbn1_b = dw1.data_ptr(), dg1.data_ptr(), db1.data_ptr()
-        ba.dw2, ba.dbn2_w, ba.dbn2_b = dw2.data_ptr(), dg2.data_ptr(), db2.data_ptr()
-        with torch.cuda.device(dev):
-            rc = _lib.lib().gfs3d_edgeconv_backward_f32(ctypes.byref(ba), _stream())
-        _lib.check(rc, "gfs3d_edgeconv_backward_f32")
-        del ws
-        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 8
+        grads = ctx.c.backward(dy, ctx.sync)
+        dx, dw1, dg1, db1, dw2, dg2, db2 = grads
+        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 9
 
 
-def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2):
+def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
+                   sync: Optional[BNSync] = None):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
-    training, like nn.BatchNorm2d does)."""
+    training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks."""
     if training:
         for bn in (bn1, bn2):
             if bn.num_batches_tracked is not None:
@@ -189,7 +256,7 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
     mom = bn1.momentum if bn1.momentum is not None else 0.1
     return EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
                                   bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
-                                  bool(training), float(bn1.eps), float(mom), float(slope))
+                                  bool(training), float(bn1.eps), float(mom), float(slope), sync)
 
 
 # --------------------------------------------------------------------------

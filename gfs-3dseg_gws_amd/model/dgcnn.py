@@ -64,8 +64,9 @@ class conv2d(nn.Module):
         """(conv1, bn1, conv2, bn2) when this block has the shape the HIP EdgeConv
         kernel implements (two bias-free 1x1 convs to 64 channels with BN + LeakyReLU)."""
         m = list(self.layer)
-        ok = (len(m) == 6 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], nn.BatchNorm2d)
-              and isinstance(m[3], nn.Conv2d) and isinstance(m[4], nn.BatchNorm2d)
+        bn_types = (nn.BatchNorm2d, nn.SyncBatchNorm)        # convert_sync_batchnorm() keeps weights/buffers
+        ok = (len(m) == 6 and isinstance(m[0], nn.Conv2d) and isinstance(m[1], bn_types)
+              and isinstance(m[3], nn.Conv2d) and isinstance(m[4], bn_types)
               and m[0].bias is None and m[3].bias is None
               and m[0].out_channels == ops.EC_WIDTH and m[3].out_channels == ops.EC_WIDTH
               and m[1].track_running_stats and m[4].track_running_stats and m[1].affine and m[4].affine)
@@ -103,6 +104,7 @@ class DGCNN(nn.Module):
             self.edge_convs.append(conv2d(2 * prev, widths))
             prev = widths[-1]
         self.conv = conv1d(sum(w[-1] for w in edgeconv_widths), mlp_widths)
+        self.bn_sync = None      # gfs3d.ops.BNSync: whole-batch BatchNorm statistics under block-sharded DP
 
     def edgeconv_features(self, x):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv)."""
@@ -110,7 +112,7 @@ class DGCNN(nn.Module):
         for block in self.edge_convs:
             c1, bn1, c2, bn2 = block.fused_parts()
             idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True)
-            x = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU)
+            x = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU, sync=self.bn_sync)
             feats.append(x)
         return feats
 

@@ -106,6 +106,20 @@ typedef struct gfs3d_edgeconv_bwd_args {
 
 int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *a, void *stream);
 
+/* Phased variants for SYNCHRONISED BatchNorm under block-sharded data parallelism (the reference
+ * is one device = whole-batch statistics).  Both passes split at their two global reductions:
+ *   forward   phase 0: projections + BN1 sums -> acc[0:128]      phase 1: BN1 finalize, heavy pass, BN2
+ *             sums -> acc[128:256]                                phase 2: BN2 finalize, epilogue
+ *   backward  phase 0: BN2-backward sums -> acc[0:128]            phase 1: heavy pass ..., BN1-backward sums
+ *             -> acc[128:256]                                     phase 2: BN1 backward, dx, dW1
+ * Between phases the caller all-reduces (SUM) the 128 doubles just produced over the ranks; `acc`
+ * is a caller-owned device buffer of 512 doubles (the library keeps each rank's own sums in
+ * acc[256:512] for the parameter gradients), `stat_count` the GLOBAL number of (b,n,k) samples
+ * (<= 0: this rank's).  The workspace must not be touched between the phases of one pass.
+ * Phases 0,1,2 with acc = NULL, stat_count = 0 are exactly the monolithic calls above. */
+int gfs3d_edgeconv_forward_phase_f32(const gfs3d_edgeconv_args *a, int phase, double *acc, double stat_count, void *stream);
+int gfs3d_edgeconv_backward_phase_f32(const gfs3d_edgeconv_bwd_args *a, int phase, double *acc, double stat_count, void *stream);
+
 /* ------------------------------------------------------------------ K3 --
  * Point x prototype cosine matching on MFMA (fp32-in / fp32-acc).
  *

@@ -548,3 +548,57 @@ def test_kmeans_assign_mfma_vs_fp64(dev, M, C, K):
     assert maxerr(sums, exp_sums) < 1e-3 * max(1.0, float(exp_sums.abs().max()))
     exp_inertia = float(d[torch.arange(M), lab].sum())
     assert abs(float(inertia) - exp_inertia) < 1e-3 * exp_inertia
+
+
+def test_edgeconv_synchronised_batchnorm_two_shards_equal_whole_batch(dev):
+    """Phased C ABI (gfs3d_edgeconv_*_phase_f32): two block shards whose fp64 BN sums are exchanged
+    between the phases reproduce the single-device whole-batch forward, running statistics and
+    gradients (shard parameter gradients add up to the whole-batch ones) - SURVEY 8(e)-2."""
+    from gfs3d import ops
+    B, C, N, k = 4, 9, 256, 20
+    p = _block_params(C, 321)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, N, generator=g).to(dev)
+    cot = torch.randn(B, 64, N, generator=g).to(dev)
+    idx = ops.knn_topk(x, k, want_i64=False, want_i32=True)
+
+    def make(xs, ids, private):
+        blk = _make_block(p, C, dev).train()
+        c1, bn1, c2, bn2 = blk.fused_parts()
+        run = ops.EdgeConvRun(xs, ids, c1.weight.detach(), bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean,
+                              bn1.running_var, c2.weight.detach(), bn2.weight.detach(), bn2.bias.detach(),
+                              bn2.running_mean, bn2.running_var, True, 1e-5, 0.1, 0.2, private_workspace=private)
+        return run, bn1, bn2
+
+    whole, wbn1, wbn2 = make(x, idx, True)
+    y = whole.forward().clone()
+    gw = [t_.clone() for t_ in whole.backward(cot)]
+
+    shards = [make(x[:2].contiguous(), idx[:2].contiguous(), True), make(x[2:].contiguous(), idx[2:].contiguous(), True)]
+    accs = [torch.zeros(512, dtype=torch.float64, device=dev) for _ in shards]
+    count = float(B * N * k)
+
+    def exchange(lo):
+        tot = accs[0][lo:lo + 128] + accs[1][lo:lo + 128]
+        for a_ in accs:
+            a_[lo:lo + 128] = tot
+
+    for ph in range(3):
+        for (run, _, _), a_ in zip(shards, accs):
+            run.forward_phase(ph, a_, count)
+        if ph < 2:
+            exchange(128 * ph)
+    ys = torch.cat([s_[0].y for s_ in shards], 0)
+    assert maxerr(ys, y) < 1e-5
+    for (run, b1, b2) in shards:
+        assert maxerr(b1.running_var, wbn1.running_var) < 1e-6 and maxerr(b2.running_mean, wbn2.running_mean) < 1e-6
+    for ph in range(3):
+        for i, ((run, _, _), a_) in enumerate(zip(shards, accs)):
+            run.backward_phase(ph, a_, count, cot[2 * i:2 * i + 2] if ph == 0 else None)
+        if ph < 2:
+            exchange(128 * ph)
+    dx = torch.cat([s_[0].dx for s_ in shards], 0)
+    assert relerr(dx, gw[0]) < TOL
+    for j, name in enumerate(("dw1", "dg1", "db1", "dw2", "dg2", "db2"), start=1):
+        tot = getattr(shards[0][0], name) + getattr(shards[1][0], name)
+        assert relerr(tot, gw[j]) < TOL, name
