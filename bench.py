@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true", help="whole-batch BatchNorm statistics across ranks (N>1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,6 +113,8 @@ def main():
 
     torch.manual_seed(0)
     net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev).train()
+    if args.sync_bn and world > 1:
+        net = gdist.enable_sync_batchnorm(net)
     bucket = gdist.FlatGradBucket(net.parameters())
     opt = torch.optim.Adam(net.parameters(), lr=1e-3)
     x = synthetic_blocks(B_PER_GPU, NPTS, seed=rank).to(dev)
@@ -172,7 +175,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: S3DIS-shaped blocks, batch=32x2048x9 per GPU, k=20, DGCNN+EdgeConv fwd/bwd "
                                    "(train mode, BN batch stats) + grad all-reduce + Adam",
-                       "blocks_per_gpu": B_PER_GPU, "points": NPTS, "k": KNN, "parallelism": f"block-sharded dp{world}"},
+                       "blocks_per_gpu": B_PER_GPU, "points": NPTS, "k": KNN, "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and world > 1 else "")},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

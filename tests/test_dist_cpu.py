@@ -71,6 +71,18 @@ def _worker(rank, world, port, out):
     proto.sum().backward()
     res["fake_proto"], res["fake_chosen"] = proto.detach().numpy(), sorted(int(c) for c in chosen)
     res["fake_grad"] = pf.grad.numpy().copy()
+    # 5. synchronised BatchNorm wiring: BNSync sums fp64 statistics over the ranks; the converted model keeps
+    #    its state_dict keys and every EdgeConv block still resolves to the fused HIP path
+    from gfs3d import ops
+    sync = ops.BNSync.from_group()
+    t = torch.full((128,), float(rank + 1), dtype=torch.float64)
+    sync.all_reduce(t)
+    res["sync_sum"], res["sync_world"] = float(t[0]), sync.world_size
+    keys = list(m.state_dict().keys())
+    m2 = gd.enable_sync_batchnorm(m)
+    res["sync_keys_same"] = list(m2.state_dict().keys()) == keys
+    res["sync_attached"] = m2.encoder.bn_sync is not None and all(
+        len(blk.fused_parts()) == 4 for blk in m2.encoder.edge_convs)
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -89,6 +101,8 @@ def test_dp_helpers_world2_gloo():
     ref = load_golden("metric")["res"]
     assert np.allclose(a["metric"], ref, atol=1e-12) and np.allclose(b["metric"], ref, atol=1e-12)
     assert a["max"] == 1.0 and b["max"] == 1.0
+    assert a["sync_sum"] == b["sync_sum"] == 3.0 and a["sync_world"] == 2
+    assert a["sync_keys_same"] and a["sync_attached"] and b["sync_attached"]
     # single-process reference for (4)
     import random, types, sys
     from conftest import PKG
