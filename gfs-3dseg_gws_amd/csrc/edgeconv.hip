@@ -454,7 +454,8 @@ ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmi
 // ===========================================================================
 // B1: g = dy * lrelu'(y) in point-major layout; partial sums of g and g*xhat2.
 __global__ void __launch_bounds__(256)
-ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const float *__restrict__ y_pm,
+ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const float *__restrict__ dy_pm,
+                   const float *__restrict__ y_pm,
                    const float *__restrict__ hsel, const float *__restrict__ stats, int N, float slope,
                    float *__restrict__ g_pm, double *__restrict__ partial)
 {
@@ -465,7 +466,7 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
     {
         const int p = tid & 63;
         for (int c = wv; c < EC; c += 4)
-            tile[p][c] = (n0 + p < N) ? dy_cf[(size_t)b * dy_bstride + (size_t)c * N + n0 + p] : 0.f;
+            tile[p][c] = (dy_cf && n0 + p < N) ? dy_cf[(size_t)b * dy_bstride + (size_t)c * N + n0 + p] : 0.f;
     }
     __syncthreads();
     const float mean2 = stats[ST_MEAN2 * EC + co], rstd2 = stats[ST_RSTD2 * EC + co];
@@ -474,7 +475,8 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
         const int n = n0 + p;
         if (n >= N) break;
         const size_t o = ((size_t)b * N + n) * EC + co;
-        const float g = tile[p][co] * (y_pm[o] > 0.f ? 1.f : slope);
+        const float dy = dy_pm ? tile[p][co] + dy_pm[o] : tile[p][co];     // both consumers of the block output
+        const float g = dy * (y_pm[o] > 0.f ? 1.f : slope);
         g_pm[o] = g;
         s += (double)g;
         sx += (double)(g * ((hsel[o] - mean2) * rstd2));
@@ -1064,7 +1066,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
-        hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, a->y_pm, a->hsel, a->stats,
+        hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
                            a->N, a->slope, g, acc1);
         GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
         if (hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
@@ -1156,7 +1158,7 @@ static int check_bwd(const gfs3d_edgeconv_bwd_args *ba, const char *who)
     if (rc) return rc;
     GFS3D_REQUIRE(a->training, "%s: only the training-mode (batch statistics) backward exists", who);
     GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm, "%s: NULL saved buffer", who);
-    GFS3D_REQUIRE(ba->dy_cf && ba->dx && ba->dw1 && ba->dbn1_w && ba->dbn1_b && ba->dw2 && ba->dbn2_w && ba->dbn2_b,
+    GFS3D_REQUIRE((ba->dy_cf || ba->dy_pm) && ba->dx && ba->dw1 && ba->dbn1_w && ba->dbn1_b && ba->dw2 && ba->dbn2_w && ba->dbn2_b,
                   "%s: NULL gradient buffer", who);
     GFS3D_REQUIRE(ba->dy_bstride >= (long long)EC * a->N, "%s: bad dy_bstride", who);
     return GFS3D_OK;

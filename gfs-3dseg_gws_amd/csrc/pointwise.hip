@@ -1,0 +1,729 @@
+// K4: point-wise MLP stack  [Conv1d 1x1 -> BatchNorm1d -> LeakyReLU] x L  on the fp32 MFMA pipe.
+//
+// Replaces `self.conv(torch.cat(edgeconv_outputs, dim=1))` of DGCNN.forward (reference
+// model/dgcnn.py:121-122, the conv1d class dgcnn.py:64-80).  The EdgeConv kernels already keep a
+// point-major copy of every block output, so the stack runs entirely in point-major layout
+// ((B*N, C) rows): the concatenation is a list of K-segments, no transposes, and every BatchNorm /
+// LeakyReLU pass is folded into the prologue or epilogue of the neighbouring GEMM:
+//
+//   forward (train)   H_l = act(bn_{l-1}(H_{l-1})) W_l^T   + per-channel sum / sum^2  (fp64 atomics)
+//                     y   = act(bn_L(H_L)) written channel-first (B, C_L, N)
+//   backward          G_L = dy^T * act'                     + sum g, sum g h
+//                     dW_l = dH_l^T act(bn(H_{l-1}))        (split-K over the points, fp32 atomics)
+//                     G_{l-1} = (dH_l W_l) * act'           + sums;   dH_l = a g + b + c h  (BN backward)
+//
+// fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32); 128 x {128,64} block tiles, K-step 32, operands
+// staged through padded LDS and read with ds_read_b128 (K permuted identically for both operands).
+#include "common.h"
+
+namespace gfs3d {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PW_BM = 128, PW_BK = 32, PW_LD = 36;      // LD 36: conflict-free ds_read_b128 of 32-float rows
+enum { PRO_NONE = 0, PRO_BNACT = 1, PRO_BWD = 2 };
+enum { EPI_RAW_STATS = 0, EPI_AFFINE_ACT = 1, EPI_BWD_ACT = 2, EPI_PLAIN = 3 };
+enum { PST_SCALE = 0, PST_SHIFT = 1, PST_MEAN = 2, PST_RSTD = 3 };
+
+struct RowGemm {
+    const float *a[4];        // A operand: K-segments of width a_segw, rows of stride lda   (M, K)
+    const float *a2[4];       // PRO_BWD: second tensor (h) of the same shape
+    int a_segw, lda;
+    const float *pa, *pb, *pc;  // prologue coefficients per K channel
+    const float *w;           // (Nc, K) row-major, K contiguous
+    int M, K, Nc;
+    float slope;
+    float *out[4];            // point-major output, column segments of width o_segw (row stride o_segw)
+    int o_segw;
+    float *out_cf;            // OUT_CF: (B, Nc, npts) channel-first
+    int npts;
+    const float *ea, *eb;     // epilogue scale / shift per output channel
+    const float *eh;          // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc)
+    double *acc;              // (2, Nc) column sums
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// Out(M, Nc) = T(A)(M, K) . W(Nc, K)^T          grid: 8 * ncb * ceil(nrb / 8) blocks of 256 threads
+template <int BN, int PRO, int EPI, bool OUT_CF>
+__global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
+{
+    extern __shared__ f32x4 pw_smem4[];
+    float *smem = reinterpret_cast<float *>(pw_smem4);
+    constexpr int TM = (BN == 128) ? 2 : 1, TN = 2, WM = TM * 32, NB = BN / 32;
+    float *sA = smem;                               // [2][128][36]
+    float *sB = smem + 2 * PW_BM * PW_LD;           // [2][BN][36]
+    const int ncb = g.Nc / BN, nrb = (g.M + PW_BM - 1) / PW_BM;
+    // blocks i, i+8, i+16.. share an XCD (and its L2): give them the column blocks of one row block
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int rb = (slot / ncb) * 8 + xcd, cb = slot % ncb;
+    if (rb >= nrb) return;
+    const int row0 = rb * PW_BM, col0 = cb * BN;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = (BN == 128) ? (wv >> 1) : wv, wn = (BN == 128) ? (wv & 1) : 0;
+    const int c4 = t & 7, r0 = t >> 3;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], ra2[4], rw[NB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int kt) {
+        const int kcol = kt * PW_BK + 4 * c4;
+        const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
+        const float *ap = g.a[seg] + koff;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = row0 + r0 + 32 * p;
+            ra[p] = row < g.M ? ldg4(ap + (size_t)row * g.lda) : zero4;
+        }
+        if (PRO == PRO_BWD) {
+            const float *ap2 = g.a2[seg] + koff;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + r0 + 32 * p;
+                ra2[p] = row < g.M ? ldg4(ap2 + (size_t)row * g.lda) : zero4;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) rw[p] = ldg4(g.w + (size_t)(col0 + r0 + 32 * p) * g.K + kcol);
+    };
+    auto store = [&](int kt, int buf) {
+        const int kcol = kt * PW_BK + 4 * c4;
+        f32x4 ca = zero4, cb4 = zero4, cc = zero4;
+        if (PRO != PRO_NONE) { ca = ldg4(g.pa + kcol); cb4 = ldg4(g.pb + kcol); }
+        if (PRO == PRO_BWD) cc = ldg4(g.pc + kcol);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 v = ra[p];
+            if (PRO == PRO_BNACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], ca[e], cb4[e]), g.slope);
+            } else if (PRO == PRO_BWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(ra2[p][e], cc[e], fmaf(v[e], ca[e], cb4[e]));
+            }
+            if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
+            *reinterpret_cast<f32x4 *>(&sA[(buf * PW_BM + r0 + 32 * p) * PW_LD + 4 * c4]) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            *reinterpret_cast<f32x4 *>(&sB[(buf * BN + r0 + 32 * p) * PW_LD + 4 * c4]) = rw[p];
+    };
+
+    const int KT = g.K / PW_BK;
+    load(0);
+    store(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load(kt + 1);
+        const float *pa = &sA[(buf * PW_BM + wm * WM + li) * PW_LD + 4 * lh];
+        const float *pb = &sB[(buf * BN + wn * 64 + li) * PW_LD + 4 * lh];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(pa + i * 32 * PW_LD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(pb + j * 32 * PW_LD + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (OUT_CF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);
+                        else        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (kt + 1 < KT) store(kt + 1, buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    if (OUT_CF) {                               // D rows = channels, lanes = points
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pt = row0 + wm * WM + i * 32 + li;
+            if (pt >= g.M) continue;
+            const int b = pt / g.npts, n = pt - b * g.npts;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float z = fmaf(acc[i][j][r], g.ea[ch], g.eb[ch]);
+                    g.out_cf[((size_t)b * g.Nc + ch) * g.npts + n] = lrelu(z, g.slope);
+                }
+        }
+        return;
+    }
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wn * 64 + j * 32 + li;
+        const int seg = col / g.o_segw, ocol = col - seg * g.o_segw;
+        float *op = g.out[seg] + ocol;
+        float ea = 0.f, eb = 0.f;
+        if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = g.ea[col]; eb = g.eb[col]; }
+        s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (EPI == EPI_RAW_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                if (EPI == EPI_AFFINE_ACT) v = lrelu(fmaf(v, ea, eb), g.slope);
+                if (EPI == EPI_BWD_ACT) {
+                    const float h = g.eh[(size_t)row * g.Nc + col];
+                    v = fmaf(h, ea, eb) > 0.f ? v : v * g.slope;
+                    s1[j] += v; s2[j] = fmaf(v, h, s2[j]);
+                }
+                op[(size_t)row * g.o_segw] = v;
+            }
+    }
+    if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
+        float *red = smem;                      // [4 waves][TN][2][32]  (staging buffers are idle: last loop barrier passed)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (lh == 0) { red[((wv * TN + j) * 2 + 0) * 32 + li] = s1[j]; red[((wv * TN + j) * 2 + 1) * 32 + li] = s2[j]; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int which = t / BN, col = t - which * BN;
+            const int cwn = col >> 6, j = (col >> 5) & 1, i = col & 31;
+            float s = 0.f;
+            if (BN == 128) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) s += red[(((m * 2 + cwn) * TN + j) * 2 + which) * 32 + i];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) s += red[((m * TN + j) * 2 + which) * 32 + i];
+            }
+            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)s);
+        }
+    }
+}
+
+struct WGrad {
+    const float *u, *u2;      // (M, Co): PRO_BWD combine a u + b + c u2 with per-Co coefficients, or plain u
+    int ldu;
+    const float *ua, *ub, *uc;
+    const float *v[4];        // (M, Ci) in column segments of width v_segw, row stride ldv
+    int v_segw, ldv;
+    const float *va, *vb;     // PRO_BNACT per-Ci scale / shift
+    float slope;
+    int M, Co, Ci, rows_per_split, nsplit;
+    float *dw;                // (Co, Ci) zeroed by the launcher, accumulated with fp32 atomics
+};
+
+// dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci]  over this block's slice of the points
+template <int BMU, int BNV, int VPRO>
+__global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
+{
+    extern __shared__ f32x4 pw_smem4[];
+    float *smem = reinterpret_cast<float *>(pw_smem4);
+    constexpr int TM = BMU / 64, TN = BNV / 64;
+    constexpr int UC4 = BMU / 4, RUS = 256 / UC4, NU = 32 / RUS;     // U tile [32][BMU]: float4 per row, rows per pass, passes
+    constexpr int VC4 = BNV / 4, RVS = 256 / VC4, NV = 32 / RVS;
+    float *sU = smem;                       // [2][32][BMU]
+    float *sV = smem + 2 * 32 * BMU;        // [2][32][BNV]
+    const int nci = g.Ci / BNV, ntile = (g.Co / BMU) * nci;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+    if (split >= g.nsplit) return;
+    const int co0 = (tile / nci) * BMU, ci0 = (tile % nci) * BNV;
+    const int m0 = split * g.rows_per_split, m1 = min(g.M, m0 + g.rows_per_split);
+    if (m0 >= m1) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int cu = t % UC4, ru = t / UC4;
+    const int cv = t % VC4, rv = t / VC4;
+    const float *up = g.u + co0 + 4 * cu, *up2 = g.u2 ? g.u2 + co0 + 4 * cu : nullptr;
+    const int vseg = ci0 / g.v_segw;
+    const float *vp = g.v[vseg] + (ci0 - vseg * g.v_segw) + 4 * cv;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ua = zero4, ub = zero4, uc = zero4, va = zero4, vb = zero4;
+    if (up2) { ua = ldg4(g.ua + co0 + 4 * cu); ub = ldg4(g.ub + co0 + 4 * cu); uc = ldg4(g.uc + co0 + 4 * cu); }
+    if (VPRO == PRO_BNACT) { va = ldg4(g.va + ci0 + 4 * cv); vb = ldg4(g.vb + ci0 + 4 * cv); }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rU[NU], rU2[NU], rV[NV];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < NU; ++p) {
+            const int m = m0 + kt * 32 + ru + RUS * p;
+            rU[p] = m < m1 ? ldg4(up + (size_t)m * g.ldu) : zero4;
+            if (up2) rU2[p] = m < m1 ? ldg4(up2 + (size_t)m * g.ldu) : zero4;
+        }
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int m = m0 + kt * 32 + rv + RVS * p;
+            rV[p] = m < m1 ? ldg4(vp + (size_t)m * g.ldv) : zero4;
+        }
+    };
+    auto store = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < NU; ++p) {
+            f32x4 v = rU[p];
+            if (up2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rU2[p][e], uc[e], fmaf(v[e], ua[e], ub[e]));
+                if (m0 + kt * 32 + ru + RUS * p >= m1) v = zero4;
+            }
+            *reinterpret_cast<f32x4 *>(&sU[(buf * 32 + ru + RUS * p) * BMU + 4 * cu]) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            f32x4 v = rV[p];
+            if (VPRO == PRO_BNACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], va[e], vb[e]), g.slope);
+                if (m0 + kt * 32 + rv + RVS * p >= m1) v = zero4;
+            }
+            *reinterpret_cast<f32x4 *>(&sV[(buf * 32 + rv + RVS * p) * BNV + 4 * cv]) = v;
+        }
+    };
+
+    const int KT = (m1 - m0 + 31) / 32;
+    load(0);
+    store(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load(kt + 1);
+        const float *pu = &sU[(buf * 32 + lh) * BMU + wm * (BMU / 2) + li];
+        const float *pv = &sV[(buf * 32 + lh) * BNV + wn * (BNV / 2) + li];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = pu[2 * s * BMU + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = pv[2 * s * BNV + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store(kt + 1, buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * (BMU / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ci = ci0 + wn * (BNV / 2) + j * 32 + li;
+                atomicAdd(&g.dw[(size_t)co * g.Ci + ci], acc[i][j][r]);
+            }
+}
+
+// y_cf(b, c, n) = act(scale h(b n, c) + shift): 64 points x 64 channels per block, grid (ceil(N/64), C/64, B)
+__global__ void __launch_bounds__(256)
+pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int c = tid & 63, wv = tid >> 6;
+    const float sc = stats[PST_SCALE * C + c0 + c], sh = stats[PST_SHIFT * C + c0 + c];
+    for (int p = wv; p < 64; p += 4) {
+        const int n = n0 + p;
+        tile[p][c] = n < N ? lrelu(fmaf(h[((size_t)b * N + n) * C + c0 + c], sc, sh), slope) : 0.f;
+    }
+    __syncthreads();
+    const int p = tid & 63;
+    if (n0 + p < N)
+        for (int cc = wv; cc < 64; cc += 4) y_cf[((size_t)b * C + c0 + cc) * N + n0 + p] = tile[p][cc];
+}
+
+// g(b n, c) = dy_cf(b, c, n) * act'(scale h + shift);  acc[0][c] += sum g, acc[1][c] += sum g h
+__global__ void __launch_bounds__(256)
+pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ h, const float *__restrict__ stats, int N, int C,
+                 float slope, float *__restrict__ gout, double *__restrict__ acc)
+{
+    __shared__ float tile[64][65];
+    __shared__ float red[4][2][64];
+    const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int c = tid & 63, wv = tid >> 6;
+    {
+        const int p = tid & 63;
+        for (int cc = wv; cc < 64; cc += 4)
+            tile[p][cc] = n0 + p < N ? dy_cf[((size_t)b * C + c0 + cc) * N + n0 + p] : 0.f;
+    }
+    __syncthreads();
+    const float sc = stats[PST_SCALE * C + c0 + c], sh = stats[PST_SHIFT * C + c0 + c];
+    float s = 0.f, sx = 0.f;
+    for (int p = wv; p < 64; p += 4) {
+        const int n = n0 + p;
+        if (n >= N) break;
+        const size_t o = ((size_t)b * N + n) * C + c0 + c;
+        const float hv = h[o];
+        const float gv = fmaf(hv, sc, sh) > 0.f ? tile[p][c] : tile[p][c] * slope;
+        gout[o] = gv;
+        s += gv;
+        sx = fmaf(gv, hv, sx);
+    }
+    red[wv][0][c] = s;
+    red[wv][1][c] = sx;
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6;
+        const float tsum = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        atomicAdd(&acc[which * C + c0 + c], (double)tsum);
+    }
+}
+
+// batch statistics -> (scale, shift, mean, rstd) and the running-statistics update of nn.BatchNorm1d
+__global__ void pw_bn_finalize_kernel(const double *__restrict__ acc, int C, double count, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, float *__restrict__ rm, float *__restrict__ rv,
+                                      float eps, float momentum, int training, float *__restrict__ stats)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = acc[c] / count;
+        var = acc[C + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+        if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * var * (count > 1.0 ? count / (count - 1.0) : 1.0));
+    } else {
+        mean = rm[c];
+        var = rv[c];
+    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    stats[PST_SCALE * C + c] = sc;
+    stats[PST_SHIFT * C + c] = beta[c] - (float)mean * sc;
+    stats[PST_MEAN * C + c] = (float)mean;
+    stats[PST_RSTD * C + c] = rstd;
+}
+
+// BatchNorm backward coefficients: dh = a g + b + c h; parameter gradients
+__global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, int C, double count, const float *__restrict__ stats,
+                                   float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double a = stats[PST_SCALE * C + c], mean = stats[PST_MEAN * C + c], rstd = stats[PST_RSTD * C + c];
+    const double S1 = acc[c], S2 = rstd * (acc[C + c] - mean * S1);        // sum g, sum g xhat
+    const double cc = -a * rstd * S2 / count;
+    coef[c] = (float)a;
+    coef[C + c] = (float)(-a * S1 / count - cc * mean);
+    coef[2 * C + c] = (float)cc;
+    dgamma[c] = (float)S2;
+    dbeta[c] = (float)S1;
+}
+
+// wt(Ci, Co) = w(Co, Ci)^T   (weights only: a few hundred KB)
+__global__ void pw_transpose_kernel(const float *__restrict__ w, int Co, int Ci, float *__restrict__ wt)
+{
+    __shared__ float tile[32][33];
+    const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8)
+        if (x < Ci && y0 + j < Co) tile[j][threadIdx.x] = w[(size_t)(y0 + j) * Ci + x];
+    __syncthreads();
+    const int xo = blockIdx.y * 32 + threadIdx.x;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int yo = blockIdx.x * 32 + j;
+        if (xo < Co && yo < Ci) wt[(size_t)yo * Co + xo] = tile[threadIdx.x][j];
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <int BN, int PRO, int EPI, bool OUT_CF>
+int launch_rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
+{
+    const size_t lds = sizeof(float) * 2 * (PW_BM + BN) * PW_LD;
+    static bool attr_done = false;               // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_rowgemm_kernel<BN, PRO, EPI, OUT_CF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+        attr_done = true;
+    }
+    const int ncb = rg.Nc / BN, nrb = (rg.M + PW_BM - 1) / PW_BM;
+    const unsigned grid = 8u * ncb * ((nrb + 7) / 8);
+    hipLaunchKernelGGL((pw_rowgemm_kernel<BN, PRO, EPI, OUT_CF>), dim3(grid), dim3(256), lds, st, rg);
+    GFS3D_LAUNCH_CHECK("pw_rowgemm_kernel");
+    return GFS3D_OK;
+}
+
+template <int PRO, int EPI, bool OUT_CF>
+int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
+{
+    if (rg.Nc % 128 == 0) return launch_rowgemm<128, PRO, EPI, OUT_CF>(rg, st, who);
+    return launch_rowgemm<64, PRO, EPI, OUT_CF>(rg, st, who);
+}
+
+template <int BMU, int BNV, int VPRO>
+int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
+{
+    const size_t lds = sizeof(float) * 2 * 32 * (BMU + BNV);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_wgrad_kernel<BMU, BNV, VPRO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+        attr_done = true;
+    }
+    const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
+    // ~1024 blocks; a split is a multiple of 32 points
+    int nsplit = (1024 + ntile - 1) / ntile;
+    int rows = (wg.M + nsplit - 1) / nsplit;
+    rows = (rows + 31) / 32 * 32;
+    if (rows < 256) rows = 256;
+    nsplit = (wg.M + rows - 1) / rows;
+    wg.rows_per_split = rows;
+    wg.nsplit = nsplit;
+    const unsigned grid = 8u * ntile * ((nsplit + 7) / 8);
+    hipLaunchKernelGGL((pw_wgrad_kernel<BMU, BNV, VPRO>), dim3(grid), dim3(256), lds, st, wg);
+    GFS3D_LAUNCH_CHECK("pw_wgrad_kernel");
+    return GFS3D_OK;
+}
+
+template <int BNV, int VPRO>
+int launch_wgrad(const WGrad &wg, hipStream_t st, const char *who)
+{
+    if (wg.Co % 128 == 0) return launch_wgrad_t<128, BNV, VPRO>(wg, st, who);
+    return launch_wgrad_t<64, BNV, VPRO>(wg, st, who);
+}
+
+struct PwPlan {
+    int L, M, in_width, maxw;
+    size_t off_acc, off_coef, off_wt[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], total;
+};
+
+PwPlan pw_plan(int B, int N, int n_seg, int n_layers, const int *width)
+{
+    PwPlan p{};
+    p.L = n_layers;
+    p.M = B * N;
+    p.in_width = GFS3D_PW_SEG_WIDTH * n_seg;
+    p.maxw = 0;
+    for (int l = 0; l < n_layers; ++l) p.maxw = width[l] > p.maxw ? width[l] : p.maxw;
+    size_t o = 0;
+    p.off_acc = o;  o = align_up(o + sizeof(double) * 2 * p.maxw, 256);
+    p.off_coef = o; o = align_up(o + sizeof(float) * 3 * p.maxw, 256);
+    for (int l = 0; l < n_layers; ++l) {
+        const int ci = l ? width[l - 1] : p.in_width;
+        p.off_wt[l] = o; o = align_up(o + sizeof(float) * (size_t)ci * width[l], 256);
+    }
+    for (int l = 0; l < n_layers; ++l) { p.off_g[l] = o; o = align_up(o + sizeof(float) * (size_t)p.M * width[l], 256); }
+    p.total = o;
+    return p;
+}
+
+int pw_check(const gfs3d_pointwise_args *a, const char *who, bool need_y)
+{
+    GFS3D_REQUIRE(a, "%s: NULL args", who);
+    GFS3D_REQUIRE(a->B >= 1 && a->N >= 1, "%s: bad shape B=%d N=%d", who, a->B, a->N);
+    GFS3D_REQUIRE((long long)a->B * a->N < (1ll << 31), "%s: B*N too large", who);
+    GFS3D_REQUIRE(a->n_seg >= 1 && a->n_seg <= GFS3D_PW_MAX_SEGS, "%s: n_seg=%d unsupported (1..%d)", who, a->n_seg, GFS3D_PW_MAX_SEGS);
+    GFS3D_REQUIRE(a->n_layers >= 1 && a->n_layers <= GFS3D_PW_MAX_LAYERS, "%s: n_layers=%d unsupported (1..%d)", who, a->n_layers,
+                  GFS3D_PW_MAX_LAYERS);
+    for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(a->x_seg[s], "%s: NULL x_seg[%d]", who, s);
+    for (int l = 0; l < a->n_layers; ++l) {
+        GFS3D_REQUIRE(a->width[l] >= 64 && a->width[l] % 64 == 0 && a->width[l] <= 1024,
+                      "%s: layer width %d unsupported (multiple of 64, <= 1024)", who, a->width[l]);
+        GFS3D_REQUIRE(a->w[l] && a->bn_w[l] && a->bn_b[l] && a->stats[l], "%s: NULL parameter of layer %d", who, l);
+        GFS3D_REQUIRE(a->training || (a->bn_rm[l] && a->bn_rv[l]), "%s: eval mode needs running statistics (layer %d)", who, l);
+        GFS3D_REQUIRE(a->h[l] || (!a->training && l == a->n_layers - 1), "%s: NULL h[%d]", who, l);
+    }
+    GFS3D_REQUIRE(a->y_cf || !need_y, "%s: NULL y_cf", who);
+    GFS3D_REQUIRE(a->workspace, "%s: NULL workspace", who);
+    return GFS3D_OK;
+}
+
+void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev)
+{
+    if (l == 0) {
+        for (int s = 0; s < a->n_seg; ++s) rg.a[s] = a->x_seg[s];
+        rg.a_segw = GFS3D_PW_SEG_WIDTH;
+        rg.lda = GFS3D_PW_SEG_WIDTH;
+        rg.K = GFS3D_PW_SEG_WIDTH * a->n_seg;
+    } else {
+        rg.a[0] = prev;
+        rg.a_segw = a->width[l - 1];
+        rg.lda = a->width[l - 1];
+        rg.K = a->width[l - 1];
+    }
+}
+
+}  // namespace
+}  // namespace gfs3d
+
+using namespace gfs3d;
+
+extern "C" size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width)
+{
+    if (B < 1 || N < 1 || n_seg < 1 || n_seg > GFS3D_PW_MAX_SEGS || n_layers < 1 || n_layers > GFS3D_PW_MAX_LAYERS || !width) return 0;
+    return pw_plan(B, N, n_seg, n_layers, width).total;
+}
+
+extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream)
+{
+    const char *who = "gfs3d_pointwise_forward_f32";
+    if (int rc = pw_check(a, who, true)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    if (a->workspace_bytes < p.total) {
+        set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
+        return GFS3D_ERR_WORKSPACE;
+    }
+    char *ws = static_cast<char *>(a->workspace);
+    double *acc = reinterpret_cast<double *>(ws + p.off_acc);
+    const int L = a->n_layers, M = p.M;
+    ProfScope prof(6, st);
+    for (int l = 0; l < L; ++l) {
+        const int C = a->width[l];
+        RowGemm rg{};
+        fill_a(rg, a, l, l ? a->h[l - 1] : nullptr);
+        rg.w = a->w[l];
+        rg.M = M;
+        rg.Nc = C;
+        rg.slope = a->slope;
+        rg.out[0] = a->h[l];
+        rg.o_segw = C;
+        rg.acc = acc;
+        int rc;
+        if (a->training) {
+            if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+            if (l == 0) rc = rowgemm<PRO_NONE, EPI_RAW_STATS, false>(rg, st, who);
+            else {
+                rg.pa = a->stats[l - 1] + PST_SCALE * a->width[l - 1];
+                rg.pb = a->stats[l - 1] + PST_SHIFT * a->width[l - 1];
+                rc = rowgemm<PRO_BNACT, EPI_RAW_STATS, false>(rg, st, who);
+            }
+            if (rc) return rc;
+            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
+                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l]);
+            GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
+        } else {
+            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
+                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l]);
+            GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
+            rg.ea = a->stats[l] + PST_SCALE * C;
+            rg.eb = a->stats[l] + PST_SHIFT * C;
+            if (l == L - 1) {
+                rg.out_cf = a->y_cf;
+                rg.npts = a->N;
+                rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, true>(rg, st, who);
+            } else
+                rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, false>(rg, st, who);
+            if (rc) return rc;
+        }
+    }
+    if (a->training) {
+        const int C = a->width[L - 1];
+        hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->h[L - 1], a->stats[L - 1], a->N, C,
+                           a->slope, a->y_cf);
+        GFS3D_LAUNCH_CHECK("pw_out_kernel");
+    }
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, void *stream)
+{
+    const char *who = "gfs3d_pointwise_backward_f32";
+    GFS3D_REQUIRE(ba, "%s: NULL args", who);
+    const gfs3d_pointwise_args *a = &ba->f;
+    if (int rc = pw_check(a, who, false)) return rc;
+    GFS3D_REQUIRE(a->training, "%s: backward is implemented for training mode (batch statistics)", who);
+    GFS3D_REQUIRE(ba->dy_cf, "%s: NULL dy_cf", who);
+    for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(ba->dx_seg[s], "%s: NULL dx_seg[%d]", who, s);
+    for (int l = 0; l < a->n_layers; ++l)
+        GFS3D_REQUIRE(ba->dw[l] && ba->dbn_w[l] && ba->dbn_b[l], "%s: NULL gradient buffer of layer %d", who, l);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    if (a->workspace_bytes < p.total) {
+        set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
+        return GFS3D_ERR_WORKSPACE;
+    }
+    char *ws = static_cast<char *>(a->workspace);
+    double *acc = reinterpret_cast<double *>(ws + p.off_acc);
+    float *coef = reinterpret_cast<float *>(ws + p.off_coef);
+    const int L = a->n_layers, M = p.M;
+    ProfScope prof(7, st);
+    {
+        const int C = a->width[L - 1];
+        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
+                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]), acc);
+        GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
+        float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
+        float *wt = reinterpret_cast<float *>(ws + p.off_wt[l]);
+        hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->stats[l], coef,
+                           ba->dbn_w[l], ba->dbn_b[l]);
+        GFS3D_LAUNCH_CHECK("pw_bwd_coef_kernel");
+        // dW_l
+        if (hipMemsetAsync(ba->dw[l], 0, sizeof(float) * (size_t)C * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+        WGrad wg{};
+        wg.u = gl; wg.u2 = a->h[l]; wg.ldu = C;
+        wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
+        wg.slope = a->slope;
+        wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
+        int rc;
+        if (l == 0) {
+            for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
+            wg.v_segw = GFS3D_PW_SEG_WIDTH; wg.ldv = GFS3D_PW_SEG_WIDTH;
+            rc = launch_wgrad<64, PRO_NONE>(wg, st, who);
+        } else {
+            wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
+            wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
+            rc = (Ci % 128 == 0) ? launch_wgrad<128, PRO_BNACT>(wg, st, who) : launch_wgrad<64, PRO_BNACT>(wg, st, who);
+        }
+        if (rc) return rc;
+        // dA_{l-1} = dH_l W_l
+        hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (C + 31) / 32), dim3(32, 8), 0, st, a->w[l], C, Ci, wt);
+        GFS3D_LAUNCH_CHECK("pw_transpose_kernel");
+        RowGemm rg{};
+        rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
+        rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
+        rg.w = wt;
+        rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
+        if (l == 0) {
+            for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
+            rg.o_segw = GFS3D_PW_SEG_WIDTH;
+            rc = launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
+        } else {
+            rg.out[0] = reinterpret_cast<float *>(ws + p.off_g[l - 1]);
+            rg.o_segw = Ci;
+            rg.ea = a->stats[l - 1] + PST_SCALE * Ci;
+            rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
+            rg.eh = a->h[l - 1];
+            rg.acc = acc;
+            // stream order: pw_bwd_coef_kernel(l) above has consumed acc; it now collects the sums of layer l-1
+            if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+            rc = rowgemm<PRO_BWD, EPI_BWD_ACT, false>(rg, st, who);
+        }
+        if (rc) return rc;
+    }
+    return GFS3D_OK;
+}

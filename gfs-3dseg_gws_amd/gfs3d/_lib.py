@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
-_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip")
 _lib = None
 
 
@@ -41,6 +41,35 @@ class EdgeConvBwdArgs(Structure):
         ("dx", c_void_p),
         ("dw1", c_void_p), ("dbn1_w", c_void_p), ("dbn1_b", c_void_p),
         ("dw2", c_void_p), ("dbn2_w", c_void_p), ("dbn2_b", c_void_p),
+        ("dy_pm", c_void_p),
+    ]
+
+
+PW_MAX_LAYERS, PW_MAX_SEGS, PW_SEG_WIDTH = 4, 4, 64
+
+
+class PointwiseArgs(Structure):
+    _fields_ = [
+        ("B", c_int), ("N", c_int), ("n_seg", c_int), ("n_layers", c_int),
+        ("width", c_int * PW_MAX_LAYERS),
+        ("training", c_int),
+        ("eps", c_float), ("momentum", c_float), ("slope", c_float),
+        ("x_seg", c_void_p * PW_MAX_SEGS),
+        ("w", c_void_p * PW_MAX_LAYERS),
+        ("bn_w", c_void_p * PW_MAX_LAYERS), ("bn_b", c_void_p * PW_MAX_LAYERS),
+        ("bn_rm", c_void_p * PW_MAX_LAYERS), ("bn_rv", c_void_p * PW_MAX_LAYERS),
+        ("h", c_void_p * PW_MAX_LAYERS), ("stats", c_void_p * PW_MAX_LAYERS),
+        ("y_cf", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+    ]
+
+
+class PointwiseBwdArgs(Structure):
+    _fields_ = [
+        ("f", PointwiseArgs),
+        ("dy_cf", c_void_p),
+        ("dx_seg", c_void_p * PW_MAX_SEGS),
+        ("dw", c_void_p * PW_MAX_LAYERS), ("dbn_w", c_void_p * PW_MAX_LAYERS), ("dbn_b", c_void_p * PW_MAX_LAYERS),
     ]
 
 
@@ -57,6 +86,9 @@ SYMBOLS = {
     "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),
     "gfs3d_edgeconv_forward_phase_f32": (c_int, [POINTER(EdgeConvArgs), c_int, c_void_p, c_double, c_void_p]),
     "gfs3d_edgeconv_backward_phase_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_int, c_void_p, c_double, c_void_p]),
+    "gfs3d_pointwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "gfs3d_pointwise_forward_f32": (c_int, [POINTER(PointwiseArgs), c_void_p]),
+    "gfs3d_pointwise_backward_f32": (c_int, [POINTER(PointwiseBwdArgs), c_void_p]),
     "gfs3d_word_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import EdgeConvArgs, EdgeConvBwdArgs
+from ._lib import PointwiseArgs, PointwiseBwdArgs, PW_MAX_LAYERS, PW_MAX_SEGS, PW_SEG_WIDTH, EdgeConvArgs, EdgeConvBwdArgs
 
 EC_WIDTH = 64
 MAX_K = 32
@@ -120,9 +120,9 @@ class EdgeConvRun:
             self.indeg = torch.empty((B, N), **f32)
             self.hsel = torch.empty((B, N, EC_WIDTH), **f32)
             self.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
-            self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)
         else:
-            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.y_pm = None
+            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = None
+        self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)      # point-major copy: input of the point-wise stack (K4)
         self.y = torch.empty((B, EC_WIDTH, N), **f32)
         nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(B, C, N, k)
         self._private_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
@@ -147,21 +147,25 @@ class EdgeConvRun:
         for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm"):
             t = getattr(self, name)
             setattr(a, name, t.data_ptr() if t is not None else None)
-        a.y_cf, a.y_cf_bstride = self.y.data_ptr(), EC_WIDTH * self.N
+        a.y_cf, a.y_cf_bstride = (self.y.data_ptr() if self.y is not None else None), EC_WIDTH * self.N
         ws = self._private_ws if self._private_ws is not None else _workspace(self.x.device, self._nbytes)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         return ws
 
-    def _bwd_args(self, dy):
+    def _bwd_args(self, dy, dy_pm=None):
         dev = self.x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.dy = dy.contiguous()
+        if dy is None and dy_pm is None:
+            raise RuntimeError("gfs3d.edgeconv: backward without a gradient")
+        self.dy = dy.contiguous() if dy is not None else None
+        self.dy_pm = dy_pm.contiguous() if dy_pm is not None else None
         self.dx = torch.empty_like(self.x)
         self.dw1, self.dw2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
         self.dg1, self.db1, self.dg2, self.db2 = (torch.empty(EC_WIDTH, **f32) for _ in range(4))
         ba = EdgeConvBwdArgs()
         ws = self._args(ba.f, with_running=False)
-        ba.dy_cf, ba.dy_bstride = self.dy.data_ptr(), EC_WIDTH * self.N
+        ba.dy_cf, ba.dy_bstride = (self.dy.data_ptr() if self.dy is not None else None), EC_WIDTH * self.N
+        ba.dy_pm = self.dy_pm.data_ptr() if self.dy_pm is not None else None
         ba.dx = self.dx.data_ptr()
         ba.dw1, ba.dbn1_w, ba.dbn1_b = self.dw1.data_ptr(), self.dg1.data_ptr(), self.db1.data_ptr()
         ba.dw2, ba.dbn2_w, ba.dbn2_b = self.dw2.data_ptr(), self.dg2.data_ptr(), self.db2.data_ptr()
@@ -176,9 +180,9 @@ class EdgeConvRun:
         _lib.check(rc, "gfs3d_edgeconv_forward_phase_f32")
         del ws
 
-    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None):
+    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None, dy_pm=None):
         if phase == 0:
-            self._ba = self._bwd_args(dy)
+            self._ba = self._bwd_args(dy, dy_pm)
         ba, ws = self._ba
         with torch.cuda.device(self.x.device):
             rc = _lib.lib().gfs3d_edgeconv_backward_phase_f32(ctypes.byref(ba), phase, _p(acc), float(stat_count), _stream())
@@ -204,9 +208,9 @@ class EdgeConvRun:
         self.forward_phase(2, acc, count)
         return self.y
 
-    def backward(self, dy, sync: Optional[BNSync] = None):
+    def backward(self, dy, sync: Optional[BNSync] = None, dy_pm=None):
         if sync is None:
-            ba, ws = self._bwd_args(dy)
+            ba, ws = self._bwd_args(dy, dy_pm)
             with torch.cuda.device(self.x.device):
                 rc = _lib.lib().gfs3d_edgeconv_backward_f32(ctypes.byref(ba), _stream())
             _lib.check(rc, "gfs3d_edgeconv_backward_f32")
@@ -214,7 +218,7 @@ class EdgeConvRun:
         else:
             acc = torch.zeros(512, dtype=torch.float64, device=self.x.device)
             count = float(self.B) * self.N * self.k * sync.world_size
-            self.backward_phase(0, acc, count, dy)
+            self.backward_phase(0, acc, count, dy, dy_pm)
             sync.all_reduce(acc[0:128])
             self.backward_phase(1, acc, count)
             sync.all_reduce(acc[128:256])
@@ -224,28 +228,34 @@ class EdgeConvRun:
 
 class EdgeConvFunction(torch.autograd.Function):
     """y = max_k LReLU(BN2(W2 LReLU(BN1(W1 [x_j - x_i ; x_i]))))  for one block
-    (model/dgcnn.py:116-118), forward and backward in HIP."""
+    (model/dgcnn.py:116-118), forward and backward in HIP.  Returns (y (B,64,N), y_pm (B,N,64)): the same
+    values channel-first (the reference layout) and point-major (what the point-wise stack consumes);
+    gradients arriving through either are added."""
 
     @staticmethod
     def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync):
         run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope)
         y = run.forward(sync)
+        run.y = None                     # outputs must not be reachable from ctx (reference cycle through grad_fn)
+        ctx.set_materialize_grads(False)
         if training:
             ctx.c = run
             ctx.sync = sync
-        return y
+        return y, run.y_pm.detach()      # alias: the backward reads y_pm (sign of the activation)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy_pm):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
-        grads = ctx.c.backward(dy, ctx.sync)
+        if dy is None and dy_pm is None:
+            return (None,) * 17
+        grads = ctx.c.backward(dy, ctx.sync, dy_pm)
         dx, dw1, dg1, db1, dw2, dg2, db2 = grads
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 9
 
 
 def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
-                   sync: Optional[BNSync] = None):
+                   sync: Optional[BNSync] = None, want_pm: bool = False):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
     training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks."""
@@ -254,9 +264,143 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
     mom = bn1.momentum if bn1.momentum is not None else 0.1
-    return EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
-                                  bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
-                                  bool(training), float(bn1.eps), float(mom), float(slope), sync)
+    y, y_pm = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
+                                     bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
+                                     bool(training), float(bn1.eps), float(mom), float(slope), sync)
+    return (y, y_pm) if want_pm else y
+
+
+# --------------------------------------------------------------------------
+# K4
+# --------------------------------------------------------------------------
+class PointwiseRun:
+    """One invocation of the point-wise stack [Conv1d 1x1 -> BatchNorm1d -> LeakyReLU] x L on point-major
+    64-channel segments (model/dgcnn.py:64-80, 121-122)."""
+
+    def __init__(self, xs, layers, training, eps, momentum, slope):
+        if not 1 <= len(xs) <= PW_MAX_SEGS or not 1 <= len(layers) <= PW_MAX_LAYERS:
+            raise NotImplementedError("gfs3d.pointwise: 1..4 input segments and 1..4 layers are implemented in HIP")
+        for t in xs:
+            _need_gpu(t, "x_seg")
+            if t.dim() != 3 or t.shape[-1] != PW_SEG_WIDTH or t.shape != xs[0].shape:
+                raise RuntimeError("gfs3d.pointwise: inputs must be equal-shape point-major (B,N,64) tensors")
+        self.xs = [t.contiguous() for t in xs]
+        self.B, self.N = self.xs[0].shape[:2]
+        self.layers = [(w.contiguous(), g, b, rm, rv) for (w, g, b, rm, rv) in layers]
+        self.widths = [int(w.shape[0]) for (w, *_r) in self.layers]
+        prev = PW_SEG_WIDTH * len(xs)
+        for (w, *_r), c in zip(self.layers, self.widths):
+            if w.numel() != c * prev or c % 64 or c > 1024:
+                raise NotImplementedError("gfs3d.pointwise: layer widths must be multiples of 64 (<= 1024) and chain")
+            prev = c
+        self.training = bool(training)
+        self.scalars = (float(eps), float(momentum), float(slope))
+        dev = self.xs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        M = self.B * self.N
+        L = len(self.layers)
+        self.h = [torch.empty((M, c), **f32) if (self.training or l < L - 1) else None for l, c in enumerate(self.widths)]
+        self.stats = [torch.empty((4, c), **f32) for c in self.widths]
+        self.y = torch.empty((self.B, self.widths[-1], self.N), **f32)
+        arr = (ctypes.c_int * L)(*self.widths)
+        self._nbytes = _lib.lib().gfs3d_pointwise_workspace_bytes(self.B, self.N, len(xs), L, arr)
+
+    def _args(self, a: PointwiseArgs):
+        eps, momentum, slope = self.scalars
+        a.B, a.N, a.n_seg, a.n_layers = self.B, self.N, len(self.xs), len(self.layers)
+        a.training = 1 if self.training else 0
+        a.eps, a.momentum, a.slope = eps, momentum, slope
+        for s_, t in enumerate(self.xs):
+            a.x_seg[s_] = t.data_ptr()
+        for l, (w, g, b, rm, rv) in enumerate(self.layers):
+            a.width[l] = self.widths[l]
+            a.w[l], a.bn_w[l], a.bn_b[l] = w.data_ptr(), g.data_ptr(), b.data_ptr()
+            a.bn_rm[l] = rm.data_ptr() if rm is not None else None
+            a.bn_rv[l] = rv.data_ptr() if rv is not None else None
+            a.h[l] = self.h[l].data_ptr() if self.h[l] is not None else None
+            a.stats[l] = self.stats[l].data_ptr()
+        a.y_cf = self.y.data_ptr() if self.y is not None else None      # not needed by the backward
+        ws = _workspace(self.xs[0].device, self._nbytes)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        return ws
+
+    def forward(self):
+        a = PointwiseArgs()
+        ws = self._args(a)
+        with torch.cuda.device(self.xs[0].device):
+            rc = _lib.lib().gfs3d_pointwise_forward_f32(ctypes.byref(a), _stream())
+        _lib.check(rc, "gfs3d_pointwise_forward_f32")
+        del ws
+        return self.y
+
+    def backward(self, dy):
+        dev = self.xs[0].device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.dy = dy.contiguous()
+        self.dxs = [torch.empty_like(t) for t in self.xs]
+        self.dws = [torch.empty_like(w) for (w, *_r) in self.layers]
+        self.dgs = [torch.empty(c, **f32) for c in self.widths]
+        self.dbs = [torch.empty(c, **f32) for c in self.widths]
+        ba = PointwiseBwdArgs()
+        saved = self.layers
+        self.layers = [(w, g, b, None, None) for (w, g, b, rm, rv) in saved]      # running stats are not touched
+        ws = self._args(ba.f)
+        self.layers = saved
+        ba.dy_cf = self.dy.data_ptr()
+        for s_, t in enumerate(self.dxs):
+            ba.dx_seg[s_] = t.data_ptr()
+        for l in range(len(self.layers)):
+            ba.dw[l], ba.dbn_w[l], ba.dbn_b[l] = self.dws[l].data_ptr(), self.dgs[l].data_ptr(), self.dbs[l].data_ptr()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gfs3d_pointwise_backward_f32(ctypes.byref(ba), _stream())
+        _lib.check(rc, "gfs3d_pointwise_backward_f32")
+        del ws
+        return self.dxs, self.dws, self.dgs, self.dbs
+
+
+class PointwiseStackFunction(torch.autograd.Function):
+    """act(bn_L(... act(bn_1(W_1 cat(xs))) ...)) -> (B, C_L, N); tensors = xs + [w, gamma, beta] * L + [rm, rv] * L."""
+
+    @staticmethod
+    def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, *tensors):
+        xs = tensors[:n_seg]
+        par = tensors[n_seg:n_seg + 3 * n_layers]
+        run_ = tensors[n_seg + 3 * n_layers:]
+        layers = [(par[3 * l], par[3 * l + 1], par[3 * l + 2], run_[2 * l], run_[2 * l + 1]) for l in range(n_layers)]
+        run = PointwiseRun(xs, layers, training, eps, momentum, slope)
+        y = run.forward()
+        run.y = None
+        if training:
+            ctx.c = run
+        ctx.n = (n_seg, n_layers)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not hasattr(ctx, "c"):
+            raise RuntimeError("gfs3d.pointwise: backward is implemented for training mode (batch statistics) only")
+        n_seg, n_layers = ctx.n
+        dxs, dws, dgs, dbs = ctx.c.backward(dy)
+        par = []
+        for l in range(n_layers):
+            par += [dws[l], dgs[l], dbs[l]]
+        return (None,) * 6 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers)
+
+
+def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2):
+    """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64) segments."""
+    if training:
+        for _c, bn in parts:
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    bn0 = parts[0][1]
+    mom = bn0.momentum if bn0.momentum is not None else 0.1
+    par, run_ = [], []
+    for conv, bn in parts:
+        par += [conv.weight, bn.weight, bn.bias]
+        run_ += [bn.running_mean, bn.running_var]
+    return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope),
+                                        *xs_pm, *par, *run_)
 
 
 # --------------------------------------------------------------------------

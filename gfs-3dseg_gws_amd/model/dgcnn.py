@@ -88,6 +88,23 @@ class conv1d(nn.Module):
     def forward(self, x):
         return self.layer(x)
 
+    def fused_parts(self):
+        """[(conv, bn)] when the stack has the shape the HIP point-wise kernels implement (bias-free 1x1 convs
+        to multiples of 64 channels, BatchNorm1d, LeakyReLU(0.2); at most 4 layers) - else None."""
+        m = list(self.layer)
+        if len(m) % 3 or not 3 <= len(m) <= 12:
+            return None
+        parts = []
+        for i in range(0, len(m), 3):
+            c, bn, act = m[i], m[i + 1], m[i + 2]
+            ok = (isinstance(c, nn.Conv1d) and type(bn) is nn.BatchNorm1d and isinstance(act, nn.LeakyReLU)
+                  and c.bias is None and c.kernel_size == (1,) and c.out_channels % 64 == 0 and c.out_channels <= 1024
+                  and bn.affine and bn.track_running_stats and abs(act.negative_slope - _LRELU) < 1e-12)
+            if not ok:
+                return None
+            parts.append((c, bn))
+        return parts
+
 
 class DGCNN(nn.Module):
     """Stacked EdgeConv blocks (kNN graph rebuilt on every block's features) followed by
@@ -106,19 +123,26 @@ class DGCNN(nn.Module):
         self.conv = conv1d(sum(w[-1] for w in edgeconv_widths), mlp_widths)
         self.bn_sync = None      # gfs3d.ops.BNSync: whole-batch BatchNorm statistics under block-sharded DP
 
-    def edgeconv_features(self, x):
-        """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv)."""
-        feats = []
+    def edgeconv_features(self, x, with_point_major=False):
+        """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
+        with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
+        feats, feats_pm = [], []
         for block in self.edge_convs:
             c1, bn1, c2, bn2 = block.fused_parts()
             idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True)
-            x = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU, sync=self.bn_sync)
+            x, x_pm = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
+                                         sync=self.bn_sync, want_pm=True)
             feats.append(x)
-        return feats
+            feats_pm.append(x_pm)
+        return (feats, feats_pm) if with_point_major else feats
 
     def forward(self, x):
-        feats = self.edgeconv_features(x)
-        out = self.conv(torch.cat(feats, dim=1))
+        feats, feats_pm = self.edgeconv_features(x, with_point_major=True)
+        parts = self.conv.fused_parts() if self.bn_sync is None and len(feats) <= ops.PW_MAX_SEGS else None
+        if parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats):
+            out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU)       # K4: no cat, no transposes
+        else:
+            out = self.conv(torch.cat(feats, dim=1))
         if self.return_edgeconvs:
             return feats, out
         return feats[0], out

@@ -38,8 +38,9 @@ const char *gfs3d_last_error(void);
  * with hipEvents on the launch stream.  gfs3d_profile_read synchronises the recorded
  * events of one kernel id, returns the summed device time in ms and the number of
  * launches, and clears them.  Ids: 0 knn_topk, 1 ec_main_fwd, 2 ec_main_bwd,
- * 3 proto_mfma (word assign / get_pred), 4 ec_stats1, 5 kmeans_assign. */
-#define GFS3D_PROF_KERNELS 6
+ * 3 proto_mfma (word assign / get_pred), 4 ec_stats1, 5 kmeans_assign, 6 pointwise stack forward (all its
+ * kernels), 7 pointwise stack backward. */
+#define GFS3D_PROF_KERNELS 8
 int gfs3d_profile_enable(int on);
 int gfs3d_profile_read(int kernel_id, double *total_ms, long long *launches);
 
@@ -102,6 +103,7 @@ typedef struct gfs3d_edgeconv_bwd_args {
     long long dy_bstride;
     float *dx;
     float *dw1, *dbn1_w, *dbn1_b, *dw2, *dbn2_w, *dbn2_b;
+    const float *dy_pm;      /* optional (B*N, 64) point-major gradient w.r.t. y_pm, ADDED to dy_cf (either may be NULL) */
 } gfs3d_edgeconv_bwd_args;
 
 int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *a, void *stream);
@@ -119,6 +121,54 @@ int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *a, void *stream);
  * Phases 0,1,2 with acc = NULL, stat_count = 0 are exactly the monolithic calls above. */
 int gfs3d_edgeconv_forward_phase_f32(const gfs3d_edgeconv_args *a, int phase, double *acc, double stat_count, void *stream);
 int gfs3d_edgeconv_backward_phase_f32(const gfs3d_edgeconv_bwd_args *a, int phase, double *acc, double stat_count, void *stream);
+
+/* ------------------------------------------------------------------ K4 --
+ * Point-wise MLP stack [Conv1d 1x1 (no bias) -> BatchNorm1d -> LeakyReLU(slope)] x n_layers on the
+ * concatenation of n_seg 64-channel feature maps.  Replaces `self.conv(torch.cat(edgeconv_outputs, 1))`,
+ * model/dgcnn.py:121-122 with the conv1d stack of model/dgcnn.py:64-80 (2 x [cuDNN conv, BatchNorm,
+ * LeakyReLU] + the cat in the reference).
+ *   x_seg[s]  (B*N, 64) point-major: the y_pm buffers the EdgeConv entry points leave behind
+ *   w[l]      (width[l], width[l-1]) = nn.Conv1d.weight[:, :, 0]; width[-1] = 64 * n_seg
+ *   bn_*[l]   BatchNorm1d affine parameters and running statistics (updated in place when training)
+ *   h[l]      (B*N, width[l]) pre-BatchNorm activations, kept for the backward (training); in eval mode
+ *             the post-activation values (h[n_layers-1] may then be NULL)
+ *   stats[l]  (4, width[l]) scale, shift, mean, 1/std actually applied
+ *   y_cf      (B, width[n_layers-1], N) channel-first result (what the reference returns)
+ * widths: multiples of 64, <= 1024.  Backward (training mode): dy_cf (B, width[last], N) ->
+ * dx_seg[s] (B*N, 64) point-major, dw[l], dbn_w[l], dbn_b[l]; f.y_cf and the running statistics are not used. */
+#define GFS3D_PW_MAX_LAYERS 4
+#define GFS3D_PW_MAX_SEGS 4
+#define GFS3D_PW_SEG_WIDTH 64
+typedef struct gfs3d_pointwise_args {
+    int B, N, n_seg, n_layers;
+    int width[GFS3D_PW_MAX_LAYERS];
+    int training;
+    float eps, momentum, slope;
+    const float *x_seg[GFS3D_PW_MAX_SEGS];
+    const float *w[GFS3D_PW_MAX_LAYERS];
+    const float *bn_w[GFS3D_PW_MAX_LAYERS];
+    const float *bn_b[GFS3D_PW_MAX_LAYERS];
+    float *bn_rm[GFS3D_PW_MAX_LAYERS];
+    float *bn_rv[GFS3D_PW_MAX_LAYERS];
+    float *h[GFS3D_PW_MAX_LAYERS];
+    float *stats[GFS3D_PW_MAX_LAYERS];
+    float *y_cf;
+    void *workspace;
+    size_t workspace_bytes;
+} gfs3d_pointwise_args;
+
+typedef struct gfs3d_pointwise_bwd_args {
+    gfs3d_pointwise_args f;
+    const float *dy_cf;
+    float *dx_seg[GFS3D_PW_MAX_SEGS];
+    float *dw[GFS3D_PW_MAX_LAYERS];
+    float *dbn_w[GFS3D_PW_MAX_LAYERS];
+    float *dbn_b[GFS3D_PW_MAX_LAYERS];
+} gfs3d_pointwise_bwd_args;
+
+size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width);
+int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream);
+int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream);
 
 /* ------------------------------------------------------------------ K3 --
  * Point x prototype cosine matching on MFMA (fp32-in / fp32-acc).
