@@ -116,7 +116,7 @@ def main():
     if args.sync_bn and world > 1:
         net = gdist.enable_sync_batchnorm(net)
     bucket = gdist.FlatGradBucket(net.parameters())
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     x = synthetic_blocks(B_PER_GPU, NPTS, seed=rank).to(dev)
 
     def step():

@@ -1059,7 +1059,8 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
     float *mu = reinterpret_cast<float *>(ws + p.off_mu);
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
-    double *acc1 = acc, *acc2 = acc + 2 * EC, *loc1 = acc + 4 * EC, *loc2 = acc + 6 * EC;
+    // monolithic call: this rank's sums ARE the global sums, no local copies needed
+    double *acc1 = acc, *acc2 = acc + 2 * EC, *loc1 = acc_user ? acc + 4 * EC : acc1, *loc2 = acc_user ? acc + 6 * EC : acc2;
     dim3 tgrid((a->N + 63) / 64, a->B);
     if (phase == 0) {
         if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
@@ -1069,7 +1070,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
                            a->N, a->slope, g, acc1);
         GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
-        if (hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        if (acc_user && hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("%s: hipMemcpyAsync failed", who);
             return GFS3D_ERR_HIP;
         }
@@ -1114,7 +1115,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         }
         hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
         GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
-        if (hipMemcpyAsync(loc2, acc2, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        if (acc_user && hipMemcpyAsync(loc2, acc2, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("%s: hipMemcpyAsync failed", who);
             return GFS3D_ERR_HIP;
         }

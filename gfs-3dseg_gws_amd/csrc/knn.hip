@@ -16,12 +16,18 @@
 //   per-candidate path is ~6 VALU ops; a sorted insert is ~5*K).
 //   The 4 partial lists are merged by wave 0 in candidate-quarter order, which
 //   keeps "equal distance -> lower index first".
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace gfs3d {
 
 constexpr int KNN_TJ = 16;       // candidates per LDS tile
-constexpr int KNN_QMIN = 24;     // queue slots per lane (>= TJ + 8)
+constexpr int KNN_QMIN = 32;     // queue slots per lane (>= TJ + 16)
+// bound pass: sample every 2nd tile when the distance itself is cheap (C <= 10: 5 MFMAs per tile); at C = 64 the
+// extra 32 MFMAs per sampled tile cost what the saved inserts gain (fp32 MFMA and VALU share the SIMD's issue time)
+constexpr int KNN_TWO_PASS_SMALL_C = 2, KNN_TWO_PASS_LARGE_C = 0;
+constexpr int KNN_TWO_PASS_MIN_N = 512;   // below this the bound pass costs more than the inserts it saves
 
 template <int K>
 struct TopList {
@@ -31,18 +37,19 @@ struct TopList {
 #pragma unroll
         for (int t = 0; t < K; ++t) { v[t] = -__builtin_inff(); i[t] = -1; }
     }
-    // stable insert: goes after every entry >= val
+    // stable insert: goes after every entry >= val.  Per slot: one compare, one v_med3 for the value (the list is
+    // sorted, so slot t becomes clamp(val, v[t], v[t-1])) and two selects for the index.
     __device__ __forceinline__ void insert(float val, int id) {
+        bool here = val > v[K - 1];
 #pragma unroll
         for (int t = K - 1; t >= 1; --t) {
             const bool sh = val > v[t - 1];
-            const bool here = val > v[t];
             i[t] = sh ? i[t - 1] : (here ? id : i[t]);
-            v[t] = sh ? v[t - 1] : (here ? val : v[t]);
+            v[t] = __builtin_amdgcn_fmed3f(v[t - 1], val, v[t]);
+            here = sh;
         }
-        const bool h0 = val > v[0];
-        i[0] = h0 ? id : i[0];
-        v[0] = h0 ? val : v[0];
+        i[0] = here ? id : i[0];
+        v[0] = fmaxf(v[0], val);
     }
 };
 
@@ -244,90 +251,181 @@ knn_sqnorm_kernel(const float *__restrict__ x, int C, int N, float *__restrict__
     sq[(size_t)b * N + n] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// largest float strictly below a finite v (-inf stays -inf)
+__device__ __forceinline__ float next_below(float v)
+{
+    if (v == -__builtin_inff()) return v;
+    if (v == 0.f) return -__builtin_bit_cast(float, 1u);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return __builtin_bit_cast(float, v > 0.f ? u - 1u : u + 1u);
+}
+
 template <int CS, int K>
 __global__ void __launch_bounds__(256, 2)
-knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int C, int N, int k,
+knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int B, int C, int N, int k, int two_pass,
                 int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
 {
     constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int nq = (N + 127) / 128;
+    const int b = blockIdx.x / nq, qblk = blockIdx.x % nq;
+    const int q0 = qblk * 128 + w * 32;
     if (q0 >= N) return;                               // whole wave out of range (wave-uniform)
-    const int per_wave = 2 * QS * 64;
-    float *qv = smem + (size_t)w * per_wave;
-    int *qid = reinterpret_cast<int *>(qv + QS * 64);
+    // candidate queue of this wave: [QS][64] entries of (distance bits, candidate id)
+    uint2 *queue = reinterpret_cast<uint2 *>(smem) + (size_t)w * QS * 64;
     const float *xb = x + (size_t)b * C * N;
+    const float *sqb = sqg + (size_t)b * N;
+    // Buffer descriptors (wave-uniform base + per-lane 32-bit offset + scalar offset): the CS loads of a tile need
+    // no per-load address arithmetic.  Lane half h reads channel 2s+h; where 2s+1 >= C (odd C, or C < 2 CS) both
+    // halves read the valid row min(2s, C-1) instead and the QUERY operand of the missing channel is zero.
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xb), 0, C * N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_sq =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sqb), 0, (int)min((size_t)(B - b) * N * 4 + 16, (size_t)0x7fffffff), 0x00020000);
+    auto chan_off = [&](int s) { return min(2 * s, C - 1) * N * 4; };   // byte offset of channel 2s (scalar)
 
     float qb[CS];
     {
-        const int qi = min(q0 + j, N - 1);
+        const int voff_lo = min(q0 + j, N - 1) * 4, voff = voff_lo + h * N * 4;
 #pragma unroll
         for (int s = 0; s < CS; ++s) {
-            const int c = 2 * s + h;
-            qb[s] = (c < C) ? xb[(size_t)c * N + qi] : 0.f;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (2 * s + 1 < C) ? voff : voff_lo, chan_off(s), 0));
+            qb[s] = (2 * s + h < C) ? v : 0.f;
         }
     }
-    const float sqq = sqg[(size_t)b * N + min(q0 + j, N - 1)];
-    const float *sqb = sqg + (size_t)b * N;
-
-    TopListOrd<K> best;
-    best.init();
-    float thr = -__builtin_inff();
-    int cnt = 0;
+    const float sqq = sqb[min(q0 + j, N - 1)];
 
     float a[CS];
     auto load_tile = [&](float (&dst)[CS], int j0) {
-        const int ci = min(j0 + j, N - 1);
+        const int voff_lo = min(j0 + j, N - 1) * 4, voff = voff_lo + h * N * 4;
 #pragma unroll
-        for (int s = 0; s < CS; ++s) {
-            const int c = 2 * s + h;
-            dst[s] = (c < C) ? xb[(size_t)c * N + ci] : 0.f;
-        }
+        for (int s = 0; s < CS; ++s)
+            dst[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (2 * s + 1 < C) ? voff : voff_lo, chan_off(s), 0));
     };
-    // norms of the 16 candidate rows this lane sees in a tile: rows 4h + 8g + {0..3}, g = 0..3
+    // norms of the 16 candidate rows this lane sees in a tile: rows 4h + 8g + {0..3}, g = 0..3 (one 16-byte load per g;
+    // rows past N are never used)
     float sqc[16];
     auto load_sq = [&](int j0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sqc[r] = sqb[min(j0 + (r & 3) + 8 * (r >> 2) + 4 * h, N - 1)];
+        for (int g = 0; g < 4; ++g) {
+            // (bit-cast the whole vector: element-wise casts of the builtin's result are narrowed to one dword by hipcc 7.2)
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sq, (j0 + 8 * g + 4 * h) * 4, 0, 0));
+            sqc[4 * g + 0] = v.x; sqc[4 * g + 1] = v.y; sqc[4 * g + 2] = v.z; sqc[4 * g + 3] = v.w;
+        }
     };
-    load_tile(a, 0);
-    for (int j0 = 0; j0 < N; j0 += 32) {
+
+    // ---- pass 1 (optional): a lower bound of the k-th best distance from a SAMPLE of the candidate tiles.  The 16
+    // candidates a lane sees in one tile are a bucket; the K largest bucket maxima are K distinct candidates, so
+    // the K-th largest maximum (over both lane halves of a query) is <= the K-th best value.  One max per element
+    // plus a K-long v_med3 chain per sampled tile - no indices, no divergence.  Pass 2 then queues only the few
+    // candidates above the bound instead of ~K ln(N / K) per lane, and its sorted inserts (60 VALU each, executed
+    // for the slowest lane of the wave) stop dominating the instruction count.
+    float thr = -__builtin_inff();
+    if (two_pass > 0) {
+        const int step = 32 * two_pass;                  // every two_pass-th tile is sampled
+        float bm[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) bm[t] = -__builtin_inff();
+        auto bm_insert = [&](float m) {
+#pragma unroll
+            for (int t = K - 1; t >= 1; --t) bm[t] = __builtin_amdgcn_fmed3f(bm[t - 1], m, bm[t]);
+            bm[0] = fmaxf(bm[0], m);
+        };
+        load_tile(a, 0);
+        for (int j0 = 0; j0 < N; j0 += step) {
+            load_sq(j0);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qb[s], acc, 0, 0, 0);
+            if (j0 + step < N) load_tile(a, j0 + step);
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cand = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
+                m = fmaxf(m, cand < N ? pd : -__builtin_inff());
+            }
+            bm_insert(m);
+        }
+        float other[K];
+#pragma unroll
+        for (int t = 0; t < K; ++t) other[t] = __shfl_xor(bm[t], 32, 64);
+#pragma unroll
+        for (int t = 0; t < K; ++t) bm_insert(other[t]);
+        thr = next_below(bm[K - 1]);       // the strict '>' below must keep candidates equal to the bound
+    }
+
+    // ---- pass 2: exact selection among the candidates above the bound.  Candidate tiles are fetched TWO tiles ahead
+    // (a0 / a1 ping-pong): one tile of selection work does not cover an L2 / Infinity-Cache round trip.
+    TopListOrd<K> best;
+    best.init();
+    int cnt = 0;
+    uint2 *qslot = queue + lane;                        // next free entry of this lane
+    float a1[CS];
+    auto process = [&](float (&cur)[CS], int j0) {
         load_sq(j0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qb[s], acc, 0, 0, 0);
-        // the MFMAs have consumed a[]: refill it with the next tile while the selection below runs
-        if (j0 + 32 < N) load_tile(a, j0 + 32);
+        for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], qb[s], acc, 0, 0, 0);
+        // the MFMAs have consumed cur[]: refill it with the tile after next while the selection below runs
+        if (j0 + 64 < N) load_tile(cur, j0 + 64);
         __builtin_amdgcn_wave_barrier();
+        const int cbase = j0 + 4 * h;
+        if (j0 + 32 <= N) {                              // a ragged last tile takes the checked path
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int cand = j0 + row;
-            const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
-            if (pd > thr && cand < N) {
-                qv[cnt * 64 + lane] = pd;
-                qid[cnt * 64 + lane] = cand;
-                ++cnt;
+            for (int r = 0; r < 16; ++r) {
+                const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
+                if (pd > thr) {
+                    *qslot = make_uint2(__builtin_bit_cast(unsigned, pd), (unsigned)(cbase + (r & 3) + 8 * (r >> 2)));
+                    qslot += 64;
+                    ++cnt;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cand = cbase + (r & 3) + 8 * (r >> 2);
+                const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
+                if (pd > thr && cand < N) {
+                    *qslot = make_uint2(__builtin_bit_cast(unsigned, pd), (unsigned)cand);
+                    qslot += 64;
+                    ++cnt;
+                }
             }
         }
         if (__any(cnt > QS - 16)) {
             const int mx = wave_max(cnt);
             for (int s = 0; s < mx; ++s)
-                if (s < cnt) best.insert(qv[s * 64 + lane], qid[s * 64 + lane]);
+                if (s < cnt) {
+                    const uint2 e = queue[s * 64 + lane];
+                    best.insert(__builtin_bit_cast(float, e.x), (int)e.y);
+                }
             cnt = 0;
-            thr = best.v[K - 1];
+            qslot = queue + lane;
+            thr = fmaxf(thr, best.v[K - 1]);
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    load_tile(a, 0);
+    if (32 < N) load_tile(a1, 32);
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        process(a, j0);
+        if (j0 + 32 < N) process(a1, j0 + 32);
     }
     {
         const int mx = wave_max(cnt);
         for (int s = 0; s < mx; ++s)
-            if (s < cnt) best.insert(qv[s * 64 + lane], qid[s * 64 + lane]);
+            if (s < cnt) {
+                const uint2 e = queue[s * 64 + lane];
+                best.insert(__builtin_bit_cast(float, e.x), (int)e.y);
+            }
     }
     // merge the h=1 half-list into h=0 (interleaved candidate subsets -> full comparator)
 #pragma unroll
@@ -337,7 +435,7 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
         if (h == 0) best.insert_ordered(ov, oi);
     }
     __builtin_amdgcn_wave_barrier();
-    int *outl = qid;                                   // [K][32]
+    int *outl = reinterpret_cast<int *>(queue);        // [K][32]
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < K; ++t) outl[t * 32 + j] = best.i[t];
@@ -358,11 +456,16 @@ static int launch_knn_mfma(const float *x, float *sq, int B, int C, int N, int k
 {
     constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
     const size_t lds = sizeof(float) * 4 * (size_t)(2 * QS * 64);
-    dim3 grid((N + 127) / 128, B);
+    dim3 grid(((N + 127) / 128) * B);
+    static const int two_pass_env = [] { const char *e = getenv("GFS3D_KNN_TWO_PASS"); return e ? atoi(e) : -1; }();   // tuning only
+    int two_pass = two_pass_env >= 0 ? two_pass_env : (CS <= 8 ? KNN_TWO_PASS_SMALL_C : KNN_TWO_PASS_LARGE_C);
+    // the sample must hold at least K buckets (2 per sampled tile and query), else there is no bound to be had
+    while (two_pass > 0 && 2 * ((N / 32 + two_pass - 1) / two_pass) < 2 * K) --two_pass;
+    if (N < KNN_TWO_PASS_MIN_N) two_pass = 0;
     ProfScope prof(0, st);
     hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
     GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
-    hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, sq, C, N, k, idx64, idx32);
+    hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, sq, B, C, N, k, two_pass, idx64, idx32);
     GFS3D_LAUNCH_CHECK("gfs3d_knn_topk_f32(mfma)");
     return GFS3D_OK;
 }
@@ -396,7 +499,7 @@ static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64
 extern "C" size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k)
 {
     (void)C; (void)k;
-    return (B < 1 || N < 1) ? 0 : sizeof(float) * (size_t)B * N;
+    return (B < 1 || N < 1) ? 0 : sizeof(float) * (size_t)B * N + 64;    // norms + slack for 16-byte reads at the end
 }
 
 extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
@@ -410,10 +513,11 @@ extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
     GFS3D_REQUIRE(B <= 65535, "gfs3d_knn_topk_f32: B=%d exceeds grid.y", B);
     if (B == 0) return GFS3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C <= 64 && k <= 32) {          // MFMA path; needs B*N floats of workspace for the point norms
+    if (C <= 64 && k <= 32) {          // MFMA path; the workspace holds the point norms
+        GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "gfs3d_knn_topk_f32: C*N too large for 32-bit buffer offsets");
         GFS3D_REQUIRE(workspace != nullptr, "gfs3d_knn_topk_f32: NULL workspace");
-        if (workspace_bytes < sizeof(float) * (size_t)B * N) {
-            set_error("gfs3d_knn_topk_f32: workspace %zu < required %zu", workspace_bytes, sizeof(float) * (size_t)B * N);
+        if (workspace_bytes < gfs3d_knn_workspace_bytes(B, C, N, k)) {
+            set_error("gfs3d_knn_topk_f32: workspace %zu < required %zu", workspace_bytes, gfs3d_knn_workspace_bytes(B, C, N, k));
             return GFS3D_ERR_WORKSPACE;
         }
         float *sq = static_cast<float *>(workspace);

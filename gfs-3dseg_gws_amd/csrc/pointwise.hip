@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
             }
     }
     if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
-        float *red = smem;                      // [4 waves][TN][2][32]  (staging buffers are idle: last loop barrier passed)
+        float *red = smem;                      // [4 waves][TN][2][32]  (the staging buffer is idle: last loop barrier passed)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32, 64);
@@ -231,15 +231,15 @@ struct WGrad {
 
 // dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci]  over this block's slice of the points
 template <int BMU, int BNV, int VPRO>
-__global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
+__global__ void __launch_bounds__(256, 3) pw_wgrad_kernel(const WGrad g)
 {
     extern __shared__ f32x4 pw_smem4[];
     float *smem = reinterpret_cast<float *>(pw_smem4);
     constexpr int TM = BMU / 64, TN = BNV / 64;
     constexpr int UC4 = BMU / 4, RUS = 256 / UC4, NU = 32 / RUS;     // U tile [32][BMU]: float4 per row, rows per pass, passes
     constexpr int VC4 = BNV / 4, RVS = 256 / VC4, NV = 32 / RVS;
-    float *sU = smem;                       // [2][32][BMU]
-    float *sV = smem + 2 * 32 * BMU;        // [2][32][BNV]
+    float *sU = smem;                       // [32][BMU]
+    float *sV = smem + 32 * BMU;            // [32][BNV]
     const int nci = g.Ci / BNV, ntile = (g.Co / BMU) * nci;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
             rV[p] = m < m1 ? ldg4(vp + (size_t)m * g.ldv) : zero4;
         }
     };
-    auto store = [&](int kt, int buf) {
+    auto store = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < NU; ++p) {
             f32x4 v = rU[p];
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(rU2[p][e], uc[e], fmaf(v[e], ua[e], ub[e]));
                 if (m0 + kt * 32 + ru + RUS * p >= m1) v = zero4;
             }
-            *reinterpret_cast<f32x4 *>(&sU[(buf * 32 + ru + RUS * p) * BMU + 4 * cu]) = v;
+            *reinterpret_cast<f32x4 *>(&sU[(ru + RUS * p) * BMU + 4 * cu]) = v;
         }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
@@ -300,19 +300,18 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
                 for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], va[e], vb[e]), g.slope);
                 if (m0 + kt * 32 + rv + RVS * p >= m1) v = zero4;
             }
-            *reinterpret_cast<f32x4 *>(&sV[(buf * 32 + rv + RVS * p) * BNV + 4 * cv]) = v;
+            *reinterpret_cast<f32x4 *>(&sV[(rv + RVS * p) * BNV + 4 * cv]) = v;
         }
     };
 
     const int KT = (m1 - m0 + 31) / 32;
+    const float *pu = &sU[lh * BMU + wm * (BMU / 2) + li];
+    const float *pv = &sV[lh * BNV + wn * (BNV / 2) + li];
     load(0);
-    store(0, 0);
-    __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
+        store(kt);
+        __syncthreads();
         if (kt + 1 < KT) load(kt + 1);
-        const float *pu = &sU[(buf * 32 + lh) * BMU + wm * (BMU / 2) + li];
-        const float *pv = &sV[(buf * 32 + lh) * BNV + wn * (BNV / 2) + li];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             float af[TM], bf[TN];
@@ -326,7 +325,6 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad_kernel(const WGrad g)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store(kt + 1, buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -482,7 +480,7 @@ int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
 {
-    const size_t lds = sizeof(float) * 2 * 32 * (BMU + BNV);
+    const size_t lds = sizeof(float) * 32 * (BMU + BNV);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_wgrad_kernel<BMU, BNV, VPRO>),
@@ -491,8 +489,8 @@ int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
         attr_done = true;
     }
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
-    // ~1024 blocks; a split is a multiple of 32 points
-    int nsplit = (1024 + ntile - 1) / ntile;
+    // ~3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
+    int nsplit = (768 + ntile - 1) / ntile;
     int rows = (wg.M + nsplit - 1) / nsplit;
     rows = (rows + 31) / 32 * 32;
     if (rows < 256) rows = 256;
@@ -526,7 +524,7 @@ PwPlan pw_plan(int B, int N, int n_seg, int n_layers, const int *width)
     p.maxw = 0;
     for (int l = 0; l < n_layers; ++l) p.maxw = width[l] > p.maxw ? width[l] : p.maxw;
     size_t o = 0;
-    p.off_acc = o;  o = align_up(o + sizeof(double) * 2 * p.maxw, 256);
+    p.off_acc = o;  o = align_up(o + sizeof(double) * 2 * p.maxw * n_layers, 256);      // [layer][2][maxw]
     p.off_coef = o; o = align_up(o + sizeof(float) * 3 * p.maxw, 256);
     for (int l = 0; l < n_layers; ++l) {
         const int ci = l ? width[l - 1] : p.in_width;
@@ -598,8 +596,13 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
     double *acc = reinterpret_cast<double *>(ws + p.off_acc);
     const int L = a->n_layers, M = p.M;
     ProfScope prof(6, st);
+    if (a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
+        set_error("%s: hipMemsetAsync failed", who);
+        return GFS3D_ERR_HIP;
+    }
     for (int l = 0; l < L; ++l) {
         const int C = a->width[l];
+        double *acc_l = acc + (size_t)2 * p.maxw * l;
         RowGemm rg{};
         fill_a(rg, a, l, l ? a->h[l - 1] : nullptr);
         rg.w = a->w[l];
@@ -608,10 +611,9 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
         rg.slope = a->slope;
         rg.out[0] = a->h[l];
         rg.o_segw = C;
-        rg.acc = acc;
+        rg.acc = acc_l;
         int rc;
         if (a->training) {
-            if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
             if (l == 0) rc = rowgemm<PRO_NONE, EPI_RAW_STATS, false>(rg, st, who);
             else {
                 rg.pa = a->stats[l - 1] + PST_SCALE * a->width[l - 1];
@@ -619,7 +621,7 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
                 rc = rowgemm<PRO_BNACT, EPI_RAW_STATS, false>(rg, st, who);
             }
             if (rc) return rc;
-            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
+            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc_l, C, (double)M, a->bn_w[l], a->bn_b[l],
                                a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l]);
             GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
         } else {
@@ -670,16 +672,18 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
     ProfScope prof(7, st);
     {
         const int C = a->width[L - 1];
-        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
         hipLaunchKernelGGL(pw_bwd_in_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
-                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]), acc);
+                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]),
+                           acc + (size_t)2 * p.maxw * (L - 1));
         GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
     }
     for (int l = L - 1; l >= 0; --l) {
         const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
         float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
         float *wt = reinterpret_cast<float *>(ws + p.off_wt[l]);
-        hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->stats[l], coef,
+        double *acc_l = acc + (size_t)2 * p.maxw * l;
+        hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc_l, C, (double)M, a->stats[l], coef,
                            ba->dbn_w[l], ba->dbn_b[l]);
         GFS3D_LAUNCH_CHECK("pw_bwd_coef_kernel");
         // dW_l
@@ -718,9 +722,7 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
             rg.ea = a->stats[l - 1] + PST_SCALE * Ci;
             rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
             rg.eh = a->h[l - 1];
-            rg.acc = acc;
-            // stream order: pw_bwd_coef_kernel(l) above has consumed acc; it now collects the sums of layer l-1
-            if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+            rg.acc = acc + (size_t)2 * p.maxw * (l - 1);
             rc = rowgemm<PRO_BWD, EPI_BWD_ACT, false>(rg, st, who);
         }
         if (rc) return rc;

@@ -36,8 +36,11 @@ def shard_range(n_items: int, rank: Optional[int] = None, world_size: Optional[i
 
 
 class FlatGradBucket:
-    """All parameter gradients live in ONE flat fp32 buffer (p.grad are views into it), so the
-    data-parallel exchange is a single all-reduce with no packing copies."""
+    """Data-parallel gradient exchange as ONE all-reduce: after backward the parameter gradients are
+    packed into a flat fp32 buffer by a single multi-tensor copy, summed over the ranks, and handed
+    back to the parameters as views of that buffer (no per-parameter collectives, no unpack copies).
+    `zero()` drops the previous gradients so autograd writes each one once instead of launching an
+    accumulate kernel per parameter."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -46,22 +49,32 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.views: List[torch.Tensor] = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
 
     def zero(self) -> None:
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
 
     def all_reduce_mean(self) -> None:
         """SUM over ranks then divide by world size (mean over the global batch when every
         rank's loss is a mean over its equally sized shard)."""
         if not is_dist() or dist.get_world_size() == 1:
             return
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                v.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g_ for _, g_ in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
 
 def all_reduce_counts(counts: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,23 @@
+"""Time the point-wise stack (K4) at BASELINE config 2 size; run under rocprofv3 --kernel-trace --stats for per-kernel times."""
+import sys, time, torch
+sys.path.insert(0, "gfs-3dseg_gws_amd")
+from gfs3d import ops
+from model.dgcnn import conv1d
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+conv = conv1d(192, [512, 256]).to(dev).train()
+xs = [torch.randn(32, 2048, 64, device=dev).requires_grad_(True) for _ in range(3)]
+cot = torch.randn(32, 256, 2048, device=dev)
+parts = conv.fused_parts()
+def step():
+    for p in conv.parameters(): p.grad = None
+    for t in xs: t.grad = None
+    y = ops.pointwise_stack(xs, parts, True)
+    y.backward(cot)
+for _ in range(3): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n): step()
+torch.cuda.synchronize()
+print("pointwise fwd+bwd ms/iter", (time.perf_counter() - t0) / n * 1e3)

@@ -37,14 +37,14 @@ def _worker(rank, world, port, out):
     res = {}
     # 1. shards are disjoint and cover everything
     res["shard"] = gd.shard_range(37)
-    # 2. flat-bucket gradient all-reduce = mean over ranks, grads stay views of the bucket
+    # 2. flat-bucket gradient all-reduce = mean over ranks; afterwards the grads are views of the bucket
     torch.manual_seed(0)
     lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
     bucket = gd.FlatGradBucket(lin.parameters())
     x = torch.full((4, 5), float(rank + 1))
     bucket.zero()
     lin(x).sum().backward()
-    local = bucket.flat.clone()
+    local = torch.cat([p.grad.reshape(-1) for p in lin.parameters()]).clone()
     bucket.all_reduce_mean()
     res["local_grad"], res["mean_grad"] = local.numpy(), bucket.flat.numpy().copy()
     res["views"] = all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in lin.parameters())
