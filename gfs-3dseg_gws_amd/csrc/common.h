@@ -60,4 +60,9 @@ __device__ __forceinline__ int wave_max(int v) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// pointwise.hip: out(M, Nc) = a(M, K) . w(Nc, K)^T on MFMA, point-major; the Nc columns are written as segments of
+// width o_segw to out[0], out[1], ...  (K % 32 == 0, Nc % 64 == 0, o_segw % 64 == 0, at most 4 segments)
+int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw, hipStream_t st,
+                  const char *who);
+
 }  // namespace gfs3d

@@ -70,6 +70,18 @@ ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, i
     }
 }
 
+// F1 on MFMA (C == 64, point-major x available): rows 0..63 of wpq = Wa, rows 64..127 = Wb - Wa, so that
+// [P | Q](M, 128) = x_pm(M, C) . wpq^T is one plain GEMM (pointwise.hip).
+__global__ void ec_wpq_kernel(const float *__restrict__ w1, int C, float *__restrict__ wpq)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= EC * C) return;
+    const int co = e / C, c = e - co * C;
+    const float a = w1[(size_t)co * 2 * C + c];
+    wpq[e] = a;
+    wpq[EC * C + e] = w1[(size_t)co * 2 * C + C + c] - a;
+}
+
 // ---------------------------------------------------------------------------
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
@@ -1006,11 +1018,19 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
     if (phase == 0) {
-        const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(ec_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
-        GFS3D_LAUNCH_CHECK("ec_pq_kernel");
+        if (a->x_pm && a->C % 32 == 0) {
+            float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
+            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq);
+            GFS3D_LAUNCH_CHECK("ec_wpq_kernel");
+            float *outs[2] = {a->P, a->Q};
+            if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, st, who)) return rc;
+        } else {
+            const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
+            if (lds > 64 * 1024)
+                hipFuncSetAttribute(reinterpret_cast<const void *>(ec_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
+            GFS3D_LAUNCH_CHECK("ec_pq_kernel");
+        }
         if (a->training) {
             if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
                 set_error("%s: hipMemsetAsync failed", who);

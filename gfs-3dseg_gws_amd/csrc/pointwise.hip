@@ -572,6 +572,21 @@ void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev
 }
 
 }  // namespace
+
+int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw, hipStream_t st,
+                  const char *who)
+{
+    if (K % PW_BK || Nc % 64 || o_segw % 64 || Nc / o_segw > 4 || Nc % o_segw) {
+        set_error("%s: pw_plain_gemm: unsupported shape K=%d Nc=%d segw=%d", who, K, Nc, o_segw);
+        return GFS3D_ERR_INVALID;
+    }
+    RowGemm rg{};
+    rg.a[0] = a; rg.a_segw = K; rg.lda = lda; rg.K = K;
+    rg.w = w; rg.M = M; rg.Nc = Nc;
+    for (int s = 0; s < Nc / o_segw; ++s) rg.out[s] = out[s];
+    rg.o_segw = o_segw;
+    return rowgemm<PRO_NONE, EPI_PLAIN, false>(rg, st, who);
+}
 }  // namespace gfs3d
 
 using namespace gfs3d;

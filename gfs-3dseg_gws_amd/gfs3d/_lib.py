@@ -31,6 +31,7 @@ class EdgeConvArgs(Structure):
         ("P", c_void_p), ("Q", c_void_p), ("SP", c_void_p), ("SQ", c_void_p), ("indeg", c_void_p),
         ("stats", c_void_p), ("hsel", c_void_p), ("jsel", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("x_pm", c_void_p),
     ]
 
 

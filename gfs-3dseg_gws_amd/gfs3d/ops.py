@@ -93,7 +93,7 @@ class EdgeConvRun:
     the C ABI either monolithically or phase by phase (synchronised BatchNorm)."""
 
     def __init__(self, x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope,
-                 private_workspace: bool = False):
+                 private_workspace: bool = False, x_pm: Optional[torch.Tensor] = None):
         for t, nme in ((x, "x"), (w1, "conv1.weight"), (w2, "conv2.weight")):
             _need_gpu(t, nme)
         self.x = x.contiguous()
@@ -104,6 +104,9 @@ class EdgeConvRun:
         if w1.numel() != EC_WIDTH * 2 * C or w2.numel() != EC_WIDTH * EC_WIDTH:
             raise NotImplementedError("gfs3d.edgeconv: only EdgeConv widths [64, 64] are implemented in HIP")
         self.B, self.C, self.N, self.k, self.idx = B, C, N, k, idx
+        if x_pm is not None and (tuple(x_pm.shape) != (B, N, C) or not x_pm.is_contiguous() or x_pm.dtype != torch.float32):
+            raise RuntimeError("gfs3d.edgeconv: x_pm must be the contiguous (B,N,C) fp32 point-major copy of x")
+        self.x_pm = x_pm
         self.training = bool(training)
         self.scalars = (float(eps), float(momentum), float(slope))
         self.w1, self.w2 = w1.contiguous(), w2.contiguous()
@@ -150,6 +153,7 @@ class EdgeConvRun:
         a.y_cf, a.y_cf_bstride = (self.y.data_ptr() if self.y is not None else None), EC_WIDTH * self.N
         ws = self._private_ws if self._private_ws is not None else _workspace(self.x.device, self._nbytes)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.x_pm = self.x_pm.data_ptr() if self.x_pm is not None else None
         return ws
 
     def _bwd_args(self, dy, dy_pm=None):
@@ -233,8 +237,8 @@ class EdgeConvFunction(torch.autograd.Function):
     gradients arriving through either are added."""
 
     @staticmethod
-    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync):
-        run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope)
+    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync, x_pm):
+        run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope, x_pm=x_pm)
         y = run.forward(sync)
         run.y = None                     # outputs must not be reachable from ctx (reference cycle through grad_fn)
         ctx.set_materialize_grads(False)
@@ -248,17 +252,19 @@ class EdgeConvFunction(torch.autograd.Function):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
         if dy is None and dy_pm is None:
-            return (None,) * 17
+            return (None,) * 18
         grads = ctx.c.backward(dy, ctx.sync, dy_pm)
         dx, dw1, dg1, db1, dw2, dg2, db2 = grads
-        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 9
+        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 10
 
 
 def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
-                   sync: Optional[BNSync] = None, want_pm: bool = False):
+                   sync: Optional[BNSync] = None, want_pm: bool = False, x_pm: Optional[torch.Tensor] = None):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
-    training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks."""
+    training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks.  `x_pm`: the
+    (B,N,C) point-major values of x when the caller has them (the previous block's second output) - the input
+    projections then run as one MFMA GEMM; the gradient still flows through x."""
     if training:
         for bn in (bn1, bn2):
             if bn.num_batches_tracked is not None:
@@ -266,7 +272,8 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
     mom = bn1.momentum if bn1.momentum is not None else 0.1
     y, y_pm = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
                                      bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
-                                     bool(training), float(bn1.eps), float(mom), float(slope), sync)
+                                     bool(training), float(bn1.eps), float(mom), float(slope), sync,
+                                     x_pm.detach() if x_pm is not None else None)
     return (y, y_pm) if want_pm else y
 
 

@@ -87,6 +87,8 @@ typedef struct gfs3d_edgeconv_args {
     uint8_t *jsel;                /* (B, N, 64) neighbour slot j that won the max */
     void *workspace;
     size_t workspace_bytes;       /* >= gfs3d_edgeconv_workspace_bytes() */
+    const float *x_pm;            /* optional (B*N, C) point-major copy of x (the previous block's y_pm): with C == 64 the
+                                     two projections run as one MFMA GEMM; NULL = channel-first path */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);
