@@ -33,6 +33,7 @@ struct RowGemm {
     int a_segw, lda;
     const float *pa, *pb, *pc;  // prologue coefficients per K channel
     const float *w;           // (Nc, K) row-major, K contiguous
+    const void *w3;           // bf16x3 image of w for the split kernel: [Nc][K/32][3 planes][32] bf16
     int M, K, Nc;
     float slope;
     float *out[4];            // point-major output, column segments of width o_segw (row stride o_segw)
@@ -45,6 +46,81 @@ struct RowGemm {
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// Shared epilogue of the row GEMMs: acc[TM][TN] are 32x32 MFMA result tiles (column on the lane, rows in the 16
+// registers); wave (wm, wn) owns rows wm*WM.. and columns wn*64.. of the block tile at (row0, col0).
+template <int BN, int EPI, bool OUT_CF, int TM, int TN>
+__device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)[TM][TN], float *smem, int row0, int col0, int wm,
+                                                 int wn, int wv, int t, int li, int lh)
+{
+    constexpr int WM = TM * 32;
+    if (OUT_CF) {                               // D rows = channels, lanes = points
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pt = row0 + wm * WM + i * 32 + li;
+            if (pt >= g.M) continue;
+            const int b = pt / g.npts, n = pt - b * g.npts;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float z = fmaf(acc[i][j][r], g.ea[ch], g.eb[ch]);
+                    g.out_cf[((size_t)b * g.Nc + ch) * g.npts + n] = lrelu(z, g.slope);
+                }
+        }
+        return;
+    }
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wn * 64 + j * 32 + li;
+        const int seg = col / g.o_segw, ocol = col - seg * g.o_segw;
+        float *op = g.out[seg] + ocol;
+        float ea = 0.f, eb = 0.f;
+        if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = g.ea[col]; eb = g.eb[col]; }
+        s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (EPI == EPI_RAW_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                if (EPI == EPI_AFFINE_ACT) v = lrelu(fmaf(v, ea, eb), g.slope);
+                if (EPI == EPI_BWD_ACT) {
+                    const float h = g.eh[(size_t)row * g.Nc + col];
+                    v = fmaf(h, ea, eb) > 0.f ? v : v * g.slope;
+                    s1[j] += v; s2[j] = fmaf(v, h, s2[j]);
+                }
+                op[(size_t)row * g.o_segw] = v;
+            }
+    }
+    if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
+        float *red = smem;                      // [4 waves][TN][2][32]  (the staging buffer is idle: last loop barrier passed)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+            if (lh == 0) { red[((wv * TN + j) * 2 + 0) * 32 + li] = s1[j]; red[((wv * TN + j) * 2 + 1) * 32 + li] = s2[j]; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int which = t / BN, col = t - which * BN;
+            const int cwn = col >> 6, j = (col >> 5) & 1, i = col & 31;
+            float s = 0.f;
+            if (BN == 128) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) s += red[(((m * 2 + cwn) * TN + j) * 2 + which) * 32 + i];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) s += red[((m * TN + j) * 2 + which) * 32 + i];
+            }
+            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)s);
+        }
+    }
+}
 
 // Out(M, Nc) = T(A)(M, K) . W(Nc, K)^T          grid: 8 * ncb * ceil(nrb / 8) blocks of 256 threads
 template <int BN, int PRO, int EPI, bool OUT_CF>
@@ -148,73 +224,166 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
         __syncthreads();
     }
 
-    // ---------------------------------------------------------------- epilogue
-    if (OUT_CF) {                               // D rows = channels, lanes = points
+    rowgemm_epilogue<BN, EPI, OUT_CF, TM, TN>(g, acc, smem, row0, col0, wm, wn, wv, t, li, lh);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix cores at fp32 accuracy ("bf16x6").  An fp32 number is EXACTLY the sum of three
+// bf16 numbers (truncation splits: 8 + 8 + 8 significand bits), so a . b = sum over the six piece products of
+// weight >= 2^-24 (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi; each product is exact in the fp32 accumulator
+// input) - what is dropped is below fp32 rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace
+// eight v_mfma_f32_32x32x2_f32 (64 cycles, K = 2 each): 2.7x less matrix time, and on gfx950 the fp32 MFMA runs
+// at the vector rate on issue time it shares with the VALU (scripts/micro/), so this is the only way to a GEMM
+// faster than the vector peak.  A is split once per block while it is staged into LDS (4 VALU per element + the
+// packing), W comes pre-split from pw_split_w_kernel.
+// LDS row (one K-step of 32 for one tile row): [hi 32 x bf16 | mid | lo | 16 B pad] = 208 B = 13 sixteen-byte slots
+// (odd, so the 16-lane groups of ds_read_b128 hit 16 different slots).
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PW6_ROW = 208;
+
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);                  // exact: the low 16 significand bits
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m)); // exact, <= 8 significant bits: low half is 0
+}
+// two fp32 bit patterns whose low halves are dropped -> one dword of two bf16 (a first)
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// w3[n][kt][plane][32] = bf16 pieces of w(n, 32 kt + j);  w element (n, k) is read at w[n * sn + k * sk]
+__global__ void pw_split_w_kernel(const float *__restrict__ w, int Nc, int K, long long sn, long long sk, unsigned short *__restrict__ w3)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Nc * K) return;
+    const int n = e / K, k = e - n * K;
+    unsigned h, m, l;
+    split3(w[(size_t)n * sn + (size_t)k * sk], h, m, l);
+    unsigned short *o = w3 + ((size_t)n * (K / 32) + k / 32) * 96 + (k & 31);
+    o[0] = (unsigned short)(h >> 16);
+    o[32] = (unsigned short)(m >> 16);
+    o[64] = (unsigned short)(l >> 16);
+}
+
+template <int BN, int PRO, int EPI, bool OUT_CF>
+__global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
+{
+    extern __shared__ f32x4 pw_smem4[];
+    char *smem = reinterpret_cast<char *>(pw_smem4);
+    constexpr int TM = (BN == 128) ? 2 : 1, TN = 2, WM = TM * 32, NB = BN * 12 / 256;
+    char *sA = smem;                                // [128][208 B]
+    char *sB = smem + PW_BM * PW6_ROW;              // [BN][208 B]
+    const int ncb = g.Nc / BN, nrb = (g.M + PW_BM - 1) / PW_BM;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int rb = (slot / ncb) * 8 + xcd, cb = slot % ncb;
+    if (rb >= nrb) return;
+    const int row0 = rb * PW_BM, col0 = cb * BN;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = (BN == 128) ? (wv >> 1) : wv, wn = (BN == 128) ? (wv & 1) : 0;
+    const int c4 = t & 7, r0 = t >> 3;
+    const int KT = g.K / PW_BK;
+
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int pt = row0 + wm * WM + i * 32 + li;
-            if (pt >= g.M) continue;
-            const int b = pt / g.npts, n = pt - b * g.npts;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[4], ra2[4], rw[NB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int kt) {
+        const int kcol = kt * PW_BK + 4 * c4;
+        const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
+        const float *ap = g.a[seg] + koff;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = row0 + r0 + 32 * p;
+            ra[p] = row < g.M ? ldg4(ap + (size_t)row * g.lda) : zero4;
+        }
+        if (PRO == PRO_BWD) {
+            const float *ap2 = g.a2[seg] + koff;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + r0 + 32 * p;
+                ra2[p] = row < g.M ? ldg4(ap2 + (size_t)row * g.lda) : zero4;
+            }
+        }
+        const char *w3 = static_cast<const char *>(g.w3);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int q = t + 256 * p, row = q / 12, part = q - row * 12;
+            rw[p] = ldg4(reinterpret_cast<const float *>(w3 + ((size_t)(col0 + row) * KT + kt) * 192 + part * 16));
+        }
+    };
+    auto store = [&](int kt) {
+        const int kcol = kt * PW_BK + 4 * c4;
+        f32x4 ca = zero4, cb4 = zero4, cc = zero4;
+        if (PRO != PRO_NONE) { ca = ldg4(g.pa + kcol); cb4 = ldg4(g.pb + kcol); }
+        if (PRO == PRO_BWD) cc = ldg4(g.pc + kcol);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 v = ra[p];
+            if (PRO == PRO_BNACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], ca[e], cb4[e]), g.slope);
+            } else if (PRO == PRO_BWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(ra2[p][e], cc[e], fmaf(v[e], ca[e], cb4[e]));
+            }
+            if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[e], h[e], m[e], l[e]);
+            char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+            *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+            *reinterpret_cast<uint2 *>(dst + 128) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+        }
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const int q = t + 256 * p, row = q / 12, part = q - row * 12;
+            *reinterpret_cast<f32x4 *>(sB + row * PW6_ROW + part * 16) = rw[p];
+        }
+    };
+
+    const char *pa = sA + (wm * WM + li) * PW6_ROW + lh * 16;
+    const char *pb = sB + (wn * 64 + li) * PW6_ROW + lh * 16;
+    load(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        store(kt);
+        __syncthreads();
+        if (kt + 1 < KT) load(kt + 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pa + i * 32 * PW6_ROW + pl * 64 + kb * 32));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float z = fmaf(acc[i][j][r], g.ea[ch], g.eb[ch]);
-                    g.out_cf[((size_t)b * g.Nc + ch) * g.npts + n] = lrelu(z, g.slope);
-                }
-        }
-        return;
-    }
-    float s1[TN], s2[TN];
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pb + j * 32 * PW6_ROW + pl * 64 + kb * 32));
+            // smallest pieces first: (lo hi) (hi lo) (mid mid) (mid hi) (hi mid) (hi hi)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + wn * 64 + j * 32 + li;
-        const int seg = col / g.o_segw, ocol = col - seg * g.o_segw;
-        float *op = g.out[seg] + ocol;
-        float ea = 0.f, eb = 0.f;
-        if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = g.ea[col]; eb = g.eb[col]; }
-        s1[j] = 0.f; s2[j] = 0.f;
+            for (int term = 0; term < 6; ++term)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= g.M) continue;
-                float v = acc[i][j][r];
-                if (EPI == EPI_RAW_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
-                if (EPI == EPI_AFFINE_ACT) v = lrelu(fmaf(v, ea, eb), g.slope);
-                if (EPI == EPI_BWD_ACT) {
-                    const float h = g.eh[(size_t)row * g.Nc + col];
-                    v = fmaf(h, ea, eb) > 0.f ? v : v * g.slope;
-                    s1[j] += v; s2[j] = fmaf(v, h, s2[j]);
-                }
-                op[(size_t)row * g.o_segw] = v;
-            }
-    }
-    if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
-        float *red = smem;                      // [4 waves][TN][2][32]  (the staging buffer is idle: last loop barrier passed)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            s1[j] += __shfl_xor(s1[j], 32, 64);
-            s2[j] += __shfl_xor(s2[j], 32, 64);
-            if (lh == 0) { red[((wv * TN + j) * 2 + 0) * 32 + li] = s1[j]; red[((wv * TN + j) * 2 + 1) * 32 + li] = s2[j]; }
+                    for (int j = 0; j < TN; ++j) {
+                        if (OUT_CF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[term]], af[i][PA[term]], acc[i][j], 0, 0, 0);
+                        else        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bf[j][PB[term]], acc[i][j], 0, 0, 0);
+                    }
         }
         __syncthreads();
-        if (t < 2 * BN) {
-            const int which = t / BN, col = t - which * BN;
-            const int cwn = col >> 6, j = (col >> 5) & 1, i = col & 31;
-            float s = 0.f;
-            if (BN == 128) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) s += red[(((m * 2 + cwn) * TN + j) * 2 + which) * 32 + i];
-            } else {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) s += red[((m * TN + j) * 2 + which) * 32 + i];
-            }
-            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)s);
-        }
     }
+    rowgemm_epilogue<BN, EPI, OUT_CF, TM, TN>(g, acc, reinterpret_cast<float *>(smem), row0, col0, wm, wn, wv, t, li, lh);
 }
 
 struct WGrad {
@@ -436,25 +605,23 @@ __global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, int C, double
     dbeta[c] = (float)S1;
 }
 
-// wt(Ci, Co) = w(Co, Ci)^T   (weights only: a few hundred KB)
-__global__ void pw_transpose_kernel(const float *__restrict__ w, int Co, int Ci, float *__restrict__ wt)
+// ------------------------------------------------------------------ host side
+template <int BN, int PRO, int EPI, bool OUT_CF>
+int launch_rowgemm6(const RowGemm &rg, hipStream_t st, const char *who)
 {
-    __shared__ float tile[32][33];
-    const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
-    for (int j = threadIdx.y; j < 32; j += 8)
-        if (x < Ci && y0 + j < Co) tile[j][threadIdx.x] = w[(size_t)(y0 + j) * Ci + x];
-    __syncthreads();
-    const int xo = blockIdx.y * 32 + threadIdx.x;
-    for (int j = threadIdx.y; j < 32; j += 8) {
-        const int yo = blockIdx.x * 32 + j;
-        if (xo < Co && yo < Ci) wt[(size_t)yo * Co + xo] = tile[threadIdx.x][j];
-    }
+    const size_t lds = (size_t)(PW_BM + BN) * PW6_ROW;
+    const int ncb = rg.Nc / BN, nrb = (rg.M + PW_BM - 1) / PW_BM;
+    const unsigned grid = 8u * ncb * ((nrb + 7) / 8);
+    hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF>), dim3(grid), dim3(256), lds, st, rg);
+    GFS3D_LAUNCH_CHECK("pw_rowgemm6_kernel");
+    (void)who;
+    return GFS3D_OK;
 }
 
-// ------------------------------------------------------------------ host side
 template <int BN, int PRO, int EPI, bool OUT_CF>
 int launch_rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 {
+    if (rg.w3) return launch_rowgemm6<BN, PRO, EPI, OUT_CF>(rg, st, who);
     const size_t lds = sizeof(float) * 2 * (PW_BM + BN) * PW_LD;
     static bool attr_done = false;               // per instantiation
     if (!attr_done) {
@@ -510,9 +677,16 @@ int launch_wgrad(const WGrad &wg, hipStream_t st, const char *who)
     return launch_wgrad_t<64, BNV, VPRO>(wg, st, who);
 }
 
+int split_weights(const float *w, int Nc, int K, long long sn, long long sk, void *w3, hipStream_t st)
+{
+    hipLaunchKernelGGL(pw_split_w_kernel, dim3((Nc * K + 255) / 256), dim3(256), 0, st, w, Nc, K, sn, sk, static_cast<unsigned short *>(w3));
+    GFS3D_LAUNCH_CHECK("pw_split_w_kernel");
+    return GFS3D_OK;
+}
+
 struct PwPlan {
     int L, M, in_width, maxw;
-    size_t off_acc, off_coef, off_wt[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], total;
+    size_t off_acc, off_coef, off_w3[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], total;
 };
 
 PwPlan pw_plan(int B, int N, int n_seg, int n_layers, const int *width)
@@ -528,7 +702,7 @@ PwPlan pw_plan(int B, int N, int n_seg, int n_layers, const int *width)
     p.off_coef = o; o = align_up(o + sizeof(float) * 3 * p.maxw, 256);
     for (int l = 0; l < n_layers; ++l) {
         const int ci = l ? width[l - 1] : p.in_width;
-        p.off_wt[l] = o; o = align_up(o + sizeof(float) * (size_t)ci * width[l], 256);
+        p.off_w3[l] = o; o = align_up(o + 6 * (size_t)ci * width[l], 256);      // bf16x3 image of W_l (or of W_l^T)
     }
     for (int l = 0; l < n_layers; ++l) { p.off_g[l] = o; o = align_up(o + sizeof(float) * (size_t)p.M * width[l], 256); }
     p.total = o;
@@ -621,6 +795,8 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
         RowGemm rg{};
         fill_a(rg, a, l, l ? a->h[l - 1] : nullptr);
         rg.w = a->w[l];
+        rg.w3 = ws + p.off_w3[l];
+        if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st)) return rc;
         rg.M = M;
         rg.Nc = C;
         rg.slope = a->slope;
@@ -696,7 +872,7 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
     for (int l = L - 1; l >= 0; --l) {
         const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
         float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
-        float *wt = reinterpret_cast<float *>(ws + p.off_wt[l]);
+        void *w3t = ws + p.off_w3[l];
         double *acc_l = acc + (size_t)2 * p.maxw * l;
         hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc_l, C, (double)M, a->stats[l], coef,
                            ba->dbn_w[l], ba->dbn_b[l]);
@@ -720,12 +896,11 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
         }
         if (rc) return rc;
         // dA_{l-1} = dH_l W_l
-        hipLaunchKernelGGL(pw_transpose_kernel, dim3((Ci + 31) / 32, (C + 31) / 32), dim3(32, 8), 0, st, a->w[l], C, Ci, wt);
-        GFS3D_LAUNCH_CHECK("pw_transpose_kernel");
+        if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st)) return rc2;      // pieces of W_l^T (Ci, C)
         RowGemm rg{};
         rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
         rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
-        rg.w = wt;
+        rg.w3 = w3t;
         rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
         if (l == 0) {
             for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
