@@ -29,7 +29,7 @@ B_PER_GPU, NPTS, KNN, CIN = 32, 2048, 20, 9
 PEAK_FP32_TFLOPS = 157.3       # MI355X dense fp32 (vector == matrix) peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_kernel", 3: "proto_mfma_kernel",
-           4: "ec_stats1_kernel", 5: "kmeans_assign_kernel"}
+           4: "ec_stats1_kernel", 5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd"}
 
 
 def algorithmic_flops(kid, B):
@@ -43,6 +43,11 @@ def algorithmic_flops(kid, B):
         return B * 3 * N * k * 2 * 64 * 64, 3
     if kid == 2:
         return B * 3 * N * k * 2 * (2 * 64 * 64), 3
+    mlp = 2 * (192 * 512 + 512 * 256)          # point-wise stack 192 -> 512 -> 256, flops per point (forward)
+    if kid == 6:
+        return B * N * mlp, 1
+    if kid == 7:
+        return B * N * 2 * mlp, 1
     return 0, 0
 
 
@@ -162,6 +167,13 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": hbm_traffic(KERNELS[dom]),
                 "avg_launch_ms": round(avg_ms, 4), "launches": n,
                 "per_kernel_ms_per_step": {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}}
+        # the point-wise stack runs on the bf16 matrix cores at fp32 accuracy (6 bf16 products per fp32 product):
+        # algorithmic fp32 TFLOP/s of its two launch groups (all kernels of a pass), against the same fp32 peak
+        for kid in (6, 7):
+            if kid in prof:
+                fl, _ = algorithmic_flops(kid, B_PER_GPU)
+                roof[KERNELS[kid]] = {"ms_per_step": round(prof[kid][0] / args.steps, 4),
+                                      "algorithmic_TFLOPps": round(fl / (prof[kid][0] / args.steps * 1e-3) / 1e12, 2)}
         if 0 in prof:       # "kNN HBM GB/s" of the metric: algorithmic bytes 4CN + 8Nk per block and layer
             kb = B_PER_GPU * sum(4 * C * NPTS + 8 * NPTS * KNN for C in (CIN, 64, 64))
             kms = prof[0][0] / args.steps

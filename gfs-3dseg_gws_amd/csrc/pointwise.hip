@@ -508,6 +508,161 @@ __global__ void __launch_bounds__(256, 3) pw_wgrad_kernel(const WGrad g)
             }
 }
 
+// dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci] on the bf16 matrix cores (bf16x6, see pw_rowgemm6_kernel).  The reduction
+// runs over the POINTS, so both operands are transposed while they are staged: a thread owns 4 channels x 2
+// consecutive points, splits the 8 values and writes, per channel and piece, one dword (2 bf16) into that channel's
+// LDS row - rows are channels, 32 points per K-step; lanes of a 16-lane group walk along a row (conflict-free).
+template <int BMU, int BNV, int VPRO>
+__global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
+{
+    extern __shared__ f32x4 pw_smem4[];
+    char *smem = reinterpret_cast<char *>(pw_smem4);
+    constexpr int TM = BMU / 64, TN = BNV / 64, NU = BMU / 64, NV = BNV / 64;      // (quad, pair) items per thread
+    char *sU = smem;                          // [BMU][208 B]
+    char *sV = smem + BMU * PW6_ROW;          // [BNV][208 B]
+    const int nci = g.Ci / BNV, ntile = (g.Co / BMU) * nci;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+    if (split >= g.nsplit) return;
+    const int co0 = (tile / nci) * BMU, ci0 = (tile % nci) * BNV;
+    const int m0 = split * g.rows_per_split, m1 = min(g.M, m0 + g.rows_per_split);
+    if (m0 >= m1) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int pair = t & 15, quad0 = t >> 4;                 // item p: channel quad quad0 + 16 p, points 2 pair, 2 pair + 1
+    const float *up = g.u + co0, *up2 = g.u2 ? g.u2 + co0 : nullptr;
+    const int vseg = ci0 / g.v_segw;
+    const float *vp = g.v[vseg] + (ci0 - vseg * g.v_segw);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ua[NU], ub[NU], uc[NU], va[NV], vb[NV];
+#pragma unroll
+    for (int p = 0; p < NU; ++p) {
+        ua[p] = ub[p] = uc[p] = zero4;
+        if (up2) {
+            const int c = co0 + 4 * (quad0 + 16 * p);
+            ua[p] = ldg4(g.ua + c); ub[p] = ldg4(g.ub + c); uc[p] = ldg4(g.uc + c);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        va[p] = vb[p] = zero4;
+        if (VPRO == PRO_BNACT) { const int c = ci0 + 4 * (quad0 + 16 * p); va[p] = ldg4(g.va + c); vb[p] = ldg4(g.vb + c); }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 rU[NU][2], rU2[NU][2], rV[NV][2];
+    auto load = [&](int kt) {
+        const int m = m0 + kt * 32 + 2 * pair;
+#pragma unroll
+        for (int p = 0; p < NU; ++p)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const size_t o = (size_t)(m + e) * g.ldu + 4 * (quad0 + 16 * p);
+                rU[p][e] = m + e < m1 ? ldg4(up + o) : zero4;
+                if (up2) rU2[p][e] = m + e < m1 ? ldg4(up2 + o) : zero4;
+            }
+#pragma unroll
+        for (int p = 0; p < NV; ++p)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                rV[p][e] = m + e < m1 ? ldg4(vp + (size_t)(m + e) * g.ldv + 4 * (quad0 + 16 * p)) : zero4;
+    };
+    // one item: 4 channels x 2 points -> per channel and piece one dword at [channel row][piece][pair]
+    auto put = [&](char *base, int quad, const f32x4 &x0, const f32x4 &x1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned h0, m0_, l0, h1, m1_, l1;
+            split3(x0[c], h0, m0_, l0);
+            split3(x1[c], h1, m1_, l1);
+            char *dst = base + (4 * quad + c) * PW6_ROW + pair * 4;
+            *reinterpret_cast<unsigned *>(dst) = pack_hi16(h0, h1);
+            *reinterpret_cast<unsigned *>(dst + 64) = pack_hi16(m0_, m1_);
+            *reinterpret_cast<unsigned *>(dst + 128) = pack_hi16(l0, l1);
+        }
+    };
+    auto store = [&](int kt) {
+        const int m = m0 + kt * 32 + 2 * pair;
+#pragma unroll
+        for (int p = 0; p < NU; ++p) {
+            f32x4 x[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                x[e] = rU[p][e];
+                if (up2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[e][c] = fmaf(rU2[p][e][c], uc[p][c], fmaf(x[e][c], ua[p][c], ub[p][c]));
+                    if (m + e >= m1) x[e] = zero4;
+                }
+            }
+            put(sU, quad0 + 16 * p, x[0], x[1]);
+        }
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            f32x4 x[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                x[e] = rV[p][e];
+                if (VPRO == PRO_BNACT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[e][c] = lrelu(fmaf(x[e][c], va[p][c], vb[p][c]), g.slope);
+                    if (m + e >= m1) x[e] = zero4;
+                }
+            }
+            put(sV, quad0 + 16 * p, x[0], x[1]);
+        }
+    };
+
+    const int KT = (m1 - m0 + 31) / 32;
+    const char *pu = sU + (wm * (BMU / 2) + li) * PW6_ROW + lh * 16;
+    const char *pv = sV + (wn * (BNV / 2) + li) * PW6_ROW + lh * 16;
+    load(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        store(kt);
+        __syncthreads();
+        if (kt + 1 < KT) load(kt + 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pu + i * 32 * PW6_ROW + pl * 64 + kb * 32));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pv + j * 32 * PW6_ROW + pl * 64 + kb * 32));
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bf[j][PB[term]], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * (BMU / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ci = ci0 + wn * (BNV / 2) + j * 32 + li;
+                atomicAdd(&g.dw[(size_t)co * g.Ci + ci], acc[i][j][r]);
+            }
+}
+
 // y_cf(b, c, n) = act(scale h(b n, c) + shift): 64 points x 64 channels per block, grid (ceil(N/64), C/64, B)
 __global__ void __launch_bounds__(256)
 pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf)
@@ -647,14 +802,8 @@ int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
 {
-    const size_t lds = sizeof(float) * 32 * (BMU + BNV);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_wgrad_kernel<BMU, BNV, VPRO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-        attr_done = true;
-    }
+    const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
+    (void)who;
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
     // ~3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
     int nsplit = (768 + ntile - 1) / ntile;
@@ -665,8 +814,8 @@ int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
     wg.rows_per_split = rows;
     wg.nsplit = nsplit;
     const unsigned grid = 8u * ntile * ((nsplit + 7) / 8);
-    hipLaunchKernelGGL((pw_wgrad_kernel<BMU, BNV, VPRO>), dim3(grid), dim3(256), lds, st, wg);
-    GFS3D_LAUNCH_CHECK("pw_wgrad_kernel");
+    hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO>), dim3(grid), dim3(256), lds, st, wg);
+    GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
     return GFS3D_OK;
 }
 

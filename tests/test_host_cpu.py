@@ -31,10 +31,8 @@ def test_library_exports_every_declared_symbol():
     assert L.gfs3d_version() >= 100
 
 
-def test_args_struct_matches_header_field_order():
-    from gfs3d._lib import EdgeConvArgs
-    header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
-    body = header.split("typedef struct gfs3d_edgeconv_args {")[1].split("} gfs3d_edgeconv_args;")[0]
+def _header_fields(header, name):
+    body = header.split("typedef struct %s {" % name)[1].split("} %s;" % name)[0]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
@@ -42,8 +40,28 @@ def test_args_struct_matches_header_field_order():
         if not decl:
             continue
         for part in decl.split(","):
-            names.append(re.sub(r"[\s\*]", " ", part).split()[-1])
-    assert names == [f[0] for f in EdgeConvArgs._fields_]
+            tok = re.sub(r"[\s\*]", " ", part).split()[-1]
+            names.append(re.sub(r"\[.*\]", "", tok))
+    return names
+
+
+def test_args_structs_match_header_field_order_and_size():
+    """The ctypes mirrors follow include/gfs3d.h field by field (nested struct `f` first in the backward args), and
+    a C compiler agrees on their size."""
+    import ctypes, subprocess, tempfile
+    from gfs3d import _lib
+    header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
+    pairs = [("gfs3d_edgeconv_args", _lib.EdgeConvArgs), ("gfs3d_edgeconv_bwd_args", _lib.EdgeConvBwdArgs),
+             ("gfs3d_pointwise_args", _lib.PointwiseArgs), ("gfs3d_pointwise_bwd_args", _lib.PointwiseBwdArgs)]
+    for cname, cls in pairs:
+        assert _header_fields(header, cname) == [f[0] for f in cls._fields_], cname
+    src = '#include <stdio.h>\n#include "gfs3d.h"\nint main(void){printf("%zu %zu %zu %zu\\n",' + ",".join(
+        "sizeof(%s)" % c for c, _ in pairs) + ");return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
+    assert sizes == [ctypes.sizeof(cls) for _, cls in pairs]
 
 
 def test_dgcnn_state_dict_and_seeded_init_match_reference():
