@@ -193,6 +193,8 @@ class EdgeConvRun:
         _lib.check(rc, "gfs3d_edgeconv_backward_phase_f32")
         if phase == 2:
             del self._ba
+            return self._take_grads()
+        return None
 
     def forward(self, sync: Optional[BNSync] = None):
         if sync is None or not self.training:
@@ -226,8 +228,15 @@ class EdgeConvRun:
             sync.all_reduce(acc[0:128])
             self.backward_phase(1, acc, count)
             sync.all_reduce(acc[128:256])
-            self.backward_phase(2, acc, count)
-        return self.dx, self.dw1, self.dg1, self.db1, self.dw2, self.dg2, self.db2
+            return self.backward_phase(2, acc, count)
+        return self._take_grads()
+
+    def _take_grads(self):
+        """Hand the gradient tensors to the caller and forget them: autograd's AccumulateGrad adopts a gradient
+        without a copy only if nothing else references it."""
+        out = (self.dx, self.dw1, self.dg1, self.db1, self.dw2, self.dg2, self.db2)
+        self.dx = self.dw1 = self.dg1 = self.db1 = self.dw2 = self.dg2 = self.db2 = self.dy = self.dy_pm = None
+        return out
 
 
 class EdgeConvFunction(torch.autograd.Function):
@@ -259,13 +268,15 @@ class EdgeConvFunction(torch.autograd.Function):
 
 
 def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
-                   sync: Optional[BNSync] = None, want_pm: bool = False, x_pm: Optional[torch.Tensor] = None):
+                   sync: Optional[BNSync] = None, want_pm: bool = False, x_pm: Optional[torch.Tensor] = None,
+                   track: bool = True):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
     training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks.  `x_pm`: the
     (B,N,C) point-major values of x when the caller has them (the previous block's second output) - the input
-    projections then run as one MFMA GEMM; the gradient still flows through x."""
-    if training:
+    projections then run as one MFMA GEMM; the gradient still flows through x.  `track=False`: the caller
+    bumps `num_batches_tracked` itself (one multi-tensor add for a whole network)."""
+    if training and track:
         for bn in (bn1, bn2):
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
@@ -362,7 +373,9 @@ class PointwiseRun:
             rc = _lib.lib().gfs3d_pointwise_backward_f32(ctypes.byref(ba), _stream())
         _lib.check(rc, "gfs3d_pointwise_backward_f32")
         del ws
-        return self.dxs, self.dws, self.dgs, self.dbs
+        out = (self.dxs, self.dws, self.dgs, self.dbs)
+        self.dxs = self.dws = self.dgs = self.dbs = self.dy = None          # see EdgeConvRun._take_grads
+        return out
 
 
 class PointwiseStackFunction(torch.autograd.Function):
@@ -394,9 +407,9 @@ class PointwiseStackFunction(torch.autograd.Function):
         return (None,) * 6 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers)
 
 
-def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2):
+def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: bool = True):
     """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64) segments."""
-    if training:
+    if training and track:
         for _c, bn in parts:
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)

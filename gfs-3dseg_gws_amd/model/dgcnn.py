@@ -126,15 +126,20 @@ class DGCNN(nn.Module):
     def edgeconv_features(self, x, with_point_major=False):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
         with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
-        feats, feats_pm = [], []
+        feats, feats_pm, bns = [], [], []
         x_pm = None
         for block in self.edge_convs:
             c1, bn1, c2, bn2 = block.fused_parts()
             idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True)
             x, x_pm = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
-                                         sync=self.bn_sync, want_pm=True, x_pm=x_pm)
+                                         sync=self.bn_sync, want_pm=True, x_pm=x_pm, track=False)
+            bns += [bn1, bn2]
             feats.append(x)
             feats_pm.append(x_pm)
+        if self.training:               # nn.BatchNorm bookkeeping of all blocks in one multi-tensor add
+            counters = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)
         return (feats, feats_pm) if with_point_major else feats
 
     def forward(self, x):
