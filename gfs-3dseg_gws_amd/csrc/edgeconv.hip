@@ -539,8 +539,16 @@ ec_bwd_coef_kernel(const double *__restrict__ red, const double *__restrict__ re
 // dH2 = Cc*H2 + Bc + [slot == winner] A*g is elementwise in the C/D layout (the routed term is
 // one compare per register); a1 in C/D layout comes from the same LDS transpose buffer (no
 // second gather); dy1 = dA1 * LReLU'(z1) (sign of a1); G_Q in-lane, G_P as 2x128-B atomic rows.
-// LDS: W2 [64][68] (block) + one [32][68] transpose tile and 32 neighbour ids per wave.
+// LDS: W2 [64][68] (block) + per wave one [32][68] transpose tile, the neighbour ids of all tiles of the
+// super-tile [8][32] and the Q' rows of its 8 points [8][64].
+// Memory pipeline: the kernel sits at the VGPR cap, so the gathered P' half rows of tile t+1 arrive by LDS-DMA
+// (global_load_lds, per-lane source row, no VGPR destination) into the transpose tile's bytes, which are idle
+// from the last dH2 read of tile t to the a1 write of tile t+1.  The DMA is issued BEFORE tile t's 32 G_P atomic
+// instructions: vmcnt retires in issue order, so `s_waitcnt vmcnt(32)` at the top of tile t+1 covers the gather
+// without waiting for the atomics' round trips (plain loads at the tile top would wait for every older atomic).
 // ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr int BWD_WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC;      // floats per wave: transpose tile | ids | Q' tile
 constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -556,13 +564,13 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     float *sW = smem;                                   // [64][TLD]  W2[co][ci]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    float *tr = sW + EC * TLD + (size_t)wv * (32 * TLD + 32);   // [32][TLD] transpose tile
-    int *mrow = reinterpret_cast<int *>(tr + 32 * TLD);         // [32] neighbour id of each tile row
+    float *tr = sW + EC * TLD + (size_t)wv * BWD_WAVE_LDS;      // [32][TLD] transpose tile == [8][64 lanes][4] DMA image
+    int *mall = reinterpret_cast<int *>(tr + 32 * TLD);         // [8][32] neighbour id of each row of each tile
+    float *qt = reinterpret_cast<float *>(mall + 8 * 32);       // [8][64] Q' rows of the super-tile's points
 
     for (int e = tid; e < EC * EC; e += 256) sW[(e >> 6) * TLD + (e & 63)] = w2[e];
-    const float A0 = coef[CF_A + i], A1 = coef[CF_A + 32 + i];
-    const float Bc0 = coef[CF_BC + i], Bc1 = coef[CF_BC + 32 + i];
-    const float Cc0 = coef[CF_CC + i], Cc1 = coef[CF_CC + 32 + i];
+    float *sC = sW + EC * TLD + 4 * BWD_WAVE_LDS;       // [192] BN2-backward constants (re-read per tile: the kernel is at the VGPR cap)
+    if (tid < CF_TOTAL) sC[tid] = coef[tid];
     f32x16 dW00, dW01, dW10, dW11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW00[r] = 0.f; dW01[r] = 0.f; dW10[r] = 0.f; dW11[r] = 0.f; }
@@ -577,31 +585,53 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
         const int ptA = min(n0 + pA, BN - 1);
         const int bA = ptA / N;
         float Ag0[4], Ag1[4], gq0[4], gq1[4];
-        int js0[4], js1[4];
-        size_t gbase[4];
+        unsigned js0 = 0, js1 = 0;                      // winning slot of the 4 points, one byte each
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pt = n0 + 4 * h + q;
             const bool ok = pt < BN;
             const size_t o = (size_t)min(pt, BN - 1) * EC + i;
-            Ag0[q] = ok ? A0 * g_pm[o] : 0.f;
-            Ag1[q] = ok ? A1 * g_pm[o + 32] : 0.f;
-            js0[q] = ok ? (int)jsel[o] : 255;
-            js1[q] = ok ? (int)jsel[o + 32] : 255;
+            Ag0[q] = ok ? coef[CF_A + i] * g_pm[o] : 0.f;
+            Ag1[q] = ok ? coef[CF_A + 32 + i] * g_pm[o + 32] : 0.f;
+            js0 |= (ok ? (unsigned)jsel[o] : 255u) << (8 * q);
+            js1 |= (ok ? (unsigned)jsel[o + 32] : 255u) << (8 * q);
             gq0[q] = 0.f; gq1[q] = 0.f;
-            gbase[q] = (size_t)(min(pt, BN - 1) / N) * N;
         }
+        // neighbour ids of every tile (lane half h takes tiles h, h+2, ...), Q' rows by DMA, first P' gather by DMA
+        // (global row index b N + m: the gather and the G_P atomics both address rows of (B N, 64) arrays)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = 2 * tt + h;
+            if (t < T) mall[t * 32 + i] = bA * N + idx[(size_t)ptA * k + min(4 * t + jjA, k - 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        auto gather = [&](int t) {                     // lane (edge row i, half h): 8 x 16 B of P'[m][32h..32h+31]
+            const float *src = Pp + (size_t)mall[t * 32 + i] * EC + 32 * h;
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+                __builtin_amdgcn_global_load_lds(src + 4 * v, (lds_void *)(tr + v * 256), 16, 0, 0);
+        };
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int pt = min(n0 + (lane >> 4) + 4 * c, BN - 1);
+            __builtin_amdgcn_global_load_lds(Qp + (size_t)pt * EC + 4 * (lane & 15),
+                                             (lds_void *)(qt + c * 256), 16, 0, 0);
+        }
+        gather(0);
+        asm volatile("" ::: "memory");
         for (int t = 0; t < T; ++t) {
-            const int jA = min(4 * t + jjA, k - 1);
-            const int mA = idx[(size_t)ptA * k + jA];
-            if (h == 0) mrow[i] = mA;
+            // tile 0: everything older (ids, Q', P' gather); later tiles: all but the previous tile's 32 atomics
+            if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            const int *mrow = mall + t * 32;
             float a[32];
             {
-                const float4 *p4 = reinterpret_cast<const float4 *>(Pp + ((size_t)bA * N + mA) * EC + 32 * h);
-                const float4 *q4 = reinterpret_cast<const float4 *>(Qp + (size_t)ptA * EC + 32 * h);
+                const float4 *p4 = reinterpret_cast<const float4 *>(tr) + lane;              // DMA image [v][lane]
+                const float4 *q4 = reinterpret_cast<const float4 *>(qt + pA * EC + 32 * h);
 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
-                    const float4 pv = p4[v], qv = q4[v];
+                    const float4 pv = p4[v * 64], qv = q4[v];
                     float z;
                     z = pv.x + qv.x; a[4 * v + 0] = fmaxf(z, z * slope);
                     z = pv.y + qv.y; a[4 * v + 1] = fmaxf(z, z * slope);
@@ -640,13 +670,14 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             }
             __builtin_amdgcn_wave_barrier();
             // dH2 in place (C/D layout): Cc*h2 + Bc + routed term; masked rows -> 0
+            const float Bc0 = sC[CF_BC + i], Bc1 = sC[CF_BC + 32 + i], Cc0 = sC[CF_CC + i], Cc1 = sC[CF_CC + 32 + i];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = r >> 2;
                 const int j = 4 * t + (r & 3);
                 const bool ok = (j < k) && (n0 + 4 * h + q < BN);
-                const float d0 = fmaf(Cc0, acc0[r], Bc0) + (js0[q] == j ? Ag0[q] : 0.f);
-                const float d1 = fmaf(Cc1, acc1[r], Bc1) + (js1[q] == j ? Ag1[q] : 0.f);
+                const float d0 = fmaf(Cc0, acc0[r], Bc0) + ((int)((js0 >> (8 * q)) & 255u) == j ? Ag0[q] : 0.f);
+                const float d1 = fmaf(Cc1, acc1[r], Bc1) + ((int)((js1 >> (8 * q)) & 255u) == j ? Ag1[q] : 0.f);
                 acc0[r] = ok ? d0 : 0.f;
                 acc1[r] = ok ? d1 : 0.f;
             }
@@ -657,6 +688,13 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 dW01 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc0[r], aD1[r], dW01, 0, 0, 0);
                 dW10 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD0[r], dW10, 0, 0, 0);
                 dW11 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD1[r], dW11, 0, 0, 0);
+            }
+            // a1 is needed once more, for LReLU'(z1): keep its signs as two bit masks instead of 32 registers
+            unsigned pos0 = 0u, pos1 = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pos0 |= (aD0[r] > 0.f ? 1u : 0u) << r;
+                pos1 |= (aD1[r] > 0.f ? 1u : 0u) << r;
             }
             // dH2: C/D layout -> A-layout through the transpose tile
 #pragma unroll
@@ -670,6 +708,12 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 const float4 d4 = *reinterpret_cast<const float4 *>(tr + i * TLD + 32 * h + 4 * v);
                 a[4 * v + 0] = d4.x; a[4 * v + 1] = d4.y; a[4 * v + 2] = d4.z; a[4 * v + 3] = d4.w;
             }
+            // the transpose tile is idle until the next tile's a1 write: start the next gather into it, ahead of this
+            // tile's atomics in issue order
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t + 1 < T) gather(t + 1);
+            asm volatile("" ::: "memory");
             // (3) dA1 = dH2 W2 :  B[k = co = 32h+s][j = ci]
             f32x16 e0, e1;
 #pragma unroll
@@ -687,15 +731,15 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 const int q = r >> 2;
                 const int j = 4 * t + (r & 3);
                 const bool ok = (j < k) && (n0 + 4 * h + q < BN);
-                if (ok) {
-                    const float dy0 = e0[r] * (aD0[r] > 0.f ? 1.f : slope);
-                    const float dy1 = e1[r] * (aD1[r] > 0.f ? 1.f : slope);
-                    gq0[q] += dy0;
-                    gq1[q] += dy1;
-                    const size_t row = (gbase[q] + (size_t)mrow[drow(r, h)]) * EC + i;
-                    atomicAdd(&GP[row], dy0);
-                    atomicAdd(&GP[row + 32], dy1);
-                }
+                // exactly 32 atomic instructions per tile (the vmcnt(32) above counts on it): masked rows add 0 to a
+                // valid row (their neighbour slot and point index are clamped)
+                const float dy0 = ok ? e0[r] * ((pos0 >> r) & 1u ? 1.f : slope) : 0.f;
+                const float dy1 = ok ? e1[r] * ((pos1 >> r) & 1u ? 1.f : slope) : 0.f;
+                gq0[q] += dy0;
+                gq1[q] += dy1;
+                const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;
+                atomicAdd(&GP[row], dy0);
+                atomicAdd(&GP[row + 32], dy1);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1106,7 +1150,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             const size_t total = (size_t)BN * EC;
             hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
-            const size_t lds = sizeof(float) * (EC * TLD + 4 * (32 * TLD + 32));
+            const size_t lds = sizeof(float) * (EC * TLD + 4 * BWD_WAVE_LDS + CF_TOTAL);
             ProfScope prof(2, st);
             hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_mfma), dim3(256), lds, st, Pp, Qp, a->idx, a->w2, coef,
                                g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
