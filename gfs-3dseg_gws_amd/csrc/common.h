@@ -58,6 +58,23 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
+
+// ---- fp32-accurate products on the bf16 matrix cores ("bf16x6", see pointwise.hip) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// x == h + m + l exactly, each piece a bf16 (stored in the high half of a dword): truncation splits of 8 + 8 + 8 bits
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);                  // exact: the low 16 significand bits
+    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m)); // exact, <= 8 significant bits: low half is 0
+}
+// two fp32 bit patterns whose low halves are dropped -> one dword of two bf16 (a first)
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// piece pairs of a.b in ascending weight: (lo hi) (hi lo) (mid mid) (mid hi) (hi mid) (hi hi); pieces 0 = hi, 1 = mid, 2 = lo
+#define GFS3D_X6_PA {2, 0, 1, 1, 0, 0}
+#define GFS3D_X6_PB {0, 2, 1, 0, 1, 0}
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // pointwise.hip: out(M, Nc) = a(M, K) . w(Nc, K)^T on MFMA, point-major; the Nc columns are written as segments of

@@ -274,7 +274,8 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 }
 
 // ---------------------------------------------------------------------------
-// F4: the heavy forward pass on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32).
+// F4: the heavy forward pass on the bf16 matrix cores at fp32 accuracy (bf16x6: every fp32 operand is the exact
+// sum of three bf16 pieces, six piece products per fp32 product - pointwise.hip has the derivation).
 //
 //   H2[edge][c_out] = sum_c a1[edge][c] * W2[c_out][c]      A = a1 rows, B = W2^T
 //
@@ -285,9 +286,11 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 // over the k neighbours and the BN2 statistics are in-lane reductions over accumulator
 // registers - no LDS, no shuffles.  k <= 32 (8 tiles); slots j >= k are masked.
 // A-operand: lane (i, h) gathers the 128-B half row P'[m][32h..32h+31] of ITS edge (8 x
-// dwordx4 from the L2-resident projection), adds Q'[n], applies LeakyReLU.  B-operand: both
-// 32-column halves of W2^T live in 64 VGPRs for the whole kernel.  Channel order inside the
-// fma chain is (32h+s) for step s: k=0 -> channel s, k=1 -> channel 32+s.
+// dwordx4 from the L2-resident projection), adds Q'[n], applies LeakyReLU and splits the 32 values into
+// bf16 pieces (4 VALU each + packing).  B-operand: W2 pre-split in LDS, row = [hi 64 x bf16 | mid | lo | pad]
+// = 400 B = 25 sixteen-byte slots (odd: conflict-free ds_read_b128).  K-block kb of v_mfma_f32_32x32x16_bf16
+// holds channels 8kb..8kb+7 (lane half 0) and 32+8kb.. (lane half 1) for both operands.
+// 48 MFMAs of 32 cycles per 32-edge tile instead of 64 of 64 cycles.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
@@ -297,20 +300,27 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    uint8_t *__restrict__ jmax, uint8_t *__restrict__ jmin,
                    double *__restrict__ partial)
 {
-    constexpr int WLD = EC + 4;                         // padded W2 rows: conflict-free ds_read_b128 fragments
-    __shared__ __attribute__((aligned(16))) float sW[EC * WLD];
+    constexpr int WROW = 3 * 2 * EC + 16;               // bytes per W2 row image
+    __shared__ __attribute__((aligned(16))) unsigned char sW3[EC * WROW];
     __shared__ double red[4][2][2][EC];                 // [wave][half][s|ss][64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    for (int e = tid; e < EC * EC; e += 256) sW[(e >> 6) * WLD + (e & 63)] = w2[e];
+    for (int e = tid; e < EC * EC; e += 256) {
+        unsigned ph, pm, pl;
+        split3(w2[e], ph, pm, pl);
+        unsigned short *o = reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * WROW) + (e & 63);
+        o[0] = (unsigned short)(ph >> 16);
+        o[EC] = (unsigned short)(pm >> 16);
+        o[2 * EC] = (unsigned short)(pl >> 16);
+    }
     __syncthreads();
 
     const int pA = 4 * ((i >> 2) & 1) + (i >> 3);       // point (0..7) of this lane's A rows
     const int jjA = i & 3;
     const int T = (k + 3) >> 2;
     double sd0 = 0.0, ssd0 = 0.0, sd1 = 0.0, ssd1 = 0.0;
-    const float4 *wrow0 = reinterpret_cast<const float4 *>(sW + i * WLD + 32 * h);
-    const float4 *wrow1 = reinterpret_cast<const float4 *>(sW + (32 + i) * WLD + 32 * h);
+    const unsigned char *wrow0 = sW3 + i * WROW + 64 * h;            // + piece * 128 + kb * 16
+    const unsigned char *wrow1 = sW3 + (32 + i) * WROW + 64 * h;
 
     const int nst = (BN + 7) >> 3;
     for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
@@ -347,36 +357,54 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             for (int v = 0; v < 8; ++v) pf[v] = p4[v];
         }
         for (int t = 0; t < T; ++t) {
-            float a[32];
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                float z;
-                z = pf[v].x + qA[4 * v + 0]; a[4 * v + 0] = fmaxf(z, z * slope);   // LeakyReLU, 0 < slope < 1
-                z = pf[v].y + qA[4 * v + 1]; a[4 * v + 1] = fmaxf(z, z * slope);
-                z = pf[v].z + qA[4 * v + 2]; a[4 * v + 2] = fmaxf(z, z * slope);
-                z = pf[v].w + qA[4 * v + 3]; a[4 * v + 3] = fmaxf(z, z * slope);
-            }
-            {
-                const float4 *p4 = reinterpret_cast<const float4 *>(prow_base + (size_t)m_next * EC);
-#pragma unroll
-                for (int v = 0; v < 8; ++v) pf[v] = p4[v];      // (harmless re-read of the last row after the last tile)
-                m_next = myidx[min(4 * (t + 2) + jjA, k - 1)];
-            }
+            const float4 *p4n = reinterpret_cast<const float4 *>(prow_base + (size_t)m_next * EC);
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const float4 w0 = wrow0[v], w1 = wrow1[v];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w0.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w0.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w1.w, acc1, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) {
+                // a1 for channels 8kb..8kb+7 of this lane's half row, then refill those two pieces with the next
+                // tile's row (harmless re-read of the last row after the last tile): the loads overlap the MFMAs
+                float av[8];
+                {
+                    const float4 x0 = pf[2 * kb], x1 = pf[2 * kb + 1];
+                    float z;
+                    z = x0.x + qA[8 * kb + 0]; av[0] = fmaxf(z, z * slope);          // LeakyReLU, 0 < slope < 1
+                    z = x0.y + qA[8 * kb + 1]; av[1] = fmaxf(z, z * slope);
+                    z = x0.z + qA[8 * kb + 2]; av[2] = fmaxf(z, z * slope);
+                    z = x0.w + qA[8 * kb + 3]; av[3] = fmaxf(z, z * slope);
+                    z = x1.x + qA[8 * kb + 4]; av[4] = fmaxf(z, z * slope);
+                    z = x1.y + qA[8 * kb + 5]; av[5] = fmaxf(z, z * slope);
+                    z = x1.z + qA[8 * kb + 6]; av[6] = fmaxf(z, z * slope);
+                    z = x1.w + qA[8 * kb + 7]; av[7] = fmaxf(z, z * slope);
+                }
+                pf[2 * kb] = p4n[2 * kb];
+                pf[2 * kb + 1] = p4n[2 * kb + 1];
+                uint4 ap[3];                             // bf16 pieces, two per dword
+                {
+                    unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) split3(av[e], ph[e], pm[e], pl[e]);
+                    ap[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+                    ap[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+                    ap[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+                }
+                uint4 b0[3], b1[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    b0[pc] = *reinterpret_cast<const uint4 *>(wrow0 + pc * 128 + kb * 16);
+                    b1[pc] = *reinterpret_cast<const uint4 *>(wrow1 + pc * 128 + kb * 16);
+                }
+                constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            m_next = myidx[min(4 * (t + 2) + jjA, k - 1)];
             // branch-free epilogue: masked rows look like -inf / +inf / 0 to the reductions
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

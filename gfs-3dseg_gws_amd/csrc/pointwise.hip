@@ -239,18 +239,7 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
 // LDS row (one K-step of 32 for one tile row): [hi 32 x bf16 | mid | lo | 16 B pad] = 208 B = 13 sixteen-byte slots
 // (odd, so the 16-lane groups of ds_read_b128 hit 16 different slots).
 // ---------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PW6_ROW = 208;
-
-__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l)
-{
-    h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, h);                  // exact: the low 16 significand bits
-    m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m)); // exact, <= 8 significant bits: low half is 0
-}
-// two fp32 bit patterns whose low halves are dropped -> one dword of two bf16 (a first)
-__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // w3[n][kt][plane][32] = bf16 pieces of w(n, 32 kt + j);  w element (n, k) is read at w[n * sn + k * sk]
 __global__ void pw_split_w_kernel(const float *__restrict__ w, int Nc, int K, long long sn, long long sk, unsigned short *__restrict__ w3)
@@ -369,8 +358,8 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pb + j * 32 * PW6_ROW + pl * 64 + kb * 32));
-            // smallest pieces first: (lo hi) (hi lo) (mid mid) (mid hi) (hi mid) (hi hi)
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            // smallest pieces first
+            constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
             for (int term = 0; term < 6; ++term)
 #pragma unroll
@@ -640,7 +629,7 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pv + j * 32 * PW6_ROW + pl * 64 + kb * 32));
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
             for (int term = 0; term < 6; ++term)
 #pragma unroll
