@@ -557,8 +557,8 @@ ec_bwd_coef_kernel(const double *__restrict__ red, const double *__restrict__ re
 }
 
 // ---------------------------------------------------------------------------
-// B3: heavy backward pass on the matrix pipe (direct form, three fp32 MFMA products per
-// 32-edge tile, same super-tile row mapping as ec_main_fwd_kernel):
+// B3: heavy backward pass on the bf16 matrix cores at fp32 accuracy (bf16x6 as in ec_main_fwd_kernel; direct form,
+// three matrix products per 32-edge tile, 3 x 48 MFMAs of 32 cycles; same super-tile row mapping as the forward):
 //   (1) H2  = A1 W2^T                       A-layout a1 (lane = edge) x W2 from LDS
 //   (2) dW2 += dH2^T A1                     both operands in C/D layout (lane = channel,
 //                                           register = edge): the accumulator of (1), turned
@@ -567,8 +567,9 @@ ec_bwd_coef_kernel(const double *__restrict__ red, const double *__restrict__ re
 // dH2 = Cc*H2 + Bc + [slot == winner] A*g is elementwise in the C/D layout (the routed term is
 // one compare per register); a1 in C/D layout comes from the same LDS transpose buffer (no
 // second gather); dy1 = dA1 * LReLU'(z1) (sign of a1); G_Q in-lane, G_P as 2x128-B atomic rows.
-// LDS: W2 [64][68] (block) + per wave one [32][68] transpose tile, the neighbour ids of all tiles of the
-// super-tile [8][32] and the Q' rows of its 8 points [8][64].
+// LDS: bf16 piece images of W2 (rows co, for (1)) and of W2^T (rows ci, for (3)), 25.6 KB each, shared by the 8 waves
+// of the block; per wave one [32][68] transpose tile, the neighbour ids of all tiles of the super-tile [8][32] and
+// the Q' rows of its 8 points [8][64].
 // Memory pipeline: the kernel sits at the VGPR cap, so the gathered P' half rows of tile t+1 arrive by LDS-DMA
 // (global_load_lds, per-lane source row, no VGPR destination) into the transpose tile's bytes, which are idle
 // from the last dH2 read of tile t to the a1 write of tile t+1.  The DMA is issued BEFORE tile t's 32 G_P atomic
@@ -581,7 +582,11 @@ constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__global__ void __launch_bounds__(256, 2)
+constexpr int BWD_WAVES = 4;
+constexpr int BWD_WROW = 3 * 2 * EC + 16;                          // bytes per row of a W2 piece image
+constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES * BWD_WAVE_LDS + 192);
+
+__global__ void __launch_bounds__(64 * BWD_WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2, const float *__restrict__ coef,
                    const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
@@ -589,16 +594,29 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *sW = smem;                                   // [64][TLD]  W2[co][ci]
+    unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] bf16 pieces of W2
+    unsigned char *sW3T = sW3 + EC * BWD_WROW;                           // [ci][hi | mid | lo][co] pieces of W2^T
+    float *wbase = reinterpret_cast<float *>(sW3T + EC * BWD_WROW);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    float *tr = sW + EC * TLD + (size_t)wv * BWD_WAVE_LDS;      // [32][TLD] transpose tile == [8][64 lanes][4] DMA image
+    float *tr = wbase + (size_t)wv * BWD_WAVE_LDS;              // [32][TLD] transpose tile == [8][64 lanes][4] DMA image
     int *mall = reinterpret_cast<int *>(tr + 32 * TLD);         // [8][32] neighbour id of each row of each tile
     float *qt = reinterpret_cast<float *>(mall + 8 * 32);       // [8][64] Q' rows of the super-tile's points
 
-    for (int e = tid; e < EC * EC; e += 256) sW[(e >> 6) * TLD + (e & 63)] = w2[e];
-    float *sC = sW + EC * TLD + 4 * BWD_WAVE_LDS;       // [192] BN2-backward constants (re-read per tile: the kernel is at the VGPR cap)
+    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
+        const int co = e >> 6, ci = e & 63;
+        unsigned ph, pm, pl;
+        split3(w2[e], ph, pm, pl);
+        unsigned short *o = reinterpret_cast<unsigned short *>(sW3 + co * BWD_WROW) + ci;
+        unsigned short *ot = reinterpret_cast<unsigned short *>(sW3T + ci * BWD_WROW) + co;
+        o[0] = ot[0] = (unsigned short)(ph >> 16);
+        o[EC] = ot[EC] = (unsigned short)(pm >> 16);
+        o[2 * EC] = ot[2 * EC] = (unsigned short)(pl >> 16);
+    }
+    float *sC = wbase + BWD_WAVES * BWD_WAVE_LDS;       // [192] BN2-backward constants (re-read per tile: the kernel is at the VGPR cap)
     if (tid < CF_TOTAL) sC[tid] = coef[tid];
+    const unsigned char *wr0 = sW3 + i * BWD_WROW + 64 * h, *wr1 = sW3 + (32 + i) * BWD_WROW + 64 * h;        // + piece * 128 + kb * 16
+    const unsigned char *wt0 = sW3T + i * BWD_WROW + 64 * h, *wt1 = sW3T + (32 + i) * BWD_WROW + 64 * h;
     f32x16 dW00, dW01, dW10, dW11;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW00[r] = 0.f; dW01[r] = 0.f; dW10[r] = 0.f; dW11[r] = 0.f; }
@@ -608,7 +626,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     __syncthreads();
 
     const int nst = (BN + 7) >> 3;
-    for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
+    for (int st = blockIdx.x * BWD_WAVES + wv; st < nst; st += gridDim.x * BWD_WAVES) {
         const int n0 = st * 8;
         const int ptA = min(n0 + pA, BN - 1);
         const int bA = ptA / N;
@@ -667,22 +685,36 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                     z = pv.w + qv.w; a[4 * v + 3] = fmaxf(z, z * slope);
                 }
             }
+            constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+            // bf16 pieces of 8 consecutive values, two per dword: [0] hi, [1] mid, [2] lo
+            auto pieces = [&](const float *v8, uint4 (&out)[3]) {
+                unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) split3(v8[e], ph[e], pm[e], pl[e]);
+                out[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+                out[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+                out[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+            };
             // (1) H2 = A1 W2^T
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const float4 w0 = *reinterpret_cast<const float4 *>(sW + i * TLD + 32 * h + 4 * v);
-                const float4 w1 = *reinterpret_cast<const float4 *>(sW + (32 + i) * TLD + 32 * h + 4 * v);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w0.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 0], w1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w0.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 1], w1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w0.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 2], w1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w0.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * v + 3], w1.w, acc1, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) {
+                uint4 ap[3], b0[3], b1[3];
+                pieces(a + 8 * kb, ap);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    b0[pc] = *reinterpret_cast<const uint4 *>(wr0 + pc * 128 + kb * 16);
+                    b1[pc] = *reinterpret_cast<const uint4 *>(wr1 + pc * 128 + kb * 16);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // a1: A-layout -> C/D layout through the transpose tile
 #pragma unroll
@@ -709,20 +741,41 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 acc0[r] = ok ? d0 : 0.f;
                 acc1[r] = ok ? d1 : 0.f;
             }
-            // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]   (register r <-> the same edge in both operands)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dW00 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc0[r], aD0[r], dW00, 0, 0, 0);
-                dW01 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc0[r], aD1[r], dW01, 0, 0, 0);
-                dW10 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD0[r], dW10, 0, 0, 0);
-                dW11 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc1[r], aD1[r], dW11, 0, 0, 0);
-            }
             // a1 is needed once more, for LReLU'(z1): keep its signs as two bit masks instead of 32 registers
             unsigned pos0 = 0u, pos1 = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 pos0 |= (aD0[r] > 0.f ? 1u : 0u) << r;
                 pos1 |= (aD1[r] > 0.f ? 1u : 0u) << r;
+            }
+            // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]   (register r <-> the same edge in both operands)
+            // (K-block kb = registers 8kb..8kb+7 of both lane halves: the same 16 edges in both operands)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float v8[8];
+                uint4 d[3], x0[3], x1[3];
+                pieces(aD0 + 8 * kb, x0);
+                pieces(aD1 + 8 * kb, x1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = acc0[8 * kb + e];
+                pieces(v8, d);
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const bf16x8 da = __builtin_bit_cast(bf16x8, d[PA[term]]);
+                    dW00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x0[PB[term]]), dW00, 0, 0, 0);
+                    dW01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x1[PB[term]]), dW01, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = acc1[8 * kb + e];
+                pieces(v8, d);
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const bf16x8 da = __builtin_bit_cast(bf16x8, d[PA[term]]);
+                    dW10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x0[PB[term]]), dW10, 0, 0, 0);
+                    dW11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x1[PB[term]]), dW11, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // dH2: C/D layout -> A-layout through the transpose tile
 #pragma unroll
@@ -747,11 +800,21 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float b0 = sW[(32 * h + s) * TLD + i];
-                const float b1 = sW[(32 * h + s) * TLD + 32 + i];
-                e0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0, e0, 0, 0, 0);
-                e1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1, e1, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) {                    // K = co: lane half h holds co 32h + 8kb ..
+                uint4 ap[3], b0[3], b1[3];
+                pieces(a + 8 * kb, ap);
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    b0[pc] = *reinterpret_cast<const uint4 *>(wt0 + pc * 128 + kb * 16);
+                    b1[pc] = *reinterpret_cast<const uint4 *>(wt1 + pc * 128 + kb * 16);
+                }
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
+                    e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), e0, 0, 0, 0);
+                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), e1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // dy1 = dA1 * LReLU'(z1); G_Q (in-lane), G_P (atomic 128-B half rows)
 #pragma unroll
@@ -783,7 +846,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     // block-level sum of the four waves' dW2 accumulators, then one partial per block
     __syncthreads();
     float *sD = smem;                                   // reuse: [64][64]
-    for (int e = tid; e < EC * EC; e += 256) sD[e] = 0.f;
+    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) sD[e] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -795,7 +858,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * BWD_PART;
-    for (int e = tid; e < EC * EC; e += 256) out[e] = sD[e];
+    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) out[e] = sD[e];
 }
 
 // B4: dW2 = block partials summed in double
@@ -986,7 +1049,8 @@ ec_bwd_dw1_kernel(const double *__restrict__ red, int C, int CP, float *__restri
 struct Plan {
     int g_heavy;        // blocks of the grid-stride heavy kernels
     int g_pq;           // workgroups of ec_bwd_pq_kernel (one weight-gradient partial each)
-    int g_mfma;         // blocks of the MFMA kernels (4 waves each, a wave walks super-tiles of 8 points)
+    int g_mfma;         // blocks of the forward MFMA kernel (4 waves each, a wave walks super-tiles of 8 points)
+    int g_bwd;          // blocks of the heavy backward kernel (8 waves each, one block per CU)
     int tiles;          // ceil(N/64) * B
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
@@ -1011,6 +1075,7 @@ static Plan make_plan(int B, int C, int N, int k)
         if (gm > 512) gm = 512;                  // 2 resident workgroups per CU
         if (gm < 1) gm = 1;
         p.g_mfma = gm;
+        p.g_bwd = (gm + 1) / 2;          // one block per CU (LDS)
     }
     int maxparts = p.tiles > g ? p.tiles : g;
     if (p.g_mfma > maxparts) maxparts = p.g_mfma;
@@ -1178,13 +1243,19 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             const size_t total = (size_t)BN * EC;
             hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
-            const size_t lds = sizeof(float) * (EC * TLD + 4 * BWD_WAVE_LDS + CF_TOTAL);
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
+                if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+                attr_done = true;
+            }
             ProfScope prof(2, st);
-            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_mfma), dim3(256), lds, st, Pp, Qp, a->idx, a->w2, coef,
+            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, coef,
                                g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
-        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_mfma, BWD_PART, dred);
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred);
         GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
         hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
         GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
