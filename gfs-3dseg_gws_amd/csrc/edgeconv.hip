@@ -953,28 +953,54 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
 #pragma unroll
         for (int r = 0; r < 16; ++r) wacc[u][r] = 0.f;
 
+    // Software pipeline over the tiles (the LDS footprint allows one workgroup = one wave per SIMD per CU, so nothing
+    // else hides the global latency): the inputs of tile t+1 are loaded into registers before the MFMA phase of tile t
+    // and turned into the LDS images of tile t+1 after it.
+    float rx[32];                                // x tile elements e = tid + 256 j  (c = e >> 6, p = e & 63), CP <= 128
+    float rP[16], rQ[16], rGP[16], rGQ[16], rSP[16], rSQ[16], rdeg[16];          // points p = wv + 4 j, channel co
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
+        const float *xb = x + (size_t)b * C * N;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int e = tid + 256 * j, c = e >> 6, p = e & 63;
+            rx[j] = (e < CP * 64 && c < C && n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = n0 + wv + 4 * j;
+            const bool ok = n < N;
+            const size_t o = ((size_t)b * N + (ok ? n : 0)) * EC + co;
+            rdeg[j] = ok ? indeg[(size_t)b * N + n] : 0.f;
+            rP[j] = P[o]; rQ[j] = Q[o]; rGP[j] = GP[o]; rGQ[j] = GQ[o]; rSP[j] = SP[o]; rSQ[j] = SQ[o];
+        }
+    };
+    auto stage = [&](int tile) {
+        const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int e = tid + 256 * j, c = e >> 6, p = e & 63;
+            if (e < CP * 64) xT[p * XLD + c] = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = wv + 4 * j;
+            const bool ok = n0 + p < N;
+            const float dq = A1 * (rGQ[j] - kf * mu_dy - mu_dyx * rstd1 * (rSP[j] + kf * (rQ[j] - mean1)));
+            const float dp = A1 * (rGP[j] - rdeg[j] * mu_dy - mu_dyx * rstd1 * (rdeg[j] * (rP[j] - mean1) + rSQ[j]));
+            dPt[p * PQ_LD + co] = ok ? dp : 0.f;
+            dQt[p * PQ_LD + co] = ok ? dq : 0.f;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) {
+        fetch(blockIdx.x);
+        stage(blockIdx.x);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
-        __syncthreads();                         // previous tile's MFMA reads of LDS are done
-        const float *xb = x + (size_t)b * C * N;
-        for (int e = tid; e < CP * 64; e += 256) {
-            const int c = e >> 6, p = e & 63;
-            xT[p * XLD + c] = (c < C && n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
-        }
-        for (int p = wv; p < 64; p += 4) {
-            const int n = n0 + p;
-            float dp = 0.f, dq = 0.f;
-            if (n < N) {
-                const size_t o = ((size_t)b * N + n) * EC + co;
-                const float deg = indeg[(size_t)b * N + n];
-                const float pv = P[o], qv = Q[o];
-                dq = A1 * (GQ[o] - kf * mu_dy - mu_dyx * rstd1 * (SP[o] + kf * (qv - mean1)));
-                dp = A1 * (GP[o] - deg * mu_dy - mu_dyx * rstd1 * (deg * (pv - mean1) + SQ[o]));
-            }
-            dPt[p * PQ_LD + co] = dp;
-            dQt[p * PQ_LD + co] = dq;
-        }
-        __syncthreads();
+        const int next = tile + gridDim.x;
+        __syncthreads();                         // the LDS images of this tile are complete
+        if (next < ntiles) fetch(next);          // in flight during the MFMA phase below
         // ---- dx tiles: (c tile rt < CT) x (point tile ct < 2); K = 128 (lane half h = 0: dP part, 1: dQ part)
         for (int task = wv; task < 2 * CT; task += 4) {
             const int rt = task >> 1, ct = task & 1;
@@ -1016,6 +1042,8 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
                 }
             }
         }
+        __syncthreads();                     // every wave has finished reading this tile's LDS images
+        if (next < ntiles) stage(next);
     }
     // one partial per workgroup: [2][64][CP]
     float *out = partial + (size_t)blockIdx.x * 2 * EC * CP;
