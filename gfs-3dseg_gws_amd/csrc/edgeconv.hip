@@ -86,27 +86,28 @@ __global__ void ec_wpq_kernel(const float *__restrict__ w1, int C, float *__rest
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+constexpr int ST1_WAVES = 16;       // every block ends in 128 same-address fp64 atomics (~14 ns each, serialised): few big blocks
+__global__ void __launch_bounds__(64 * ST1_WAVES)
 ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ idx,
                  int BN, int N, int k, float *__restrict__ SP, double *__restrict__ partial)
 {
-    __shared__ double red[4][2][EC];
+    __shared__ double red[ST1_WAVES][2][EC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double s = 0.0, ss = 0.0;
-    for (int pt = blockIdx.x * 4 + wv; pt < BN; pt += gridDim.x * 4) {
+    for (int pt = blockIdx.x * ST1_WAVES + wv; pt < BN; pt += gridDim.x * ST1_WAVES) {
         const int b = pt / N;
         const float q = Q[(size_t)pt * EC + lane];
         const int myidx = (lane < k) ? idx[(size_t)pt * k + lane] : 0;
         float sp = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int j0 = 0; j0 < k; j0 += 4) {               // 4 independent row gathers in flight
-            float pv[4];
+        for (int j0 = 0; j0 < k; j0 += 10) {              // 10 independent row gathers in flight
+            float pv[10];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 10; ++u) {
                 const int m = __shfl(myidx, min(j0 + u, k - 1), 64);
                 pv[u] = P[((size_t)b * N + m) * EC + lane];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 10; ++u) {
                 if (j0 + u < k) {
                     const float h = pv[u] + q;
                     sp += pv[u];
@@ -124,7 +125,9 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
     __syncthreads();
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6;
-        const double t = red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane];
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < ST1_WAVES; ++w) t += red[w][which][lane];
         atomicAdd(&partial[which * EC + lane], t);          // 128 fp64 accumulators (zeroed by the launcher)
     }
 }
@@ -166,6 +169,12 @@ rev_gather_kernel(const float *__restrict__ Q, const int *__restrict__ cnt, cons
         const int mine = (lane < dd) ? slot[(size_t)tm * REV_CAP + lane] : 0;
         float acc = 0.f;
         int s = 0;
+        for (; s + 8 <= dd; s += 8) {                      // 8 independent row gathers in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Q[(size_t)__shfl(mine, s + u, 64) * EC + lane];
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
         for (; s + 4 <= dd; s += 4) {
             const float v0 = Q[(size_t)__shfl(mine, s + 0, 64) * EC + lane];
             const float v1 = Q[(size_t)__shfl(mine, s + 1, 64) * EC + lane];
@@ -492,6 +501,7 @@ ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmi
 // ===========================================================================
 // backward
 // ===========================================================================
+constexpr int PREP_TILES = 4;
 // B1: g = dy * lrelu'(y) in point-major layout; partial sums of g and g*xhat2.
 __global__ void __launch_bounds__(256)
 ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const float *__restrict__ dy_pm,
@@ -501,25 +511,47 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
 {
     __shared__ float tile[64][65];
     __shared__ double red[4][2][EC];
-    const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, b = blockIdx.y;
     const int co = tid & 63, wv = tid >> 6;
-    {
-        const int p = tid & 63;
-        for (int c = wv; c < EC; c += 4)
-            tile[p][c] = (dy_cf && n0 + p < N) ? dy_cf[(size_t)b * dy_bstride + (size_t)c * N + n0 + p] : 0.f;
-    }
-    __syncthreads();
     const float mean2 = stats[ST_MEAN2 * EC + co], rstd2 = stats[ST_RSTD2 * EC + co];
     double s = 0.0, sx = 0.0;
-    for (int p = wv; p < 64; p += 4) {
-        const int n = n0 + p;
-        if (n >= N) break;
+    // a block walks PREP_TILES tiles of 64 points (its 128 fp64 atomics at the end are same-address traffic)
+    for (int tt = 0; tt < PREP_TILES; ++tt) {
+    const int n0 = (blockIdx.x * PREP_TILES + tt) * 64;
+    if (n0 >= N) break;
+    __syncthreads();
+    // all 16 loads of a thread are issued before the first use (the loops are fully unrolled): the kernel is pure
+    // streaming and lives on memory-level parallelism
+    float ry[16], rh[16], rd[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int n = min(n0 + wv + 4 * j, N - 1);
         const size_t o = ((size_t)b * N + n) * EC + co;
-        const float dy = dy_pm ? tile[p][co] + dy_pm[o] : tile[p][co];     // both consumers of the block output
-        const float g = dy * (y_pm[o] > 0.f ? 1.f : slope);
-        g_pm[o] = g;
-        s += (double)g;
-        sx += (double)(g * ((hsel[o] - mean2) * rstd2));
+        ry[j] = y_pm[o];
+        rh[j] = hsel[o];
+        rd[j] = dy_pm ? dy_pm[o] : 0.f;                                     // both consumers of the block output
+    }
+    {
+        const int p = tid & 63;
+        float rt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            rt[j] = (dy_cf && n0 + p < N) ? dy_cf[(size_t)b * dy_bstride + (size_t)(wv + 4 * j) * N + n0 + p] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tile[p][wv + 4 * j] = rt[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int p = wv + 4 * j, n = n0 + p;
+        if (n < N) {
+            const size_t o = ((size_t)b * N + n) * EC + co;
+            const float g = (tile[p][co] + rd[j]) * (ry[j] > 0.f ? 1.f : slope);
+            g_pm[o] = g;
+            s += (double)g;
+            sx += (double)(g * ((rh[j] - mean2) * rstd2));
+        }
+    }
     }
     red[wv][0][co] = s;
     red[wv][1][co] = sx;
@@ -880,11 +912,20 @@ ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float mean1 = stats[ST_MEAN1 * EC + lane], rstd1 = stats[ST_RSTD1 * EC + lane];
     double s = 0.0, sx = 0.0;
-    for (int pt = blockIdx.x * 4 + wv; pt < BN; pt += gridDim.x * 4) {
-        const size_t o = (size_t)pt * EC + lane;
-        const float gq = GQ[o], gp = GP[o];
-        s += (double)gq;
-        sx += (double)(P[o] * rstd1 * gp) + (double)((Q[o] - mean1) * rstd1 * gq);
+    const int stride = gridDim.x * 4;
+    for (int pt0 = blockIdx.x * 4 + wv; pt0 < BN; pt0 += 4 * stride) {      // 16 row loads in flight per wave
+        float gq[4], gp[4], pv[4], qv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)min(pt0 + u * stride, BN - 1) * EC + lane;
+            gq[u] = GQ[o]; gp[u] = GP[o]; pv[u] = P[o]; qv[u] = Q[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pt0 + u * stride < BN) {
+                s += (double)gq[u];
+                sx += (double)(pv[u] * rstd1 * gp[u]) + (double)((qv[u] - mean1) * rstd1 * gq[u]);
+            }
     }
     red[wv][0][lane] = s;
     red[wv][1][lane] = sx;
@@ -1202,7 +1243,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
                 return GFS3D_ERR_HIP;
             }
             ProfScope prof(4, st);
-            hipLaunchKernelGGL(ec_stats1_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
+            hipLaunchKernelGGL(ec_stats1_kernel, dim3((p.g_heavy + 3) / 4), dim3(64 * ST1_WAVES), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
                                a->SP, acc1);
             GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
         }
@@ -1252,7 +1293,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
-        hipLaunchKernelGGL(ec_bwd_prep_kernel, tgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
+        hipLaunchKernelGGL(ec_bwd_prep_kernel, dim3(((a->N + 63) / 64 + PREP_TILES - 1) / PREP_TILES, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
                            a->N, a->slope, g, acc1);
         GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
         if (acc_user && hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
@@ -1304,7 +1345,8 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, st, a->Q, ovf_cnt, ovf, a->SQ);
             GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
         }
-        hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
+        // every block ends in 128 same-address fp64 atomics: few, long-running blocks
+        hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy < 256 ? p.g_heavy : 256), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
         GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
         if (acc_user && hipMemcpyAsync(loc2, acc2, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("%s: hipMemcpyAsync failed", who);
