@@ -71,6 +71,71 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         }
         return;
     }
+    if (BN == 128) {
+        // Through LDS, so that the global side is 16-byte wide and coalesced over whole rows (the direct form issues 64
+        // scalar loads + 64 scalar stores per lane): two passes of 64 tile rows; in pass ps the two waves with wm == ps
+        // drop their 64 x 64 accumulators into a [64][132] image, then thread t handles columns 4 (t & 31) .. +3 of
+        // rows (t >> 5) + 8 jj.
+        constexpr int ELD = 132;
+        const int c4 = (t & 31) * 4, rr = t >> 5;
+        const int gcol = col0 + c4;
+        const int seg = gcol / g.o_segw, ocol = gcol - seg * g.o_segw;
+        float *op = g.out[seg] + ocol;
+        f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, ts1 = ea, ts2 = ea;
+        if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = ldg4(g.ea + gcol); eb = ldg4(g.eb + gcol); }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            __syncthreads();
+            if (wm == ps) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ELD + wn * 64 + j * 32 + li] = acc[i][j][r];
+            }
+            __syncthreads();
+            f32x4 hv[8];
+            if (EPI == EPI_BWD_ACT) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int row = row0 + ps * 64 + rr + 8 * jj;
+                    hv[jj] = row < g.M ? ldg4(g.eh + (size_t)row * g.Nc + gcol) : ea;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int row = row0 + ps * 64 + rr + 8 * jj;
+                if (row >= g.M) continue;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(&smem[(rr + 8 * jj) * ELD + c4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (EPI == EPI_RAW_STATS) { ts1[e] += v[e]; ts2[e] = fmaf(v[e], v[e], ts2[e]); }
+                    if (EPI == EPI_AFFINE_ACT) v[e] = lrelu(fmaf(v[e], ea[e], eb[e]), g.slope);
+                    if (EPI == EPI_BWD_ACT) {
+                        const float hh = hv[jj][e];
+                        v[e] = fmaf(hh, ea[e], eb[e]) > 0.f ? v[e] : v[e] * g.slope;
+                        ts1[e] += v[e]; ts2[e] = fmaf(v[e], hh, ts2[e]);
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(op + (size_t)row * g.o_segw) = v;
+            }
+        }
+        if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
+            __syncthreads();
+            float *red = smem;                  // [8 thread rows][2][128]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { red[(rr * 2 + 0) * 128 + c4 + e] = ts1[e]; red[(rr * 2 + 1) * 128 + c4 + e] = ts2[e]; }
+            __syncthreads();
+            const int which = t >> 7, col = t & 127;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[(q * 2 + which) * 128 + col];
+            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)sum);
+        }
+        return;
+    }
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -671,31 +736,45 @@ pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int 
 }
 
 // g(b n, c) = dy_cf(b, c, n) * act'(scale h + shift);  acc[0][c] += sum g, acc[1][c] += sum g h
+// grid (ceil(N / 256), C / 64, B): a block walks 4 tiles of 64 points (loads batched ahead of their use; one set of
+// same-address fp64 atomics per block)
+constexpr int PW_IN_TILES = 4;
 __global__ void __launch_bounds__(256)
 pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ h, const float *__restrict__ stats, int N, int C,
                  float slope, float *__restrict__ gout, double *__restrict__ acc)
 {
     __shared__ float tile[64][65];
     __shared__ float red[4][2][64];
-    const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int tid = threadIdx.x, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int c = tid & 63, wv = tid >> 6;
-    {
-        const int p = tid & 63;
-        for (int cc = wv; cc < 64; cc += 4)
-            tile[p][cc] = n0 + p < N ? dy_cf[((size_t)b * C + c0 + cc) * N + n0 + p] : 0.f;
-    }
-    __syncthreads();
     const float sc = stats[PST_SCALE * C + c0 + c], sh = stats[PST_SHIFT * C + c0 + c];
     float s = 0.f, sx = 0.f;
-    for (int p = wv; p < 64; p += 4) {
-        const int n = n0 + p;
-        if (n >= N) break;
-        const size_t o = ((size_t)b * N + n) * C + c0 + c;
-        const float hv = h[o];
-        const float gv = fmaf(hv, sc, sh) > 0.f ? tile[p][c] : tile[p][c] * slope;
-        gout[o] = gv;
-        s += gv;
-        sx = fmaf(gv, hv, sx);
+    for (int tt = 0; tt < PW_IN_TILES; ++tt) {
+        const int n0 = (blockIdx.x * PW_IN_TILES + tt) * 64;
+        if (n0 >= N) break;
+        __syncthreads();
+        float rh[16], rt[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rh[j] = h[((size_t)b * N + min(n0 + wv + 4 * j, N - 1)) * C + c0 + c];
+        {
+            const int p = tid & 63;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rt[j] = n0 + p < N ? dy_cf[((size_t)b * C + c0 + wv + 4 * j) * N + n0 + p] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) tile[p][wv + 4 * j] = rt[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int p = wv + 4 * j, n = n0 + p;
+            if (n < N) {
+                const float hv = rh[j];
+                const float gv = fmaf(hv, sc, sh) > 0.f ? tile[p][c] : tile[p][c] * slope;
+                gout[((size_t)b * N + n) * C + c0 + c] = gv;
+                s += gv;
+                sx = fmaf(gv, hv, sx);
+            }
+        }
     }
     red[wv][0][c] = s;
     red[wv][1][c] = sx;
@@ -1002,7 +1081,7 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
     {
         const int C = a->width[L - 1];
         if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
-        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
+        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
                            a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]),
                            acc + (size_t)2 * p.maxw * (L - 1));
         GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
