@@ -585,8 +585,12 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
     const int wm = wv >> 1, wn = wv & 1;
     const int pair = t & 15, quad0 = t >> 4;                 // item p: channel quad quad0 + 16 p, points 2 pair, 2 pair + 1
     const float *up = g.u + co0, *up2 = g.u2 ? g.u2 + co0 : nullptr;
-    const int vseg = ci0 / g.v_segw;
-    const float *vp = g.v[vseg] + (ci0 - vseg * g.v_segw);
+    const float *vp[NV];                                     // a V tile may span several 64-channel input segments
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int ch = ci0 + 4 * (quad0 + 16 * p), vseg = ch / g.v_segw;
+        vp[p] = g.v[vseg] + (ch - vseg * g.v_segw);
+    }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ua[NU], ub[NU], uc[NU], va[NV], vb[NV];
 #pragma unroll
@@ -626,7 +630,7 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
         for (int p = 0; p < NV; ++p)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                rV[p][e] = m + e < m1 ? ldg4(vp + (size_t)(m + e) * g.ldv + 4 * (quad0 + 16 * p)) : zero4;
+                rV[p][e] = m + e < m1 ? ldg4(vp[p] + (size_t)(m + e) * g.ldv) : zero4;
     };
     // one item: 4 channels x 2 points -> per channel and piece one dword at [channel row][piece][pair]
     auto put = [&](char *base, int quad, const f32x4 &x0, const f32x4 &x1) {
@@ -871,10 +875,18 @@ template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
-    (void)who;
+    if (lds > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_wgrad6_kernel<BMU, BNV, VPRO>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+            attr_done = true;
+        }
+    }
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
-    // ~3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
-    int nsplit = (768 + ntile - 1) / ntile;
+    // 2-3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
+    int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;
     int rows = (wg.M + nsplit - 1) / nsplit;
     rows = (rows + 31) / 32 * 32;
     if (rows < 256) rows = 256;
@@ -1105,7 +1117,8 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
         if (l == 0) {
             for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
             wg.v_segw = GFS3D_PW_SEG_WIDTH; wg.ldv = GFS3D_PW_SEG_WIDTH;
-            rc = launch_wgrad<64, PRO_NONE>(wg, st, who);
+            // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once
+            rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
         } else {
             wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
             wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
