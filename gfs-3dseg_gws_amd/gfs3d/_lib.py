@@ -9,12 +9,12 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
-_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip")
 _lib = None
 
 
@@ -90,6 +90,11 @@ SYMBOLS = {
     "gfs3d_pointwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "gfs3d_pointwise_forward_f32": (c_int, [POINTER(PointwiseArgs), c_void_p]),
     "gfs3d_pointwise_backward_f32": (c_int, [POINTER(PointwiseBwdArgs), c_void_p]),
+    "gfs3d_attention_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_void_p,
+                                            c_void_p, c_void_p, c_void_p]),
+    "gfs3d_attention_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                             c_float, c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gfs3d_attention_dropout_mask": (c_int, [c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p]),
     "gfs3d_word_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,

@@ -424,6 +424,64 @@ def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: boo
 
 
 # --------------------------------------------------------------------------
+# K5
+# --------------------------------------------------------------------------
+class AttentionFunction(torch.autograd.Function):
+    """dropout(softmax(q^T k * scale)) v^T -> (B, 64, N) without the (B, N, N) score matrix (model/attention.py:44-48)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, p_drop, seed, keep_mask):
+        for t_, nme in ((q, "q"), (k, "k"), (v, "v")):
+            _need_gpu(t_, nme)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, D, N = q.shape
+        if k.shape != q.shape or v.shape != q.shape:
+            raise RuntimeError("gfs3d.attention: q, k, v must have the same (B, 64, N) shape")
+        if keep_mask is not None:
+            keep_mask = keep_mask.to(torch.uint8).contiguous()
+            if tuple(keep_mask.shape) != (B, N, N):
+                raise RuntimeError("gfs3d.attention: keep_mask must be (B, N, N)")
+        out = torch.empty_like(q)
+        lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().gfs3d_attention_forward_f32(_p(q), _p(k), _p(v), B, D, N, float(scale), float(p_drop), int(seed),
+                                                        _p(keep_mask), _p(out), _p(lse), _stream())
+        _lib.check(rc, "gfs3d_attention_forward_f32")
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.mask = keep_mask
+        ctx.cfg = (float(scale), float(p_drop), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        scale, p_drop, seed = ctx.cfg
+        B, D, N = q.shape
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        ws = torch.empty((B, N), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().gfs3d_attention_backward_f32(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), B, D, N, scale, p_drop, seed,
+                                                         _p(ctx.mask), _p(dq), _p(dk), _p(dv), _p(ws), _stream())
+        _lib.check(rc, "gfs3d_attention_backward_f32")
+        return dq, dk, dv, None, None, None, None
+
+
+def attention(q, k, v, scale: float, p_drop: float = 0.0, seed: int = 0, keep_mask: Optional[torch.Tensor] = None):
+    """Fused scaled-dot-product attention over points; `p_drop`: dropout on the attention weights (training)."""
+    return AttentionFunction.apply(q, k, v, scale, p_drop, seed, keep_mask)
+
+
+def attention_dropout_mask(B: int, N: int, p_drop: float, seed: int, device) -> torch.Tensor:
+    """The (B, N, N) keep decisions AttentionFunction makes for (seed, p_drop)."""
+    mask = torch.empty((B, N, N), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        rc = _lib.lib().gfs3d_attention_dropout_mask(B, N, float(p_drop), int(seed), _p(mask), _stream())
+    _lib.check(rc, "gfs3d_attention_dropout_mask")
+    return mask
+
+
+# --------------------------------------------------------------------------
 # K3
 # --------------------------------------------------------------------------
 def _bstride(t: torch.Tensor) -> int:

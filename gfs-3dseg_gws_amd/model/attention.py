@@ -1,8 +1,9 @@
 """Self-attention head of the CAPL model - same constructor, parameter names
 (q_map/k_map/v_map.weight) and forward contract as the reference
-model/attention.py:10-48.  It is on the forward path but not one of the
-north-star kernels: it runs as device GEMMs
-through torch (rocBLAS) and never materialises more than one (B,N,N) tensor.
+model/attention.py:10-48.  On the GPU with the reference's head size (64) the
+softmax(q^T k / sqrt(d)) v product runs as ONE fused HIP kernel (K5, gfs3d_attention_forward_f32: no (B,N,N) tensor,
+dropout decisions from a counter-based hash so that the backward regenerates them); other head sizes use the torch
+formulation below.
 """
 import torch
 import torch.nn as nn
@@ -23,6 +24,13 @@ class SelfAttention(nn.Module):
     def forward(self, x):
         """x (B, in_channel, N) -> (B, out_channel, N)."""
         q, k, v = self.q_map(x), self.k_map(x), self.v_map(x)
+        if x.is_cuda and self.out_channel == 64:
+            from gfs3d import ops
+            p = float(self.dropout.p) if self.training else 0.0
+            mask = self._forced_keep_mask if (self.training and self._forced_keep_mask is not None) else None
+            # one draw from torch's generator per call: reproducible under torch.manual_seed like nn.Dropout
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and mask is None) else 0
+            return ops.attention(q, k, v, 1.0 / self.temperature, p, seed, mask)
         attn = torch.bmm(q.transpose(1, 2) / self.temperature, k)
         attn = F.softmax(attn, dim=-1)
         if self._forced_keep_mask is not None and self.training:

@@ -39,8 +39,8 @@ const char *gfs3d_last_error(void);
  * events of one kernel id, returns the summed device time in ms and the number of
  * launches, and clears them.  Ids: 0 knn_topk, 1 ec_main_fwd, 2 ec_main_bwd,
  * 3 proto_mfma (word assign / get_pred), 4 ec_stats1, 5 kmeans_assign, 6 pointwise stack forward (all its
- * kernels), 7 pointwise stack backward. */
-#define GFS3D_PROF_KERNELS 8
+ * kernels), 7 pointwise stack backward, 8 attention forward, 9 attention backward. */
+#define GFS3D_PROF_KERNELS 10
 int gfs3d_profile_enable(int on);
 int gfs3d_profile_read(int kernel_id, double *total_ms, long long *launches);
 
@@ -171,6 +171,23 @@ typedef struct gfs3d_pointwise_bwd_args {
 size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width);
 int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream);
 int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream);
+
+/* ------------------------------------------------------------------ K5 --
+ * Fused self-attention over the points of a block.  Replaces SelfAttention.forward after the three 1x1 projections,
+ * model/attention.py:39-48:  y = dropout(softmax_k(q^T k * scale)) v^T  without materialising the (B, N, N) scores.
+ *   q, k, v (B, 64, N) channel-first; scale = 1 / sqrt(64) in the reference; out (B, 64, N); lse (B, N) = log-sum-exp
+ *   of every query's scores (kept for the backward).
+ *   Dropout (p_drop > 0): weight (q, k) of item b is kept iff hash(seed, b, q N + k) >= p_drop 2^32 and scaled by
+ *   1 / (1 - p_drop); the backward regenerates the same decisions from (seed, p_drop).  keep_mask, if not NULL, is an
+ *   explicit (B, N, N) byte mask used instead (tests; p_drop then only sets the scale).
+ *   gfs3d_attention_dropout_mask writes the decisions of (seed, p_drop) as such a mask.
+ * Backward: dout (B, 64, N) -> dq, dk, dv (B, 64, N); workspace: B*N floats. */
+int gfs3d_attention_forward_f32(const float *q, const float *k, const float *v, int B, int D, int N, float scale, float p_drop,
+                                unsigned long long seed, const uint8_t *keep_mask, float *out, float *lse, void *stream);
+int gfs3d_attention_backward_f32(const float *q, const float *k, const float *v, const float *out, const float *lse,
+                                 const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
+                                 const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, void *stream);
+int gfs3d_attention_dropout_mask(int B, int N, float p_drop, unsigned long long seed, uint8_t *mask, void *stream);
 
 /* ------------------------------------------------------------------ K3 --
  * Point x prototype cosine matching on MFMA (fp32-in / fp32-acc).
