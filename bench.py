@@ -167,6 +167,9 @@ def main():
         roof = {"bound": "mfma", "kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": hbm_traffic(KERNELS[dom]),
                 "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                "note": "achieved = algorithmic fp32 flops / time against the fp32 (vector == fp32-MFMA) peak; the EdgeConv and "
+                        "point-wise GEMMs run on the bf16 matrix cores at fp32 accuracy (exact 3-way bf16 split, 6 piece "
+                        "products per fp32 product); kNN stays on the bit-exact fp32 MFMA chain",
                 "per_kernel_ms_per_step": {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}}
         # the point-wise stack runs on the bf16 matrix cores at fp32 accuracy (6 bf16 products per fp32 product):
         # algorithmic fp32 TFLOP/s of its two launch groups (all kernels of a pass), against the same fp32 peak
