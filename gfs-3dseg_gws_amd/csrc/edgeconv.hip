@@ -207,7 +207,7 @@ rev_overflow_kernel(const float *__restrict__ Q, const int *__restrict__ ovf_cnt
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(1024)
-reduce_parts_kernel(const T *__restrict__ partial, int nparts, int width, double *__restrict__ out)
+reduce_parts_kernel(const T *__restrict__ partial, int nparts, int width, double *__restrict__ out, float *__restrict__ fout = nullptr)
 {
     __shared__ double red[16][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -222,47 +222,57 @@ reduce_parts_kernel(const T *__restrict__ partial, int nparts, int width, double
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][el];
         out[e] = t;
+        if (fout) fout[e] = (float)t;
     }
 }
 
 // ---------------------------------------------------------------------------
-// F3: finalize BN statistics -> stats rows (mean, rstd, scale, shift); running
-// stats update (momentum, unbiased variance) when training.  1 block x 64.
+// F3: BN statistics of channel c -> (mean, rstd, scale, shift); `writer` also stores them as stats rows
+// row0..row0+3 and updates the running statistics (momentum, unbiased variance) when training.
+// Called from the prologue of the kernel that consumes the constants (every block recomputes its 64 channels
+// from the 128 fp64 sums - a separate 5 us launch per BatchNorm otherwise).
 // ---------------------------------------------------------------------------
-__global__ void ec_bn_finalize_kernel(const double *__restrict__ partial, int nparts, double count,
-                                      const float *__restrict__ gamma, const float *__restrict__ beta,
-                                      float *__restrict__ rm, float *__restrict__ rv,
-                                      float eps, float momentum, int training,
-                                      float *__restrict__ stats, int row0)
+struct BnFin {
+    const double *acc;            // [2][64] sums (training) or NULL (constants are already in `stats`)
+    double count;
+    const float *gamma, *beta;
+    float *rm, *rv;
+    float eps, momentum;
+    int training;
+};
+__device__ __forceinline__ void bn_constants(const BnFin &f, int c, bool writer, float *__restrict__ stats, int row0,
+                                             float &scale, float &shift)
 {
-    const int c = threadIdx.x;
+    if (!f.acc && f.training) {                          // already finalised (backward pass)
+        scale = stats[(row0 + 2) * EC + c];
+        shift = stats[(row0 + 3) * EC + c];
+        return;
+    }
     float mean, var;
-    if (training) {
-        double s = 0.0, ss = 0.0;
-        for (int p = 0; p < nparts; ++p) {
-            s += partial[((size_t)p * 2 + 0) * EC + c];
-            ss += partial[((size_t)p * 2 + 1) * EC + c];
-        }
-        const double mu = s / count;
-        double v = ss / count - mu * mu;
+    if (f.training) {
+        const double mu = f.acc[c] / f.count;
+        double v = f.acc[EC + c] / f.count - mu * mu;
         if (v < 0.0) v = 0.0;
         mean = (float)mu;
         var = (float)v;
-        if (rm) {
-            const double unbiased = (count > 1.0) ? v * count / (count - 1.0) : v;
-            rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
-            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+        if (writer && f.rm) {
+            const double unbiased = (f.count > 1.0) ? v * f.count / (f.count - 1.0) : v;
+            f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * mean;
+            f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unbiased;
         }
     } else {
-        mean = rm[c];
-        var = rv[c];
+        mean = f.rm[c];
+        var = f.rv[c];
     }
-    const float rstd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * rstd;
-    stats[(row0 + 0) * EC + c] = mean;
-    stats[(row0 + 1) * EC + c] = rstd;
-    stats[(row0 + 2) * EC + c] = sc;
-    stats[(row0 + 3) * EC + c] = beta[c] - mean * sc;
+    const float rstd = 1.0f / sqrtf(var + f.eps);
+    scale = f.gamma[c] * rstd;
+    shift = f.beta[c] - mean * scale;
+    if (writer) {
+        stats[(row0 + 0) * EC + c] = mean;
+        stats[(row0 + 1) * EC + c] = rstd;
+        stats[(row0 + 2) * EC + c] = scale;
+        stats[(row0 + 3) * EC + c] = shift;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -271,15 +281,17 @@ __global__ void ec_bn_finalize_kernel(const double *__restrict__ partial, int np
 // constants in registers.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, const float *__restrict__ stats,
+ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, const BnFin fin, float *__restrict__ stats,
                    size_t total, float *__restrict__ Pp, float *__restrict__ Qp)
 {
+    __shared__ float sc[EC], sh[EC];
+    if (threadIdx.x < EC) bn_constants(fin, threadIdx.x, blockIdx.x == 0, stats, (int)ST_MEAN1, sc[threadIdx.x], sh[threadIdx.x]);
+    __syncthreads();
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int c = (int)(e & 63);
-    const float s = stats[ST_SCALE1 * EC + c], t = stats[ST_SHIFT1 * EC + c];
-    Pp[e] = P[e] * s;
-    Qp[e] = fmaf(Q[e], s, t);
+    Pp[e] = P[e] * sc[c];
+    Qp[e] = fmaf(Q[e], sc[c], sh[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -467,14 +479,17 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 __global__ void __launch_bounds__(256)
 ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmin,
                    const uint8_t *__restrict__ jmax, const uint8_t *__restrict__ jmin,
-                   const float *__restrict__ stats, int N, float slope,
+                   const BnFin fin, float *__restrict__ stats, int N, float slope,
                    float *__restrict__ y_cf, long long y_bstride, float *__restrict__ y_pm,
                    float *__restrict__ hsel, uint8_t *__restrict__ jsel)
 {
     __shared__ float tile[64][65];
+    __shared__ float scs[EC], shs[EC];
     const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
     const int co = tid & 63, wv = tid >> 6;
-    const float sc = stats[ST_SCALE2 * EC + co], sh = stats[ST_SHIFT2 * EC + co];
+    if (tid < EC) bn_constants(fin, tid, blockIdx.x == 0 && blockIdx.y == 0, stats, (int)ST_MEAN2, scs[tid], shs[tid]);
+    __syncthreads();
+    const float sc = scs[co], sh = shs[co];
     for (int p = wv; p < 64; p += 4) {
         const int n = n0 + p;
         float y = 0.f;
@@ -569,23 +584,26 @@ enum { CF_A = 0, CF_BC = 64, CF_CC = 128, CF_TOTAL = 192 };
 // B2: finalize dgamma2 / dbeta2 and the per-channel constants of the BN2 backward:
 //     dh2 = A*route + Bc + Cc*h2   with  A = gamma2*rstd2 (= scale2),
 //     Bc = -A (m1 - mean2 rstd2 m2),  Cc = -A rstd2 m2,  m1 = mean(dy2), m2 = mean(dy2 xhat2).
-__global__ void __launch_bounds__(64)
-ec_bwd_coef_kernel(const double *__restrict__ red, const double *__restrict__ red_local, double count,
-                   const float *__restrict__ stats,
-                   float *__restrict__ dbn2_w, float *__restrict__ dbn2_b, float *__restrict__ coef)
+struct CoefIn {
+    const double *red, *red_local;    // [2][64] sums over the whole (possibly multi-rank) batch / over this rank
+    double count;
+    const float *stats;
+    float *dbn2_w, *dbn2_b;
+};
+// per-channel constants of channel c into sC[192]; `writer` also stores this rank's dgamma2 / dbeta2
+__device__ __forceinline__ void bwd_coef(const CoefIn &f, int c, bool writer, float *sC)
 {
-    // red = sums over the WHOLE (possibly multi-rank) batch -> the means of the BN backward;
-    // red_local = this rank's sums -> this rank's share of dgamma/dbeta (summed later by the gradient all-reduce)
-    const int c = threadIdx.x;
-    const double s = red[c], sx = red[EC + c];
-    dbn2_b[c] = (float)red_local[c];
-    dbn2_w[c] = (float)red_local[EC + c];
-    const double m1 = s / count, m2 = sx / count;
-    const double A = stats[ST_SCALE2 * EC + c];
-    const double mean2 = stats[ST_MEAN2 * EC + c], rstd2 = stats[ST_RSTD2 * EC + c];
-    coef[CF_A + c] = (float)A;
-    coef[CF_BC + c] = (float)(-A * (m1 - mean2 * rstd2 * m2));
-    coef[CF_CC + c] = (float)(-A * rstd2 * m2);
+    const double s = f.red[c], sx = f.red[EC + c];
+    if (writer) {
+        f.dbn2_b[c] = (float)f.red_local[c];
+        f.dbn2_w[c] = (float)f.red_local[EC + c];
+    }
+    const double m1 = s / f.count, m2 = sx / f.count;
+    const double A = f.stats[ST_SCALE2 * EC + c];
+    const double mean2 = f.stats[ST_MEAN2 * EC + c], rstd2 = f.stats[ST_RSTD2 * EC + c];
+    sC[CF_A + c] = (float)A;
+    sC[CF_BC + c] = (float)(-A * (m1 - mean2 * rstd2 * m2));
+    sC[CF_CC + c] = (float)(-A * rstd2 * m2);
 }
 
 // ---------------------------------------------------------------------------
@@ -620,7 +638,7 @@ constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES 
 
 __global__ void __launch_bounds__(64 * BWD_WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
-                   const float *__restrict__ w2, const float *__restrict__ coef,
+                   const float *__restrict__ w2, const CoefIn cin,
                    const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
                    int BN, int N, int k, float slope,
                    float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial)
@@ -646,7 +664,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
         o[2 * EC] = ot[2 * EC] = (unsigned short)(pl >> 16);
     }
     float *sC = wbase + BWD_WAVES * BWD_WAVE_LDS;       // [192] BN2-backward constants (re-read per tile: the kernel is at the VGPR cap)
-    if (tid < CF_TOTAL) sC[tid] = coef[tid];
+    if (tid < EC) bwd_coef(cin, tid, blockIdx.x == 0, sC);       // (a separate 5 us launch otherwise)
     const unsigned char *wr0 = sW3 + i * BWD_WROW + 64 * h, *wr1 = sW3 + (32 + i) * BWD_WROW + 64 * h;        // + piece * 128 + kb * 16
     const unsigned char *wt0 = sW3T + i * BWD_WROW + 64 * h, *wt1 = sW3T + (32 + i) * BWD_WROW + 64 * h;
     f32x16 dW00, dW01, dW10, dW11;
@@ -669,8 +687,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             const int pt = n0 + 4 * h + q;
             const bool ok = pt < BN;
             const size_t o = (size_t)min(pt, BN - 1) * EC + i;
-            Ag0[q] = ok ? coef[CF_A + i] * g_pm[o] : 0.f;
-            Ag1[q] = ok ? coef[CF_A + 32 + i] * g_pm[o + 32] : 0.f;
+            Ag0[q] = ok ? sC[CF_A + i] * g_pm[o] : 0.f;
+            Ag1[q] = ok ? sC[CF_A + 32 + i] * g_pm[o + 32] : 0.f;
             js0 |= (ok ? (unsigned)jsel[o] : 255u) << (8 * q);
             js1 |= (ok ? (unsigned)jsel[o + 32] : 255u) << (8 * q);
             gq0[q] = 0.f; gq1[q] = 0.f;
@@ -893,14 +911,6 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) out[e] = sD[e];
 }
 
-// B4: dW2 = block partials summed in double
-__global__ void __launch_bounds__(256)
-ec_bwd_dw2_kernel(const double *__restrict__ red, float *__restrict__ dw2)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < EC * EC) dw2[e] = (float)red[e];
-}
-
 // B5: BN1 backward reductions: sum_n GQ (= sum_e dy1) and
 //     sum_e dy1*xhat1 = sum_m P''[m] GP[m] + sum_n Q''[n] GQ[n].   partial [grid][2][64] doubles
 __global__ void __launch_bounds__(256)
@@ -941,7 +951,7 @@ __global__ void ec_bwd_bn1_final_kernel(const double *__restrict__ partial, cons
                                         float *__restrict__ dbn1_w, float *__restrict__ dbn1_b, float *__restrict__ mu)
 {
     const int c = threadIdx.x;
-    const double s = partial[c], sx = partial[EC + c];      // whole-batch sums (see ec_bwd_coef_kernel)
+    const double s = partial[c], sx = partial[EC + c];      // whole-batch sums (see bwd_coef)
     dbn1_b[c] = (float)local[c];
     dbn1_w[c] = (float)local[EC + c];
     mu[c] = (float)(s / count);
@@ -1248,21 +1258,17 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
         }
     } else if (phase == 1) {
-        hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc1, 1, count, a->bn1_w, a->bn1_b,
-                           a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN1);
-        GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(1)");
+        const BnFin fin1{acc1, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training};
         const size_t total = (size_t)BN * EC;
-        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
+        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, fin1, a->stats, total, Pp, Qp);
         GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         ProfScope prof(1, st);
         hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, acc2);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     } else {
-        hipLaunchKernelGGL(ec_bn_finalize_kernel, dim3(1), dim3(EC), 0, st, acc2, 1, count, a->bn2_w, a->bn2_b,
-                           a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training, a->stats, (int)ST_MEAN2);
-        GFS3D_LAUNCH_CHECK("ec_bn_finalize_kernel(2)");
-        hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, a->stats, a->N, a->slope,
+        const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
+        hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, fin2, a->stats, a->N, a->slope,
                            a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
     }
@@ -1279,7 +1285,6 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
     const double count = stat_count > 0.0 ? stat_count : (double)BN * a->k;
     float *g = reinterpret_cast<float *>(ws + p.off_g);
     float *GP = reinterpret_cast<float *>(ws + p.off_GP), *GQ = reinterpret_cast<float *>(ws + p.off_GQ);
-    float *coef = reinterpret_cast<float *>(ws + p.off_coef);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
     double *dred = reinterpret_cast<double *>(ws + p.off_dred);
     float *mu = reinterpret_cast<float *>(ws + p.off_mu);
@@ -1301,8 +1306,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             return GFS3D_ERR_HIP;
         }
     } else if (phase == 1) {
-        hipLaunchKernelGGL(ec_bwd_coef_kernel, dim3(1), dim3(EC), 0, st, acc1, loc1, count, a->stats, ba->dbn2_w, ba->dbn2_b, coef);
-        GFS3D_LAUNCH_CHECK("ec_bwd_coef_kernel");
+        const CoefIn cin{acc1, loc1, count, a->stats, ba->dbn2_w, ba->dbn2_b};
         if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
@@ -1310,7 +1314,8 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
         {
             const size_t total = (size_t)BN * EC;
-            hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, a->stats, total, Pp, Qp);
+            const BnFin done{nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, a->eps, a->momentum, 1};
+            hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, done, a->stats, total, Pp, Qp);
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
             static bool attr_done = false;
             if (!attr_done) {
@@ -1320,14 +1325,12 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 attr_done = true;
             }
             ProfScope prof(2, st);
-            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, coef,
+            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
                                g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
-        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred);
+        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred, ba->dw2);
         GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
-        hipLaunchKernelGGL(ec_bwd_dw2_kernel, dim3(EC * EC / 256), dim3(256), 0, st, dred, ba->dw2);
-        GFS3D_LAUNCH_CHECK("ec_bwd_dw2_kernel");
         {   // reverse graph -> SQ, indeg
             int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
             int *slot = reinterpret_cast<int *>(ws + p.off_slot);
