@@ -262,12 +262,17 @@ __device__ __forceinline__ float next_below(float v)
     return __builtin_bit_cast(float, v > 0.f ? u - 1u : u + 1u);
 }
 
+// queue slots per lane: with the bound pass (small C) few candidates queue up, and 24 slots (flush above 8) leave room
+// for a third workgroup per CU
+template <int CS, int K>
+constexpr int knn_mfma_queue() { return (CS <= 8 && K <= 24) ? 24 : ((K > KNN_QMIN) ? K : KNN_QMIN); }
+
 template <int CS, int K>
 __global__ void __launch_bounds__(256, 2)
 knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int B, int C, int N, int k, int two_pass,
                 int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
 {
-    constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
+    constexpr int QS = knn_mfma_queue<CS, K>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -360,13 +365,12 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
         thr = next_below(bm[K - 1]);       // the strict '>' below must keep candidates equal to the bound
     }
 
-    // ---- pass 2: exact selection among the candidates above the bound.  Candidate tiles are fetched TWO tiles ahead
-    // (a0 / a1 ping-pong): one tile of selection work does not cover an L2 / Infinity-Cache round trip.
+    // ---- pass 2: exact selection among the candidates above the bound (next tile in flight during the selection;
+    // a second tile of lookahead was measured: no gain, 32 more registers)
     TopListOrd<K> best;
     best.init();
     int cnt = 0;
     uint2 *qslot = queue + lane;                        // next free entry of this lane
-    float a1[CS];
     auto process = [&](float (&cur)[CS], int j0) {
         load_sq(j0);
         f32x16 acc;
@@ -374,8 +378,8 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], qb[s], acc, 0, 0, 0);
-        // the MFMAs have consumed cur[]: refill it with the tile after next while the selection below runs
-        if (j0 + 64 < N) load_tile(cur, j0 + 64);
+        // the MFMAs have consumed cur[]: refill it with the next tile while the selection below runs
+        if (j0 + 32 < N) load_tile(cur, j0 + 32);
         __builtin_amdgcn_wave_barrier();
         const int cbase = j0 + 4 * h;
         if (j0 + 32 <= N) {                              // a ragged last tile takes the checked path
@@ -414,11 +418,7 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
         __builtin_amdgcn_wave_barrier();
     };
     load_tile(a, 0);
-    if (32 < N) load_tile(a1, 32);
-    for (int j0 = 0; j0 < N; j0 += 64) {
-        process(a, j0);
-        if (j0 + 32 < N) process(a1, j0 + 32);
-    }
+    for (int j0 = 0; j0 < N; j0 += 32) process(a, j0);
     {
         const int mx = wave_max(cnt);
         for (int s = 0; s < mx; ++s)
@@ -454,7 +454,7 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 template <int CS, int K>
 static int launch_knn_mfma(const float *x, float *sq, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
 {
-    constexpr int QS = (K > KNN_QMIN) ? K : KNN_QMIN;
+    constexpr int QS = knn_mfma_queue<CS, K>();
     const size_t lds = sizeof(float) * 4 * (size_t)(2 * QS * 64);
     dim3 grid(((N + 127) / 128) * B);
     static const int two_pass_env = [] { const char *e = getenv("GFS3D_KNN_TWO_PASS"); return e ? atoi(e) : -1; }();   // tuning only
