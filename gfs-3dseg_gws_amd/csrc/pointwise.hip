@@ -81,7 +81,8 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         const int gcol = col0 + c4;
         const int seg = gcol / g.o_segw, ocol = gcol - seg * g.o_segw;
         float *op = g.out[seg] + ocol;
-        f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea, ts1 = ea, ts2 = ea;
+        f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
+        double ts1[4] = {0.0, 0.0, 0.0, 0.0}, ts2[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: sum x^2 - mean^2 cancels when |mean| >> std
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = ldg4(g.ea + gcol); eb = ldg4(g.eb + gcol); }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
@@ -111,12 +112,12 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&smem[(rr + 8 * jj) * ELD + c4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (EPI == EPI_RAW_STATS) { ts1[e] += v[e]; ts2[e] = fmaf(v[e], v[e], ts2[e]); }
+                    if (EPI == EPI_RAW_STATS) { ts1[e] += (double)v[e]; ts2[e] += (double)v[e] * (double)v[e]; }
                     if (EPI == EPI_AFFINE_ACT) v[e] = lrelu(fmaf(v[e], ea[e], eb[e]), g.slope);
                     if (EPI == EPI_BWD_ACT) {
                         const float hh = hv[jj][e];
                         v[e] = fmaf(hh, ea[e], eb[e]) > 0.f ? v[e] : v[e] * g.slope;
-                        ts1[e] += v[e]; ts2[e] = fmaf(v[e], hh, ts2[e]);
+                        ts1[e] += (double)v[e]; ts2[e] += (double)v[e] * (double)hh;
                     }
                 }
                 *reinterpret_cast<f32x4 *>(op + (size_t)row * g.o_segw) = v;
@@ -124,19 +125,19 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         }
         if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
             __syncthreads();
-            float *red = smem;                  // [8 thread rows][2][128]
+            double *red = reinterpret_cast<double *>(smem);      // [8 thread rows][2][128]
 #pragma unroll
             for (int e = 0; e < 4; ++e) { red[(rr * 2 + 0) * 128 + c4 + e] = ts1[e]; red[(rr * 2 + 1) * 128 + c4 + e] = ts2[e]; }
             __syncthreads();
             const int which = t >> 7, col = t & 127;
-            float sum = 0.f;
+            double sum = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) sum += red[(q * 2 + which) * 128 + col];
-            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)sum);
+            atomicAdd(&g.acc[which * g.Nc + col0 + col], sum);
         }
         return;
     }
-    float s1[TN], s2[TN];
+    double s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + wn * 64 + j * 32 + li;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         float *op = g.out[seg] + ocol;
         float ea = 0.f, eb = 0.f;
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = g.ea[col]; eb = g.eb[col]; }
-        s1[j] = 0.f; s2[j] = 0.f;
+        s1[j] = 0.0; s2[j] = 0.0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -152,18 +153,18 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                 const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= g.M) continue;
                 float v = acc[i][j][r];
-                if (EPI == EPI_RAW_STATS) { s1[j] += v; s2[j] = fmaf(v, v, s2[j]); }
+                if (EPI == EPI_RAW_STATS) { s1[j] += (double)v; s2[j] += (double)v * (double)v; }
                 if (EPI == EPI_AFFINE_ACT) v = lrelu(fmaf(v, ea, eb), g.slope);
                 if (EPI == EPI_BWD_ACT) {
                     const float h = g.eh[(size_t)row * g.Nc + col];
                     v = fmaf(h, ea, eb) > 0.f ? v : v * g.slope;
-                    s1[j] += v; s2[j] = fmaf(v, h, s2[j]);
+                    s1[j] += (double)v; s2[j] += (double)v * (double)h;
                 }
                 op[(size_t)row * g.o_segw] = v;
             }
     }
     if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
-        float *red = smem;                      // [4 waves][TN][2][32]  (the staging buffer is idle: last loop barrier passed)
+        double *red = reinterpret_cast<double *>(smem);      // [4 waves][TN][2][32]  (the staging buffer is idle: last loop barrier passed)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32, 64);
@@ -174,7 +175,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         if (t < 2 * BN) {
             const int which = t / BN, col = t - which * BN;
             const int cwn = col >> 6, j = (col >> 5) & 1, i = col & 31;
-            float s = 0.f;
+            double s = 0.0;
             if (BN == 128) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) s += red[(((m * 2 + cwn) * TN + j) * 2 + which) * 32 + i];
@@ -182,7 +183,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) s += red[((m * TN + j) * 2 + which) * 32 + i];
             }
-            atomicAdd(&g.acc[which * g.Nc + col0 + col], (double)s);
+            atomicAdd(&g.acc[which * g.Nc + col0 + col], s);
         }
     }
 }

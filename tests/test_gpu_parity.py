@@ -138,7 +138,8 @@ def test_edgeconv_eval_forward(dev, B, C, N, k):
     assert maxerr(y, ref) < TOL
 
 
-@pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (2, 64, 128, 20), (1, 9, 131, 7)])
+@pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (2, 64, 128, 20), (1, 9, 131, 7), (1, 9, 5, 3), (1, 64, 33, 1),
+                                     (2, 9, 70, 32)])
 def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     from gfs3d import ops
     p = _block_params(C, 200 + C)
@@ -638,6 +639,8 @@ def _pw_reference(conv, xs_pm, cot, train):
     (1, 130, 1, [64]),
     (2, 96, 2, [192, 128, 64]),
     (3, 70, 4, [256]),
+    (1, 20, 1, [64, 128]),         # fewer points than one K-step of the weight-gradient kernel
+    (1, 2, 2, [64]),
 ])
 def test_pointwise_stack_train_matches_torch(dev, B, N, nseg, widths):
     """K4 forward / backward (batch statistics) vs nn.Conv1d + nn.BatchNorm1d + LeakyReLU in fp64:
@@ -785,7 +788,7 @@ def _attn_reference(q, k, v, scale, keep=None, p=0.0):
     return (q, k, v), y
 
 
-@pytest.mark.parametrize("B,N", [(2, 300), (1, 2048), (3, 97)])
+@pytest.mark.parametrize("B,N", [(2, 300), (1, 2048), (3, 97), (1, 5), (2, 31), (1, 33), (1, 129)])
 def test_attention_eval_matches_torch(dev, B, N):
     """K5 forward without dropout vs softmax(q^T k / 8) v in fp64 (ragged N: partial key and query tiles)."""
     from gfs3d import ops
@@ -796,7 +799,7 @@ def test_attention_eval_matches_torch(dev, B, N):
     assert maxerr(y, y_ref) < TOL
 
 
-@pytest.mark.parametrize("B,N,mode", [(2, 200, "mask"), (1, 320, "hash"), (2, 96, "none")])
+@pytest.mark.parametrize("B,N,mode", [(2, 200, "mask"), (1, 320, "hash"), (2, 96, "none"), (1, 7, "mask"), (1, 33, "hash")])
 def test_attention_train_forward_backward_matches_torch(dev, B, N, mode):
     """K5 with dropout on the attention weights: an explicit keep mask (what the golden tests force), the kernel's own
     counter-based decisions (read back through gfs3d_attention_dropout_mask) and no dropout; forward and the three
