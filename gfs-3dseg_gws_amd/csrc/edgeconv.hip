@@ -946,17 +946,11 @@ ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ 
                   red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
     }
 }
-// finalize: dbn1_b, dbn1_w, mu_dy, mu_dyx -> mu[2][64]
-__global__ void ec_bwd_bn1_final_kernel(const double *__restrict__ partial, const double *__restrict__ local, double count,
-                                        float *__restrict__ dbn1_w, float *__restrict__ dbn1_b, float *__restrict__ mu)
-{
-    const int c = threadIdx.x;
-    const double s = partial[c], sx = partial[EC + c];      // whole-batch sums (see bwd_coef)
-    dbn1_b[c] = (float)local[c];
-    dbn1_w[c] = (float)local[EC + c];
-    mu[c] = (float)(s / count);
-    mu[EC + c] = (float)(sx / count);
-}
+struct Bn1Fin {
+    const double *red, *red_local;    // [2][64] sums over the whole (possibly multi-rank) batch / over this rank
+    double count;
+    float *dbn1_w, *dbn1_b;
+};
 
 // B6: dP, dQ per point (BN1 backward, elementwise), then on the matrix pipe
 //        dx[c][p]  = sum_o Wa[o][c] dP[p][o] + Wd[o][c] dQ[p][o]          (K = 128: dP half | dQ half)
@@ -971,7 +965,7 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
                  const float *__restrict__ P, const float *__restrict__ Q,
                  const float *__restrict__ SP, const float *__restrict__ SQ, const float *__restrict__ indeg,
                  const float *__restrict__ GP, const float *__restrict__ GQ,
-                 const float *__restrict__ stats, const float *__restrict__ mu,
+                 const float *__restrict__ stats, const Bn1Fin fin,
                  int C, int N, int k, int tiles_per_b, int ntiles, float *__restrict__ dx, float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -993,7 +987,12 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         wd[c * PQ_LD + o] = bb - a;
     }
     const float A1 = stats[ST_SCALE1 * EC + co], mean1 = stats[ST_MEAN1 * EC + co], rstd1 = stats[ST_RSTD1 * EC + co];
-    const float mu_dy = mu[co], mu_dyx = mu[EC + co];
+    // BN1-backward means of dy1 and dy1 * xhat1 (block 0 also stores this rank's dgamma1 / dbeta1)
+    const float mu_dy = (float)(fin.red[co] / fin.count), mu_dyx = (float)(fin.red[EC + co] / fin.count);
+    if (blockIdx.x == 0 && tid < EC) {
+        fin.dbn1_b[tid] = (float)fin.red_local[tid];
+        fin.dbn1_w[tid] = (float)fin.red_local[EC + tid];
+    }
     const float kf = (float)k;
 
     // weight-gradient tasks: (which in {dP,dQ}) x (o tile in {0,1}) x (c tile < CT); wave w owns tasks w, w+4, ...
@@ -1110,16 +1109,33 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         }
     }
 }
-// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd     (red = workgroup partials summed in double, [2][64][CP])
-__global__ void __launch_bounds__(256)
-ec_bwd_dw1_kernel(const double *__restrict__ red, int C, int CP, float *__restrict__ dw1)
+// B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd, straight from the workgroup partials [nparts][2][64][CP] (summed in double).
+// block = 64 outputs x 16 part-groups
+__global__ void __launch_bounds__(1024)
+ec_bwd_dw1_kernel(const float *__restrict__ partial, int nparts, int C, int CP, float *__restrict__ dw1)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= EC * C) return;
+    __shared__ double red[16][2][64];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;                      // (o, c) pair
     const int o = e / C, c = e - o * C;
-    const double a = red[(size_t)o * CP + c], d = red[(size_t)(EC + o) * CP + c];
-    dw1[(size_t)o * 2 * C + c] = (float)(a - d);
-    dw1[(size_t)o * 2 * C + C + c] = (float)d;
+    double sa = 0.0, sd = 0.0;
+    if (e < EC * C) {
+        const size_t width = 2 * (size_t)EC * CP;
+        for (int p = grp; p < nparts; p += 16) {
+            sa += (double)partial[p * width + (size_t)o * CP + c];
+            sd += (double)partial[p * width + (size_t)(EC + o) * CP + c];
+        }
+    }
+    red[grp][0][el] = sa;
+    red[grp][1][el] = sd;
+    __syncthreads();
+    if (grp == 0 && e < EC * C) {
+        double a = 0.0, d = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { a += red[g][0][el]; d += red[g][1][el]; }
+        dw1[(size_t)o * 2 * C + c] = (float)(a - d);
+        dw1[(size_t)o * 2 * C + C + c] = (float)d;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1231,7 +1247,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax), *jmin = reinterpret_cast<uint8_t *>(ws + p.off_jmin);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     double *acc1 = acc, *acc2 = acc + 2 * EC;
-    float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
+    float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
     if (phase == 0) {
         if (a->x_pm && a->C % 32 == 0) {
@@ -1287,7 +1303,6 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
     float *GP = reinterpret_cast<float *>(ws + p.off_GP), *GQ = reinterpret_cast<float *>(ws + p.off_GQ);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
     double *dred = reinterpret_cast<double *>(ws + p.off_dred);
-    float *mu = reinterpret_cast<float *>(ws + p.off_mu);
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     // monolithic call: this rank's sums ARE the global sums, no local copies needed
@@ -1311,12 +1326,14 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
-        float *Pp = reinterpret_cast<float *>(ws + p.off_Pp), *Qp = reinterpret_cast<float *>(ws + p.off_Qp);
+        float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
         {
-            const size_t total = (size_t)BN * EC;
-            const BnFin done{nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, a->eps, a->momentum, 1};
-            hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, done, a->stats, total, Pp, Qp);
-            GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+            if (!(a->Pp && a->Qp)) {                  // the forward did not leave the folded projections behind
+                const size_t total = (size_t)BN * EC;
+                const BnFin done{nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, a->eps, a->momentum, 1};
+                hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, done, a->stats, total, Pp, Qp);
+                GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+            }
             static bool attr_done = false;
             if (!attr_done) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel),
@@ -1356,19 +1373,16 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             return GFS3D_ERR_HIP;
         }
     } else {
-        hipLaunchKernelGGL(ec_bwd_bn1_final_kernel, dim3(1), dim3(EC), 0, st, acc2, loc2, count, ba->dbn1_w, ba->dbn1_b, mu);
-        GFS3D_LAUNCH_CHECK("ec_bwd_bn1_final_kernel");
+        const Bn1Fin fin{acc2, loc2, count, ba->dbn1_w, ba->dbn1_b};
         const int CP = ((a->C + 31) / 32) * 32;
         const size_t lds = sizeof(float) * (2 * 64 * PQ_LD + 2 * (size_t)CP * PQ_LD + 64 * (size_t)(CP + 1));
         if (lds > 64 * 1024)
             hipFuncSetAttribute(reinterpret_cast<const void *>(ec_bwd_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         const int tiles_per_b = (a->N + 63) / 64;
         hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
-                           GP, GQ, a->stats, mu, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);
+                           GP, GQ, a->stats, fin, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);
         GFS3D_LAUNCH_CHECK("ec_bwd_pq_kernel");
-        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((2 * EC * CP + 63) / 64), dim3(1024), 0, st, wpart, p.g_pq, 2 * EC * CP, dred);
-        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(dw1)");
-        hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, dred, a->C, CP, ba->dw1);
+        hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 63) / 64), dim3(1024), 0, st, wpart, p.g_pq, a->C, CP, ba->dw1);
         GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
     }
     return GFS3D_OK;
@@ -1379,6 +1393,7 @@ static int check_fwd(const gfs3d_edgeconv_args *a, const char *who)
     int rc = check_args(a, who);
     if (rc) return rc;
     GFS3D_REQUIRE(a->y_cf || a->y_pm, "%s: no output buffer", who);
+    GFS3D_REQUIRE((a->Pp == nullptr) == (a->Qp == nullptr), "%s: Pp and Qp go together", who);
     GFS3D_REQUIRE(a->training || (a->bn1_rm && a->bn1_rv && a->bn2_rm && a->bn2_rv), "%s: eval mode needs running statistics", who);
     if (a->training)
         GFS3D_REQUIRE(a->SP && a->SQ && a->indeg && a->hsel && a->jsel && a->y_pm,

@@ -32,6 +32,7 @@ class EdgeConvArgs(Structure):
         ("stats", c_void_p), ("hsel", c_void_p), ("jsel", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("x_pm", c_void_p),
+        ("Pp", c_void_p), ("Qp", c_void_p),
     ]
 
 

@@ -123,8 +123,10 @@ class EdgeConvRun:
             self.indeg = torch.empty((B, N), **f32)
             self.hsel = torch.empty((B, N, EC_WIDTH), **f32)
             self.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
+            self.Pp = torch.empty((B, N, EC_WIDTH), **f32)        # BN-folded projections, reused by the backward
+            self.Qp = torch.empty((B, N, EC_WIDTH), **f32)
         else:
-            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = None
+            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.Pp = self.Qp = None
         self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)      # point-major copy: input of the point-wise stack (K4)
         self.y = torch.empty((B, EC_WIDTH, N), **f32)
         nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(B, C, N, k)
@@ -147,7 +149,7 @@ class EdgeConvRun:
         a.bn2_rm = rm2.data_ptr() if rm2 is not None else None
         a.bn2_rv = rv2.data_ptr() if rv2 is not None else None
         a.P, a.Q, a.stats = self.P.data_ptr(), self.Q.data_ptr(), self.stats.data_ptr()
-        for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm"):
+        for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm", "Pp", "Qp"):
             t = getattr(self, name)
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.y_cf, a.y_cf_bstride = (self.y.data_ptr() if self.y is not None else None), EC_WIDTH * self.N

@@ -89,6 +89,8 @@ typedef struct gfs3d_edgeconv_args {
     size_t workspace_bytes;       /* >= gfs3d_edgeconv_workspace_bytes() */
     const float *x_pm;            /* optional (B*N, C) point-major copy of x (the previous block's y_pm): with C == 64 the
                                      two projections run as one MFMA GEMM; NULL = channel-first path */
+    float *Pp, *Qp;               /* optional (B, N, 64) each: the BatchNorm-folded projections the heavy kernels read; forward
+                                     writes them here and backward reuses them (NULL: scratch, recomputed in backward) */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);
