@@ -355,8 +355,60 @@ def g_harness():
          base_coding=base_coding.numpy(), bg_coding=bg_coding.numpy())
 
 
+# ---------------------------------------------------------------- (16) dataloaders/loader.py block sampling
+def g_loader():
+    """sample_pointcloud (loader.py:39-129) on synthetic block files; numpy's RNG draws are recorded so that the
+    restatement (and the device pipeline) can be fed the same point indices.  np.int was removed from numpy:
+    shimmed to int for the call (loader.py:104).  Augmentation needs transforms3d (absent) -> not captured."""
+    import tempfile
+    import dataloaders.loader as ref_loader
+    if not hasattr(np, "int"):
+        np.int = int
+    rng = np.random.default_rng(5)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "data"))
+        cases = [("a", 3000, 7, np.float32), ("b", 1500, 8, np.float64), ("c", 2048, 7, np.float32)]
+        for name, n, cols, dt in cases:
+            data = np.zeros((n, cols), dtype=dt)
+            data[:, 0:3] = rng.random((n, 3)) * np.array([1.0, 1.0, 3.0]) + np.array([12.0, -7.0, 0.5])
+            data[:, 3:6] = np.floor(rng.random((n, 3)) * 256)
+            data[:, 6] = rng.integers(0, 13, n)
+            if cols == 8:
+                data[:, 7] = rng.integers(0, 50, n)
+            np.save(os.path.join(d, "data", name + ".npy"), data)
+            out["data_" + name] = data
+        runs = [("a", dict(random_sample=True)),                                   # pre-train style
+                ("b", dict(random_sample=True)),                                   # fewer points than num_point
+                ("a", dict(sampled_class=4, support=True)),                        # support cloud, binary label
+                ("c", dict(sampled_class=9, support=False)),                       # query cloud, class-index labels
+                ("b", dict(sampled_class=2, support=False, use_all_classes=True))]
+        sampled_classes = [4, 9, 2, 11]
+        for i, (name, kw) in enumerate(runs):
+            rec = []
+            orig = np.random.choice
+
+            def tap(a, size=None, replace=True, p=None, _o=orig, _r=rec):
+                r = _o(a, size, replace, p)
+                _r.append(np.asarray(r).copy())
+                return r
+            np.random.seed(100 + i)
+            np.random.choice = tap
+            try:
+                pc, gt, seg = ref_loader.sample_pointcloud(d, 2048, "xyzrgbXYZ", False, None, name, sampled_classes, **kw)
+            finally:
+                np.random.choice = orig
+            out[f"r{i}_scan"] = np.array(name)
+            out[f"r{i}_inds"] = np.concatenate(rec)
+            out[f"r{i}_pc"], out[f"r{i}_gt"], out[f"r{i}_seg"] = pc, np.asarray(gt), np.asarray(seg)
+            out[f"r{i}_kw"] = np.array([kw.get("sampled_class", 0), int(kw.get("support", False)),
+                                        int(kw.get("random_sample", False)), int(kw.get("use_all_classes", False))])
+    out["sampled_classes"] = np.array(sampled_classes)
+    save("loader", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["knn", "edge_feature", "dgcnn", "capl", "basis", "metric", "harness"]
+    which = sys.argv[1:] or ["knn", "edge_feature", "dgcnn", "capl", "basis", "metric", "harness", "loader"]
     for w in which:
         globals()["g_" + w]()

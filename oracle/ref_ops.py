@@ -393,3 +393,71 @@ def synthetic_blocks(B: int, N: int = 2048, seed: int = 0, dup_tail: int = 0) ->
     if dup_tail > 0:  # loader samples with replacement when a block is short (loader.py:66)
         x[:, N - dup_tail:, :] = x[:, :dup_tail, :]
     return x.transpose(1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------
+# dataloaders/loader.py block sampling - numpy restatement
+# --------------------------------------------------------------------------
+def loader_sample_indices(labels, num_point, sampled_class=0, random_sample=False, rng=None):
+    """Point indices of one block (loader.py:67-82).  `rng` = numpy Generator-like with .choice (np.random by default).
+    random_sample: num_point draws, with replacement iff the block is smaller.  Otherwise the sampled class keeps
+    its share of the block (all of its points if the block is smaller than num_point), drawn without replacement,
+    and the rest is drawn from the whole block."""
+    import numpy as _np
+    rng = _np.random if rng is None else rng
+    n = len(labels)
+    if random_sample:
+        return rng.choice(_np.arange(n), num_point, replace=(n < num_point))
+    valid = _np.nonzero(labels == sampled_class)[0]
+    n_valid = len(valid) if n < num_point else int(len(valid) / float(n) * num_point)
+    a = rng.choice(valid, n_valid, replace=False)
+    b = rng.choice(_np.arange(n), num_point - n_valid, replace=(n < num_point))
+    return _np.concatenate([a, b])
+
+
+def loader_augment_matrix(scale=1.0, angle=0.0, mirror_x=False, mirror_y=False):
+    """The 3x3 matrix augment_pointcloud builds (loader.py:132-146): uniform zoom, rotation about z, x / y mirrors
+    (transforms3d.zooms.zfdir2mat / axangles.axangle2mat written out)."""
+    import numpy as _np
+    m = _np.eye(3) * scale
+    c, s_ = _np.cos(angle), _np.sin(angle)
+    m = _np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]) @ m
+    if mirror_x:
+        m = _np.diag([-1.0, 1.0, 1.0]) @ m
+    if mirror_y:
+        m = _np.diag([1.0, -1.0, 1.0]) @ m
+    return m
+
+
+def loader_assemble(data, inds, pc_attribs="xyzrgbXYZ", sampled_classes=(), sampled_class=0, support=False,
+                    use_all_classes=False, augm_matrix=None, jitter=None):
+    """Gathered rows -> (ptcloud (n, 3 per attribute), groundtruth (n,), segment_label (n,))  (loader.py:84-129).
+    augm_matrix / jitter: what augment_pointcloud draws (xyz <- xyz M^T, then + jitter), None = no augmentation."""
+    import numpy as _np
+    d = data[inds]
+    xyz = d[:, 0:3].copy()
+    rgb = d[:, 3:6]
+    xyz -= _np.amin(xyz, axis=0)
+    if augm_matrix is not None:
+        xyz = _np.dot(xyz, _np.asarray(augm_matrix).T)
+    if jitter is not None:
+        xyz = xyz + _np.asarray(jitter).astype(_np.float32)
+    parts = []
+    if "xyz" in pc_attribs:
+        parts.append(xyz)
+    if "rgb" in pc_attribs:
+        parts.append(rgb / 255.)
+    if "XYZ" in pc_attribs:
+        XYZ = xyz - _np.amin(xyz, axis=0)
+        parts.append(XYZ / _np.amax(XYZ, axis=0))
+    pc = _np.concatenate(parts, axis=1)
+    labels = d[:, 6].astype(int)
+    if support:
+        gt = labels == sampled_class
+    else:
+        gt = _np.zeros_like(labels)
+        off = 0 if use_all_classes else 1
+        for i, c in enumerate(sampled_classes):
+            gt[labels == c] = i + off
+    seg = d[:, 7] if d.shape[1] == 8 else _np.zeros(d.shape[0], dtype=d.dtype)
+    return pc, gt, seg

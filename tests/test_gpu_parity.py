@@ -847,3 +847,42 @@ def test_self_attention_module_uses_fused_kernel(dev):
     torch.manual_seed(5)
     y2 = att(x)
     assert maxerr(y1, y2) == 0.0 and maxerr(y1, y) > 1e-3
+
+
+# ------------------------------------------------------------------ device input pipeline
+def test_device_pipeline_matches_reference_loader(dev):
+    """gfs3d.pipeline.assemble on the device, fed the point indices the reference drew (golden 16): features within 1 ulp
+    (after the Dataset's float32 cast; the device's fp32 division), identical labels and segment labels; sample_indices keeps the reference's
+    counts (class share, replacement only for small blocks)."""
+    from gfs3d import pipeline
+    g = load_golden("loader")
+    classes = [int(c) for c in g["sampled_classes"]]
+    for i in range(5):
+        data = torch.from_numpy(g["data_" + str(g[f"r{i}_scan"])]).to(dev)
+        sc, support, rnd, use_all = (int(v) for v in g[f"r{i}_kw"])
+        inds = torch.from_numpy(g[f"r{i}_inds"]).to(dev)
+        pc, gt, seg = pipeline.assemble(data[inds], "xyzrgbXYZ", classes, sc, bool(support), bool(use_all))
+        assert tuple(pc.shape) == (9, 2048) and pc.dtype == torch.float32
+        ref_pc = g[f"r{i}_pc"].T.astype(np.float32)
+        assert np.abs(pc.cpu().numpy() - ref_pc).max() <= 1.2e-7 * max(1.0, float(np.abs(ref_pc).max())), i       # <= 1 ulp (device division)
+        assert np.array_equal(gt.cpu().numpy(), g[f"r{i}_gt"].astype(np.int64)), i
+        assert np.array_equal(seg.cpu().numpy(), g[f"r{i}_seg"].astype(np.float32)), i
+        gen = torch.Generator(device=dev).manual_seed(i)
+        mine = pipeline.sample_indices(data[:, 6], 2048, None if rnd else sc, bool(rnd), gen)
+        assert mine.numel() == 2048 and int(mine.min()) >= 0 and int(mine.max()) < data.shape[0]
+        if data.shape[0] >= 2048:
+            assert mine.unique().numel() >= 2048 - (0 if rnd else int((data[:, 6] == sc).sum()))   # no replacement inside a draw
+        if not rnd:
+            n_cls = int((data[:, 6] == sc).sum())
+            want = n_cls if data.shape[0] < 2048 else int(n_cls / data.shape[0] * 2048)
+            assert int((data[mine[:want], 6] == sc).sum()) == want
+    # batched sampler: shapes, determinism under a seeded generator, augmentation keeps the unit box
+    blocks = [torch.from_numpy(g["data_a"]), torch.from_numpy(g["data_c"])]
+    smp = pipeline.BlockSampler(blocks, dev)
+    cfg = {"scale": 1.1, "rot": 1, "mirror_prob": 0.5, "jitter": 1}
+    x1, y1, s1 = smp.batch([0, 1, 0], 2048, sampled_classes=classes, generator=torch.Generator(device=dev).manual_seed(3))
+    x2, y2, s2 = smp.batch([0, 1, 0], 2048, sampled_classes=classes, generator=torch.Generator(device=dev).manual_seed(3))
+    assert tuple(x1.shape) == (3, 9, 2048) and tuple(y1.shape) == (3, 2048) and torch.equal(x1, x2) and torch.equal(y1, y2)
+    assert float(x1[:, 6:9].min()) == 0.0 and float(x1[:, 6:9].max()) == 1.0 and int(y1.max()) <= len(classes)
+    xa, _, _ = smp.batch([0, 1], 2048, sampled_classes=classes, pc_augm=True, pc_augm_config=cfg)
+    assert float(xa[:, 6:9].min()) == 0.0 and abs(float(xa[:, 6:9].max()) - 1.0) < 1e-6

@@ -199,3 +199,21 @@ def test_metric():
     r = R.evaluate_metric_gfs(list(g["prs_sc"]), list(g["gts_sc"]), list(range(21)), list(g["novel_sc"]),
                               list(g["order_sc"]), scannet=True)
     close(np.array(r[:4]), g["res_sc"], 1e-12); close(r[4], g["iou_sc"], 1e-12)
+
+
+def test_loader_restatement_matches_reference_sample_pointcloud():
+    """oracle loader_assemble / loader_sample_indices vs the real dataloaders.loader.sample_pointcloud (golden 16):
+    with the recorded numpy draws the restatement reproduces ptcloud, labels and segment labels exactly; with the
+    same numpy seed it also reproduces the draws."""
+    g = load_golden("loader")
+    classes = [int(c) for c in g["sampled_classes"]]
+    for i in range(5):
+        data = g["data_" + str(g[f"r{i}_scan"])]
+        sc, support, rnd, use_all = (int(v) for v in g[f"r{i}_kw"])
+        np.random.seed(100 + i)
+        inds = R.loader_sample_indices(data[:, 6], 2048, sc, bool(rnd))
+        assert np.array_equal(inds, g[f"r{i}_inds"]), i
+        pc, gt, seg = R.loader_assemble(data, inds, "xyzrgbXYZ", classes, sc, bool(support), bool(use_all))
+        assert np.array_equal(pc, g[f"r{i}_pc"]) and pc.dtype == g[f"r{i}_pc"].dtype, i
+        assert np.array_equal(gt, g[f"r{i}_gt"]), i
+        assert np.array_equal(seg, g[f"r{i}_seg"]), i
