@@ -114,7 +114,7 @@ def main():
 
     from gfs3d import _lib, dist as gdist
     from model.dgcnn import DGCNN
-    from oracle.ref_ops import synthetic_blocks     # input recipe only
+    from gfs3d.synthetic import synthetic_blocks    # input recipe; oracle/ is used by cpu_baseline() only
     L = _lib.lib()
 
     torch.manual_seed(0)

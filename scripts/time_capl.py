@@ -2,7 +2,7 @@
 import sys, time, types, random, torch
 sys.path.insert(0, "gfs-3dseg_gws_amd"); sys.path.insert(0, ".")
 from model.capl import mpti_net_Point_GeoAsWeight_v2
-from oracle.ref_ops import synthetic_blocks
+from gfs3d.synthetic import synthetic_blocks
 dev = torch.device("cuda:0")
 a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
                           base_widths=[128, 64], output_dim=64, eval_weight=1.2)

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gfs-3dseg_gws_amd"))
 import torch
 from gfs3d import ops
-from oracle.ref_ops import synthetic_blocks
+from gfs3d.synthetic import synthetic_blocks
 dev = torch.device("cuda:0")
 x9 = synthetic_blocks(32, 2048, seed=0).to(dev)
 x64 = torch.randn(32, 64, 2048, device=dev)
