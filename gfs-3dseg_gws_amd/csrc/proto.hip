@@ -198,6 +198,155 @@ static int dispatch_proto(const float *feat, long long bs, int B, int C, int N, 
 }
 
 // ---------------------------------------------------------------------------
+// Backward of the cosine heads with respect to the point features (the autograd of capl.py:344-353 and of
+// get_pred, capl.py:290-322):
+//   d[w][n]   = scale * dout[w][n]                                      (logits)
+//             = scale * soft[w][n] (dsoft[w][n] - sum_w' soft dsoft)     (softmax over the words)
+//   dfhat[c]  = sum_w ghat[w][c] d[w]        - a (C x K) . (K x points) contraction on MFMA: A = the prototype
+//               chunk from LDS (rows = channels), B = d straight from registers (the lane owns ONE point, register
+//               (t, r) <-> prototype row 32 t + acc_row(r, h): the C/D layout of the forward kernel)
+//   dfeat[c]  = (dfhat[c] - fhat[c] <fhat, dfhat>) / max(|f|, eps)       in-lane over the accumulator registers
+// One workgroup = 128 points; a wave owns 32 points, ALL prototypes (NT row tiles) and ALL channels (CT tiles of 32).
+// ---------------------------------------------------------------------------
+template <int NT, int CT, int MODE>
+__global__ void __launch_bounds__(256)
+proto_bwd_feat_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
+                      const float *__restrict__ proto, int P, int K, float scale,
+                      const float *__restrict__ soft,        // SOFTMAX: (B,K,N) forward result
+                      const float *__restrict__ dup,         // (B,K,N) gradient of soft / of the logits
+                      float *__restrict__ dfeat)             // (B,C,N)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *gs = smem;                          // [NT*32][PR_LD]  prototype chunk (64 channels)
+    float *ginv = gs + NT * 32 * PR_LD;        // [NT*32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 128 + wv * 32 + j;
+    const int nc = min(n, N - 1);
+    const float *fb = feat + (size_t)b * feat_bstride;
+    const float *pb = proto + (P > 1 ? (size_t)b * K * C : 0);
+
+    if (tid < NT * 32) {                        // 1 / max(|g_w|, eps) over all channels
+        float gsq = 0.f;
+        if (tid < K)
+            for (int c = 0; c < C; ++c) { const float v = pb[(size_t)tid * C + c]; gsq = fmaf(v, v, gsq); }
+        ginv[tid] = (tid < K) ? 1.0f / fmaxf(sqrtf(gsq), NORM_EPS) : 0.f;
+    }
+    __syncthreads();
+
+    // d[t][r] for prototype row w = 32 t + acc_row(r, h), already multiplied by scale / |g_w|
+    float dot = 0.f;
+    if (MODE == MODE_SOFTMAX) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                if (w < K) {
+                    const size_t o = ((size_t)b * K + w) * N + nc;
+                    dot = fmaf(soft[o], dup[o], dot);
+                }
+            }
+        dot += __shfl_xor(dot, 32, 64);
+    }
+    float d[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            float v = 0.f;
+            if (w < K) {
+                const size_t o = ((size_t)b * K + w) * N + nc;
+                v = (MODE == MODE_SOFTMAX) ? soft[o] * (dup[o] - dot) : dup[o];
+                v *= scale * ginv[w];
+            }
+            d[t][r] = v;
+        }
+
+    f32x16 G[CT];                               // dfhat, rows = channel 32 ct + acc_row(r, h), column = point
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[ct][r] = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CT / 2; ++cc) {       // 64-channel chunks
+        const int c0 = cc * PR_CH;
+        __syncthreads();
+        for (int e = tid; e < NT * 32 * PR_CH; e += 256) {
+            const int w = e >> 6, c = e & 63;
+            gs[w * PR_LD + c] = (w < K && c0 + c < C) ? pb[(size_t)w * C + c0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *row = gs + (t * 32 + acc_row(r, h)) * PR_LD + j;     // A[i = channel j][k = h] = g[w][c0 + j]
+                G[2 * cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[0], d[t][r], G[2 * cc], 0, 0, 0);
+                G[2 * cc + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32], d[t][r], G[2 * cc + 1], 0, 0, 0);
+            }
+    }
+    // normalisation backward, in-lane: |f|^2 and <f, dfhat> over this lane's channels, then the other lane half's
+    float fsq = 0.f, fd = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = ct * 32 + acc_row(r, h);
+            const float fv = (c < C) ? fb[(size_t)c * N + nc] : 0.f;
+            fsq = fmaf(fv, fv, fsq);
+            fd = fmaf(fv, G[ct][r], fd);
+        }
+    fsq += __shfl_xor(fsq, 32, 64);
+    fd += __shfl_xor(fd, 32, 64);
+    const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
+    const float coef = fd * finv * finv;         // <fhat, dfhat> / |f|
+    if (n < N) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = ct * 32 + acc_row(r, h);
+                if (c < C) {
+                    const float fv = fb[(size_t)c * N + n];
+                    dfeat[((size_t)b * C + c) * N + n] = (G[ct][r] - fv * coef) * finv;
+                }
+            }
+    }
+}
+
+template <int NT, int CT, int MODE>
+static int launch_proto_bwd(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
+                            const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
+{
+    const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(proto_bwd_feat_kernel<NT, CT, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
+    }
+    dim3 grid((N + 127) / 128, B);
+    ProfScope prof(3, st);
+    hipLaunchKernelGGL((proto_bwd_feat_kernel<NT, CT, MODE>), grid, dim3(256), lds, st, feat, bs, C, N, proto, P, K, scale, soft, dup, dfeat);
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
+template <int MODE>
+static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
+                              const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
+{
+    const int nt = (K + 31) / 32, ct = (C + 63) / 64 * 2;
+#define GFS3D_PB(NT_, CT_) return launch_proto_bwd<NT_, CT_, MODE>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who)
+    if (ct <= 2) { if (nt <= 1) GFS3D_PB(1, 2); if (nt <= 2) GFS3D_PB(2, 2); if (nt <= 4) GFS3D_PB(4, 2); GFS3D_PB(8, 2); }
+    if (ct <= 4) { if (nt <= 1) GFS3D_PB(1, 4); if (nt <= 2) GFS3D_PB(2, 4); if (nt <= 4) GFS3D_PB(4, 4); GFS3D_PB(8, 4); }
+    if (nt <= 1) GFS3D_PB(1, 6); if (nt <= 2) GFS3D_PB(2, 6); if (nt <= 4) GFS3D_PB(4, 6); GFS3D_PB(8, 6);
+#undef GFS3D_PB
+}
+
+// ---------------------------------------------------------------------------
 // k-means assignment (Lloyd step), first version: 64 points per workgroup in LDS,
 // centroids streamed through LDS in tiles of 64; thread (p, q) scores point p
 // against centroids q, q+4, ... of the tile.  sums/counts accumulate with float
@@ -493,4 +642,20 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
                        pts, M, C, cent, K, label, sums, counts, inertia);
     GFS3D_LAUNCH_CHECK("gfs3d_kmeans_assign_f32");
     return GFS3D_OK;
+}
+
+extern "C" int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                             const float *proto, int P, int K, float scale,
+                                             const float *soft, const float *dup, float *dfeat, void *stream)
+{
+    using namespace gfs3d;
+    const char *who = "gfs3d_proto_backward_feat_f32";
+    GFS3D_REQUIRE(feat && proto && dup && dfeat, "%s: NULL pointer", who);
+    GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && C <= 192 && N >= 1, "%s: bad shape B=%d C=%d N=%d (C <= 192)", who, B, C, N);
+    GFS3D_REQUIRE(K >= 1 && K <= 256, "%s: need 1 <= K <= 256, got %d", who, K);
+    GFS3D_REQUIRE(P == 1 || P == B, "%s: P must be 1 or B (got %d)", who, P);
+    GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "%s: bad feat_bstride", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
+    return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who);
 }

@@ -100,6 +100,8 @@ SYMBOLS = {
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
                                        c_void_p, c_void_p]),
+    "gfs3d_proto_backward_feat_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_kmeans_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
 }

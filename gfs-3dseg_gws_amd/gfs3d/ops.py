@@ -532,10 +532,27 @@ def proto_cosine_raw(feat: torch.Tensor, proto: torch.Tensor, scale: float = 10.
     return out
 
 
+def proto_backward_feat(feat: torch.Tensor, proto: torch.Tensor, scale: float, dup: torch.Tensor,
+                        soft: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient of a cosine head w.r.t. the point features: `dup` is the gradient of the logits (get_pred) or, with
+    `soft` given, of the softmax over the words (word assignment).  One fused HIP kernel (softmax backward,
+    (C x K).(K x points) contraction on MFMA, normalisation backward)."""
+    B, C, N = feat.shape
+    proto = proto.contiguous()
+    P = 1 if proto.dim() == 2 else proto.shape[0]
+    K = proto.shape[-2]
+    dup = dup.contiguous()
+    dfeat = torch.empty((B, C, N), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.lib().gfs3d_proto_backward_feat_f32(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
+                                                      _p(soft), _p(dup), _p(dfeat), _stream())
+    _lib.check(rc, "gfs3d_proto_backward_feat_f32")
+    return dfeat
+
+
 class WordAssignFunction(torch.autograd.Function):
     """Differentiable wrt the point features (the words `gp` carry no grad,
-    capl.py:49-50).  Backward is the softmax/normalise chain rule as two device
-    matmuls on the saved soft assignment."""
+    capl.py:49-50).  Backward: one fused HIP kernel (proto_backward_feat)."""
 
     @staticmethod
     def forward(ctx, feat, words, scale):
@@ -548,14 +565,9 @@ class WordAssignFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dsoft, _d1, _d2):
         feat, words, soft = ctx.saved_tensors
-        # d(scale*cos) = soft * (dsoft - sum_w soft*dsoft)
-        dlog = soft * (dsoft - (soft * dsoft).sum(dim=1, keepdim=True)) * ctx.scale
-        gn = torch.nn.functional.normalize(words, p=2, dim=1)                  # (Kw,C)
-        fnorm = feat.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)           # (B,1,N)
-        fhat = feat / fnorm
-        dfhat = torch.matmul(gn.t().unsqueeze(0), dlog)                        # (B,C,N)
-        dfeat = (dfhat - fhat * (fhat * dfhat).sum(dim=1, keepdim=True)) / fnorm
-        return dfeat, None, None
+        if feat.shape[1] > 192:
+            raise NotImplementedError("gfs3d.word_assign: the backward kernel handles up to 192 feature channels")
+        return proto_backward_feat(feat, words, ctx.scale, dsoft, soft), None, None
 
 
 class ProtoCosineFunction(torch.autograd.Function):
@@ -572,19 +584,21 @@ class ProtoCosineFunction(torch.autograd.Function):
     def backward(ctx, dout):
         feat, proto = ctx.saved_tensors
         s = ctx.scale
-        fnorm = feat.norm(p=2, dim=1, keepdim=True).clamp_min(1e-12)
-        fhat = feat / fnorm                                                      # (B,C,N)
-        pnorm = proto.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-12)
-        phat = proto / pnorm                                                     # (K,C) | (B,K,C)
-        d = dout * s
-        if proto.dim() == 2:
-            dfhat = torch.matmul(phat.t().unsqueeze(0), d)                       # (B,C,N)
-            dphat = torch.einsum("bkn,bcn->kc", d, fhat)
-        else:
-            dfhat = torch.matmul(phat.transpose(1, 2), d)
-            dphat = torch.matmul(d, fhat.transpose(1, 2))                        # (B,K,C)
-        dfeat = (dfhat - fhat * (fhat * dfhat).sum(dim=1, keepdim=True)) / fnorm
-        dproto = (dphat - phat * (phat * dphat).sum(dim=-1, keepdim=True)) / pnorm
+        dfeat = dproto = None
+        if ctx.needs_input_grad[0]:
+            if feat.shape[1] > 192:
+                raise NotImplementedError("gfs3d.proto_cosine: the backward kernel handles up to 192 feature channels")
+            dfeat = proto_backward_feat(feat, proto, s, dout)                    # fused HIP kernel
+        if ctx.needs_input_grad[1]:                                              # (K, C) / (B, K, C): a skinny reduction over the points
+            fhat = torch.nn.functional.normalize(feat, p=2, dim=1, eps=1e-12)    # (B,C,N)
+            pnorm = proto.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-12)
+            phat = proto / pnorm
+            d = dout * s
+            if proto.dim() == 2:
+                dphat = torch.einsum("bkn,bcn->kc", d, fhat)
+            else:
+                dphat = torch.matmul(d, fhat.transpose(1, 2))                    # (B,K,C)
+            dproto = (dphat - phat * (phat * dphat).sum(dim=-1, keepdim=True)) / pnorm
         return dfeat, dproto, None
 
 

@@ -211,6 +211,11 @@ int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, int B, int 
                           float *soft, int32_t *assign, float *onehot, void *stream);
 int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int C, int N,
                            const float *proto, int P, int K, float scale, float *out, void *stream);
+/* Backward of the two cosine heads with respect to the point features: dup = gradient of `soft` (word
+ * assignment; pass the forward's soft) or of the logits (get_pred; soft = NULL); dfeat (B, C, N) dense, C <= 192. */
+int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                  const float *proto, int P, int K, float scale,
+                                  const float *soft, const float *dup, float *dfeat, void *stream);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
 
