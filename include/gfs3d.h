@@ -8,6 +8,10 @@
  * tensors are dense fp32 in the layout given; `stream` is a hipStream_t passed
  * as void* (NULL = default stream).  No entry point allocates, frees or
  * synchronises: callers hand in outputs and a workspace (graph-capture safe).
+ * The training EdgeConv forward forks a few kernels onto a library-owned side
+ * stream (one per device, created on first use) and joins it back into `stream`
+ * with events before it returns work to the caller; GFS3D_EC_OVERLAP=0 keeps
+ * everything on `stream`.
  *
  * Return value: 0 on success, non-zero error code otherwise;
  * gfs3d_last_error() gives a thread-local human-readable message.  Nothing
@@ -80,8 +84,8 @@ typedef struct gfs3d_edgeconv_args {
     /* saved for backward (outputs of forward, inputs of backward) */
     float *P, *Q;                 /* (B, N, 64): Wa x_n and (Wb - Wa) x_n */
     float *SP;                    /* (B, N, 64): sum_j P[idx[n,j]] (written by forward) */
-    float *SQ;                    /* (B, N, 64) scratch of backward: sum over in-edges of Q */
-    float *indeg;                 /* (B, N) scratch of backward: in-degree in the kNN graph (as float) */
+    float *SQ;                    /* (B, N, 64): sum over in-edges of Q (reverse kNN graph; written by the training forward) */
+    float *indeg;                 /* (B, N): in-degree in the kNN graph, as float (written by the training forward) */
     float *stats;                 /* (8, 64): mean1 rstd1 scale1 shift1 mean2 rstd2 scale2 shift2 */
     float *hsel;                  /* (B, N, 64) pre-BN2 value that won the max */
     uint8_t *jsel;                /* (B, N, 64) neighbour slot j that won the max */
