@@ -43,6 +43,9 @@ def relerr(a, b):
     (2, 9, 256, 20, "blocks"), (2, 64, 256, 20, "randn"), (1, 9, 256, 20, "dup"), (2, 9, 2048, 20, "blocks"),
     (1, 64, 2048, 20, "randn"), (3, 3, 100, 7, "randn"), (1, 5, 33, 33, "randn"), (2, 9, 130, 1, "blocks"),
     (1, 9, 300, 32, "blocks"), (1, 16, 257, 40, "randn"), (1, 192, 128, 20, "randn"), (1, 3, 16, 5, "same"),
+    # wide-C path (lazy selection): every distance tied, exact twins, heavily tied integer features, ragged last tile
+    (1, 64, 256, 20, "same"), (2, 64, 512, 20, "twins"), (2, 16, 1000, 20, "ints"), (1, 32, 2048, 12, "ints"),
+    (1, 64, 77, 20, "randn"),
 ])
 def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
     from gfs3d import ops
@@ -53,6 +56,11 @@ def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
         x = R.synthetic_blocks(B, N, seed=7, dup_tail=N // 8)
     elif kind == "same":
         x = torch.zeros(B, C, N)
+    elif kind == "twins":
+        x = torch.randn(B, C, N, generator=g)
+        x[:, :, N // 2:] = x[:, :, :N // 2]
+    elif kind == "ints":
+        x = torch.randint(0, 3, (B, C, N), generator=g).float()
     else:
         x = torch.randn(B, C, N, generator=g)
     i64, i32 = ops.knn_topk(x.to(dev), k, want_i64=True, want_i32=True)
