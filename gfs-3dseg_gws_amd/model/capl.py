@@ -189,19 +189,22 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             fake_novel = random.sample(present, len(present) // 2)
         proto = _unit(main_proto, 1)
         feat = _unit(x, 1)
-        for cls in fake_novel:
-            cls = int(cls)
-            m = (labels == cls).to(feat.dtype)
-            num, den = (feat * m).sum(0).sum(-1), m.sum(0).sum(-1)
+        fake = [int(c) for c in fake_novel]
+        if fake:
+            # all fake-novel classes at once (the reference loops over them, capl.py:392-408): masked sums as one
+            # batched GEMM against the (b, F, n) class masks, rows replaced by index_copy (== proto (1 - pick) + mean pick)
+            cls_idx = torch.tensor(fake, dtype=torch.long, device=feat.device)
+            m = (labels == cls_idx.view(1, -1, 1)).to(feat.dtype)              # (b, F, n)
+            num = torch.matmul(feat, m.transpose(1, 2)).sum(0).t()             # (F, C)
+            den = m.sum((0, 2))                                                # (F,)
             if dp:   # masked mean over the GLOBAL support half: differentiable SUM all-reduce of (sum, count)
                 from torch.distributed.nn.functional import all_reduce as _ar
-                num, den = _ar(num), _ar(den)
-            mean = num / (den + _EPS)
+                packed = _ar(torch.cat([num, den.unsqueeze(1)], dim=1))
+                num, den = packed[:, :-1], packed[:, -1]
+            mean = num / (den + _EPS).unsqueeze(1)
             if post_processing:
-                mean = self.post_processing_hard_coding(mean)
-            pick = torch.zeros(proto.size(0), 1, dtype=proto.dtype, device=proto.device)
-            pick[cls - 1] = 1
-            proto = proto * (1 - pick) + mean.unsqueeze(0) * pick
+                mean = torch.stack([self.post_processing_hard_coding(row) for row in mean.unbind(0)])
+            proto = proto.index_copy(0, cls_idx - 1, mean)
         return proto, fake_novel
 
     def post_processing_hard_coding(self, coding):
