@@ -617,7 +617,7 @@ __device__ __forceinline__ void bwd_coef(const CoefIn &f, int c, bool writer, fl
 // dH2 = Cc*H2 + Bc + [slot == winner] A*g is elementwise in the C/D layout (the routed term is
 // one compare per register); a1 in C/D layout comes from the same LDS transpose buffer (no
 // second gather); dy1 = dA1 * LReLU'(z1) (sign of a1); G_Q in-lane, G_P as 2x128-B atomic rows.
-// LDS: bf16 piece images of W2 (rows co, for (1)) and of W2^T (rows ci, for (3)), 25.6 KB each, shared by the 8 waves
+// LDS: bf16 piece images of W2 (rows co, for (1)) and of W2^T (rows ci, for (3)), 25.6 KB each, shared by the 4 waves
 // of the block; per wave one [32][68] transpose tile, the neighbour ids of all tiles of the super-tile [8][32] and
 // the Q' rows of its 8 points [8][64].
 // Memory pipeline: the kernel sits at the VGPR cap, so the gathered P' half rows of tile t+1 arrive by LDS-DMA
@@ -625,6 +625,9 @@ __device__ __forceinline__ void bwd_coef(const CoefIn &f, int c, bool writer, fl
 // from the last dH2 read of tile t to the a1 write of tile t+1.  The DMA is issued BEFORE tile t's 32 G_P atomic
 // instructions: vmcnt retires in issue order, so `s_waitcnt vmcnt(32)` at the top of tile t+1 covers the gather
 // without waiting for the atomics' round trips (plain loads at the tile top would wait for every older atomic).
+// Occupancy: 256 VGPRs + 96 AGPRs (64 of them the dW2 accumulators, live across all tiles), so ONE wave per SIMD.
+// Measured alternative: 8 waves per block (256 registers each, no spill in the tile loop) with dW2 summed per tile
+// through ds_add_f32 into a block-wide [64][64] image - 0.37 -> 1.02 ms per launch, the LDS float adds are that slow.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) char lds_char;
 // 16 B per lane, global -> LDS without a VGPR destination: lane l lands at lds_base + 16 l.  Issued as inline asm
@@ -1156,7 +1159,7 @@ struct Plan {
     int g_heavy;        // blocks of the grid-stride heavy kernels
     int g_pq;           // workgroups of ec_bwd_pq_kernel (one weight-gradient partial each)
     int g_mfma;         // blocks of the forward MFMA kernel (4 waves each, a wave walks super-tiles of 8 points)
-    int g_bwd;          // blocks of the heavy backward kernel (8 waves each, one block per CU)
+    int g_bwd;          // blocks of the heavy backward kernel (4 waves each: one per SIMD, one block per CU)
     int tiles;          // ceil(N/64) * B
     size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)

@@ -453,116 +453,6 @@ struct WGrad {
     float *dw;                // (Co, Ci) zeroed by the launcher, accumulated with fp32 atomics
 };
 
-// dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci]  over this block's slice of the points
-template <int BMU, int BNV, int VPRO>
-__global__ void __launch_bounds__(256, 3) pw_wgrad_kernel(const WGrad g)
-{
-    extern __shared__ f32x4 pw_smem4[];
-    float *smem = reinterpret_cast<float *>(pw_smem4);
-    constexpr int TM = BMU / 64, TN = BNV / 64;
-    constexpr int UC4 = BMU / 4, RUS = 256 / UC4, NU = 32 / RUS;     // U tile [32][BMU]: float4 per row, rows per pass, passes
-    constexpr int VC4 = BNV / 4, RVS = 256 / VC4, NV = 32 / RVS;
-    float *sU = smem;                       // [32][BMU]
-    float *sV = smem + 32 * BMU;            // [32][BNV]
-    const int nci = g.Ci / BNV, ntile = (g.Co / BMU) * nci;
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
-    if (split >= g.nsplit) return;
-    const int co0 = (tile / nci) * BMU, ci0 = (tile % nci) * BNV;
-    const int m0 = split * g.rows_per_split, m1 = min(g.M, m0 + g.rows_per_split);
-    if (m0 >= m1) return;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int cu = t % UC4, ru = t / UC4;
-    const int cv = t % VC4, rv = t / VC4;
-    const float *up = g.u + co0 + 4 * cu, *up2 = g.u2 ? g.u2 + co0 + 4 * cu : nullptr;
-    const int vseg = ci0 / g.v_segw;
-    const float *vp = g.v[vseg] + (ci0 - vseg * g.v_segw) + 4 * cv;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ua = zero4, ub = zero4, uc = zero4, va = zero4, vb = zero4;
-    if (up2) { ua = ldg4(g.ua + co0 + 4 * cu); ub = ldg4(g.ub + co0 + 4 * cu); uc = ldg4(g.uc + co0 + 4 * cu); }
-    if (VPRO == PRO_BNACT) { va = ldg4(g.va + ci0 + 4 * cv); vb = ldg4(g.vb + ci0 + 4 * cv); }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 rU[NU], rU2[NU], rV[NV];
-    auto load = [&](int kt) {
-#pragma unroll
-        for (int p = 0; p < NU; ++p) {
-            const int m = m0 + kt * 32 + ru + RUS * p;
-            rU[p] = m < m1 ? ldg4(up + (size_t)m * g.ldu) : zero4;
-            if (up2) rU2[p] = m < m1 ? ldg4(up2 + (size_t)m * g.ldu) : zero4;
-        }
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            const int m = m0 + kt * 32 + rv + RVS * p;
-            rV[p] = m < m1 ? ldg4(vp + (size_t)m * g.ldv) : zero4;
-        }
-    };
-    auto store = [&](int kt) {
-#pragma unroll
-        for (int p = 0; p < NU; ++p) {
-            f32x4 v = rU[p];
-            if (up2) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(rU2[p][e], uc[e], fmaf(v[e], ua[e], ub[e]));
-                if (m0 + kt * 32 + ru + RUS * p >= m1) v = zero4;
-            }
-            *reinterpret_cast<f32x4 *>(&sU[(ru + RUS * p) * BMU + 4 * cu]) = v;
-        }
-#pragma unroll
-        for (int p = 0; p < NV; ++p) {
-            f32x4 v = rV[p];
-            if (VPRO == PRO_BNACT) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], va[e], vb[e]), g.slope);
-                if (m0 + kt * 32 + rv + RVS * p >= m1) v = zero4;
-            }
-            *reinterpret_cast<f32x4 *>(&sV[(rv + RVS * p) * BNV + 4 * cv]) = v;
-        }
-    };
-
-    const int KT = (m1 - m0 + 31) / 32;
-    const float *pu = &sU[lh * BMU + wm * (BMU / 2) + li];
-    const float *pv = &sV[lh * BNV + wn * (BNV / 2) + li];
-    load(0);
-    for (int kt = 0; kt < KT; ++kt) {
-        store(kt);
-        __syncthreads();
-        if (kt + 1 < KT) load(kt + 1);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = pu[2 * s * BMU + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = pv[2 * s * BNV + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * (BMU / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ci = ci0 + wn * (BNV / 2) + j * 32 + li;
-                atomicAdd(&g.dw[(size_t)co * g.Ci + ci], acc[i][j][r]);
-            }
-}
-
 // dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci] on the bf16 matrix cores (bf16x6, see pw_rowgemm6_kernel).  The reduction
 // runs over the POINTS, so both operands are transposed while they are staged: a thread owns 4 channels x 2
 // consecutive points, splits the 8 values and writes, per channel and piece, one dword (2 bf16) into that channel's
