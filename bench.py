@@ -150,6 +150,23 @@ def main():
     L.gfs3d_profile_enable(0)
     elapsed = gdist.max_over_ranks(elapsed, dev)
 
+    # north-star side figure (BASELINE.json: "kNN + EdgeConv forward at B=32 x 2048"): the three kNN + EdgeConv
+    # blocks alone, eval mode (running statistics), after and outside the timed region
+    fwd_ms = None
+    if rank == 0:
+        net.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                net.edgeconv_features(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                net.edgeconv_features(x)
+            e1.record()
+            torch.cuda.synchronize()
+            fwd_ms = e0.elapsed_time(e1) / 20
+        net.train()
+
     # per-kernel device time from the in-library hipEvent brackets (same stream as the launches)
     import ctypes
     prof = {}
@@ -183,6 +200,14 @@ def main():
             kms = prof[0][0] / args.steps
             roof["knn"] = {"ms_per_step": round(kms, 4), "algorithmic_GBps": round(kb / (kms * 1e-3) / 1e9, 2),
                            "algorithmic_TFLOPps": round(algorithmic_flops(0, B_PER_GPU)[0] / (kms * 1e-3) / 1e12, 2)}
+        if fwd_ms:
+            # SURVEY 8(d) per block: kNN 1.19 GF + EdgeConv fwd 2.44 GF; compulsory bytes 2.10 MB + 3.80 MB.
+            # 565-640 flop/B: the fp32 roof binds, not HBM (the north star's "HBM roofline" cannot: 189 MB is 24 us at 8 TB/s)
+            gf, mb = B_PER_GPU * (1.19 + 2.44), B_PER_GPU * (2.10 + 3.80)
+            roof["fwd_knn_edgeconv_eval"] = {"ms": round(fwd_ms, 4), "blocks_per_s": round(B_PER_GPU / (fwd_ms * 1e-3), 1),
+                                             "algorithmic_TFLOPps": round(gf / fwd_ms, 2),
+                                             "frac_of_fp32_peak": round(gf / fwd_ms / PEAK_FP32_TFLOPS, 4),
+                                             "algorithmic_GBps": round(mb / fwd_ms, 1)}
         ms_step = elapsed / args.steps * 1e3
         line = {
             "metric": "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd", "value": round(world * B_PER_GPU / (elapsed / args.steps), 2),
