@@ -390,13 +390,8 @@ extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
     a.out = out; a.lse = lse; a.dout = dout; a.Dq = workspace;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_DKV_LDS);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AT_DKV_LDS);
-        if (e1 != hipSuccess || e2 != hipSuccess) { set_error("%s: hipFuncSetAttribute failed", who); return GFS3D_ERR_HIP; }
-        attr_done = true;
-    }
+    GFS3D_ENSURE_LDS(attn_bwd_dkv_kernel<true>, AT_DKV_LDS, who);
+    GFS3D_ENSURE_LDS(attn_bwd_dkv_kernel<false>, AT_DKV_LDS, who);
     ProfScope prof(9, st);
     hipLaunchKernelGGL(attn_bwd_D_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, dout, out, N, workspace);
     GFS3D_LAUNCH_CHECK("attn_bwd_D_kernel");

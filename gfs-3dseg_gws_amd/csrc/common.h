@@ -78,6 +78,31 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize, per kernel AND per device.
+// `seen` is the call site's static table (one per kernel instantiation): the largest size granted so far on each device.
+constexpr int GFS3D_MAX_DEVICES = 32;
+struct LdsGrant { int bytes[GFS3D_MAX_DEVICES] = {}; };
+static inline int ensure_dynamic_lds(const void *kernel, size_t bytes, LdsGrant &seen, const char *who)
+{
+    if (bytes <= 64 * 1024) return GFS3D_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const bool track = dev >= 0 && dev < GFS3D_MAX_DEVICES;
+    if (track && seen.bytes[dev] >= (int)bytes) return GFS3D_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(%zu B of LDS): %s", who, bytes, hipGetErrorString(e));
+        return GFS3D_ERR_HIP;
+    }
+    if (track) seen.bytes[dev] = (int)bytes;
+    return GFS3D_OK;
+}
+#define GFS3D_ENSURE_LDS(kernel, bytes, who)                                                             \
+    do {                                                                                                 \
+        static ::gfs3d::LdsGrant grant__;                                                                \
+        if (int rc__ = ::gfs3d::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), bytes, grant__, who)) return rc__; \
+    } while (0)
+
 // pointwise.hip: out(M, Nc) = a(M, K) . w(Nc, K)^T on MFMA, point-major; the Nc columns are written as segments of
 // width o_segw to out[0], out[1], ...  (K % 32 == 0, Nc % 64 == 0, o_segw % 64 == 0, at most 4 segments)
 int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw, hipStream_t st,

@@ -1300,8 +1300,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, st, who)) return rc;
         } else {
             const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
-            if (lds > 64 * 1024)
-                hipFuncSetAttribute(reinterpret_cast<const void *>(ec_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            GFS3D_ENSURE_LDS(ec_pq_kernel, lds, who);
             hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
             GFS3D_LAUNCH_CHECK("ec_pq_kernel");
         }
@@ -1411,13 +1410,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, done, a->stats, total, Pp, Qp);
                 GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
             }
-            static bool attr_done = false;
-            if (!attr_done) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ec_main_bwd_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES);
-                if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-                attr_done = true;
-            }
+            GFS3D_ENSURE_LDS(ec_main_bwd_kernel, BWD_LDS_BYTES, who);
             ProfScope prof(2, st);
             hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
                                g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
@@ -1436,8 +1429,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         const Bn1Fin fin{acc2, loc2, count, ba->dbn1_w, ba->dbn1_b};
         const int CP = ((a->C + 31) / 32) * 32;
         const size_t lds = sizeof(float) * (2 * 64 * PQ_LD + 2 * (size_t)CP * PQ_LD + 64 * (size_t)(CP + 1));
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute(reinterpret_cast<const void *>(ec_bwd_pq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        GFS3D_ENSURE_LDS(ec_bwd_pq_kernel, lds, who);
         const int tiles_per_b = (a->N + 63) / 64;
         hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
                            GP, GQ, a->stats, fin, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);

@@ -479,14 +479,7 @@ static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64
         set_error("gfs3d_knn_topk_f32: C=%d needs %zu B of LDS (> 160 KiB)", C, lds);
         return GFS3D_ERR_INVALID;
     }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_topk_kernel<K>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("gfs3d_knn_topk_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return GFS3D_ERR_HIP;
-        }
-    }
+    GFS3D_ENSURE_LDS(knn_topk_kernel<K>, lds, "gfs3d_knn_topk_f32");
     dim3 grid((N + 63) / 64, B);
     ProfScope prof(0, st);
     hipLaunchKernelGGL(knn_topk_kernel<K>, grid, dim3(256), lds, st, x, C, N, k, idx64, idx32);

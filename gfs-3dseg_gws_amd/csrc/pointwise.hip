@@ -741,13 +741,7 @@ int launch_rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 {
     if (rg.w3) return launch_rowgemm6<BN, PRO, EPI, OUT_CF>(rg, st, who);
     const size_t lds = sizeof(float) * 2 * (PW_BM + BN) * PW_LD;
-    static bool attr_done = false;               // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_rowgemm_kernel<BN, PRO, EPI, OUT_CF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-        attr_done = true;
-    }
+    GFS3D_ENSURE_LDS((pw_rowgemm_kernel<BN, PRO, EPI, OUT_CF>), lds, who);
     const int ncb = rg.Nc / BN, nrb = (rg.M + PW_BM - 1) / PW_BM;
     const unsigned grid = 8u * ncb * ((nrb + 7) / 8);
     hipLaunchKernelGGL((pw_rowgemm_kernel<BN, PRO, EPI, OUT_CF>), dim3(grid), dim3(256), lds, st, rg);
@@ -766,15 +760,7 @@ template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
-    if (lds > 64 * 1024) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pw_wgrad6_kernel<BMU, BNV, VPRO>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-            attr_done = true;
-        }
-    }
+    GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO>), lds, who);
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
     // 2-3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
     int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;

@@ -173,11 +173,7 @@ static int launch_proto(const float *feat, long long bs, int B, int C, int N, co
                         float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
 {
     const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(proto_mfma_kernel<NT, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-    }
+    GFS3D_ENSURE_LDS((proto_mfma_kernel<NT, MODE>), lds, who);
     dim3 grid((N + 127) / 128, B);
     ProfScope prof(3, st);
     hipLaunchKernelGGL((proto_mfma_kernel<NT, MODE>), grid, dim3(256), lds, st, feat, bs, C, N, proto, P, K, scale,
@@ -322,11 +318,7 @@ static int launch_proto_bwd(const float *feat, long long bs, int B, int C, int N
                             const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
 {
     const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(proto_bwd_feat_kernel<NT, CT, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-    }
+    GFS3D_ENSURE_LDS((proto_bwd_feat_kernel<NT, CT, MODE>), lds, who);
     dim3 grid((N + 127) / 128, B);
     ProfScope prof(3, st);
     hipLaunchKernelGGL((proto_bwd_feat_kernel<NT, CT, MODE>), grid, dim3(256), lds, st, feat, bs, C, N, proto, P, K, scale, soft, dup, dfeat);
@@ -571,11 +563,7 @@ static int launch_kmeans(const float *pts, long long M, int C, const float *cent
                          float *counts, double *inertia, hipStream_t st)
 {
     const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_mfma_kernel<NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("gfs3d_kmeans_assign_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-    }
+    GFS3D_ENSURE_LDS(kmeans_assign_mfma_kernel<NT>, lds, "gfs3d_kmeans_assign_f32");
     ProfScope prof(5, st);
     hipLaunchKernelGGL((kmeans_assign_mfma_kernel<NT>), dim3((unsigned)((M + 127) / 128)), dim3(256), lds, st,
                        pts, M, C, cent, K, label, counts, inertia);
@@ -630,11 +618,7 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
         return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st);
     }
     const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kmeans_assign_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error("gfs3d_kmeans_assign_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return GFS3D_ERR_HIP; }
-    }
+    GFS3D_ENSURE_LDS(kmeans_assign_kernel, lds, "gfs3d_kmeans_assign_f32");
     const long long nblk = (M + 63) / 64;
     GFS3D_REQUIRE(nblk < (1ll << 31), "gfs3d_kmeans_assign_f32: M too large");
     ProfScope prof(5, static_cast<hipStream_t>(stream));
