@@ -348,14 +348,15 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 #pragma unroll
             for (int s = 0; s < CS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], qb[s], acc, 0, 0, 0);
             if (j0 + step < N) load_tile(a, j0 + step);
-            float m = -__builtin_inff();
+            // max_r round(t_r - |q|^2) == round(max_r t_r - |q|^2): rounding is monotone, so one subtraction per tile
+            float mt = -__builtin_inff();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cand = j0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float pd = __fsub_rn(__fsub_rn(2.0f * acc[r], sqc[r]), sqq);
-                m = fmaxf(m, cand < N ? pd : -__builtin_inff());
+                const float t = __fsub_rn(2.0f * acc[r], sqc[r]);
+                mt = fmaxf(mt, cand < N ? t : -__builtin_inff());
             }
-            bm_insert(m);
+            bm_insert(__fsub_rn(mt, sqq));
         }
         float other[K];
 #pragma unroll
