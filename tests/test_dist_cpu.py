@@ -48,6 +48,14 @@ def _worker(rank, world, port, out):
     bucket.all_reduce_mean()
     res["local_grad"], res["mean_grad"] = local.numpy(), bucket.flat.numpy().copy()
     res["views"] = all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in lin.parameters())
+    # 2b. the same with the LAST layer's parameters (first in backward order) exchanged early, under the rest of backward
+    early = gd.FlatGradBucket(lin.parameters(), early=lin[1].parameters())
+    for _ in range(2):                                   # twice: the hook state must reset with zero()
+        early.zero()
+        lin(x).sum().backward()
+        early.all_reduce_mean()
+    res["early_grad"] = torch.cat([p.grad.reshape(-1) for p in lin.parameters()]).numpy().copy()
+    res["early_launches"] = early.early_launches
     # 3. metric: every rank evaluates its shard of the batches, counters are all-reduced
     g = np.load(os.path.join(here, "golden", "metric.npz"))
     lo, hi = gd.shard_range(len(g["prs"]))
@@ -97,6 +105,8 @@ def test_dp_helpers_world2_gloo():
     assert a["shard"] == (0, 19) and b["shard"] == (19, 37)
     mean = (a["local_grad"] + b["local_grad"]) / 2
     assert np.allclose(a["mean_grad"], mean, atol=1e-6) and np.allclose(b["mean_grad"], mean, atol=1e-6)
+    assert np.allclose(a["early_grad"], mean, atol=1e-6) and np.allclose(b["early_grad"], mean, atol=1e-6)
+    assert a["early_launches"] == 2 and b["early_launches"] == 2        # the overlapped slice ran in both steps
     assert a["views"] and b["views"]
     ref = load_golden("metric")["res"]
     assert np.allclose(a["metric"], ref, atol=1e-12) and np.allclose(b["metric"], ref, atol=1e-12)
