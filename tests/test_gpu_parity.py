@@ -894,3 +894,68 @@ def test_device_pipeline_matches_reference_loader(dev):
     assert float(x1[:, 6:9].min()) == 0.0 and float(x1[:, 6:9].max()) == 1.0 and int(y1.max()) <= len(classes)
     xa, _, _ = smp.batch([0, 1], 2048, sampled_classes=classes, pc_augm=True, pc_augm_config=cfg)
     assert float(xa[:, 6:9].min()) == 0.0 and abs(float(xa[:, 6:9].max()) - 1.0) < 1e-6
+
+
+# ------------------------------------------------------------------ block-sharded DP on the device (gloo: one GPU here)
+def _dp_rank(rank, world, port, out):
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "gfs-3dseg_gws_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfs3d import dist as gd
+    from gfs3d.synthetic import synthetic_blocks
+    from model.dgcnn import DGCNN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev).train()
+    bucket = gd.FlatGradBucket(net.parameters(), early=net.conv.parameters())
+    x = synthetic_blocks(4, 256, seed=3)
+    lo, hi = gd.shard_range(4)
+    for _ in range(2):
+        bucket.zero()
+        _, y = net(x[lo:hi].to(dev))
+        (y * y).mean().backward()
+        bucket.all_reduce_mean()
+    torch.cuda.synchronize()
+    out[rank] = {"grad": bucket.flat.cpu().numpy().copy(), "early": bucket.early_launches}
+    dist.destroy_process_group()
+
+
+def test_block_sharded_dp_two_ranks_average_their_shard_gradients(dev):
+    """bench.py's step under block-sharded DP (two gloo ranks on this one GPU; the point-wise stack's gradients are
+    exchanged early, under the EdgeConv backward): every rank ends with the mean of the two shard gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    from gfs3d import dist as gd
+    from gfs3d.synthetic import synthetic_blocks
+    from model.dgcnn import DGCNN
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(300)
+        assert p_.exitcode == 0
+    x = synthetic_blocks(4, 256, seed=3).to(dev)
+    shard_grads = []
+    for lo, hi in ((0, 2), (2, 4)):
+        torch.manual_seed(0)
+        net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev).train()
+        bucket = gd.FlatGradBucket(net.parameters(), early=net.conv.parameters())      # same flat layout as the ranks
+        _, y = net(x[lo:hi])
+        (y * y).mean().backward()
+        shard_grads.append(torch.cat([p.grad.reshape(-1) for p in bucket.params]).cpu().numpy())
+    mean = 0.5 * (shard_grads[0] + shard_grads[1])
+    scale = np.abs(mean).max()
+    for r in range(2):
+        assert out[r]["early"] == 2                                    # the overlapped slice ran in both steps
+        # (float atomics in the backward: equal to rounding, not bit for bit)
+        assert np.abs(out[r]["grad"] - mean).max() < 1e-4 * scale, r
+    assert np.array_equal(out[0]["grad"], out[1]["grad"])
