@@ -32,6 +32,93 @@ enum { MODE_LOGITS = 0, MODE_SOFTMAX = 1 };
 // row (prototype) index inside a 32x32 accumulator tile for register r of lane-half h
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Scores -> outputs, in the C/D layout both forward kernels share (lane = one point, register (t, r) <-> prototype row
+// 32 t + acc_row(r, h)): cosine scaling, then either the logits or softmax over the words + arg-max one-hot.
+// Stores go through a buffer descriptor on this batch element's (K, N) plane: the row part of the offset
+// ((32 t + acc_row(r, 0)) N, wave-uniform) rides in the scalar offset, the lane part ((4 h N + n) 4 bytes) is ONE VGPR
+// for all 16 NT stores, and a lane whose point is past N gets an offset the range check drops (no exec masking).
+// Only the row tile that straddles K needs a per-register test; tiles past K are skipped wave-uniformly.
+template <int NT, int MODE>
+__device__ __forceinline__ void proto_epilogue(f32x16 (&acc)[NT], const float *ginv, float finv, float scale, int b, int n, int N, int K, int h,
+                                               float *__restrict__ out, int32_t *__restrict__ assign, float *__restrict__ onehot)
+{
+    const int plane = (int)min((size_t)K * N * 4, (size_t)0x7fffffff);
+    const int voff = (n < N) ? (4 * h * N + n) * 4 : 0x7fffffff;
+    const float fs = finv * scale;
+    auto put = [&](const __amdgpu_buffer_rsrc_t &rs, int t, int r, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, (t * 32 + acc_row(r, 0)) * N * 4, 0);
+    };
+    if (MODE == MODE_LOGITS) {
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * K * N, 0, plane, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t * 32 >= K) break;
+            const bool full = t * 32 + 32 <= K;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                if (full || w < K) put(rs_out, t, r, acc[t][r] * ginv[w] * fs);
+            }
+        }
+        return;
+    }
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            const float v = (w < K) ? acc[t][r] * ginv[w] * fs : -__builtin_inff();
+            acc[t][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(acc[t][r] - mx);     // exp(-inf) = 0 for padded rows; |rel err| ~1e-6 at the 1e-4 contract
+            acc[t][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float rsum = 1.0f / sum;
+    // arg-max of the probabilities, ties -> lower word: a lane meets its rows in increasing order, so "first maximum"
+    // is the strict '>' (padded rows have p = 0 and the maximum has p >= 1/K_w > 0)
+    float best = -1.f;
+    int bw = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = acc[t][r] * rsum;
+            acc[t][r] = p;
+            if (p > best) { best = p; bw = t * 32 + acc_row(r, h); }
+        }
+    {   // combine the two lane halves: larger p wins, ties -> lower word index
+        const float ob = __shfl_xor(best, 32, 64);
+        const int ow = __shfl_xor(bw, 32, 64);
+        if (ob > best || (ob == best && ow < bw)) { best = ob; bw = ow; }
+    }
+    if (assign && h == 0 && n < N) assign[(size_t)b * N + n] = bw;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out ? out + (size_t)b * K * N : out, 0, out ? plane : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_oh = __builtin_amdgcn_make_buffer_rsrc(onehot ? onehot + (size_t)b * K * N : onehot, 0, onehot ? plane : 0, 0x00020000);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t * 32 >= K) break;
+        const bool full = t * 32 + 32 <= K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            if (full || w < K) {
+                put(rs_out, t, r, acc[t][r]);                       // (a NULL output has a zero-sized plane: dropped)
+                put(rs_oh, t, r, (w == bw) ? 1.f : 0.f);
+            }
+        }
+    }
+}
+
 template <int NT, int MODE>
 __global__ void __launch_bounds__(256)
 proto_mfma_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
@@ -103,69 +190,138 @@ proto_mfma_kernel(const float *__restrict__ feat, long long feat_bstride, int C,
     fsq += __shfl_xor(fsq, 32, 64);
     const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
 
-    const bool nvalid = n < N;
-    if (MODE == MODE_LOGITS) {
+    proto_epilogue<NT, MODE>(acc, ginv, finv, scale, b, n, N, K, h, out, assign, onehot);
+}
+
+// ---------------------------------------------------------------------------
+// The same contraction on the bf16 matrix cores at fp32 accuracy (bf16x6: exact 3-way bf16 split of both operands,
+// six piece products per fp32 product, see pointwise.hip) for K > 32 prototypes and C % 32 == 0 - the geometric-word
+// case (C = 192, K_w = 200), which the fp32 MFMA form ran at 15 % of its matrix rate behind unpipelined staging.
+//   workgroup = 8 waves = 256 points; a wave owns 32 points and all NT row tiles (same C/D layout, same epilogue);
+//   channels in chunks of 32: the prototype chunk is split while it is staged (registers -> [row][hi|mid|lo|pad]
+//   = 208-B rows, odd 16-B slot stride => conflict-free ds_read_b128) into one of TWO LDS images, the loads of chunk
+//   c+1 (prototype float4s and this lane's 16 point channels) are issued before the MFMAs of chunk c: one barrier
+//   per chunk, nothing waits on global memory in steady state.
+// ---------------------------------------------------------------------------
+constexpr int PX_ROW = 208;              // bytes per prototype row and 32-channel chunk
+constexpr int PX_THREADS = 512;
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(PX_THREADS)
+proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
+                const float *__restrict__ proto, int P, int K, float scale,
+                float *__restrict__ out, int32_t *__restrict__ assign, float *__restrict__ onehot)
+{
+    constexpr int NROW = NT * 32;
+    constexpr int NU = NROW * 8 / PX_THREADS;            // float4 units of a prototype chunk per thread (NT / 2)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][NROW][PX_ROW]
+    float *ginv = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);         // [NROW] 1/max(|g|,eps)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + wv * 32 + j;
+    const int nc = min(n, N - 1);
+    const float *fb = feat + (size_t)b * feat_bstride + nc;
+    const float *pb = proto + (P > 1 ? (size_t)b * K * C : 0);
+    const int c4 = tid & 7, row0 = tid >> 3;             // staging: rows row0 + 64 u, channels 4 c4 .. +3 of the chunk
+
+    f32x16 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int w = t * 32 + acc_row(r, h);
-                if (w < K && nvalid)
-                    out[((size_t)b * K + w) * N + n] = acc[t][r] * ginv[w] * finv * scale;
-            }
-    } else {
-        float mx = -__builtin_inff();
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float fsq = 0.f;
+    float gsq[NU];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+    for (int u = 0; u < NU; ++u) gsq[u] = 0.f;
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 pr[NU];
+    float fr[16];
+    auto load = [&](int c0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int w = t * 32 + acc_row(r, h);
-                const float v = (w < K) ? acc[t][r] * ginv[w] * finv * scale : -__builtin_inff();
-                acc[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = expf(acc[t][r] - mx);      // exp(-inf) = 0 for padded rows
-                acc[t][r] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        float best = -1.f;
-        int bw = 0x7fffffff;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int w = t * 32 + acc_row(r, h);
-                const float p = acc[t][r] / sum;
-                acc[t][r] = p;
-                if (w < K && (p > best || (p == best && w < bw))) { best = p; bw = w; }
-            }
-        {   // combine the two lane halves: larger p wins, ties -> lower word index
-            const float ob = __shfl_xor(best, 32, 64);
-            const int ow = __shfl_xor(bw, 32, 64);
-            if (ob > best || (ob == best && ow < bw)) { best = ob; bw = ow; }
+        for (int u = 0; u < NU; ++u) {
+            const int w = row0 + 64 * u;
+            pr[u] = (w < K) ? *reinterpret_cast<const f32x4 *>(pb + (size_t)w * C + c0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (nvalid) {
-            if (assign && h == 0) assign[(size_t)b * N + n] = bw;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int w = t * 32 + acc_row(r, h);
-                    if (w < K) {
-                        const size_t o = ((size_t)b * K + w) * N + n;
-                        if (out) out[o] = acc[t][r];
-                        if (onehot) onehot[o] = (w == bw) ? 1.f : 0.f;
-                    }
-                }
+            for (int e = 0; e < 8; ++e) fr[8 * s + e] = fb[(size_t)(c0 + 16 * s + 8 * h + e) * N];
+    };
+    auto stage = [&](unsigned char *dst_img) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                split3(pr[u][e], hh[e], mm[e], ll[e]);
+                gsq[u] = fmaf(pr[u][e], pr[u][e], gsq[u]);
+            }
+            unsigned char *dst = dst_img + (row0 + 64 * u) * PX_ROW + c4 * 8;
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(hh[0], hh[1]), pack_hi16(hh[2], hh[3]));
+            *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(pack_hi16(mm[0], mm[1]), pack_hi16(mm[2], mm[3]));
+            *reinterpret_cast<uint2 *>(dst + 128) = make_uint2(pack_hi16(ll[0], ll[1]), pack_hi16(ll[2], ll[3]));
         }
+    };
+
+    load(0);
+    stage(img);
+    uint4 bp[2][3];                                      // this lane's point: pieces of 8 channels per K-step
+    auto split_point = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                split3(fr[8 * s + e], ph[e], pm[e], pl[e]);
+                fsq = fmaf(fr[8 * s + e], fr[8 * s + e], fsq);
+            }
+            bp[s][0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+            bp[s][1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+            bp[s][2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+        }
+    };
+    split_point();
+    __syncthreads();
+
+    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+    const int nchunk = C / 32;
+    for (int c = 0; c < nchunk; ++c) {
+        const unsigned char *cur = img + (c & 1) * NROW * PX_ROW;
+        if (c + 1 < nchunk) load(32 * (c + 1));
+        const unsigned char *pa = cur + j * PX_ROW + h * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int wt = 0; wt < NT; ++wt) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pa + wt * 32 * PX_ROW + pl * 64 + s * 32));
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+                    acc[wt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]], __builtin_bit_cast(bf16x8, bp[s][PB[term]]), acc[wt], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunk) {
+            stage(img + ((c + 1) & 1) * NROW * PX_ROW);   // last read of that image: chunk c-1, a barrier ago
+            split_point();
+        }
+        __syncthreads();
     }
+    // |g_w|^2: the 8 threads of a row are 8 consecutive lanes
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float v = gsq[u];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        if (c4 == 0) ginv[row0 + 64 * u] = 1.0f / fmaxf(sqrtf(v), NORM_EPS);
+    }
+    __syncthreads();
+    fsq += __shfl_xor(fsq, 32, 64);
+    const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
+    proto_epilogue<NT, MODE>(acc, ginv, finv, scale, b, n, N, K, h, out, assign, onehot);
 }
 
 template <int NT, int MODE>
@@ -182,11 +338,31 @@ static int launch_proto(const float *feat, long long bs, int B, int C, int N, co
     return GFS3D_OK;
 }
 
+template <int NT, int MODE>
+static int launch_proto_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
+                           float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
+{
+    const size_t lds = (size_t)2 * NT * 32 * PX_ROW + sizeof(float) * NT * 32;
+    GFS3D_ENSURE_LDS((proto_x6_kernel<NT, MODE>), lds, who);
+    dim3 grid((N + 255) / 256, B);
+    ProfScope prof(3, st);
+    hipLaunchKernelGGL((proto_x6_kernel<NT, MODE>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale,
+                       out, assign, onehot);
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
 template <int MODE>
 static int dispatch_proto(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
                           float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
 {
     const int nt = (K + 31) / 32;
+    static const bool x6 = [] { const char *e = getenv("GFS3D_PROTO_X6"); return !(e && e[0] == '0'); }();     // tuning / A-B only
+    if (x6 && nt >= 2 && C % 32 == 0 && (reinterpret_cast<uintptr_t>(proto) & 15) == 0) {
+        if (nt <= 2) return launch_proto_x6<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+        if (nt <= 4) return launch_proto_x6<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+        return launch_proto_x6<8, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    }
     if (nt <= 1) return launch_proto<1, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
     if (nt <= 2) return launch_proto<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
     if (nt <= 4) return launch_proto<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
