@@ -206,37 +206,33 @@ proto_mfma_kernel(const float *__restrict__ feat, long long feat_bstride, int C,
 constexpr int PX_ROW = 208;              // bytes per prototype row and 32-channel chunk
 constexpr int PX_THREADS = 512;
 
-template <int NT, int MODE>
-__global__ void __launch_bounds__(PX_THREADS)
-proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
-                const float *__restrict__ proto, int P, int K, float scale,
-                float *__restrict__ out, int32_t *__restrict__ assign, float *__restrict__ onehot)
+// acc[t][r] = <g_w, f_n> for this lane's point n and the prototype rows w = 32 t + acc_row(r, h); fsq = this lane
+// half's share of |f_n|^2; gsq_out[w] = |g_w|^2 (LDS, valid after the trailing barrier).
+//   ROWMAJOR = false: pt = &feat[b][0][n], channel c at pt[c * cstride]  (channel-first input, 128-B coalesced rows)
+//   ROWMAJOR = true : pt = &pts[m0][0] for the wave's first point, rows of `cstride` floats, `nrows` >= 1 of the 32
+//                     valid: the wave reads its 32 x 32 chunk as 128-B row pieces (8 lanes per row) and turns it
+//                     through a wave-private LDS tile `wtile` [32][XS_LD] so that lane (j, h) gets point j's channels
+constexpr int XS_LD = 36;            // floats per row of that tile (144 B: 16-B aligned, 9 slots = odd)
+template <int NT, bool ROWMAJOR>
+__device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t cstride, int nrows, float *wtile,
+                                          const float *__restrict__ pb, int C, int K,
+                                          unsigned char *img, float *gsq_out, f32x16 (&acc)[NT], float &fsq)
 {
     constexpr int NROW = NT * 32;
     constexpr int NU = NROW * 8 / PX_THREADS;            // float4 units of a prototype chunk per thread (NT / 2)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][NROW][PX_ROW]
-    float *ginv = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);         // [NROW] 1/max(|g|,eps)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    const int n = blockIdx.x * 256 + wv * 32 + j;
-    const int nc = min(n, N - 1);
-    const float *fb = feat + (size_t)b * feat_bstride + nc;
-    const float *pb = proto + (P > 1 ? (size_t)b * K * C : 0);
     const int c4 = tid & 7, row0 = tid >> 3;             // staging: rows row0 + 64 u, channels 4 c4 .. +3 of the chunk
-
-    f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float fsq = 0.f;
+    fsq = 0.f;
     float gsq[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) gsq[u] = 0.f;
 
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 pr[NU];
     float fr[16];
     auto load = [&](int c0) {
@@ -245,10 +241,20 @@ proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, i
             const int w = row0 + 64 * u;
             pr[u] = (w < K) ? *reinterpret_cast<const f32x4 *>(pb + (size_t)w * C + c0 + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (ROWMAJOR) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int i = 0; i < 4; ++i) {              // rows (lane >> 3) + 8 i, 16 B at column 4 (lane & 7)
+                const int row = min((lane >> 3) + 8 * i, nrows - 1);
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(pt + (size_t)row * cstride + c0 + 4 * (lane & 7));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fr[8 * s + e] = fb[(size_t)(c0 + 16 * s + 8 * h + e) * N];
+                for (int e = 0; e < 4; ++e) fr[4 * i + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fr[8 * s + e] = pt[(size_t)(c0 + 16 * s + 8 * h + e) * cstride];
+        }
     };
     auto stage = [&](unsigned char *dst_img) {
 #pragma unroll
@@ -265,11 +271,24 @@ proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, i
             *reinterpret_cast<uint2 *>(dst + 128) = make_uint2(pack_hi16(ll[0], ll[1]), pack_hi16(ll[2], ll[3]));
         }
     };
-
-    load(0);
-    stage(img);
     uint4 bp[2][3];                                      // this lane's point: pieces of 8 channels per K-step
     auto split_point = [&]() {
+        if (ROWMAJOR) {                                // row pieces -> tile -> this lane's 16 channels of point j
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<f32x4 *>(wtile + ((lane >> 3) + 8 * i) * XS_LD + 4 * (lane & 7)) =
+                    f32x4{fr[4 * i], fr[4 * i + 1], fr[4 * i + 2], fr[4 * i + 3]};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(wtile + j * XS_LD + 16 * s + 8 * h + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fr[8 * s + 4 * q + e] = v[e];
+                }
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             unsigned ph[8], pm[8], pl[8];
@@ -283,6 +302,8 @@ proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, i
             bp[s][2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
         }
     };
+    load(0);
+    stage(img);
     split_point();
     __syncthreads();
 
@@ -316,8 +337,30 @@ proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, i
     for (int u = 0; u < NU; ++u) {
         float v = gsq[u];
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        if (c4 == 0) ginv[row0 + 64 * u] = 1.0f / fmaxf(sqrtf(v), NORM_EPS);
+        if (c4 == 0) gsq_out[row0 + 64 * u] = v;
     }
+    __syncthreads();
+}
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(PX_THREADS)
+proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
+                const float *__restrict__ proto, int P, int K, float scale,
+                float *__restrict__ out, int32_t *__restrict__ assign, float *__restrict__ onehot)
+{
+    constexpr int NROW = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][NROW][PX_ROW]
+    float *ginv = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);         // [NROW] |g|^2, then 1/max(|g|,eps)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + wv * 32 + j;
+    f32x16 acc[NT];
+    float fsq;
+    x6_scores<NT, false>(feat + (size_t)b * feat_bstride + min(n, N - 1), (size_t)N, 0, nullptr,
+                         proto + (P > 1 ? (size_t)b * K * C : 0), C, K, img, ginv, acc, fsq);
+    if (tid < NROW) ginv[tid] = 1.0f / fmaxf(sqrtf(ginv[tid]), NORM_EPS);
     __syncthreads();
     fsq += __shfl_xor(fsq, 32, 64);
     const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
@@ -688,7 +731,73 @@ kmeans_assign_mfma_kernel(const float *__restrict__ pts, long long M, int C, con
     }
 }
 
-constexpr int KM_CHUNK = 4096;     // points per workgroup of the sums kernel
+// The assignment step on the bf16x6 main loop of proto_x6_kernel (C % 32 == 0): 8 waves = 256 points per workgroup.
+template <int NT>
+__global__ void __launch_bounds__(PX_THREADS)
+kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ cent, int K,
+                        int32_t *__restrict__ label, float *__restrict__ counts, double *__restrict__ inertia)
+{
+    constexpr int NROW = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);
+    float *cn = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);           // [NROW] |c_k|^2
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * 256 + wv * 32, m = m0 + j;
+    float *wtile = cn + NROW + wv * 32 * XS_LD;                               // wave-private [32][XS_LD]
+    int *hist = reinterpret_cast<int *>(cn + NROW + 8 * 32 * XS_LD);          // [NROW] members of this workgroup per centroid
+    if (tid < NROW) hist[tid] = 0;                                            // (ordered by the barriers of the main loop)
+    f32x16 acc[NT];
+    float psq;
+    const long long mb = m0 < M ? m0 : M - 1;                                  // (a wave past M recomputes the last point, stores nothing)
+    x6_scores<NT, true>(pts + (size_t)mb * C, (size_t)C, (int)min((long long)32, M - mb), wtile, cent, C, K, img, cn, acc, psq);
+    psq += __shfl_xor(psq, 32, 64);
+    float best = __builtin_inff();
+    int bk = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);               // increasing within a lane: '<' keeps the lowest index of a tie
+            const float d = cn[w] - 2.f * acc[t][r];            // + |p|^2, constant per point
+            if (w < K && d < best) { best = d; bk = w; }
+        }
+    {
+        const float ob = __shfl_xor(best, 32, 64);
+        const int ok = __shfl_xor(bk, 32, 64);
+        if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+    }
+    double contrib = 0.0;
+    if (h == 0 && m < M) {
+        label[m] = bk;
+        atomicAdd(&hist[bk], 1);
+        contrib = (double)fmaxf(best + psq, 0.f);
+    }
+    // counts: one global float add per workgroup and non-empty centroid (the K counters share 7 cache lines: per-point
+    // adds from 300 k points queue up on them at the memory side)
+    __syncthreads();
+    if (tid < K && hist[tid] != 0) atomicAdd(&counts[tid], (float)hist[tid]);
+    if (inertia) {      // ONE fp64 atomic per workgroup: same-address fp64 atomics serialise at ~14 ns each
+        contrib = wave_sum(contrib);
+        __syncthreads();                                 // every wave is done with cn
+        double *red = reinterpret_cast<double *>(cn);
+        if (lane == 0) red[wv] = contrib;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < PX_THREADS / 64; ++w) tot += red[w];
+            atomicAdd(inertia, tot);
+        }
+    }
+}
+
+constexpr int KM_CHUNK = 2048;     // points per workgroup of the sums kernel
+// S[k][c] = sum_m [label_m == k] p_m[c] as a one-hot GEMM on the bf16 matrix cores: the one-hot operand is exact in
+// bf16, the point values go in as their three bf16 pieces (hi + mid + lo == the fp32 value), so the three MFMAs per
+// row tile and 16 points add exactly the fp32 values into the fp32 accumulator - 96 matrix cycles where the fp32
+// MFMA form took 512.  A workgroup owns one 32-channel column tile and KM_CHUNK points; wave w owns the centroid row
+// tiles w and w + 4 and walks all the points (lane (j, h): channel j of points 8 h .. 8 h + 7 of the step).
 __global__ void __launch_bounds__(256)
 kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K, const int32_t *__restrict__ label,
                         float *__restrict__ sums)
@@ -699,29 +808,46 @@ kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K
     const long long m0 = (long long)blockIdx.x * KM_CHUNK;
     const int c = blockIdx.y * 32 + j;                     // this lane's output channel
     const int cc = min(c, C - 1);
-    for (int e = tid; e < KM_CHUNK; e += 256) slab[e] = (m0 + e < M) ? label[m0 + e] : -1;
+    const int npts = (int)(M - m0 < KM_CHUNK ? M - m0 : KM_CHUNK);
+    for (int e = tid; e < KM_CHUNK; e += 256) slab[e] = (e < npts) ? label[m0 + e] : -1;
     __syncthreads();
     const int k0 = wv * 32 + j, k1 = (wv + 4) * 32 + j;    // centroid rows of this lane in the wave's two row tiles
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     const bool two = (wv + 4) * 32 < K;                    // second row tile in range (wave-uniform)
-    const int nsteps = (int)((M - m0 < KM_CHUNK ? M - m0 : KM_CHUNK) + 1) / 2;
-    for (int s0 = 0; s0 < nsteps; s0 += 8) {
-        float bv[8];
+    const float *col = pts + (size_t)m0 * C + cc;
+#pragma unroll 2
+    for (int p0 = 0; p0 < npts; p0 += 16) {
+        float v[8];
         int lb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = 2 * (s0 + u) + h;
-            const long long mm = m0 + e;
-            bv[u] = pts[(size_t)(mm < M ? mm : M - 1) * C + cc];
-            lb[u] = slab[e < KM_CHUNK ? e : KM_CHUNK - 1];
-            if (e >= KM_CHUNK || s0 + u >= nsteps) lb[u] = -1;
+        for (int e = 0; e < 8; ++e) {
+            const int i = p0 + 8 * h + e;
+            v[e] = col[(size_t)min(i, npts - 1) * C];       // (a point past the chunk has label -1: its row of A is zero)
+            lb[e] = slab[i];
         }
+        unsigned ph[8], pm[8], pl[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(lb[u] == k0 ? 1.f : 0.f, bv[u], acc0, 0, 0, 0);
-            if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(lb[u] == k1 ? 1.f : 0.f, bv[u], acc1, 0, 0, 0);
+        for (int e = 0; e < 8; ++e) split3(v[e], ph[e], pm[e], pl[e]);
+        const uint4 bh = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+        const uint4 bm = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+        const uint4 bl = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+        auto onehot = [&](int k) {                          // bf16 1.0 = 0x3F80, two points per dword
+            unsigned d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = (lb[2 * q] == k ? 0x3F80u : 0u) | (lb[2 * q + 1] == k ? 0x3F800000u : 0u);
+            return make_uint4(d[0], d[1], d[2], d[3]);
+        };
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, onehot(k0));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bl), acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bm), acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bh), acc0, 0, 0, 0);
+        if (two) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, onehot(k1));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bl), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bm), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bh), acc1, 0, 0, 0);
         }
     }
     if (c < C) {
@@ -738,12 +864,25 @@ template <int NT>
 static int launch_kmeans(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums,
                          float *counts, double *inertia, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
-    GFS3D_ENSURE_LDS(kmeans_assign_mfma_kernel<NT>, lds, "gfs3d_kmeans_assign_f32");
     ProfScope prof(5, st);
-    hipLaunchKernelGGL((kmeans_assign_mfma_kernel<NT>), dim3((unsigned)((M + 127) / 128)), dim3(256), lds, st,
-                       pts, M, C, cent, K, label, counts, inertia);
-    GFS3D_LAUNCH_CHECK("kmeans_assign_mfma_kernel");
+    bool x6 = false;
+    if constexpr (NT >= 2) {
+        if (C % 32 == 0 && ((reinterpret_cast<uintptr_t>(pts) | reinterpret_cast<uintptr_t>(cent)) & 15) == 0) {
+            const size_t lds = (size_t)2 * NT * 32 * PX_ROW + sizeof(float) * (2 * NT * 32 + 8 * 32 * XS_LD);
+            GFS3D_ENSURE_LDS(kmeans_assign_x6_kernel<NT>, lds, "gfs3d_kmeans_assign_f32");
+            hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT>), dim3((unsigned)((M + 255) / 256)), dim3(PX_THREADS), lds, st,
+                               pts, M, C, cent, K, label, counts, inertia);
+            GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel");
+            x6 = true;
+        }
+    }
+    if (!x6) {
+        const size_t lds = sizeof(float) * (NT * 32 * PR_LD + NT * 32);
+        GFS3D_ENSURE_LDS(kmeans_assign_mfma_kernel<NT>, lds, "gfs3d_kmeans_assign_f32");
+        hipLaunchKernelGGL((kmeans_assign_mfma_kernel<NT>), dim3((unsigned)((M + 127) / 128)), dim3(256), lds, st,
+                           pts, M, C, cent, K, label, counts, inertia);
+        GFS3D_LAUNCH_CHECK("kmeans_assign_mfma_kernel");
+    }
     hipLaunchKernelGGL(kmeans_sums_mfma_kernel, dim3((unsigned)((M + KM_CHUNK - 1) / KM_CHUNK), (C + 31) / 32), dim3(256), 0, st,
                        pts, M, C, K, label, sums);
     GFS3D_LAUNCH_CHECK("kmeans_sums_mfma_kernel");
