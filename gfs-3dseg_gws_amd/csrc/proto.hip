@@ -545,11 +545,208 @@ static int launch_proto_bwd(const float *feat, long long bs, int B, int C, int N
     return GFS3D_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same backward on the bf16 matrix cores (bf16x6) for K > 32 prototypes, C % 32 == 0, C <= 192 - the geometric
+// words.  dfhat[c][n] = sum_w ghat[w][c] d[w][n] contracts over the WORDS, so the roles of proto_x6_kernel swap:
+//   output rows = channels (CT tiles), K-steps = 16 words, one chunk = one 32-word row tile t;
+//   B operand = d[t] of the lane's point, straight from the registers of the C/D layout: K-index 8 h + e of step s is
+//               word 32 t + 16 s + (e & 3) + 8 (e >> 2) + 4 h  (register r = 8 s + e of the lane half);
+//   A operand = the prototype tile TRANSPOSED while it is staged: a thread reads 16 B along the channels of one word,
+//               splits, and writes one bf16 per channel row and piece at that word's permuted K position
+//               (image [channel][hi | mid | lo | pad], 208-B rows, two images, one barrier per chunk).
+// d[t] needs the softmax dot over ALL words first: a pre-pass over soft/dup (coalesced; the main loop reads the
+// tile's 32 values again, one chunk ahead).  1 / |g_w| comes from a block-wide pre-pass over the prototypes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int px_kpos(int u) { return 8 * ((u >> 2) & 1) + (u & 3) + 4 * (u >> 3); }   // word u of a 16-group -> K index
+
+template <int NT, int CT, int MODE>
+__global__ void __launch_bounds__(PX_THREADS)
+proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
+                    const float *__restrict__ proto, int P, int K, float scale,
+                    const float *__restrict__ soft, const float *__restrict__ dup, float *__restrict__ dfeat)
+{
+    constexpr int NROW = CT * 32;                        // image rows = channels
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][NROW][PX_ROW]
+    float *ginv = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);         // [NT*32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + wv * 32 + j;
+    const int nc = min(n, N - 1);
+    const float *fb = feat + (size_t)b * feat_bstride;
+    const float *pb = proto + (P > 1 ? (size_t)b * K * C : 0);
+    const float *sb = soft ? soft + (size_t)b * K * N + nc : nullptr;
+    const float *ub = dup + (size_t)b * K * N + nc;
+
+    {   // 1 / max(|g_w|, eps): two threads per word, float4 loads
+        const int w = tid >> 1, half = tid & 1;
+        float gsq = 0.f;
+        if (w < K)
+            for (int c = half * (C / 2); c < (half + 1) * (C / 2); c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(pb + (size_t)w * C + c);
+                gsq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], fmaf(v[3], v[3], gsq))));
+            }
+        gsq += __shfl_xor(gsq, 1, 64);
+        if (half == 0 && w < NT * 32) ginv[w] = (w < K) ? 1.0f / fmaxf(sqrtf(gsq), NORM_EPS) : 0.f;
+    }
+    float dot = 0.f;
+    if (MODE == MODE_SOFTMAX) {
+#pragma unroll 4
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                if (w < K) dot = fmaf(sb[(size_t)w * N], ub[(size_t)w * N], dot);
+            }
+        dot += __shfl_xor(dot, 32, 64);
+    }
+    __syncthreads();
+
+    // staging of tile t: units of (word, 4 channels); unit q = tid + 512 u covers word q / (C/4), channels 4 (q % (C/4))
+    constexpr int NU = (32 * CT * 8 + PX_THREADS - 1) / PX_THREADS;          // 32 words x C/4 units per tile
+    const int upw = C >> 2;                              // units per word
+    f32x4 pr[NU];
+    float sv[16], uv[16];
+    auto load = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int q = tid + PX_THREADS * u, wl = q / upw, cq = q - wl * upw, w = t * 32 + wl;
+            pr[u] = (wl < 32 && w < K) ? *reinterpret_cast<const f32x4 *>(pb + (size_t)w * C + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            const bool ok = w < K;
+            uv[r] = ok ? ub[(size_t)w * N] : 0.f;
+            sv[r] = (MODE == MODE_SOFTMAX && ok) ? sb[(size_t)w * N] : 0.f;
+        }
+    };
+    auto stage = [&](unsigned char *dst_img) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int q = tid + PX_THREADS * u, wl = q / upw, cq = q - wl * upw;
+            if (wl < 32) {
+                unsigned short *dst = reinterpret_cast<unsigned short *>(dst_img + (4 * cq) * PX_ROW) + 16 * (wl >> 4) + px_kpos(wl & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hh, mm, ll;
+                    split3(pr[u][e], hh, mm, ll);
+                    unsigned short *row = dst + e * (PX_ROW / 2);
+                    row[0] = (unsigned short)(hh >> 16);
+                    row[32] = (unsigned short)(mm >> 16);
+                    row[64] = (unsigned short)(ll >> 16);
+                }
+            }
+        }
+    };
+    uint4 bp[2][3];                                      // pieces of d[t]: K-step s <-> registers 8 s .. 8 s + 7
+    auto split_d = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s + e, w = t * 32 + acc_row(r, h);
+                float v = (MODE == MODE_SOFTMAX) ? sv[r] * (uv[r] - dot) : uv[r];
+                v *= scale * ginv[min(w, NT * 32 - 1)];
+                split3(v, ph[e], pm[e], pl[e]);
+            }
+            bp[s][0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+            bp[s][1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+            bp[s][2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+        }
+    };
+
+    f32x16 G[CT];                               // dfhat, rows = channel 32 ct + acc_row(r, h), column = point
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[ct][r] = 0.f;
+    const int ntile = (K + 31) / 32;
+    load(0);
+    stage(img);
+    split_d(0);
+    __syncthreads();
+    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+    for (int t = 0; t < ntile; ++t) {
+        const unsigned char *cur = img + (t & 1) * NROW * PX_ROW;
+        if (t + 1 < ntile) load(t + 1);
+        const unsigned char *pa = cur + j * PX_ROW + h * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pa + ct * 32 * PX_ROW + pl * 64 + s * 32));
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+                    G[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]], __builtin_bit_cast(bf16x8, bp[s][PB[term]]), G[ct], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntile) {
+            stage(img + ((t + 1) & 1) * NROW * PX_ROW);
+            split_d(t + 1);
+        }
+        __syncthreads();
+    }
+    // normalisation backward, in-lane: |f|^2 and <f, dfhat> over this lane's channels, then the other lane half's
+    const unsigned voff = (unsigned)(4 * h * N + nc) * 4u;                   // + (32 ct + acc_row(r, 0)) N 4 bytes
+    const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fb), 0, (int)min((size_t)C * N * 4, (size_t)0x7fffffff), 0x00020000);
+    float fsq = 0.f, fd = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, (ct * 32 + acc_row(r, 0)) * N * 4, 0));
+            fsq = fmaf(fv, fv, fsq);
+            fd = fmaf(fv, G[ct][r], fd);
+        }
+    fsq += __shfl_xor(fsq, 32, 64);
+    fd += __shfl_xor(fd, 32, 64);
+    const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
+    const float coef = fd * finv * finv;         // <fhat, dfhat> / |f|
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dfeat + (size_t)b * C * N, 0, (int)min((size_t)C * N * 4, (size_t)0x7fffffff), 0x00020000);
+    const int ovoff = (n < N) ? (int)voff : 0x7fffffff;                     // a lane past N: dropped by the range check
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (ct * 32 + acc_row(r, 0)) * N * 4;
+            const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, so, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ct][r] - fv * coef) * finv), rs_o, ovoff, so, 0);
+        }
+}
+
+template <int NT, int CT, int MODE>
+static int launch_proto_bwd_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
+                               const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
+{
+    const size_t lds = (size_t)2 * CT * 32 * PX_ROW + sizeof(float) * NT * 32;
+    GFS3D_ENSURE_LDS((proto_bwd_x6_kernel<NT, CT, MODE>), lds, who);
+    dim3 grid((N + 255) / 256, B);
+    ProfScope prof(3, st);
+    hipLaunchKernelGGL((proto_bwd_x6_kernel<NT, CT, MODE>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale, soft, dup, dfeat);
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
 template <int MODE>
 static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
                               const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
 {
     const int nt = (K + 31) / 32, ct = (C + 63) / 64 * 2;
+    static const bool x6 = [] { const char *e = getenv("GFS3D_PROTO_X6"); return !(e && e[0] == '0'); }();     // tuning / A-B only
+    if (x6 && nt >= 2 && C % 64 == 0 && C <= 192 && (reinterpret_cast<uintptr_t>(proto) & 15) == 0) {
+#define GFS3D_PX(NT_, CT_) return launch_proto_bwd_x6<NT_, CT_, MODE>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who)
+        if (C == 64) { if (nt <= 2) GFS3D_PX(2, 2); if (nt <= 4) GFS3D_PX(4, 2); GFS3D_PX(8, 2); }
+        if (C == 128) { if (nt <= 2) GFS3D_PX(2, 4); if (nt <= 4) GFS3D_PX(4, 4); GFS3D_PX(8, 4); }
+        if (nt <= 2) GFS3D_PX(2, 6); if (nt <= 4) GFS3D_PX(4, 6); GFS3D_PX(8, 6);
+#undef GFS3D_PX
+    }
 #define GFS3D_PB(NT_, CT_) return launch_proto_bwd<NT_, CT_, MODE>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who)
     if (ct <= 2) { if (nt <= 1) GFS3D_PB(1, 2); if (nt <= 2) GFS3D_PB(2, 2); if (nt <= 4) GFS3D_PB(4, 2); GFS3D_PB(8, 2); }
     if (ct <= 4) { if (nt <= 1) GFS3D_PB(1, 4); if (nt <= 2) GFS3D_PB(2, 4); if (nt <= 4) GFS3D_PB(4, 4); GFS3D_PB(8, 4); }
