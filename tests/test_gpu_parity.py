@@ -340,7 +340,8 @@ def test_dgcnn_full_size_train_step_is_finite_and_repeatable(dev):
 
 
 # ------------------------------------------------------------------ K3
-@pytest.mark.parametrize("B,C,N,Kw", [(2, 192, 256, 200), (1, 192, 100, 180), (2, 64, 130, 20), (1, 192, 64, 256)])
+@pytest.mark.parametrize("B,C,N,Kw", [(2, 192, 256, 200), (1, 192, 100, 180), (2, 64, 130, 20), (1, 192, 64, 256), (2, 32, 300, 33),
+                                      (1, 96, 513, 70)])
 def test_word_assign_vs_oracle(dev, B, C, N, Kw):
     from gfs3d import ops
     g = torch.Generator().manual_seed(Kw + N)
@@ -374,12 +375,15 @@ def test_proto_cosine_vs_oracle_with_grads(dev, B, C, N, K, per_sample):
     assert relerr(pd.grad, pr.grad) < TOL
 
 
-def test_word_assign_gradient(dev):
+@pytest.mark.parametrize("B,C,N,Kw", [(2, 192, 64, 50), (1, 192, 300, 200), (2, 64, 257, 33), (1, 128, 100, 256), (2, 96, 70, 40),
+                                      (1, 64, 40, 20)])
+def test_word_assign_gradient(dev, B, C, N, Kw):
+    """K3 backward w.r.t. the point features: bf16x6 kernel (K_w > 32, C in {64, 128, 192}) and the fp32 form."""
     from gfs3d import ops
-    g = torch.Generator().manual_seed(5)
-    feat = torch.randn(2, 192, 64, generator=g)
-    gp = torch.randn(50, 192, generator=g)
-    cot = torch.randn(2, 50, 64, generator=g)
+    g = torch.Generator().manual_seed(5 + N)
+    feat = torch.randn(B, C, N, generator=g)
+    gp = torch.randn(Kw, C, generator=g)
+    cot = torch.randn(B, Kw, N, generator=g)
     fr = feat.clone().requires_grad_(True)
     soft_r, _ = R.geometric_word_assign(gp, fr)
     (soft_r * cot).sum().backward()
@@ -548,7 +552,8 @@ def test_extract_geometric_words_end_to_end(dev):
     assert np.abs(w1 - w2).max() < 1e-3
 
 
-@pytest.mark.parametrize("M,C,K", [(5000, 192, 200), (4097, 64, 33), (130, 7, 3), (70000, 192, 256)])
+@pytest.mark.parametrize("M,C,K", [(5000, 192, 200), (4097, 64, 33), (130, 7, 3), (70000, 192, 256), (31, 64, 40), (257, 32, 64),
+                                   (2049, 96, 129)])
 def test_kmeans_assign_mfma_vs_fp64(dev, M, C, K):
     """Lloyd step on the matrix pipe: labels vs an fp64 arg-min (identical wherever the best two
     centroids are separated by more than fp32 rounding), sums / counts / inertia consistent with the
