@@ -964,3 +964,52 @@ def test_block_sharded_dp_two_ranks_average_their_shard_gradients(dev):
         # (float atomics in the backward: equal to rounding, not bit for bit)
         assert np.abs(out[r]["grad"] - mean).max() < 1e-4 * scale, r
     assert np.array_equal(out[0]["grad"], out[1]["grad"])
+
+
+def test_entry_points_are_graph_capture_safe(dev):
+    """include/gfs3d.h promises no allocation and no host synchronisation inside the entry points (the side-stream fork /
+    join of the training forward is event-based): a DGCNN eval forward and a whole training forward + backward captured
+    into hipGraphs replay to the eager results."""
+    from model.dgcnn import DGCNN
+    torch.manual_seed(0)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev)
+    x = R.synthetic_blocks(2, 256, seed=4).to(dev)
+    side = torch.cuda.Stream()
+
+    def warm(fn):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+
+    net.eval()
+    with torch.no_grad():
+        ref = net(x)[1].clone()
+        warm(lambda: net(x))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = net(x)[1]
+        g.replay()
+        torch.cuda.synchronize()
+        assert maxerr(out, ref) == 0.0
+    net.train()
+    params = list(net.parameters())
+
+    def step():
+        for p in params:
+            p.grad = None
+        net(x)[1].square().mean().backward()
+
+    warm(step)
+    step()
+    ref_g = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        net(x)[1].square().mean().backward()
+    g2.replay()
+    torch.cuda.synchronize()
+    for p, r_ in zip(params, ref_g):      # float atomics in the backward: equal to rounding
+        assert maxerr(p.grad, r_) <= 1e-4 * max(float(r_.abs().max()), 1e-12)
