@@ -105,7 +105,8 @@ static inline int ensure_dynamic_lds(const void *kernel, size_t bytes, LdsGrant 
 
 // pointwise.hip: out(M, Nc) = a(M, K) . w(Nc, K)^T on MFMA, point-major; the Nc columns are written as segments of
 // width o_segw to out[0], out[1], ...  (K % 32 == 0, Nc % 64 == 0, o_segw % 64 == 0, at most 4 segments)
-int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw, hipStream_t st,
-                  const char *who);
+// ea / eb (Nc floats each, or both NULL): out = fma(acc, ea[col], eb[col])
+int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw,
+                  const float *ea, const float *eb, hipStream_t st, const char *who);
 
 }  // namespace gfs3d

@@ -70,18 +70,6 @@ ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, i
     }
 }
 
-// F1 on MFMA (C == 64, point-major x available): rows 0..63 of wpq = Wa, rows 64..127 = Wb - Wa, so that
-// [P | Q](M, 128) = x_pm(M, C) . wpq^T is one plain GEMM (pointwise.hip).
-__global__ void ec_wpq_kernel(const float *__restrict__ w1, int C, float *__restrict__ wpq)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= EC * C) return;
-    const int co = e / C, c = e - co * C;
-    const float a = w1[(size_t)co * 2 * C + c];
-    wpq[e] = a;
-    wpq[EC * C + e] = w1[(size_t)co * 2 * C + C + c] - a;
-}
-
 // ---------------------------------------------------------------------------
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
@@ -273,6 +261,27 @@ __device__ __forceinline__ void bn_constants(const BnFin &f, int c, bool writer,
         stats[(row0 + 2) * EC + c] = scale;
         stats[(row0 + 3) * EC + c] = shift;
     }
+}
+
+// F1 on MFMA (C % 32 == 0, point-major x available): rows 0..63 of wpq = Wa, rows 64..127 = Wb - Wa, so that
+// [P | Q](M, 128) = x_pm(M, C) . wpq^T is one plain GEMM (pointwise.hip).  In eval mode the BatchNorm1 fold of
+// ec_prescale_kernel rides in that GEMM's epilogue instead (P' = P scale1, Q' = Q scale1 + shift1: `eab` = 128 column
+// scales, then 128 column shifts) and the prescale pass disappears.
+__global__ void ec_wpq_kernel(const float *__restrict__ w1, int C, float *__restrict__ wpq, const BnFin fin, float *__restrict__ stats,
+                              float *__restrict__ eab)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (eab && e < EC) {
+        float sc, sh;
+        bn_constants(fin, e, true, stats, (int)ST_MEAN1, sc, sh);
+        eab[e] = sc; eab[EC + e] = sc;
+        eab[2 * EC + e] = 0.f; eab[3 * EC + e] = sh;
+    }
+    if (e >= EC * C) return;
+    const int co = e / C, c = e - co * C;
+    const float a = w1[(size_t)co * 2 * C + c];
+    wpq[e] = a;
+    wpq[EC * C + e] = w1[(size_t)co * 2 * C + C + c] - a;
 }
 
 // ---------------------------------------------------------------------------
@@ -1291,13 +1300,17 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     double *acc1 = acc, *acc2 = acc + 2 * EC;
     float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
+    // eval mode with the point-major input: BatchNorm1 is folded into the projection GEMM, P / Q are never written
+    const bool fold = !a->training && a->x_pm && a->C % 32 == 0;
     if (phase == 0) {
         if (a->x_pm && a->C % 32 == 0) {
             float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
-            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq);
+            float *eab = fold ? reinterpret_cast<float *>(ws + p.off_bpart) : nullptr;       // (4, 64); likewise
+            const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
+            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq, fin1, a->stats, eab);
             GFS3D_LAUNCH_CHECK("ec_wpq_kernel");
-            float *outs[2] = {a->P, a->Q};
-            if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, st, who)) return rc;
+            float *outs[2] = {fold ? Pp : a->P, fold ? Qp : a->Q};
+            if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, eab, eab ? eab + 2 * EC : nullptr, st, who)) return rc;
         } else {
             const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
             GFS3D_ENSURE_LDS(ec_pq_kernel, lds, who);
@@ -1347,8 +1360,10 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     } else if (phase == 1) {
         const BnFin fin1{acc1, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training};
         const size_t total = (size_t)BN * EC;
-        hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, fin1, a->stats, total, Pp, Qp);
-        GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+        if (!fold) {
+            hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, fin1, a->stats, total, Pp, Qp);
+            GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
+        }
         ProfScope prof(1, st);
         hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
                            BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, acc2);

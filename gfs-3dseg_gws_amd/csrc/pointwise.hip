@@ -853,8 +853,8 @@ void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev
 
 }  // namespace
 
-int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw, hipStream_t st,
-                  const char *who)
+int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw,
+                  const float *ea, const float *eb, hipStream_t st, const char *who)
 {
     if (K % PW_BK || Nc % 64 || o_segw % 64 || Nc / o_segw > 4 || Nc % o_segw) {
         set_error("%s: pw_plain_gemm: unsupported shape K=%d Nc=%d segw=%d", who, K, Nc, o_segw);
@@ -865,6 +865,10 @@ int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc,
     rg.w = w; rg.M = M; rg.Nc = Nc;
     for (int s = 0; s < Nc / o_segw; ++s) rg.out[s] = out[s];
     rg.o_segw = o_segw;
+    if (ea && eb) {                                  // affine epilogue, identity activation
+        rg.ea = ea; rg.eb = eb; rg.slope = 1.f;
+        return rowgemm<PRO_NONE, EPI_AFFINE_ACT, false>(rg, st, who);
+    }
     return rowgemm<PRO_NONE, EPI_PLAIN, false>(rg, st, who);
 }
 }  // namespace gfs3d
