@@ -1096,6 +1096,7 @@ extern "C" int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, 
     GFS3D_REQUIRE(feat && words, "gfs3d_word_assign_f32: NULL input");
     GFS3D_REQUIRE(soft || assign || onehot, "gfs3d_word_assign_f32: no output requested");
     GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, "gfs3d_word_assign_f32: bad shape B=%d C=%d N=%d", B, C, N);
+    GFS3D_REQUIRE((long long)N * 256 * 4 < 0x7fffffffll && (long long)N * C * 4 < 0x7fffffffll, "gfs3d_word_assign_f32: N=%d too large for 32-bit plane offsets", N);
     GFS3D_REQUIRE(Kw >= 1 && Kw <= 256, "gfs3d_word_assign_f32: need 1 <= Kw <= 256, got %d", Kw);
     GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "gfs3d_word_assign_f32: bad feat_bstride");
     return dispatch_proto<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, words, 1, Kw, scale, soft, assign, onehot,
@@ -1108,6 +1109,7 @@ extern "C" int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride,
     using namespace gfs3d;
     GFS3D_REQUIRE(feat && proto && out, "gfs3d_proto_cosine_f32: NULL pointer");
     GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, "gfs3d_proto_cosine_f32: bad shape B=%d C=%d N=%d", B, C, N);
+    GFS3D_REQUIRE((long long)N * 256 * 4 < 0x7fffffffll && (long long)N * C * 4 < 0x7fffffffll, "gfs3d_proto_cosine_f32: N=%d too large for 32-bit plane offsets", N);
     GFS3D_REQUIRE(K >= 1 && K <= 256, "gfs3d_proto_cosine_f32: need 1 <= K <= 256, got %d", K);
     GFS3D_REQUIRE(P == 1 || P == B, "gfs3d_proto_cosine_f32: P must be 1 or B (got %d)", P);
     GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "gfs3d_proto_cosine_f32: bad feat_bstride");
@@ -1151,6 +1153,7 @@ extern "C" int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_b
     GFS3D_REQUIRE(K >= 1 && K <= 256, "%s: need 1 <= K <= 256, got %d", who, K);
     GFS3D_REQUIRE(P == 1 || P == B, "%s: P must be 1 or B (got %d)", who, P);
     GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "%s: bad feat_bstride", who);
+    GFS3D_REQUIRE((long long)N * 256 * 4 < 0x7fffffffll, "%s: N=%d too large for 32-bit plane offsets", who, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
     return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who);
