@@ -97,7 +97,12 @@ class FlatGradBucket:
         rank's loss is a mean over its equally sized shard)."""
         if not is_dist() or dist.get_world_size() == 1:
             return
-        if self._work is not None:                   # the early slice is in flight: exchange the rest, then join
+        if self.early:
+            # Every rank issues the SAME two collectives in the same order (early slice, remainder) whether or not its
+            # hook fired: a rank on which an early parameter received no gradient launches the slice late, here.
+            if self._work is None:
+                self._pack(0, len(self.early))
+                self._work = dist.all_reduce(self.flat[:self.n_early], op=dist.ReduceOp.SUM, async_op=True)
             self._pack(len(self.early), len(self.params))
             if self.n_early < self.flat.numel():
                 dist.all_reduce(self.flat[self.n_early:], op=dist.ReduceOp.SUM)
