@@ -105,12 +105,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # GFS3D_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("GFS3D_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gfs3d import _lib, dist as gdist
     from model.dgcnn import DGCNN
