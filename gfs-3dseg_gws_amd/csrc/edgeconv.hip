@@ -31,46 +31,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { ST_MEAN1 = 0, ST_RSTD1, ST_SCALE1, ST_SHIFT1, ST_MEAN2, ST_RSTD2, ST_SCALE2, ST_SHIFT2 };
 
 // ---------------------------------------------------------------------------
-// F1: P = Wa x, Q = (Wb - Wa) x            grid: (ceil(N/64), B), block 256
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, int N,
-             float *__restrict__ P, float *__restrict__ Q)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wa = smem;                 // [C][64]
-    float *wd = wa + C * EC;          // [C][64]
-    float *xs = wd + C * EC;          // [C][64 points]
-    const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
-    for (int e = tid; e < C * EC; e += 256) {
-        const int c = e >> 6, co = e & 63;
-        const float a = w1[(size_t)co * 2 * C + c];
-        const float bb = w1[(size_t)co * 2 * C + C + c];
-        wa[e] = a;
-        wd[e] = bb - a;
-    }
-    const float *xb = x + (size_t)b * C * N;
-    for (int e = tid; e < C * 64; e += 256) {
-        const int c = e >> 6, p = e & 63;
-        xs[e] = (n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
-    }
-    __syncthreads();
-    const int co = tid & 63, wv = tid >> 6;
-    for (int p = wv; p < 64; p += 4) {
-        if (n0 + p >= N) break;
-        float ap = 0.f, aq = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float xv = xs[c * 64 + p];
-            ap = fmaf(wa[c * EC + co], xv, ap);
-            aq = fmaf(wd[c * EC + co], xv, aq);
-        }
-        const size_t o = ((size_t)b * N + n0 + p) * EC + co;
-        P[o] = ap;
-        Q[o] = aq;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
 // ---------------------------------------------------------------------------
@@ -260,6 +220,48 @@ __device__ __forceinline__ void bn_constants(const BnFin &f, int c, bool writer,
         stats[(row0 + 1) * EC + c] = rstd;
         stats[(row0 + 2) * EC + c] = scale;
         stats[(row0 + 3) * EC + c] = shift;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// F1: P = Wa x, Q = (Wb - Wa) x            grid: (ceil(N/64), B), block 256
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, int N,
+             float *__restrict__ P, float *__restrict__ Q, const BnFin fin, float *__restrict__ stats, int fold)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wa = smem;                 // [C][64]
+    float *wd = wa + C * EC;          // [C][64]
+    float *xs = wd + C * EC;          // [C][64 points]
+    const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
+    for (int e = tid; e < C * EC; e += 256) {
+        const int c = e >> 6, co = e & 63;
+        const float a = w1[(size_t)co * 2 * C + c];
+        const float bb = w1[(size_t)co * 2 * C + C + c];
+        wa[e] = a;
+        wd[e] = bb - a;
+    }
+    const float *xb = x + (size_t)b * C * N;
+    for (int e = tid; e < C * 64; e += 256) {
+        const int c = e >> 6, p = e & 63;
+        xs[e] = (n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
+    }
+    __syncthreads();
+    const int co = tid & 63, wv = tid >> 6;
+    float sc = 1.f, sh = 0.f;                          // eval mode: the BatchNorm1 fold of ec_prescale_kernel happens here
+    if (fold) bn_constants(fin, co, blockIdx.x == 0 && blockIdx.y == 0 && wv == 0, stats, (int)ST_MEAN1, sc, sh);
+    for (int p = wv; p < 64; p += 4) {
+        if (n0 + p >= N) break;
+        float ap = 0.f, aq = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float xv = xs[c * 64 + p];
+            ap = fmaf(wa[c * EC + co], xv, ap);
+            aq = fmaf(wd[c * EC + co], xv, aq);
+        }
+        const size_t o = ((size_t)b * N + n0 + p) * EC + co;
+        P[o] = fold ? ap * sc : ap;
+        Q[o] = fold ? fmaf(aq, sc, sh) : aq;
     }
 }
 
@@ -1300,8 +1302,9 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     double *acc1 = acc, *acc2 = acc + 2 * EC;
     float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
-    // eval mode with the point-major input: BatchNorm1 is folded into the projection GEMM, P / Q are never written
-    const bool fold = !a->training && a->x_pm && a->C % 32 == 0;
+    // eval mode: BatchNorm1 (running statistics) is folded into the projection kernels, P / Q are never written and
+    // there is no prescale pass
+    const bool fold = !a->training;
     if (phase == 0) {
         if (a->x_pm && a->C % 32 == 0) {
             float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
@@ -1314,7 +1317,9 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         } else {
             const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
             GFS3D_ENSURE_LDS(ec_pq_kernel, lds, who);
-            hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, a->P, a->Q);
+            const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
+            hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, fold ? Pp : a->P, fold ? Qp : a->Q,
+                               fin1, a->stats, fold ? 1 : 0);
             GFS3D_LAUNCH_CHECK("ec_pq_kernel");
         }
         if (a->training) {
