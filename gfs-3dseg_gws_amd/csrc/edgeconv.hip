@@ -492,7 +492,7 @@ ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmi
                    const uint8_t *__restrict__ jmax, const uint8_t *__restrict__ jmin,
                    const BnFin fin, float *__restrict__ stats, int N, float slope,
                    float *__restrict__ y_cf, long long y_bstride, float *__restrict__ y_pm,
-                   float *__restrict__ hsel, uint8_t *__restrict__ jsel)
+                   float *__restrict__ hsel, uint8_t *__restrict__ jsel, float *__restrict__ y_sq)
 {
     __shared__ float tile[64][65];
     __shared__ float scs[EC], shs[EC];
@@ -516,6 +516,12 @@ ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmi
         tile[p][co] = y;
     }
     __syncthreads();
+    if (y_sq && tid < 64 && n0 + tid < N) {            // |y_n|^2 for the next layer's kNN, in its kernel's order (knn.hip: knn_sqnorm_kernel)
+        float sq = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < EC; ++c) sq = __fadd_rn(sq, __fmul_rn(tile[tid][c], tile[tid][c]));
+        y_sq[(size_t)b * N + n0 + tid] = sq;
+    }
     if (y_cf) {
         const int p = tid & 63;
         for (int c = wv; c < EC; c += 4) {
@@ -1376,7 +1382,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
         hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, fin2, a->stats, a->N, a->slope,
-                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel);
+                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
         SideLane *lane = a->training ? side_lane() : nullptr;
         if (lane && hipStreamWaitEvent(st, lane->join, 0) != hipSuccess) {

@@ -453,7 +453,8 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 }
 
 template <int CS, int K>
-static int launch_knn_mfma(const float *x, float *sq, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32, hipStream_t st)
+static int launch_knn_mfma(const float *x, float *sq, bool have_norms, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32,
+                           hipStream_t st)
 {
     constexpr int QS = knn_mfma_queue<CS, K>();
     const size_t lds = sizeof(float) * 4 * (size_t)(2 * QS * 64);
@@ -464,8 +465,10 @@ static int launch_knn_mfma(const float *x, float *sq, int B, int C, int N, int k
     while (two_pass > 0 && 2 * ((N / 32 + two_pass - 1) / two_pass) < 2 * K) --two_pass;
     if (N < KNN_TWO_PASS_MIN_N) two_pass = 0;
     ProfScope prof(0, st);
-    hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
-    GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
+    if (!have_norms) {
+        hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
+        GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
+    }
     hipLaunchKernelGGL((knn_mfma_kernel<CS, K>), grid, dim3(256), lds, st, x, sq, B, C, N, k, two_pass, idx64, idx32);
     GFS3D_LAUNCH_CHECK("gfs3d_knn_topk_f32(mfma)");
     return GFS3D_OK;
@@ -496,31 +499,48 @@ extern "C" size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k)
     return (B < 1 || N < 1) ? 0 : sizeof(float) * (size_t)B * N + 64;    // norms + slack for 16-byte reads at the end
 }
 
-extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
-                                  int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
+static int knn_entry(const char *who, const float *x, const float *norms, int B, int C, int N, int k,
+                     int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace gfs3d;
-    GFS3D_REQUIRE(x != nullptr, "gfs3d_knn_topk_f32: x is NULL");
-    GFS3D_REQUIRE(idx64 != nullptr || idx32 != nullptr, "gfs3d_knn_topk_f32: both outputs NULL");
-    GFS3D_REQUIRE(B >= 0 && C >= 1 && N >= 1, "gfs3d_knn_topk_f32: bad shape B=%d C=%d N=%d", B, C, N);
-    GFS3D_REQUIRE(k >= 1 && k <= N && k <= 64, "gfs3d_knn_topk_f32: need 1 <= k <= min(N,64), got k=%d N=%d", k, N);
-    GFS3D_REQUIRE(B <= 65535, "gfs3d_knn_topk_f32: B=%d exceeds grid.y", B);
+    GFS3D_REQUIRE(x != nullptr, "%s: x is NULL", who);
+    GFS3D_REQUIRE(idx64 != nullptr || idx32 != nullptr, "%s: both outputs NULL", who);
+    GFS3D_REQUIRE(B >= 0 && C >= 1 && N >= 1, "%s: bad shape B=%d C=%d N=%d", who, B, C, N);
+    GFS3D_REQUIRE(k >= 1 && k <= N && k <= 64, "%s: need 1 <= k <= min(N,64), got k=%d N=%d", who, k, N);
+    GFS3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y", who, B);
     if (B == 0) return GFS3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C <= 64 && k <= 32) {          // MFMA path; the workspace holds the point norms
-        GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "gfs3d_knn_topk_f32: C*N too large for 32-bit buffer offsets");
-        GFS3D_REQUIRE(workspace != nullptr, "gfs3d_knn_topk_f32: NULL workspace");
-        if (workspace_bytes < gfs3d_knn_workspace_bytes(B, C, N, k)) {
-            set_error("gfs3d_knn_topk_f32: workspace %zu < required %zu", workspace_bytes, gfs3d_knn_workspace_bytes(B, C, N, k));
-            return GFS3D_ERR_WORKSPACE;
+    if (C <= 64 && k <= 32) {          // MFMA path; the point norms come from the caller or are computed into the workspace
+        GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "%s: C*N too large for 32-bit buffer offsets", who);
+        float *sq = const_cast<float *>(norms);
+        if (!norms) {
+            GFS3D_REQUIRE(workspace != nullptr, "%s: NULL workspace", who);
+            if (workspace_bytes < gfs3d_knn_workspace_bytes(B, C, N, k)) {
+                set_error("%s: workspace %zu < required %zu", who, workspace_bytes, gfs3d_knn_workspace_bytes(B, C, N, k));
+                return GFS3D_ERR_WORKSPACE;
+            }
+            sq = static_cast<float *>(workspace);
         }
-        float *sq = static_cast<float *>(workspace);
-        if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, B, C, N, k, idx64, idx32, st);
-        if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, B, C, N, k, idx64, idx32, st);
-        return launch_knn_mfma<32, 32>(x, sq, B, C, N, k, idx64, idx32, st);
+        if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
+        if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
+        return launch_knn_mfma<32, 32>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
     }
-    // generic shapes: VALU kernel (any C that fits LDS, k <= 64)
+    // generic shapes: VALU kernel (any C that fits LDS, k <= 64); computes its own norms
     if (k <= 20) return launch_knn<20>(x, B, C, N, k, idx64, idx32, st);
     if (k <= 32) return launch_knn<32>(x, B, C, N, k, idx64, idx32, st);
     return launch_knn<64>(x, B, C, N, k, idx64, idx32, st);
+}
+
+extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
+                                  int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return knn_entry("gfs3d_knn_topk_f32", x, nullptr, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, int N, int k,
+                                        int64_t *idx64, int32_t *idx32, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(sqnorm != nullptr, "gfs3d_knn_topk_norms_f32: sqnorm is NULL");
+    return knn_entry("gfs3d_knn_topk_norms_f32", x, sqnorm, B, C, N, k, idx64, idx32, nullptr, 0, stream);
 }

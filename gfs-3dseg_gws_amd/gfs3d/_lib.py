@@ -33,6 +33,7 @@ class EdgeConvArgs(Structure):
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("x_pm", c_void_p),
         ("Pp", c_void_p), ("Qp", c_void_p),
+        ("y_sqnorm", c_void_p),
     ]
 
 
@@ -83,6 +84,7 @@ SYMBOLS = {
     "gfs3d_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_longlong)]),
     "gfs3d_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_knn_topk_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gfs3d_knn_topk_norms_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),
     "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),

@@ -51,9 +51,10 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # K1
 # --------------------------------------------------------------------------
-def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False):
+def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False, sqnorm: Optional[torch.Tensor] = None):
     """x (B,C,N) channel-first -> neighbour indices (B,N,k), nearest first.
-    Replaces knn() of model/dgcnn.py:17-23."""
+    Replaces knn() of model/dgcnn.py:17-23.  `sqnorm`: the point norms if the caller has them in the kernel's
+    summation order (the third output of `edgeconv_block(..., want_sq=True)` for the previous block's features)."""
     _need_gpu(x, "x")
     if x.dim() != 3:
         raise RuntimeError("gfs3d.knn_topk: x must be (B,C,N)")
@@ -63,8 +64,13 @@ def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = Fa
     i32 = torch.empty((B, N, k), dtype=torch.int32, device=x.device) if want_i32 else None
     with torch.cuda.device(x.device):
         L = _lib.lib()
-        ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
-        rc = L.gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
+        if sqnorm is not None:
+            if sqnorm.dtype != torch.float32 or not sqnorm.is_contiguous() or sqnorm.numel() < B * N + 16 or sqnorm.device != x.device:
+                raise RuntimeError("gfs3d.knn_topk: sqnorm must be a contiguous fp32 tensor of B*N + 16 elements on x's device")
+            rc = L.gfs3d_knn_topk_norms_f32(_p(x), _p(sqnorm), B, C, N, int(k), _p(i64), _p(i32), _stream())
+        else:
+            ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
+            rc = L.gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
     _lib.check(rc, "gfs3d_knn_topk_f32")
     if want_i64 and want_i32:
         return i64, i32
@@ -128,6 +134,7 @@ class EdgeConvRun:
         else:
             self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.Pp = self.Qp = None
         self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)      # point-major copy: input of the point-wise stack (K4)
+        self.y_sq = torch.empty(B * N + 16, **f32)            # |y_n|^2 for the next layer's kNN (+ the slack its 16-B reads need)
         self.y = torch.empty((B, EC_WIDTH, N), **f32)
         nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(B, C, N, k)
         self._private_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
@@ -156,6 +163,7 @@ class EdgeConvRun:
         ws = self._private_ws if self._private_ws is not None else _workspace(self.x.device, self._nbytes)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.x_pm = self.x_pm.data_ptr() if self.x_pm is not None else None
+        a.y_sqnorm = self.y_sq.data_ptr() if self.y_sq is not None else None
         return ws
 
     def _bwd_args(self, dy, dy_pm=None):
@@ -256,10 +264,13 @@ class EdgeConvFunction(torch.autograd.Function):
         if training:
             ctx.c = run
             ctx.sync = sync
-        return y, run.y_pm.detach()      # alias: the backward reads y_pm (sign of the activation)
+        y_sq = run.y_sq
+        run.y_sq = None
+        ctx.mark_non_differentiable(y_sq)
+        return y, run.y_pm.detach(), y_sq      # y_pm is an alias: the backward reads it (sign of the activation)
 
     @staticmethod
-    def backward(ctx, dy, dy_pm):
+    def backward(ctx, dy, dy_pm, _dy_sq=None):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
         if dy is None and dy_pm is None:
@@ -271,7 +282,7 @@ class EdgeConvFunction(torch.autograd.Function):
 
 def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
                    sync: Optional[BNSync] = None, want_pm: bool = False, x_pm: Optional[torch.Tensor] = None,
-                   track: bool = True):
+                   track: bool = True, want_sq: bool = False):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
     training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks.  `x_pm`: the
@@ -283,10 +294,12 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
     mom = bn1.momentum if bn1.momentum is not None else 0.1
-    y, y_pm = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
+    y, y_pm, y_sq = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
                                      bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
                                      bool(training), float(bn1.eps), float(mom), float(slope), sync,
                                      x_pm.detach() if x_pm is not None else None)
+    if want_sq:                              # (y, y_pm, |y|^2 in the kNN kernel's order: `knn_topk(..., sqnorm=)` of the next block)
+        return y, y_pm, y_sq
     return (y, y_pm) if want_pm else y
 
 

@@ -127,12 +127,12 @@ class DGCNN(nn.Module):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
         with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
         feats, feats_pm, bns = [], [], []
-        x_pm = None
+        x_pm = x_sq = None
         for block in self.edge_convs:
             c1, bn1, c2, bn2 = block.fused_parts()
-            idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True)
-            x, x_pm = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
-                                         sync=self.bn_sync, want_pm=True, x_pm=x_pm, track=False)
+            idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True, sqnorm=x_sq)
+            x, x_pm, x_sq = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
+                                               sync=self.bn_sync, x_pm=x_pm, track=False, want_sq=True)
             bns += [bn1, bn2]
             feats.append(x)
             feats_pm.append(x_pm)

@@ -62,6 +62,13 @@ size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k);
 int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
                        int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the point norms supplied by the caller: sqnorm[b*N + n] = sum_c x[b][c][n]^2 in sequential-c order with
+ * rounded squares (what gfs3d_edgeconv_forward_f32 leaves in y_sqnorm), B*N floats followed by >= 16 readable floats.
+ * Shapes outside the matrix path (C > 64 or k > 32) ignore the norms and behave like gfs3d_knn_topk_f32 (which then
+ * needs no workspace either). */
+int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, int N, int k,
+                             int64_t *idx64, int32_t *idx32, void *stream);
+
 /* ------------------------------------------------------------------ K2 --
  * One EdgeConv block = get_edge_feature (dgcnn.py:26-42) + conv2d block
  * [1x1 conv -> BatchNorm2d -> LeakyReLU(0.2)] x2 (dgcnn.py:45-61) + max over
@@ -95,6 +102,9 @@ typedef struct gfs3d_edgeconv_args {
                                      two projections run as one MFMA GEMM; NULL = channel-first path */
     float *Pp, *Qp;               /* optional (B, N, 64) each: the BatchNorm-folded projections the heavy kernels read; forward
                                      writes them here and backward reuses them (NULL: scratch, recomputed in backward) */
+    float *y_sqnorm;              /* optional out (B*N floats + 16 floats of slack): |y_n|^2 summed over the 64 channels in the kNN
+                                     kernel's order (sequential c, rounded squares) - hand it to gfs3d_knn_topk_norms_f32 for
+                                     the next layer's graph instead of a norm pass */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);

@@ -1013,3 +1013,26 @@ def test_entry_points_are_graph_capture_safe(dev):
     torch.cuda.synchronize()
     for p, r_ in zip(params, ref_g):      # float atomics in the backward: equal to rounding
         assert maxerr(p.grad, r_) <= 1e-4 * max(float(r_.abs().max()), 1e-12)
+
+
+def test_edgeconv_norm_handoff_is_bit_exact(dev):
+    """The |y|^2 the EdgeConv epilogue leaves for the next layer's kNN (sequential-c sum of rounded squares) gives
+    exactly the graph the kNN kernel builds when it computes the norms itself - eval and training mode."""
+    from gfs3d import ops
+    B, C, N, k = 3, 9, 700, 20
+    p = _block_params(C, 77)
+    x = R.synthetic_blocks(B, N, seed=11).to(dev)
+    idx = ops.knn_topk(x, k, want_i64=False, want_i32=True)
+    for training in (False, True):
+        blk = _make_block(p, C, dev).train(training)
+        c1, bn1, c2, bn2 = blk.fused_parts()
+        with torch.no_grad():
+            y, y_pm, y_sq = ops.edgeconv_block(x, idx, c1.weight, bn1, c2.weight, bn2, training, want_sq=True)
+        a = ops.knn_topk(y, k)
+        b = ops.knn_topk(y, k, sqnorm=y_sq)
+        assert torch.equal(a, b)
+        ref = np.zeros((B, N), dtype=np.float32)
+        yc = y.cpu().numpy()
+        for c in range(64):
+            ref = (ref + (yc[:, c, :] * yc[:, c, :]).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(y_sq[:B * N].cpu().numpy().reshape(B, N), ref)
