@@ -52,11 +52,11 @@ def algorithmic_flops(kid, B):
 
 
 def hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r01_d_hbm_traffic.json:
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r01_e_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note;
     scripts/collect_profiles.py)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")) as f:
             return json.load(f).get(kernel, {}).get("traffic_bytes_per_launch")
     except OSError:
         return None
