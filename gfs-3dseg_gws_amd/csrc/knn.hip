@@ -27,7 +27,9 @@ constexpr int KNN_QMIN = 32;     // queue slots per lane (>= TJ + 16)
 // bound pass: sample every 2nd tile when the distance itself is cheap (C <= 10: 5 MFMAs per tile); at C = 64 the
 // extra 32 MFMAs per sampled tile cost what the saved inserts gain (fp32 MFMA and VALU share the SIMD's issue time)
 constexpr int KNN_TWO_PASS_SMALL_C = 2, KNN_TWO_PASS_LARGE_C = 0;
-constexpr int KNN_TWO_PASS_MIN_N = 512;   // below this the bound pass costs more than the inserts it saves
+constexpr int KNN_TWO_PASS_MIN_N = 512;
+// (a lane's queue is merged into its list, and the threshold refreshed, once any lane holds more than QS - 16 entries;
+// flushing at 8 instead of 16 was measured: the loop set-up costs what the fresher threshold saves)   // below this the bound pass costs more than the inserts it saves
 
 template <int K>
 struct TopList {
@@ -415,6 +417,12 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
             cnt = 0;
             qslot = queue + lane;
             thr = fmaxf(thr, best.v[K - 1]);
+            // The two lane halves of a query keep separate lists over interleaved candidates, but the final answer is the
+            // top-K of their union: each half has K/2 values >= its own (K/2)-th best, so the smaller of the two (K/2)-th
+            // bests is reached by K candidates of the union - a bound close to the union's K-th best, about twice as tight
+            // as a half's own K-th.  (next_below: a tie with it may still win on the index across the halves.)
+            const float mid = best.v[K / 2 - 1];
+            thr = fmaxf(thr, next_below(fminf(mid, __shfl_xor(mid, 32, 64))));
         }
         __builtin_amdgcn_wave_barrier();
     };
