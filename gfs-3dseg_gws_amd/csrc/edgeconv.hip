@@ -324,12 +324,12 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 // holds channels 8kb..8kb+7 (lane half 0) and 32+8kb.. (lane half 1) for both operands.
 // 48 MFMAs of 32 cycles per 32-edge tile instead of 64 of 64 cycles.
 // ---------------------------------------------------------------------------
+template <bool STATS>
 __global__ void __launch_bounds__(256, 2)
 ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
-                   const float *__restrict__ w2,
-                   int BN, int N, int k, float slope, int want_stats,
-                   float *__restrict__ hmax, float *__restrict__ hmin,
-                   uint8_t *__restrict__ jmax, uint8_t *__restrict__ jmin,
+                   const float *__restrict__ w2, const float *__restrict__ gamma2,
+                   int BN, int N, int k, float slope,
+                   float *__restrict__ hsel, uint8_t *__restrict__ jsel,
                    double *__restrict__ partial)
 {
     constexpr int WROW = 3 * 2 * EC + 16;               // bytes per W2 row image
@@ -337,9 +337,12 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     __shared__ double red[4][2][2][EC];                 // [wave][half][s|ss][64]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    // max_j LReLU(BN2(h_j)) is reached at max_j h_j where scale2 >= 0 and at min_j h_j elsewhere, and sign(scale2) =
+    // sign(gamma2) whatever the batch statistics turn out to be: the rows of W2 with a negative gamma go into the image
+    // NEGATED, the kernel tracks one maximum (of +-h, exactly the negation) and undoes the sign where it stores.
     for (int e = tid; e < EC * EC; e += 256) {
         unsigned ph, pm, pl;
-        split3(w2[e], ph, pm, pl);
+        split3(gamma2[e >> 6] < 0.f ? -w2[e] : w2[e], ph, pm, pl);
         unsigned short *o = reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * WROW) + (e & 63);
         o[0] = (unsigned short)(ph >> 16);
         o[EC] = (unsigned short)(pm >> 16);
@@ -353,6 +356,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     double sd0 = 0.0, ssd0 = 0.0, sd1 = 0.0, ssd1 = 0.0;
     const unsigned char *wrow0 = sW3 + i * WROW + 64 * h;            // + piece * 128 + kb * 16
     const unsigned char *wrow1 = sW3 + (32 + i) * WROW + 64 * h;
+    const float sg0 = gamma2[i] < 0.f ? -1.f : 1.f, sg1 = gamma2[32 + i] < 0.f ? -1.f : 1.f;      // C/D layout: lane = channel
 
     const int nst = (BN + 7) >> 3;
     for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
@@ -370,13 +374,12 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 qA[4 * v + 0] = t4.x; qA[4 * v + 1] = t4.y; qA[4 * v + 2] = t4.z; qA[4 * v + 3] = t4.w;
             }
         }
-        float mx0[4], mn0[4], mx1[4], mn1[4];
-        int jx0[4], jn0[4], jx1[4], jn1[4];
+        float mx0[4], mx1[4];
+        int jx0[4], jx1[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             mx0[q] = mx1[q] = -__builtin_inff();
-            mn0[q] = mn1[q] = __builtin_inff();
-            jx0[q] = jn0[q] = jx1[q] = jn1[q] = 0;
+            jx0[q] = jx1[q] = 0;
         }
         float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
         // software pipeline: rows of tile t+1 and the neighbour id of tile t+2 are in flight while
@@ -444,15 +447,15 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 const int j = 4 * t + (r & 3);
                 const bool ok = (j < k) && (n0 + 4 * h + q < BN);
                 const float v0 = acc0[r], v1 = acc1[r];
-                const bool gx0 = ok && v0 > mx0[q], gn0 = ok && v0 < mn0[q];
-                const bool gx1 = ok && v1 > mx1[q], gn1 = ok && v1 < mn1[q];
+                const bool gx0 = ok && v0 > mx0[q];
+                const bool gx1 = ok && v1 > mx1[q];
                 mx0[q] = gx0 ? v0 : mx0[q]; jx0[q] = gx0 ? j : jx0[q];
-                mn0[q] = gn0 ? v0 : mn0[q]; jn0[q] = gn0 ? j : jn0[q];
                 mx1[q] = gx1 ? v1 : mx1[q]; jx1[q] = gx1 ? j : jx1[q];
-                mn1[q] = gn1 ? v1 : mn1[q]; jn1[q] = gn1 ? j : jn1[q];
-                const float u0 = ok ? v0 : 0.f, u1 = ok ? v1 : 0.f;
-                s0 += u0; ss0 = fmaf(u0, u0, ss0);
-                s1 += u1; ss1 = fmaf(u1, u1, ss1);
+                if (STATS) {
+                    const float u0 = ok ? v0 : 0.f, u1 = ok ? v1 : 0.f;
+                    s0 += u0; ss0 = fmaf(u0, u0, ss0);
+                    s1 += u1; ss1 = fmaf(u1, u1, ss1);
+                }
             }
         }
 #pragma unroll
@@ -460,17 +463,15 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             const int pt = n0 + 4 * h + q;
             if (pt < BN) {
                 const size_t o = (size_t)pt * EC + i;
-                hmax[o] = mx0[q]; hmax[o + 32] = mx1[q];
-                hmin[o] = mn0[q]; hmin[o + 32] = mn1[q];
-                jmax[o] = (uint8_t)jx0[q]; jmax[o + 32] = (uint8_t)jx1[q];
-                jmin[o] = (uint8_t)jn0[q]; jmin[o + 32] = (uint8_t)jn1[q];
+                hsel[o] = sg0 * mx0[q]; hsel[o + 32] = sg1 * mx1[q];          // the true pre-BN2 value
+                jsel[o] = (uint8_t)jx0[q]; jsel[o + 32] = (uint8_t)jx1[q];
             }
         }
         sd0 += (double)s0; ssd0 += (double)ss0;
         sd1 += (double)s1; ssd1 += (double)ss1;
     }
-    if (want_stats) {
-        red[wv][h][0][i] = sd0;  red[wv][h][0][i + 32] = sd1;
+    if (STATS) {
+        red[wv][h][0][i] = sg0 * sd0;  red[wv][h][0][i + 32] = sg1 * sd1;       // sums of the true h (squares need no sign)
         red[wv][h][1][i] = ssd0; red[wv][h][1][i + 32] = ssd1;
         __syncthreads();
         if (tid < 128) {
@@ -488,8 +489,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 // layouts, compact (hsel, jsel).  block = 256 threads = tile of 64 points.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmin,
-                   const uint8_t *__restrict__ jmax, const uint8_t *__restrict__ jmin,
+ec_epilogue_kernel(const float *__restrict__ hwin, const uint8_t *__restrict__ jwin,
                    const BnFin fin, float *__restrict__ stats, int N, float slope,
                    float *__restrict__ y_cf, long long y_bstride, float *__restrict__ y_pm,
                    float *__restrict__ hsel, uint8_t *__restrict__ jsel, float *__restrict__ y_sq)
@@ -506,9 +506,8 @@ ec_epilogue_kernel(const float *__restrict__ hmax, const float *__restrict__ hmi
         float y = 0.f;
         if (n < N) {
             const size_t o = ((size_t)b * N + n) * EC + co;
-            const bool up = sc >= 0.f;
-            const float h = up ? hmax[o] : hmin[o];
-            const uint8_t j = up ? jmax[o] : jmin[o];
+            const float h = hwin[o];                   // the pre-BN2 value whose image is the maximum (ec_main_fwd_kernel)
+            const uint8_t j = jwin[o];
             y = lrelu(fmaf(h, sc, sh), slope);
             if (hsel) { hsel[o] = h; jsel[o] = j; }
             if (y_pm) y_pm[o] = y;
@@ -1178,7 +1177,7 @@ struct Plan {
     int g_mfma;         // blocks of the forward MFMA kernel (4 waves each, a wave walks super-tiles of 8 points)
     int g_bwd;          // blocks of the heavy backward kernel (4 waves each: one per SIMD, one block per CU)
     int tiles;          // ceil(N/64) * B
-    size_t off_part, off_hmax, off_hmin, off_jmax, off_jmin, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
+    size_t off_part, off_hmax, off_jmax, off_Pp, off_Qp;   // forward (Pp/Qp also backward)
     size_t off_dred;                                                     // reduced partials (doubles)
     size_t off_acc;                                                      // 4 x 64 fp64 atomic accumulators (BN sums)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
@@ -1216,12 +1215,9 @@ static Plan make_plan(int B, int C, int N, int k)
     }
     p.off_acc = take(sizeof(double) * 8 * EC);
     p.off_hmax = take(sizeof(float) * BN * EC);
-    p.off_hmin = take(sizeof(float) * BN * EC);
     p.off_jmax = take(BN * EC);
-    p.off_jmin = take(BN * EC);
     p.off_Pp = take(sizeof(float) * BN * EC);
     p.off_Qp = take(sizeof(float) * BN * EC);
-    // backward reuses hmax/hmin/jmax/jmin space? keep separate: simpler, memory is plentiful
     p.off_g = take(sizeof(float) * BN * EC);
     p.off_GP = take(sizeof(float) * BN * EC);
     p.off_GQ = take(sizeof(float) * BN * EC);
@@ -1302,8 +1298,8 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
     const double count = stat_count > 0.0 ? stat_count : (double)BN * a->k;
-    float *hmax = reinterpret_cast<float *>(ws + p.off_hmax), *hmin = reinterpret_cast<float *>(ws + p.off_hmin);
-    uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax), *jmin = reinterpret_cast<uint8_t *>(ws + p.off_jmin);
+    float *hmax = reinterpret_cast<float *>(ws + p.off_hmax);          // winning pre-BN2 value / neighbour slot per (point, channel)
+    uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     double *acc1 = acc, *acc2 = acc + 2 * EC;
     float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
@@ -1376,12 +1372,16 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         }
         ProfScope prof(1, st);
-        hipLaunchKernelGGL(ec_main_fwd_kernel, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2,
-                           BN, a->N, a->k, a->slope, a->training, hmax, hmin, jmax, jmin, acc2);
+        if (a->training)
+            hipLaunchKernelGGL(ec_main_fwd_kernel<true>, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
+                               BN, a->N, a->k, a->slope, hmax, jmax, acc2);
+        else
+            hipLaunchKernelGGL(ec_main_fwd_kernel<false>, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
+                               BN, a->N, a->k, a->slope, hmax, jmax, acc2);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
-        hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, hmin, jmax, jmin, fin2, a->stats, a->N, a->slope,
+        hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, jmax, fin2, a->stats, a->N, a->slope,
                            a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
         SideLane *lane = a->training ? side_lane() : nullptr;
