@@ -325,7 +325,8 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 // 48 MFMAs of 32 cycles per 32-edge tile instead of 64 of 64 cycles.
 // ---------------------------------------------------------------------------
 template <bool STATS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, STATS ? 2 : 3)      // the eval form fits three workgroups per CU (168 VGPRs): 1.06 -> 0.99 ms eval forward;
+                                                           // forcing the training form there spills and was measured slower (0.251 -> 0.273 ms per step)
 ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2, const float *__restrict__ gamma2,
                    int BN, int N, int k, float slope,
@@ -1372,11 +1373,12 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         }
         ProfScope prof(1, st);
+        const dim3 g_fwd(min(p.g_mfma + p.g_mfma / 2, (BN + 31) / 32));       // eval: 3 resident workgroups per CU
         if (a->training)
             hipLaunchKernelGGL(ec_main_fwd_kernel<true>, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
                                BN, a->N, a->k, a->slope, hmax, jmax, acc2);
         else
-            hipLaunchKernelGGL(ec_main_fwd_kernel<false>, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
+            hipLaunchKernelGGL(ec_main_fwd_kernel<false>, g_fwd, dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
                                BN, a->N, a->k, a->slope, hmax, jmax, acc2);
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     } else {
