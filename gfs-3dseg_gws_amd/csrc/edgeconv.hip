@@ -105,6 +105,46 @@ rev_slot_kernel(const int32_t *__restrict__ idx, size_t nedges, int N, int k, in
         ovf[o] = make_int2((int)tm, (int)pt);
     }
 }
+// The same table built per point-cloud block in LDS (N <= 8192): a workgroup owns RB_TARGETS targets of one block, scans
+// that block's N k edges and appends the sources of its targets to a [RB_TARGETS][64] u16 table with LDS atomics; the
+// table then goes out as whole coalesced rows (the global form above pays a returning device atomic and a scattered
+// 4-byte store per edge: 51 -> 13 us per layer at B = 32 x 2048).
+constexpr int RB_TARGETS = 1024;
+constexpr size_t RB_LDS = sizeof(int) * RB_TARGETS + sizeof(unsigned short) * RB_TARGETS * REV_CAP;
+__global__ void __launch_bounds__(1024)
+rev_block_kernel(const int32_t *__restrict__ idx, int N, int k, int *__restrict__ cnt, int *__restrict__ slot,
+                 int *__restrict__ ovf_cnt, int2 *__restrict__ ovf)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rb_smem[];
+    int *lcnt = reinterpret_cast<int *>(rb_smem);
+    unsigned short *tab = reinterpret_cast<unsigned short *>(lcnt + RB_TARGETS);
+    const int tid = threadIdx.x, b = blockIdx.y, m0 = blockIdx.x * RB_TARGETS;
+    const int rows = min(RB_TARGETS, N - m0);
+    const int base = b * N;
+    for (int m = tid; m < RB_TARGETS; m += 1024) lcnt[m] = 0;
+    __syncthreads();
+    const int32_t *ib = idx + (size_t)base * k;
+    const int ne = N * k;
+    for (int e = tid; e < ne; e += 1024) {
+        const unsigned m = (unsigned)(ib[e] - m0);
+        if (m < (unsigned)rows) {
+            const int n = e / k;
+            const int pos = atomicAdd(&lcnt[m], 1);
+            if (pos < REV_CAP) {
+                tab[m * REV_CAP + pos] = (unsigned short)n;
+            } else {
+                const int o = atomicAdd(ovf_cnt, 1);
+                ovf[o] = make_int2(base + m0 + (int)m, base + n);
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < rows * REV_CAP; q += 1024) {      // entries past a row's count are never read
+        const int m = q / REV_CAP, pos = q - m * REV_CAP;
+        slot[(size_t)(base + m0 + m) * REV_CAP + pos] = base + (int)tab[q];
+    }
+    for (int m = tid; m < rows; m += 1024) cnt[base + m0 + m] = lcnt[m];
+}
 // wave per target point, lane = channel
 __global__ void __launch_bounds__(256)
 rev_gather_kernel(const float *__restrict__ Q, const int *__restrict__ cnt, const int *__restrict__ slot,
@@ -1340,13 +1380,24 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
                 int *slot = reinterpret_cast<int *>(ws + p.off_slot);
                 int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
                 const size_t nedges = (size_t)BN * a->k;
-                if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), rs) != hipSuccess) {
-                    set_error("%s: hipMemsetAsync failed", who);
-                    return GFS3D_ERR_HIP;
+                if (a->N <= 8192) {                    // per-block table in LDS; only the overflow counter needs zeroing
+                    GFS3D_ENSURE_LDS(rev_block_kernel, RB_LDS, who);
+                    if (hipMemsetAsync(ovf_cnt, 0, sizeof(int) * 4, rs) != hipSuccess) {
+                        set_error("%s: hipMemsetAsync failed", who);
+                        return GFS3D_ERR_HIP;
+                    }
+                    hipLaunchKernelGGL(rev_block_kernel, dim3((a->N + RB_TARGETS - 1) / RB_TARGETS, a->B), dim3(1024), RB_LDS, rs,
+                                       a->idx, a->N, a->k, cnt, slot, ovf_cnt, ovf);
+                    GFS3D_LAUNCH_CHECK("rev_block_kernel");
+                } else {
+                    if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), rs) != hipSuccess) {
+                        set_error("%s: hipMemsetAsync failed", who);
+                        return GFS3D_ERR_HIP;
+                    }
+                    hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, rs, a->idx, nedges, a->N, a->k,
+                                       cnt, slot, ovf_cnt, ovf);
+                    GFS3D_LAUNCH_CHECK("rev_slot_kernel");
                 }
-                hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, rs, a->idx, nedges, a->N, a->k,
-                                   cnt, slot, ovf_cnt, ovf);
-                GFS3D_LAUNCH_CHECK("rev_slot_kernel");
                 hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, rs, a->Q, cnt, slot, BN, a->SQ, a->indeg);
                 GFS3D_LAUNCH_CHECK("rev_gather_kernel");
                 hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, rs, a->Q, ovf_cnt, ovf, a->SQ);
