@@ -1031,7 +1031,9 @@ struct Bn1Fin {
 // round-robin to the 4 waves.  LDS rows are padded to 68 floats (conflict-free b128 / b32 reads).
 // partial: [gridDim.x][2][64][CP]  (CP = C rounded up to 32)
 constexpr int PQ_LD = EC + 4;
-__global__ void __launch_bounds__(256)
+constexpr int PQ_WAVES = 8, PQ_THREADS = 64 * PQ_WAVES;      // one workgroup per CU (86 KB of LDS): 8 waves = 2 per SIMD
+constexpr int PQ_NX = 128 * 64 / PQ_THREADS, PQ_NP = 64 / PQ_WAVES, PQ_WT = 16 / PQ_WAVES;
+__global__ void __launch_bounds__(PQ_THREADS)
 ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
                  const float *__restrict__ P, const float *__restrict__ Q,
                  const float *__restrict__ SP, const float *__restrict__ SQ, const float *__restrict__ indeg,
@@ -1050,7 +1052,7 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int co = tid & 63;
-    for (int e = tid; e < CP * EC; e += 256) {
+    for (int e = tid; e < CP * EC; e += PQ_THREADS) {
         const int c = e >> 6, o = e & 63;
         const float a = (c < C) ? w1[(size_t)o * 2 * C + c] : 0.f;
         const float bb = (c < C) ? w1[(size_t)o * 2 * C + C + c] : 0.f;
@@ -1066,30 +1068,30 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     }
     const float kf = (float)k;
 
-    // weight-gradient tasks: (which in {dP,dQ}) x (o tile in {0,1}) x (c tile < CT); wave w owns tasks w, w+4, ...
+    // weight-gradient tasks: (which in {dP,dQ}) x (o tile in {0,1}) x (c tile < CT); wave w owns tasks w, w+8, ...
     const int n_wtasks = 4 * CT;
-    f32x16 wacc[4];                              // CT <= 4  ->  at most 4 tasks per wave
+    f32x16 wacc[PQ_WT];                          // CT <= 4  ->  at most 2 tasks per wave
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < PQ_WT; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) wacc[u][r] = 0.f;
 
     // Software pipeline over the tiles (the LDS footprint allows one workgroup = one wave per SIMD per CU, so nothing
     // else hides the global latency): the inputs of tile t+1 are loaded into registers before the MFMA phase of tile t
     // and turned into the LDS images of tile t+1 after it.
-    float rx[32];                                // x tile elements e = tid + 256 j  (c = e >> 6, p = e & 63), CP <= 128
-    float rP[16], rQ[16], rGP[16], rGQ[16], rSP[16], rSQ[16], rdeg[16];          // points p = wv + 4 j, channel co
+    float rx[PQ_NX];                             // x tile elements e = tid + PQ_THREADS j  (c = e >> 6, p = e & 63), CP <= 128
+    float rP[PQ_NP], rQ[PQ_NP], rGP[PQ_NP], rGQ[PQ_NP], rSP[PQ_NP], rSQ[PQ_NP], rdeg[PQ_NP];      // points p = wv + PQ_WAVES j, channel co
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
         const float *xb = x + (size_t)b * C * N;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int e = tid + 256 * j, c = e >> 6, p = e & 63;
+        for (int j = 0; j < PQ_NX; ++j) {
+            const int e = tid + PQ_THREADS * j, c = e >> 6, p = e & 63;
             rx[j] = (e < CP * 64 && c < C && n0 + p < N) ? xb[(size_t)c * N + n0 + p] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = n0 + wv + 4 * j;
+        for (int j = 0; j < PQ_NP; ++j) {
+            const int n = n0 + wv + PQ_WAVES * j;
             const bool ok = n < N;
             const size_t o = ((size_t)b * N + (ok ? n : 0)) * EC + co;
             rdeg[j] = ok ? indeg[(size_t)b * N + n] : 0.f;
@@ -1099,13 +1101,13 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     auto stage = [&](int tile) {
         const int b = tile / tiles_per_b, n0 = (tile - b * tiles_per_b) * 64;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int e = tid + 256 * j, c = e >> 6, p = e & 63;
+        for (int j = 0; j < PQ_NX; ++j) {
+            const int e = tid + PQ_THREADS * j, c = e >> 6, p = e & 63;
             if (e < CP * 64) xT[p * XLD + c] = rx[j];
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int p = wv + 4 * j;
+        for (int j = 0; j < PQ_NP; ++j) {
+            const int p = wv + PQ_WAVES * j;
             const bool ok = n0 + p < N;
             const float dq = A1 * (rGQ[j] - kf * mu_dy - mu_dyx * rstd1 * (rSP[j] + kf * (rQ[j] - mean1)));
             const float dp = A1 * (rGP[j] - rdeg[j] * mu_dy - mu_dyx * rstd1 * (rdeg[j] * (rP[j] - mean1) + rSQ[j]));
@@ -1123,7 +1125,7 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         __syncthreads();                         // the LDS images of this tile are complete
         if (next < ntiles) fetch(next);          // in flight during the MFMA phase below
         // ---- dx tiles: (c tile rt < CT) x (point tile ct < 2); K = 128 (lane half h = 0: dP part, 1: dQ part)
-        for (int task = wv; task < 2 * CT; task += 4) {
+        for (int task = wv; task < 2 * CT; task += PQ_WAVES) {
             const int rt = task >> 1, ct = task & 1;
             const float *arow = (h ? wd : wa) + (rt * 32 + i) * PQ_LD;
             const float *brow = (h ? dQt : dPt) + (ct * 32 + i) * PQ_LD;
@@ -1149,8 +1151,8 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
         }
         // ---- weight-gradient tiles, accumulated across point tiles
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int task = wv + 4 * u;
+        for (int u = 0; u < PQ_WT; ++u) {
+            const int task = wv + PQ_WAVES * u;
             if (task < n_wtasks) {
                 const int which = task / (2 * CT), rem = task - which * 2 * CT;
                 const int ot = rem / CT, cc = rem - ot * CT;
@@ -1169,8 +1171,8 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     // one partial per workgroup: [2][64][CP]
     float *out = partial + (size_t)blockIdx.x * 2 * EC * CP;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int task = wv + 4 * u;
+    for (int u = 0; u < PQ_WT; ++u) {
+        const int task = wv + PQ_WAVES * u;
         if (task < n_wtasks) {
             const int which = task / (2 * CT), rem = task - which * 2 * CT;
             const int ot = rem / CT, cc = rem - ot * CT;
@@ -1510,7 +1512,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         const size_t lds = sizeof(float) * (2 * 64 * PQ_LD + 2 * (size_t)CP * PQ_LD + 64 * (size_t)(CP + 1));
         GFS3D_ENSURE_LDS(ec_bwd_pq_kernel, lds, who);
         const int tiles_per_b = (a->N + 63) / 64;
-        hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(256), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
+        hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(PQ_THREADS), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
                            GP, GQ, a->stats, fin, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);
         GFS3D_LAUNCH_CHECK("ec_bwd_pq_kernel");
         hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 63) / 64), dim3(1024), 0, st, wpart, p.g_pq, a->C, CP, ba->dw1);
