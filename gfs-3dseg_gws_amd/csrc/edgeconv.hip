@@ -1308,7 +1308,7 @@ constexpr int ACC_DOUBLES = 8 * EC;
 
 // The reverse-graph kernels (atomic- and latency-bound, few registers, no LDS) only need idx and Q,
 // so the training forward builds SQ/indeg for the backward on a side stream, forked once P and Q
-// exist and joined at the end of phase 2.  Measured at B=32: +1.5 % step throughput forked here,
+// exist and joined at the end of phase 2.  Measured at B=32: +2 % step throughput forked here,
 // nothing forked before ec_main_fwd_kernel, and beside ec_main_bwd_kernel the contention on the
 // atomic path costs that kernel half of what the overlap hides.
 struct SideLane {
