@@ -128,7 +128,9 @@ def main():
     net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev).train()
     if args.sync_bn and world > 1:
         net = gdist.enable_sync_batchnorm(net)
-    bucket = gdist.FlatGradBucket(net.parameters(), early=net.conv.parameters())   # conv: 88 % of the parameters, first in backward
+    # conv: 88 % of the parameters, first in backward: its slice is exchanged under the EdgeConv backward - unless synchronised
+    # BatchNorm puts other collectives inside backward (then every rank must issue them in one fixed order)
+    bucket = gdist.FlatGradBucket(net.parameters(), early=net.conv.parameters(), overlap=not (args.sync_bn and world > 1))
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     x = synthetic_blocks(B_PER_GPU, NPTS, seed=rank).to(dev)
 

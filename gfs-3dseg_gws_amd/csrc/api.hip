@@ -20,15 +20,25 @@ void set_error(const char *fmt, ...)
 struct ProfRec { int id; hipEvent_t a, b; };
 static std::mutex g_pm;
 static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;          // events are recycled: none is created in steady state
 static bool g_prof = false;
+constexpr size_t PROF_MAX_RECS = 1u << 16;      // un-read records are bounded: beyond this, launches go un-timed
+
+static bool pool_take(hipEvent_t &e)
+{
+    if (!g_pool.empty()) { e = g_pool.back(); g_pool.pop_back(); return true; }
+    return hipEventCreate(&e) == hipSuccess;
+}
 
 int prof_begin(int kernel_id, hipStream_t st)
 {
     if (!g_prof) return -1;
     std::lock_guard<std::mutex> lk(g_pm);
+    if (g_recs.size() >= PROF_MAX_RECS) return -1;
     ProfRec r;
     r.id = kernel_id;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+    if (!pool_take(r.a)) return -1;
+    if (!pool_take(r.b)) { g_pool.push_back(r.a); return -1; }
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
@@ -43,8 +53,15 @@ void prof_end(int token, hipStream_t st)
 
 extern "C" int gfs3d_profile_enable(int on)
 {
-    std::lock_guard<std::mutex> lk(gfs3d::g_pm);
-    gfs3d::g_prof = on != 0;
+    using namespace gfs3d;
+    std::lock_guard<std::mutex> lk(g_pm);
+    if (on && !g_prof)                                  // fill the pool up front: no hipEventCreate between the brackets
+        while (g_pool.size() < 2048) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            g_pool.push_back(e);
+        }
+    g_prof = on != 0;
     return GFS3D_OK;
 }
 
@@ -60,8 +77,8 @@ extern "C" int gfs3d_profile_read(int kernel_id, double *total_ms, long long *la
         if (r.id != kernel_id) { keep.push_back(r); continue; }
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; ++n; }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
     }
     g_recs.swap(keep);
     *total_ms = ms;

@@ -20,6 +20,10 @@
 // Layouts: API tensors are channel-first (B,C,N) like the reference; everything
 // internal is point-major (B,N,64) so one point's 64 channels are one 256-B row
 // (one coalesced wave64 load / one 256-B atomic row).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace gfs3d {
@@ -1314,24 +1318,76 @@ constexpr int ACC_DOUBLES = 8 * EC;
 struct SideLane {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false, tried = false;
+    bool ok = false;
+    bool pending = false;      // forked work the caller's stream has not joined yet
 };
 
-static SideLane *side_lane()
+// One lane per (device, caller stream): two host threads driving different streams never share a fork / join pair.
+static std::mutex g_lane_mutex;
+static SideLane *side_lane(hipStream_t caller)
 {
-    static SideLane lanes[16];
+    static std::map<std::pair<int, hipStream_t>, SideLane> lanes;
     static const bool enabled = [] { const char *e = getenv("GFS3D_EC_OVERLAP"); return !(e && e[0] == '0'); }();
     if (!enabled) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideLane &l = lanes[dev];
-    if (!l.tried) {
-        l.tried = true;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_lane_mutex);
+    auto it = lanes.find({dev, caller});
+    if (it == lanes.end()) {
+        SideLane l;
         l.ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&l.join, hipEventDisableTiming) == hipSuccess;
+        it = lanes.emplace(std::make_pair(dev, caller), l).first;
     }
-    return l.ok ? &l : nullptr;
+    return it->second.ok ? &it->second : nullptr;
+}
+
+// Make `st` wait for whatever its lane still has in flight (end of the forward, and every error return after the fork:
+// the side stream writes SQ / indeg / the reverse-graph scratch, which the caller may free or reuse once we return).
+static int side_join(hipStream_t st, const char *who)
+{
+    SideLane *lane = side_lane(st);
+    if (!lane || !lane->pending) return GFS3D_OK;
+    lane->pending = false;
+    if (hipEventRecord(lane->join, lane->stream) != hipSuccess || hipStreamWaitEvent(st, lane->join, 0) != hipSuccess) {
+        set_error("%s: join of the side stream failed", who);
+        return GFS3D_ERR_HIP;
+    }
+    return GFS3D_OK;
+}
+
+static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_t rs, const char *who)
+{
+    char *ws = static_cast<char *>(a->workspace);
+    const int BN = a->B * a->N;
+    int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
+    int *slot = reinterpret_cast<int *>(ws + p.off_slot);
+    int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
+    const size_t nedges = (size_t)BN * a->k;
+    if (a->N <= 8192) {                    // per-block table in LDS; only the overflow counter needs zeroing
+        GFS3D_ENSURE_LDS(rev_block_kernel, RB_LDS, who);
+        if (hipMemsetAsync(ovf_cnt, 0, sizeof(int) * 4, rs) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+        hipLaunchKernelGGL(rev_block_kernel, dim3((a->N + RB_TARGETS - 1) / RB_TARGETS, a->B), dim3(1024), RB_LDS, rs,
+                           a->idx, a->N, a->k, cnt, slot, ovf_cnt, ovf);
+        GFS3D_LAUNCH_CHECK("rev_block_kernel");
+    } else {
+        if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), rs) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+        hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, rs, a->idx, nedges, a->N, a->k,
+                           cnt, slot, ovf_cnt, ovf);
+        GFS3D_LAUNCH_CHECK("rev_slot_kernel");
+    }
+    hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, rs, a->Q, cnt, slot, BN, a->SQ, a->indeg);
+    GFS3D_LAUNCH_CHECK("rev_gather_kernel");
+    hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, rs, a->Q, ovf_cnt, ovf, a->SQ);
+    GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
+    return GFS3D_OK;
 }
 
 static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_user, double stat_count, hipStream_t st)
@@ -1368,7 +1424,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_LAUNCH_CHECK("ec_pq_kernel");
         }
         if (a->training) {
-            SideLane *lane = side_lane();              // SQ/indeg are the backward's; build them beside the statistics pass
+            SideLane *lane = side_lane(st);            // SQ/indeg are the backward's; build them beside the statistics pass
             hipStream_t rs = st;
             if (lane) {
                 if (hipEventRecord(lane->fork, st) != hipSuccess || hipStreamWaitEvent(lane->stream, lane->fork, 0) != hipSuccess) {
@@ -1376,39 +1432,9 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
                     return GFS3D_ERR_HIP;
                 }
                 rs = lane->stream;
+                lane->pending = true;                  // joined in phase 2, or by side_join() on any error return
             }
-            {   // reverse graph -> SQ, indeg
-                int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
-                int *slot = reinterpret_cast<int *>(ws + p.off_slot);
-                int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
-                const size_t nedges = (size_t)BN * a->k;
-                if (a->N <= 8192) {                    // per-block table in LDS; only the overflow counter needs zeroing
-                    GFS3D_ENSURE_LDS(rev_block_kernel, RB_LDS, who);
-                    if (hipMemsetAsync(ovf_cnt, 0, sizeof(int) * 4, rs) != hipSuccess) {
-                        set_error("%s: hipMemsetAsync failed", who);
-                        return GFS3D_ERR_HIP;
-                    }
-                    hipLaunchKernelGGL(rev_block_kernel, dim3((a->N + RB_TARGETS - 1) / RB_TARGETS, a->B), dim3(1024), RB_LDS, rs,
-                                       a->idx, a->N, a->k, cnt, slot, ovf_cnt, ovf);
-                    GFS3D_LAUNCH_CHECK("rev_block_kernel");
-                } else {
-                    if (hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t)BN + 4), rs) != hipSuccess) {
-                        set_error("%s: hipMemsetAsync failed", who);
-                        return GFS3D_ERR_HIP;
-                    }
-                    hipLaunchKernelGGL(rev_slot_kernel, dim3((unsigned)((nedges + 255) / 256)), dim3(256), 0, rs, a->idx, nedges, a->N, a->k,
-                                       cnt, slot, ovf_cnt, ovf);
-                    GFS3D_LAUNCH_CHECK("rev_slot_kernel");
-                }
-                hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, rs, a->Q, cnt, slot, BN, a->SQ, a->indeg);
-                GFS3D_LAUNCH_CHECK("rev_gather_kernel");
-                hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, rs, a->Q, ovf_cnt, ovf, a->SQ);
-                GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
-            }
-            if (lane && hipEventRecord(lane->join, rs) != hipSuccess) {
-                set_error("%s: hipEventRecord failed", who);
-                return GFS3D_ERR_HIP;
-            }
+            if (int rc = reverse_graph(a, p, rs, who)) return rc;
             if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
                 set_error("%s: hipMemsetAsync failed", who);
                 return GFS3D_ERR_HIP;
@@ -1439,11 +1465,8 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, jmax, fin2, a->stats, a->N, a->slope,
                            a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
-        SideLane *lane = a->training ? side_lane() : nullptr;
-        if (lane && hipStreamWaitEvent(st, lane->join, 0) != hipSuccess) {
-            set_error("%s: join of the side stream failed", who);
-            return GFS3D_ERR_HIP;
-        }
+        if (a->training)
+            if (int rc = side_join(st, who)) return rc;
     }
     return GFS3D_OK;
 }
@@ -1555,6 +1578,7 @@ extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *st
     using namespace gfs3d;
     int rc = check_fwd(a, "gfs3d_edgeconv_forward_f32");
     for (int ph = 0; ph < 3 && !rc; ++ph) rc = forward_phase(a, ph, nullptr, 0.0, static_cast<hipStream_t>(stream));
+    if (rc) (void)side_join(static_cast<hipStream_t>(stream), "gfs3d_edgeconv_forward_f32");      // never return with forked work un-joined
     return rc;
 }
 
@@ -1564,7 +1588,9 @@ extern "C" int gfs3d_edgeconv_forward_phase_f32(const gfs3d_edgeconv_args *a, in
     int rc = check_fwd(a, "gfs3d_edgeconv_forward_phase_f32");
     if (rc) return rc;
     GFS3D_REQUIRE(phase >= 0 && phase <= 2, "gfs3d_edgeconv_forward_phase_f32: phase must be 0, 1 or 2");
-    return forward_phase(a, phase, acc, stat_count, static_cast<hipStream_t>(stream));
+    rc = forward_phase(a, phase, acc, stat_count, static_cast<hipStream_t>(stream));
+    if (rc) (void)side_join(static_cast<hipStream_t>(stream), "gfs3d_edgeconv_forward_phase_f32");
+    return rc;
 }
 
 extern "C" int gfs3d_edgeconv_backward_f32(const gfs3d_edgeconv_bwd_args *ba, void *stream)

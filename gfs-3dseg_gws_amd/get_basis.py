@@ -73,32 +73,75 @@ def kmeans_plus_plus(points, n_clusters, rng):
     return torch.stack(centers, 0)
 
 
-def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0):
-    """Lloyd's algorithm on the GPU.  points (M,D) float32 device tensor.
-    Returns (centroids (K,D), labels (M,) int64, inertia float, n_iter)."""
-    rng = np.random.RandomState(seed)
-    cent = kmeans_plus_plus(points, n_clusters, rng) if init is None else torch.as_tensor(init).to(points)
-    cent = cent.contiguous().float()
-    scale = float(points.var(dim=0).mean()) * tol
+def _dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
+def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
+    """Lloyd iterations from `cent`.  With `sharded` points every quantity a decision depends on is global: the
+    (K x D sums, K counts) are all-reduced each iteration, so `new`, `shift` and hence the stopping iteration are
+    identical on all ranks (no rank leaves the loop while another still waits in a collective); an empty cluster
+    keeps its previous centroid, which is rank-identical too because the start was."""
     n_iter = 0
     for n_iter in range(1, max_iter + 1):
-        _, sums, counts, _ = ops.kmeans_assign(points, cent)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            # points sharded over ranks: one all-reduce of (K x D sums, K counts) per Lloyd iteration
-            torch.distributed.all_reduce(sums)
-            torch.distributed.all_reduce(counts)
+        _, sums, counts, _ = assign_fn(points, cent)
+        if sharded:
+            packed = torch.cat([sums, counts[:, None]], dim=1)          # one collective per iteration
+            torch.distributed.all_reduce(packed)
+            sums, counts = packed[:, :-1], packed[:, -1]
         new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
         shift = float(((new - cent) ** 2).sum())
-        cent = new
+        cent = new.contiguous()
         if shift <= scale:
             break
-    label, _, _, inertia = ops.kmeans_assign(points, cent)
-    return cent, label.long(), float(inertia.item()), n_iter
+    label, _, _, inertia = assign_fn(points, cent)
+    if sharded:
+        inertia = inertia.clone()
+        torch.distributed.all_reduce(inertia)
+    return cent, label, float(inertia.item()), n_iter
+
+
+def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0, n_init=1, assign_fn=None):
+    """Lloyd's algorithm on the GPU.  points (M,D) float32 device tensor - under torch.distributed THIS RANK'S SHARD of
+    the points.  Returns (centroids (K,D), labels (M,) int64 of the local points, inertia float (global), n_iter).
+
+    `n_init` > 1: that many k-means++ restarts, best inertia wins (the reference's sklearn KMeans ran 10 by default in
+    its era, get_basis.py:210; ignored when `init` is given).  Sharded points: the start centroids come from rank 0
+    (k-means++ on rank 0's shard, then broadcast), the stop threshold from the all-reduced variance, so every rank runs
+    the same number of iterations.  `assign_fn` replaces gfs3d.ops.kmeans_assign (CPU logic tests only)."""
+    assign_fn = assign_fn or ops.kmeans_assign
+    sharded = _dist_on()
+    rng = np.random.RandomState(seed)
+    if sharded:                      # global per-feature variance from (count, sum, sum of squares)
+        st = torch.stack([torch.full_like(points[0], float(points.shape[0])).double(), points.double().sum(0),
+                          (points.double() ** 2).sum(0)])
+        torch.distributed.all_reduce(st)
+        n_glob, mean = st[0], st[1] / st[0]
+        var = ((st[2] / n_glob - mean ** 2) * n_glob / (n_glob - 1).clamp_min(1)).mean()
+    else:
+        var = points.var(dim=0).mean()
+    scale = float(var) * tol
+    best = None
+    for _ in range(1 if init is not None else max(1, int(n_init))):
+        if init is not None:
+            cent = torch.as_tensor(init).to(points)
+        elif not sharded or torch.distributed.get_rank() == 0:
+            cent = kmeans_plus_plus(points, n_clusters, rng)
+        else:
+            cent = torch.empty((n_clusters, points.shape[1]), dtype=points.dtype, device=points.device)
+        cent = cent.contiguous().float()
+        if sharded:
+            torch.distributed.broadcast(cent, src=0)
+        res = _lloyd(points, cent, max_iter, scale, assign_fn, sharded)
+        if best is None or res[2] < best[2]:
+            best = res
+    cent, label, inertia, n_iter = best
+    return cent, label.long(), inertia, n_iter
 
 
 @torch.no_grad()
 def extract_geometric_words(model, blocks, labels, num_classes, num_cnt, max_per_class=300000, batch=32, seed=0,
-                            init=None, max_iter=300):
+                            init=None, max_iter=300, n_init=1):
     """blocks (M,9,N) float, labels (M,N) int (0 = background).  Returns the (num_cnt,192)
     SVD-reconstructed geometric words (numpy), like the pickle the reference writes."""
     model.eval()
@@ -125,6 +168,6 @@ def extract_geometric_words(model, blocks, labels, num_classes, num_cnt, max_per
             f = f[torch.as_tensor(pick, device=f.device)]
         chunks.append(f)
     pts = torch.cat(chunks, 0).contiguous()
-    _, label, _, _ = device_kmeans(pts, num_cnt, init=init, max_iter=max_iter, seed=seed)
+    _, label, _, _ = device_kmeans(pts, num_cnt, init=init, max_iter=max_iter, seed=seed, n_init=n_init)
     proto = Kmean2Proto(pts.cpu().numpy(), label.cpu().numpy(), num_cnt)
     return compute_svd(proto)

@@ -44,9 +44,15 @@ class FlatGradBucket:
     `early`: parameters whose gradients are complete long before backward ends (the point-wise stack of DGCNN:
     88 % of the parameters, first in backward order).  Their slice of the buffer is all-reduced asynchronously
     from a post-accumulate hook as soon as the last of them has its gradient, i.e. underneath the EdgeConv
-    backward; `all_reduce_mean()` then only exchanges the small remainder and waits for the early slice."""
+    backward; `all_reduce_mean()` then only exchanges the small remainder and waits for the early slice.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None):
+    `overlap=False` keeps the early slice in the flat layout but launches it from `all_reduce_mean()`: REQUIRED when
+    other collectives run inside backward on the same communicator (synchronised BatchNorm: gfs3d.ops.BNSync /
+    torch SyncBatchNorm) - a hook that fires on one rank and not on another would otherwise put the slice before the
+    BatchNorm all-reduces on the first and after them on the second."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], early: Optional[Iterable[torch.nn.Parameter]] = None,
+                 overlap: bool = True):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError("FlatGradBucket: no trainable parameters")
@@ -66,7 +72,9 @@ class FlatGradBucket:
         self._seen = 0
         self._work = None
         self.early_launches = 0                      # how often the overlapped path ran (tests)
-        if self.early and is_dist() and dist.get_world_size() > 1:
+        self.force_collectives = False               # tests: issue the collectives even in a 1-rank group
+        self.overlap = bool(overlap)
+        if self.early and self.overlap and is_dist():
             for p in self.early:
                 p.register_post_accumulate_grad_hook(self._on_early_grad)
 
@@ -86,6 +94,8 @@ class FlatGradBucket:
             torch._foreach_copy_([v for v, _ in have], [g_ for _, g_ in have])
 
     def _on_early_grad(self, _param) -> None:
+        if dist.get_world_size() == 1 and not self.force_collectives:
+            return
         self._seen += 1
         if self._seen == len(self.early) and self._work is None:
             self._pack(0, len(self.early))
@@ -95,7 +105,7 @@ class FlatGradBucket:
     def all_reduce_mean(self) -> None:
         """SUM over ranks then divide by world size (mean over the global batch when every
         rank's loss is a mean over its equally sized shard)."""
-        if not is_dist() or dist.get_world_size() == 1:
+        if not is_dist() or (dist.get_world_size() == 1 and not self.force_collectives):
             return
         if self.early:
             # Every rank issues the SAME two collectives in the same order (early slice, remainder) whether or not its
@@ -108,6 +118,7 @@ class FlatGradBucket:
                 dist.all_reduce(self.flat[self.n_early:], op=dist.ReduceOp.SUM)
             self._work.wait()
             self._work = None
+            self._seen = 0                       # the next backward counts from zero even if zero() is skipped
         else:
             self._pack(0, len(self.params))
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)

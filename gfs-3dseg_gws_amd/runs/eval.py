@@ -39,12 +39,20 @@ def evaluate_metric_GFS(logger, pred_labels_list, gt_labels_list, test_classes, 
     num_class = len(test_classes)
     counts = confusion_counts(pred_labels_list, gt_labels_list, all_learning_order, num_class)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # every rank passes ITS shard of the validation blocks; RCCL ("nccl") only moves device tensors
+        home = counts.device
+        if torch.distributed.get_backend() == "nccl" and not counts.is_cuda:
+            counts = counts.to(torch.device("cuda", torch.cuda.current_device()))
         torch.distributed.all_reduce(counts)
+        counts = counts.to(home)
     gt_c, pos_c, tp_c = (counts[i].cpu().numpy() for i in range(3))
 
     iou_list, base_ious, novel_ious = [], [], []
     for c in range(num_class):
-        iou = tp_c[c] / float(gt_c[c] + pos_c[c] - tp_c[c])
+        union = float(gt_c[c] + pos_c[c] - tp_c[c])
+        if union == 0.0:           # the reference divides Python numbers here (runs/eval.py:52): same exception
+            raise ZeroDivisionError("evaluate_metric_GFS: class %d appears in neither the labels nor the predictions" % c)
+        iou = tp_c[c] / union
         logger.cprint('----- [class %d]  IoU: %f -----' % (c, iou))
         iou_list.append(iou)
         if scannet and c == 0:

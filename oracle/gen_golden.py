@@ -229,6 +229,11 @@ def g_capl():
         fp, _ = m.generate_fake_proto(x=pf[2:], y=y[2:], main_proto=m.main_proto.clone(),
                                       fake_novel=[torch.tensor(2), torch.tensor(5)])
     out.update(gfp_y=y.numpy(), gfp_proto=fp.numpy())
+    # (10b) Get_Fg_Feat (capl.py:71-88) on one support cloud with a binary mask
+    fg_mask = (torch.rand(1, N, generator=torch.Generator().manual_seed(19)) > 0.55).long()
+    with torch.no_grad():
+        fg_f, fg_w = m.Get_Fg_Feat(x[1:2], fg_mask)
+    out.update(fg_mask=fg_mask.numpy(), fg_feat=fg_f.numpy(), fg_word=fg_w.argmax(1).numpy().astype(np.int16))
     # (9) forward train: capture attention dropout mask + python-random choice
     m.train()
     masks = []
@@ -274,8 +279,20 @@ def g_capl():
     x2 = synthetic_blocks(2, 128, seed=13)
     with torch.no_grad():
         pf2, sem2, oh2 = m2.getFeatures(x2)
+    # (5b/8b) ScanNet class counts: get_pred with the bg row (21+1), eval forward with base_num 15 (config 5 shapes)
+    g2 = torch.Generator().manual_seed(20)
+    p2s = torch.randn(21, 128, generator=g2)
+    coding2 = (torch.rand(21, 180, generator=g2) > 0.7).float()
+    lab21 = torch.randint(0, 21, (2, 128), generator=g2)
+    gened2 = torch.nn.functional.normalize(torch.randn(21, 128, generator=g2), dim=1)
+    with torch.no_grad():
+        sc_bg = m2.get_pred(pf2, p2s, use_bg_proto=True)
+        lg2, acc2, nacc2 = m2(x2, y=lab21, gened_proto=gened2.unsqueeze(0), eval_model=True,
+                              base_class_coding=coding2[:15], novel_class_coding=coding2[15:])
     save("capl_scannet", x=x2.numpy(), gp=gp2.numpy(), **{"sd." + k: v for k, v in sd_np(m2.state_dict()).items()},
-         gf_point=pf2.numpy(), gf_sem=sem2.numpy(), gf_word=oh2.argmax(1).numpy().astype(np.int16))
+         gf_point=pf2.numpy(), gf_sem=sem2.numpy(), gf_word=oh2.argmax(1).numpy().astype(np.int16),
+         gp_p2=p2s.numpy(), gp_2d_bg=sc_bg.numpy(), gw_coding=coding2.numpy(), gw_lab21=lab21.numpy(),
+         fe_gened=gened2.numpy(), fe_logits=lg2.numpy(), fe_acc=np.float32(acc2), fe_nacc=np.float32(nacc2))
 
 
 # ---------------------------------------------------------------- (12) get_basis numerics

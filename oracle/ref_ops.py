@@ -175,9 +175,13 @@ def geometric_word_assign(gp: Tensor, edge_convs: Tensor) -> Tuple[Tensor, Tenso
 
 def get_features(p: Params, gp: Tensor, x: Tensor, k: int = 20, n_base_convs: int = 2,
                  training: bool = False, new_stats: Optional[Dict[str, Tensor]] = None,
-                 dropout_mask: Optional[Tensor] = None, knn_fn=knn) -> Tuple[Tensor, Tensor, Tensor]:
-    """capl.py:324-362."""
-    ecs, lvl2 = dgcnn_forward(p, x, k=k, training=training, prefix="encoder.", new_stats=new_stats, knn_fn=knn_fn)
+                 dropout_mask: Optional[Tensor] = None, knn_fn=knn, encoder_out=None) -> Tuple[Tensor, Tensor, Tensor]:
+    """capl.py:324-362.  `encoder_out` = (three EdgeConv outputs, level-2 feature): run only the heads on given
+    backbone outputs (tests: gradient parity of the heads on bit-identical inputs)."""
+    if encoder_out is not None:
+        ecs, lvl2 = encoder_out
+    else:
+        ecs, lvl2 = dgcnn_forward(p, x, k=k, training=training, prefix="encoder.", new_stats=new_stats, knn_fn=knn_fn)
     lvl3 = base_learner(p, lvl2, n_base_convs, training, new_stats=new_stats)
     att = self_attention(p, lvl2, dropout_mask=dropout_mask)
     semantic = torch.cat((ecs[0], att, lvl3), dim=1)
@@ -185,6 +189,14 @@ def get_features(p: Params, gp: Tensor, x: Tensor, k: int = 20, n_base_convs: in
     fused = F.conv1d(torch.cat([soft, semantic], dim=1), p["fusion.0.weight"], p["fusion.0.bias"])
     fused = _bn(fused, p, "fusion.1", training, new_stats)
     return F.leaky_relu(fused, LRELU_SLOPE), semantic, onehot
+
+
+def get_fg_feat(p: Params, gp: Tensor, x: Tensor, y: Tensor, k: int = 20, knn_fn=knn) -> Tuple[Tensor, Tensor]:
+    """capl.py:71-88: features of ONE support cloud, foreground columns (y == 1) only ->
+    (n_fg, 128) fused features and (n_fg, K_w) one-hot words."""
+    pf, _, onehot = get_features(p, gp, x, k=k, training=False, knn_fn=knn_fn)
+    keep = y[0] == 1
+    return pf[0][:, keep].transpose(1, 0), onehot[0][:, keep].transpose(1, 0)
 
 
 def get_pred(x: Tensor, proto: Tensor, bg_proto: Optional[Tensor] = None) -> Tensor:
@@ -286,10 +298,12 @@ def capl_forward_eval(p: Params, gp: Tensor, x: Tensor, y: Optional[Tensor], gen
 
 
 def capl_forward_train(p: Params, gp: Tensor, x: Tensor, y: Tensor, base_num: int, k: int = 20,
-                       fake_novel: Optional[Sequence] = None, new_stats=None, dropout_mask=None, knn_fn=knn):
+                       fake_novel: Optional[Sequence] = None, new_stats=None, dropout_mask=None, knn_fn=knn,
+                       encoder_out=None):
     """capl.py:194-242: two CE losses on cosine logits with fake-novel prototypes."""
-    pf, _, _ = get_features(p, gp, x, k=k, training=True, new_stats=new_stats, dropout_mask=dropout_mask, knn_fn=knn_fn)
-    half = x.size(0) // 2
+    pf, _, _ = get_features(p, gp, x, k=k, training=True, new_stats=new_stats, dropout_mask=dropout_mask, knn_fn=knn_fn,
+                            encoder_out=encoder_out)
+    half = pf.size(0) // 2
     ori, fake_novel = generate_fake_proto(pf[half:], y[half:], p["main_proto"].clone(), fake_novel)
     l1 = F.cross_entropy(get_pred(pf, ori, p["bg_proto"]), y)
     rp = post_refine_proto_v2(p["main_proto"].clone(), pf, pf, p["bg_proto"]).clone()

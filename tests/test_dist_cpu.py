@@ -91,9 +91,44 @@ def _worker(rank, world, port, out):
     res["sync_keys_same"] = list(m2.state_dict().keys()) == keys
     res["sync_attached"] = m2.encoder.bn_sync is not None and all(
         len(blk.fused_parts()) == 4 for blk in m2.encoder.edge_convs)
+    # 6. device_kmeans on genuinely SHARDED points: rank 0's k-means++ start is broadcast, the stop
+    #    threshold comes from the all-reduced variance, so both ranks run the same iterations and end with the same
+    #    centroids - equal to a single-process run over all the points from the same start.  (The assignment step
+    #    is the HIP kernel in the product; this CPU logic test injects a torch stand-in for it.)
+    from get_basis import device_kmeans
+    pts_all, init = _kmeans_data()
+    lo, hi = (0, 700) if rank == 0 else (700, 2000)          # unequal shards
+    cent, lab, inertia, n_iter = device_kmeans(pts_all[lo:hi], 6, init=init, max_iter=50, tol=1e-4, assign_fn=_torch_assign)
+    cent2, _, inertia2, n_iter2 = device_kmeans(pts_all[lo:hi], 6, init=None, max_iter=50, tol=1e-4, seed=3, n_init=2,
+                                                assign_fn=_torch_assign)
+    res["km"] = (cent.numpy(), lab.numpy(), inertia, n_iter)
+    res["km_pp"] = (cent2.numpy(), inertia2, n_iter2)
+    # 7. overlap=False: the early slice is exchanged from all_reduce_mean() (the order synchronised BatchNorm needs)
+    late = gd.FlatGradBucket(lin.parameters(), early=lin[1].parameters(), overlap=False)
+    late.zero()
+    lin(x).sum().backward()
+    late.all_reduce_mean()
+    res["late_grad"] = torch.cat([p.grad.reshape(-1) for p in lin.parameters()]).numpy().copy()
+    res["late_launches"] = late.early_launches
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _kmeans_data():
+    g = torch.Generator().manual_seed(4)
+    centers = torch.randn(6, 16, generator=g) * 3
+    pts = centers[torch.randint(0, 6, (2000,), generator=g)] + 0.4 * torch.randn(2000, 16, generator=g)
+    return pts.contiguous(), pts[torch.randperm(2000, generator=g)[:6]].clone()
+
+
+def _torch_assign(pts, cent):
+    """Stand-in for gfs3d.ops.kmeans_assign in CPU logic tests: (label, sums, counts, inertia)."""
+    d = torch.cdist(pts.double(), cent.double()) ** 2
+    lab = d.argmin(1)
+    sums = torch.zeros_like(cent).index_add_(0, lab, pts)
+    counts = torch.bincount(lab, minlength=cent.shape[0]).to(pts.dtype)
+    return lab.int(), sums, counts, d.gather(1, lab[:, None]).sum().reshape(1)
 
 
 def test_dp_helpers_world2_gloo():
@@ -113,6 +148,17 @@ def test_dp_helpers_world2_gloo():
     assert a["max"] == 1.0 and b["max"] == 1.0
     assert a["sync_sum"] == b["sync_sum"] == 3.0 and a["sync_world"] == 2
     assert a["sync_keys_same"] and a["sync_attached"] and b["sync_attached"]
+    # (6) sharded k-means: identical on both ranks, equal to the single-process run on all points
+    from get_basis import device_kmeans
+    pts_all, init = _kmeans_data()
+    cent, lab, inertia, n_iter = device_kmeans(pts_all, 6, init=init, max_iter=50, tol=1e-4, assign_fn=_torch_assign)
+    assert a["km"][3] == b["km"][3] == n_iter
+    assert np.array_equal(a["km"][0], b["km"][0]) and np.abs(a["km"][0] - cent.numpy()).max() < 1e-5
+    assert np.array_equal(np.concatenate([a["km"][1], b["km"][1]]), lab.numpy())
+    assert abs(a["km"][2] - inertia) < 1e-6 * inertia and a["km"][2] == b["km"][2]
+    assert np.array_equal(a["km_pp"][0], b["km_pp"][0]) and a["km_pp"][1] == b["km_pp"][1] and a["km_pp"][2] == b["km_pp"][2]
+    assert np.allclose(a["late_grad"], mean, atol=1e-6) and np.allclose(b["late_grad"], mean, atol=1e-6)
+    assert a["late_launches"] == 0
     # single-process reference for (4)
     import random, types, sys
     from conftest import PKG

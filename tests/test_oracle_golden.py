@@ -176,6 +176,28 @@ def test_capl_scannet_shapes():
     assert (oh.argmax(1).numpy() == g["gf_word"]).all()
 
 
+def test_capl_scannet_heads_and_eval_forward():
+    """ScanNet class counts (21 + bg, base_num 15, K_w = 180): get_pred with the bg row and the eval forward."""
+    g = load_golden("capl_scannet")
+    sd = state_dict_from(g)
+    pf = torch.from_numpy(g["gf_point"])
+    close(R.get_pred(pf, torch.from_numpy(g["gp_p2"]), sd["bg_proto"]), g["gp_2d_bg"], 1e-5)
+    coding = torch.from_numpy(g["gw_coding"])
+    lg, acc, nacc = R.capl_forward_eval(sd, torch.from_numpy(g["gp"]), torch.from_numpy(g["x"]),
+                                        torch.from_numpy(g["gw_lab21"]), torch.from_numpy(g["fe_gened"]).unsqueeze(0),
+                                        coding[:15], coding[15:], base_num=15, eval_weight=1.2)
+    close(lg, g["fe_logits"]); close(acc, g["fe_acc"], 1e-6); close(nacc, g["fe_nacc"], 1e-6)
+
+
+def test_capl_get_fg_feat():
+    g = load_golden("capl")
+    f, w = R.get_fg_feat(state_dict_from(g), torch.from_numpy(g["gp"]), torch.from_numpy(g["x"][1:2]),
+                         torch.from_numpy(g["fg_mask"]))
+    assert f.shape == g["fg_feat"].shape and int(g["fg_mask"].sum()) == f.shape[0]
+    close(f, g["fg_feat"])
+    assert (w.argmax(1).numpy() == g["fg_word"]).all() and bool((w.sum(1) == 1).all())
+
+
 def test_basis_numerics():
     g = load_golden("basis")
     c, lab, inertia = R.lloyd_kmeans(g["pts"], g["init"], int(g["km_iters"]) + 2)
