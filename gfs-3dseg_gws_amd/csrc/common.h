@@ -76,6 +76,93 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 #define GFS3D_X6_PA {2, 0, 1, 1, 0, 0}
 #define GFS3D_X6_PB {0, 2, 1, 0, 1, 0}
 
+// ---- arithmetic of the GEMM-shaped kernels, selectable per call (gfs3d.h: GFS3D_COMPUTE_*) ----
+//   PREC_X6   fp32 accuracy: exact 3-way bf16 split of both operands, six piece products per fp32 product (default)
+//   PREC_BF16 ONE bf16 product per fp32 product: operands rounded to nearest-even bf16 (8 significand bits), fp32 accumulate
+//   PREC_F16  the same with IEEE half operands (11 significand bits; forward passes only - gradients underflow in half)
+// All three use the same LDS row images ([piece 0 | piece 1 | piece 2 | pad]); the reduced forms fill and read piece 0 only.
+enum { PREC_X6 = GFS3D_COMPUTE_F32, PREC_BF16 = GFS3D_COMPUTE_BF16, PREC_F16 = GFS3D_COMPUTE_F16 };
+typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
+typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 mm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mm_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int PREC> struct Mx {
+    static constexpr int NP = PREC == PREC_X6 ? 3 : 1;        // operand pieces
+    static constexpr int NTERM = PREC == PREC_X6 ? 6 : 1;     // piece products per fp32 product
+};
+// two fp32 values -> one dword of two 16-bit operands (a in the low half), rounded to nearest-even
+template <int PREC> __device__ __forceinline__ unsigned mm_pack2(float a, float b)
+{
+    static_assert(PREC == PREC_BF16 || PREC == PREC_F16, "mm_pack2: reduced forms only");
+    const mm_f32x2 v = {a, b};
+    if (PREC == PREC_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mm_bf16x2));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mm_f16x2));
+}
+// one fp32 value -> its 16-bit operand (the weight / prototype images are written one element at a time)
+template <int PREC> __device__ __forceinline__ unsigned short mm_cvt1(float a) { return (unsigned short)(mm_pack2<PREC>(a, 0.f) & 0xffffu); }
+// eight consecutive K values of one operand row -> NP dwordx4 pieces ([0] hi, [1] mid, [2] lo for PREC_X6)
+template <int PREC> __device__ __forceinline__ void mm_pieces8(const float *v8, uint4 (&out)[Mx<PREC>::NP])
+{
+    if constexpr (PREC == PREC_X6) {
+        unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(v8[e], ph[e], pm[e], pl[e]);
+        out[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
+        out[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
+        out[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+    } else {
+        out[0] = make_uint4(mm_pack2<PREC>(v8[0], v8[1]), mm_pack2<PREC>(v8[2], v8[3]), mm_pack2<PREC>(v8[4], v8[5]), mm_pack2<PREC>(v8[6], v8[7]));
+    }
+}
+// four consecutive K values -> NP dwordx2 pieces (the staging stores of 32-channel chunk images)
+template <int PREC> __device__ __forceinline__ void mm_pieces4(const float *v4, uint2 (&out)[Mx<PREC>::NP])
+{
+    if constexpr (PREC == PREC_X6) {
+        unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(v4[e], ph[e], pm[e], pl[e]);
+        out[0] = make_uint2(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]));
+        out[1] = make_uint2(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]));
+        out[2] = make_uint2(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]));
+    } else {
+        out[0] = make_uint2(mm_pack2<PREC>(v4[0], v4[1]), mm_pack2<PREC>(v4[2], v4[3]));
+    }
+}
+// one element of a 16-bit operand image: plane p of the row at `o`, planes `plane` elements apart
+template <int PREC> __device__ __forceinline__ void mm_store1(float w, unsigned short *o, int plane)
+{
+    if constexpr (PREC == PREC_X6) {
+        unsigned ph, pm, pl;
+        split3(w, ph, pm, pl);
+        o[0] = (unsigned short)(ph >> 16);
+        o[plane] = (unsigned short)(pm >> 16);
+        o[2 * plane] = (unsigned short)(pl >> 16);
+    } else {
+        o[0] = mm_cvt1<PREC>(w);
+    }
+}
+template <int PREC> __device__ __forceinline__ mm_f32x16 mm_mfma(const uint4 &a, const uint4 &b, mm_f32x16 c)
+{
+    if constexpr (PREC == PREC_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += a . b over one K-step of 16: all piece products, smallest first
+template <int PREC> __device__ __forceinline__ void mm_mac(const uint4 (&a)[Mx<PREC>::NP], const uint4 (&b)[Mx<PREC>::NP], mm_f32x16 &acc)
+{
+    if constexpr (PREC == PREC_X6) {
+        constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+#pragma unroll
+        for (int term = 0; term < 6; ++term) acc = mm_mfma<PREC>(a[PA[term]], b[PB[term]], acc);
+    } else {
+        acc = mm_mfma<PREC>(a[0], b[0], acc);
+    }
+}
+// the reduced form a call asks for, per pass: half operands cannot hold gradients (~1e-8 under a mean loss)
+static inline int prec_of(int compute, bool backward) { return compute == PREC_F16 && backward ? PREC_BF16 : compute; }
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize, per kernel AND per device.

@@ -368,7 +368,9 @@ ec_prescale_kernel(const float *__restrict__ P, const float *__restrict__ Q, con
 // holds channels 8kb..8kb+7 (lane half 0) and 32+8kb.. (lane half 1) for both operands.
 // 48 MFMAs of 32 cycles per 32-edge tile instead of 64 of 64 cycles.
 // ---------------------------------------------------------------------------
-template <bool STATS>
+// PREC (common.h): PREC_X6 as described; PREC_BF16 / PREC_F16 = one rounded 16-bit product per fp32 product
+// (8 MFMAs per 32-edge tile, one v_cvt per two operand values instead of the 3-way split).
+template <bool STATS, int PREC>
 __global__ void __launch_bounds__(256, STATS ? 2 : 3)      // the eval form fits three workgroups per CU (168 VGPRs): 1.06 -> 0.99 ms eval forward;
                                                            // forcing the training form there spills and was measured slower (0.251 -> 0.273 ms per step)
 ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
@@ -385,14 +387,8 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     // max_j LReLU(BN2(h_j)) is reached at max_j h_j where scale2 >= 0 and at min_j h_j elsewhere, and sign(scale2) =
     // sign(gamma2) whatever the batch statistics turn out to be: the rows of W2 with a negative gamma go into the image
     // NEGATED, the kernel tracks one maximum (of +-h, exactly the negation) and undoes the sign where it stores.
-    for (int e = tid; e < EC * EC; e += 256) {
-        unsigned ph, pm, pl;
-        split3(gamma2[e >> 6] < 0.f ? -w2[e] : w2[e], ph, pm, pl);
-        unsigned short *o = reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * WROW) + (e & 63);
-        o[0] = (unsigned short)(ph >> 16);
-        o[EC] = (unsigned short)(pm >> 16);
-        o[2 * EC] = (unsigned short)(pl >> 16);
-    }
+    for (int e = tid; e < EC * EC; e += 256)
+        mm_store1<PREC>(gamma2[e >> 6] < 0.f ? -w2[e] : w2[e], reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * WROW) + (e & 63), EC);
     __syncthreads();
 
     const int pA = 4 * ((i >> 2) & 1) + (i >> 3);       // point (0..7) of this lane's A rows
@@ -460,27 +456,25 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 }
                 pf[2 * kb] = p4n[2 * kb];
                 pf[2 * kb + 1] = p4n[2 * kb + 1];
-                uint4 ap[3];                             // bf16 pieces, two per dword
-                {
-                    unsigned ph[8], pm[8], pl[8];
+                constexpr int NP = Mx<PREC>::NP;
+                uint4 ap[NP];                            // 16-bit operand pieces, two per dword
+                mm_pieces8<PREC>(av, ap);
+                uint4 b0[NP], b1[NP];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) split3(av[e], ph[e], pm[e], pl[e]);
-                    ap[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
-                    ap[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
-                    ap[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
-                }
-                uint4 b0[3], b1[3];
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
+                for (int pc = 0; pc < NP; ++pc) {
                     b0[pc] = *reinterpret_cast<const uint4 *>(wrow0 + pc * 128 + kb * 16);
                     b1[pc] = *reinterpret_cast<const uint4 *>(wrow1 + pc * 128 + kb * 16);
                 }
-                constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+                if constexpr (PREC == PREC_X6) {         // interleaved: the two accumulator chains alternate
+                    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), acc1, 0, 0, 0);
+                    for (int term = 0; term < 6; ++term) {
+                        acc0 = mm_mfma<PREC>(ap[PA[term]], b0[PB[term]], acc0);
+                        acc1 = mm_mfma<PREC>(ap[PA[term]], b1[PB[term]], acc1);
+                    }
+                } else {
+                    mm_mac<PREC>(ap, b0, acc0);
+                    mm_mac<PREC>(ap, b1, acc1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -710,6 +704,7 @@ constexpr int BWD_WAVES = 4;
 constexpr int BWD_WROW = 3 * 2 * EC + 16;                          // bytes per row of a W2 piece image
 constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES * BWD_WAVE_LDS + 192);
 
+template <int PREC>
 __global__ void __launch_bounds__(64 * BWD_WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2, const CoefIn cin,
@@ -729,13 +724,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 
     for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
         const int co = e >> 6, ci = e & 63;
-        unsigned ph, pm, pl;
-        split3(w2[e], ph, pm, pl);
-        unsigned short *o = reinterpret_cast<unsigned short *>(sW3 + co * BWD_WROW) + ci;
-        unsigned short *ot = reinterpret_cast<unsigned short *>(sW3T + ci * BWD_WROW) + co;
-        o[0] = ot[0] = (unsigned short)(ph >> 16);
-        o[EC] = ot[EC] = (unsigned short)(pm >> 16);
-        o[2 * EC] = ot[2 * EC] = (unsigned short)(pl >> 16);
+        mm_store1<PREC>(w2[e], reinterpret_cast<unsigned short *>(sW3 + co * BWD_WROW) + ci, EC);
+        mm_store1<PREC>(w2[e], reinterpret_cast<unsigned short *>(sW3T + ci * BWD_WROW) + co, EC);
     }
     float *sC = wbase + BWD_WAVES * BWD_WAVE_LDS;       // [192] BN2-backward constants (re-read per tile: the kernel is at the VGPR cap)
     if (tid < EC) bwd_coef(cin, tid, blockIdx.x == 0, sC);       // (a separate 5 us launch otherwise)
@@ -808,15 +798,22 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                     z = pv.w + qv.w; a[4 * v + 3] = fmaxf(z, z * slope);
                 }
             }
-            constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
-            // bf16 pieces of 8 consecutive values, two per dword: [0] hi, [1] mid, [2] lo
-            auto pieces = [&](const float *v8, uint4 (&out)[3]) {
-                unsigned ph[8], pm[8], pl[8];
+            constexpr int NP = Mx<PREC>::NP;
+            // 16-bit operand pieces of 8 consecutive values, two per dword (PREC_X6: [0] hi, [1] mid, [2] lo)
+            auto pieces = [&](const float *v8, uint4 (&out)[NP]) { mm_pieces8<PREC>(v8, out); };
+            // both accumulator chains of a K-step, alternating
+            auto mac2 = [&](const uint4 (&a_)[NP], const uint4 (&b0_)[NP], const uint4 (&b1_)[NP], f32x16 &c0, f32x16 &c1) {
+                if constexpr (PREC == PREC_X6) {
+                    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) split3(v8[e], ph[e], pm[e], pl[e]);
-                out[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
-                out[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
-                out[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+                    for (int term = 0; term < 6; ++term) {
+                        c0 = mm_mfma<PREC>(a_[PA[term]], b0_[PB[term]], c0);
+                        c1 = mm_mfma<PREC>(a_[PA[term]], b1_[PB[term]], c1);
+                    }
+                } else {
+                    c0 = mm_mfma<PREC>(a_[0], b0_[0], c0);
+                    c1 = mm_mfma<PREC>(a_[0], b1_[0], c1);
+                }
             };
             // (1) H2 = A1 W2^T
             f32x16 acc0, acc1;
@@ -824,20 +821,15 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
-                uint4 ap[3], b0[3], b1[3];
+                uint4 ap[NP], b0[NP], b1[NP];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {               // issue the weight reads first: the split below hides them
+                for (int pc = 0; pc < NP; ++pc) {              // issue the weight reads first: the split below hides them
                     b0[pc] = *reinterpret_cast<const uint4 *>(wr0 + pc * 128 + kb * 16);
                     b1[pc] = *reinterpret_cast<const uint4 *>(wr1 + pc * 128 + kb * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 pieces(a + 8 * kb, ap);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), acc1, 0, 0, 0);
-                }
+                mac2(ap, b0, b1, acc0, acc1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // a1: A-layout -> C/D layout through the transpose tile
@@ -877,28 +869,18 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 float v8[8];
-                uint4 d[3], x0[3], x1[3];
+                uint4 d[NP], x0[NP], x1[NP];
                 pieces(aD0 + 8 * kb, x0);
                 pieces(aD1 + 8 * kb, x1);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = acc0[8 * kb + e];
                 pieces(v8, d);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const bf16x8 da = __builtin_bit_cast(bf16x8, d[PA[term]]);
-                    dW00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x0[PB[term]]), dW00, 0, 0, 0);
-                    dW01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x1[PB[term]]), dW01, 0, 0, 0);
-                }
+                mac2(d, x0, x1, dW00, dW01);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = acc1[8 * kb + e];
                 pieces(v8, d);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const bf16x8 da = __builtin_bit_cast(bf16x8, d[PA[term]]);
-                    dW10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x0[PB[term]]), dW10, 0, 0, 0);
-                    dW11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, __builtin_bit_cast(bf16x8, x1[PB[term]]), dW11, 0, 0, 0);
-                }
+                mac2(d, x0, x1, dW10, dW11);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // dH2: C/D layout -> A-layout through the transpose tile
@@ -925,20 +907,15 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {                    // K = co: lane half h holds co 32h + 8kb ..
-                uint4 ap[3], b0[3], b1[3];
+                uint4 ap[NP], b0[NP], b1[NP];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {               // issue the weight reads first: the split below hides them
+                for (int pc = 0; pc < NP; ++pc) {              // issue the weight reads first: the split below hides them
                     b0[pc] = *reinterpret_cast<const uint4 *>(wt0 + pc * 128 + kb * 16);
                     b1[pc] = *reinterpret_cast<const uint4 *>(wt1 + pc * 128 + kb * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 pieces(a + 8 * kb, ap);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, ap[PA[term]]);
-                    e0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b0[PB[term]]), e0, 0, 0, 0);
-                    e1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, b1[PB[term]]), e1, 0, 0, 0);
-                }
+                mac2(ap, b0, b1, e0, e1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // dy1 = dA1 * LReLU'(z1); G_Q (in-lane), G_P (atomic 128-B half rows)
@@ -1289,6 +1266,8 @@ static int check_args(const gfs3d_edgeconv_args *a, const char *who)
     GFS3D_REQUIRE(a->x && a->idx && a->w1 && a->bn1_w && a->bn1_b && a->w2 && a->bn2_w && a->bn2_b, "%s: NULL input", who);
     GFS3D_REQUIRE(a->P && a->Q && a->stats, "%s: NULL P/Q/stats buffer", who);
     GFS3D_REQUIRE(a->workspace != nullptr, "%s: NULL workspace", who);
+    GFS3D_REQUIRE(a->compute == GFS3D_COMPUTE_F32 || a->compute == GFS3D_COMPUTE_BF16 || a->compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
     const Plan p = make_plan(a->B, a->C, a->N, a->k);
     if (a->workspace_bytes < p.total) {
         set_error("%s: workspace %zu < required %zu", who, a->workspace_bytes, p.total);
@@ -1453,12 +1432,20 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         }
         ProfScope prof(1, st);
         const dim3 g_fwd(min(p.g_mfma + p.g_mfma / 2, (BN + 31) / 32));       // eval: 3 resident workgroups per CU
-        if (a->training)
-            hipLaunchKernelGGL(ec_main_fwd_kernel<true>, dim3(p.g_mfma), dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
-                               BN, a->N, a->k, a->slope, hmax, jmax, acc2);
-        else
-            hipLaunchKernelGGL(ec_main_fwd_kernel<false>, g_fwd, dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,
-                               BN, a->N, a->k, a->slope, hmax, jmax, acc2);
+        const int prec = prec_of(a->compute, false);
+#define GFS3D_FWD_LAUNCH(STATS_, PREC_, GRID_)                                                                                \
+        hipLaunchKernelGGL((ec_main_fwd_kernel<STATS_, PREC_>), GRID_, dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,     \
+                           BN, a->N, a->k, a->slope, hmax, jmax, acc2)
+        if (a->training) {
+            if (prec == PREC_BF16) GFS3D_FWD_LAUNCH(true, PREC_BF16, dim3(p.g_mfma));
+            else if (prec == PREC_F16) GFS3D_FWD_LAUNCH(true, PREC_F16, dim3(p.g_mfma));
+            else GFS3D_FWD_LAUNCH(true, PREC_X6, dim3(p.g_mfma));
+        } else {
+            if (prec == PREC_BF16) GFS3D_FWD_LAUNCH(false, PREC_BF16, g_fwd);
+            else if (prec == PREC_F16) GFS3D_FWD_LAUNCH(false, PREC_F16, g_fwd);
+            else GFS3D_FWD_LAUNCH(false, PREC_X6, g_fwd);
+        }
+#undef GFS3D_FWD_LAUNCH
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
@@ -1514,10 +1501,16 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a->P, a->Q, done, a->stats, total, Pp, Qp);
                 GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
             }
-            GFS3D_ENSURE_LDS(ec_main_bwd_kernel, BWD_LDS_BYTES, who);
+            const bool reduced = prec_of(a->compute, true) != PREC_X6;           // gradients: bf16 operands in both reduced modes
+            if (reduced) GFS3D_ENSURE_LDS(ec_main_bwd_kernel<PREC_BF16>, BWD_LDS_BYTES, who);
+            else GFS3D_ENSURE_LDS(ec_main_bwd_kernel<PREC_X6>, BWD_LDS_BYTES, who);
             ProfScope prof(2, st);
-            hipLaunchKernelGGL(ec_main_bwd_kernel, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
-                               g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
+            if (reduced)
+                hipLaunchKernelGGL(ec_main_bwd_kernel<PREC_BF16>, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
+                                   g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
+            else
+                hipLaunchKernelGGL(ec_main_bwd_kernel<PREC_X6>, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
+                                   g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
         hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred, ba->dw2);

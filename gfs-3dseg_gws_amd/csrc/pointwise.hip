@@ -43,6 +43,7 @@ struct RowGemm {
     const float *ea, *eb;     // epilogue scale / shift per output channel
     const float *eh;          // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc)
     double *acc;              // (2, Nc) column sums
+    int prec;                 // PREC_* of the bf16-pipe kernel (common.h)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
@@ -308,25 +309,23 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
 constexpr int PW6_ROW = 208;
 
 // w3[n][kt][plane][32] = bf16 pieces of w(n, 32 kt + j);  w element (n, k) is read at w[n * sn + k * sk]
+template <int PREC>
 __global__ void pw_split_w_kernel(const float *__restrict__ w, int Nc, int K, long long sn, long long sk, unsigned short *__restrict__ w3)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= Nc * K) return;
     const int n = e / K, k = e - n * K;
-    unsigned h, m, l;
-    split3(w[(size_t)n * sn + (size_t)k * sk], h, m, l);
-    unsigned short *o = w3 + ((size_t)n * (K / 32) + k / 32) * 96 + (k & 31);
-    o[0] = (unsigned short)(h >> 16);
-    o[32] = (unsigned short)(m >> 16);
-    o[64] = (unsigned short)(l >> 16);
+    mm_store1<PREC>(w[(size_t)n * sn + (size_t)k * sk], w3 + ((size_t)n * (K / 32) + k / 32) * 96 + (k & 31), 32);   // reduced forms: plane 0 only
 }
 
-template <int BN, int PRO, int EPI, bool OUT_CF>
+// PREC_BF16 / PREC_F16: one rounded 16-bit product per fp32 product - plane 0 of the same images, one MFMA per K-step of 16.
+template <int BN, int PRO, int EPI, bool OUT_CF, int PREC>
 __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
 {
     extern __shared__ f32x4 pw_smem4[];
     char *smem = reinterpret_cast<char *>(pw_smem4);
-    constexpr int TM = (BN == 128) ? 2 : 1, TN = 2, WM = TM * 32, NB = BN * 12 / 256;
+    constexpr int NP = Mx<PREC>::NP, PARTS = 4 * NP;          // 16-byte parts of a weight row per K-step
+    constexpr int TM = (BN == 128) ? 2 : 1, TN = 2, WM = TM * 32, NB = (BN * PARTS + 255) / 256;
     char *sA = smem;                                // [128][208 B]
     char *sB = smem + PW_BM * PW6_ROW;              // [BN][208 B]
     const int ncb = g.Nc / BN, nrb = (g.M + PW_BM - 1) / PW_BM;
@@ -369,8 +368,9 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
         const char *w3 = static_cast<const char *>(g.w3);
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-            const int q = t + 256 * p, row = q / 12, part = q - row * 12;
-            rw[p] = ldg4(reinterpret_cast<const float *>(w3 + ((size_t)(col0 + row) * KT + kt) * 192 + part * 16));
+            const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
+            if (BN * PARTS % 256 == 0 || q < BN * PARTS)
+                rw[p] = ldg4(reinterpret_cast<const float *>(w3 + ((size_t)(col0 + row) * KT + kt) * 192 + part * 16));
         }
     };
     auto store = [&](int kt) {
@@ -389,18 +389,18 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(ra2[p][e], cc[e], fmaf(v[e], ca[e], cb4[e]));
             }
             if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split3(v[e], h[e], m[e], l[e]);
+            const float v4[4] = {v[0], v[1], v[2], v[3]};
+            uint2 pc[NP];
+            mm_pieces4<PREC>(v4, pc);
             char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-            *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-            *reinterpret_cast<uint2 *>(dst + 128) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
         }
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-            const int q = t + 256 * p, row = q / 12, part = q - row * 12;
-            *reinterpret_cast<f32x4 *>(sB + row * PW6_ROW + part * 16) = rw[p];
+            const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
+            if (BN * PARTS % 256 == 0 || q < BN * PARTS)
+                *reinterpret_cast<f32x4 *>(sB + row * PW6_ROW + part * 16) = rw[p];
         }
     };
 
@@ -413,27 +413,28 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
         if (kt + 1 < KT) load(kt + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 af[TM][3], bf[TN][3];
+            uint4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pa + i * 32 * PW6_ROW + pl * 64 + kb * 32));
+                for (int pl = 0; pl < NP; ++pl)
+                    af[i][pl] = *reinterpret_cast<const uint4 *>(pa + i * 32 * PW6_ROW + pl * 64 + kb * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pb + j * 32 * PW6_ROW + pl * 64 + kb * 32));
+                for (int pl = 0; pl < NP; ++pl)
+                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pb + j * 32 * PW6_ROW + pl * 64 + kb * 32);
             // smallest pieces first
             constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < Mx<PREC>::NTERM; ++term)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        if (OUT_CF) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][PB[term]], af[i][PA[term]], acc[i][j], 0, 0, 0);
-                        else        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bf[j][PB[term]], acc[i][j], 0, 0, 0);
+                        const int ia = PREC == PREC_X6 ? PA[term] : 0, ib = PREC == PREC_X6 ? PB[term] : 0;
+                        if (OUT_CF) acc[i][j] = mm_mfma<PREC>(bf[j][ib], af[i][ia], acc[i][j]);
+                        else        acc[i][j] = mm_mfma<PREC>(af[i][ia], bf[j][ib], acc[i][j]);
                     }
         }
         __syncthreads();
@@ -451,15 +452,17 @@ struct WGrad {
     float slope;
     int M, Co, Ci, rows_per_split, nsplit;
     float *dw;                // (Co, Ci) zeroed by the launcher, accumulated with fp32 atomics
+    int prec;                 // PREC_X6 or PREC_BF16 (gradients: no half operands)
 };
 
 // dW(Co, Ci) += sum_m T(U)[m, co] T(V)[m, ci] on the bf16 matrix cores (bf16x6, see pw_rowgemm6_kernel).  The reduction
 // runs over the POINTS, so both operands are transposed while they are staged: a thread owns 4 channels x 2
 // consecutive points, splits the 8 values and writes, per channel and piece, one dword (2 bf16) into that channel's
 // LDS row - rows are channels, 32 points per K-step; lanes of a 16-lane group walk along a row (conflict-free).
-template <int BMU, int BNV, int VPRO>
+template <int BMU, int BNV, int VPRO, int PREC>
 __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 {
+    constexpr int NP = Mx<PREC>::NP;
     extern __shared__ f32x4 pw_smem4[];
     char *smem = reinterpret_cast<char *>(pw_smem4);
     constexpr int TM = BMU / 64, TN = BNV / 64, NU = BMU / 64, NV = BNV / 64;      // (quad, pair) items per thread
@@ -527,13 +530,17 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
     auto put = [&](char *base, int quad, const f32x4 &x0, const f32x4 &x1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            unsigned h0, m0_, l0, h1, m1_, l1;
-            split3(x0[c], h0, m0_, l0);
-            split3(x1[c], h1, m1_, l1);
             char *dst = base + (4 * quad + c) * PW6_ROW + pair * 4;
-            *reinterpret_cast<unsigned *>(dst) = pack_hi16(h0, h1);
-            *reinterpret_cast<unsigned *>(dst + 64) = pack_hi16(m0_, m1_);
-            *reinterpret_cast<unsigned *>(dst + 128) = pack_hi16(l0, l1);
+            if constexpr (PREC == PREC_X6) {
+                unsigned h0, m0_, l0, h1, m1_, l1;
+                split3(x0[c], h0, m0_, l0);
+                split3(x1[c], h1, m1_, l1);
+                *reinterpret_cast<unsigned *>(dst) = pack_hi16(h0, h1);
+                *reinterpret_cast<unsigned *>(dst + 64) = pack_hi16(m0_, m1_);
+                *reinterpret_cast<unsigned *>(dst + 128) = pack_hi16(l0, l1);
+            } else {
+                *reinterpret_cast<unsigned *>(dst) = mm_pack2<PREC>(x0[c], x1[c]);
+            }
         }
     };
     auto store = [&](int kt) {
@@ -578,25 +585,25 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
         if (kt + 1 < KT) load(kt + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            bf16x8 af[TM][3], bf[TN][3];
+            uint4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[i][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pu + i * 32 * PW6_ROW + pl * 64 + kb * 32));
+                for (int pl = 0; pl < NP; ++pl)
+                    af[i][pl] = *reinterpret_cast<const uint4 *>(pu + i * 32 * PW6_ROW + pl * 64 + kb * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bf[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4 *>(pv + j * 32 * PW6_ROW + pl * 64 + kb * 32));
+                for (int pl = 0; pl < NP; ++pl)
+                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pv + j * 32 * PW6_ROW + pl * 64 + kb * 32);
             constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < Mx<PREC>::NTERM; ++term)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[term]], bf[j][PB[term]], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mm_mfma<PREC>(af[i][PREC == PREC_X6 ? PA[term] : 0], bf[j][PREC == PREC_X6 ? PB[term] : 0], acc[i][j]);
         }
         __syncthreads();
     }
@@ -730,7 +737,13 @@ int launch_rowgemm6(const RowGemm &rg, hipStream_t st, const char *who)
     const size_t lds = (size_t)(PW_BM + BN) * PW6_ROW;
     const int ncb = rg.Nc / BN, nrb = (rg.M + PW_BM - 1) / PW_BM;
     const unsigned grid = 8u * ncb * ((nrb + 7) / 8);
-    hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF>), dim3(grid), dim3(256), lds, st, rg);
+    constexpr bool bwd = PRO == PRO_BWD || EPI == EPI_BWD_ACT;           // gradient GEMMs never run on half operands
+    if (rg.prec == PREC_BF16 || (rg.prec == PREC_F16 && bwd))
+        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, PREC_BF16>), dim3(grid), dim3(256), lds, st, rg);
+    else if (rg.prec == PREC_F16)
+        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, bwd ? PREC_BF16 : PREC_F16>), dim3(grid), dim3(256), lds, st, rg);
+    else
+        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, PREC_X6>), dim3(grid), dim3(256), lds, st, rg);
     GFS3D_LAUNCH_CHECK("pw_rowgemm6_kernel");
     (void)who;
     return GFS3D_OK;
@@ -760,7 +773,8 @@ template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
-    GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO>), lds, who);
+    if (wg.prec != PREC_X6) GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), lds, who);
+    else GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), lds, who);
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
     // 2-3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
     int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;
@@ -771,7 +785,8 @@ int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
     wg.rows_per_split = rows;
     wg.nsplit = nsplit;
     const unsigned grid = 8u * ntile * ((nsplit + 7) / 8);
-    hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO>), dim3(grid), dim3(256), lds, st, wg);
+    if (wg.prec != PREC_X6) hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), dim3(grid), dim3(256), lds, st, wg);
+    else hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), dim3(grid), dim3(256), lds, st, wg);
     GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
     return GFS3D_OK;
 }
@@ -783,9 +798,13 @@ int launch_wgrad(const WGrad &wg, hipStream_t st, const char *who)
     return launch_wgrad_t<64, BNV, VPRO>(wg, st, who);
 }
 
-int split_weights(const float *w, int Nc, int K, long long sn, long long sk, void *w3, hipStream_t st)
+int split_weights(const float *w, int Nc, int K, long long sn, long long sk, void *w3, hipStream_t st, int prec)
 {
-    hipLaunchKernelGGL(pw_split_w_kernel, dim3((Nc * K + 255) / 256), dim3(256), 0, st, w, Nc, K, sn, sk, static_cast<unsigned short *>(w3));
+    const dim3 grid((Nc * K + 255) / 256);
+    unsigned short *o = static_cast<unsigned short *>(w3);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(pw_split_w_kernel<PREC_BF16>, grid, dim3(256), 0, st, w, Nc, K, sn, sk, o);
+    else if (prec == PREC_F16) hipLaunchKernelGGL(pw_split_w_kernel<PREC_F16>, grid, dim3(256), 0, st, w, Nc, K, sn, sk, o);
+    else hipLaunchKernelGGL(pw_split_w_kernel<PREC_X6>, grid, dim3(256), 0, st, w, Nc, K, sn, sk, o);
     GFS3D_LAUNCH_CHECK("pw_split_w_kernel");
     return GFS3D_OK;
 }
@@ -833,6 +852,8 @@ int pw_check(const gfs3d_pointwise_args *a, const char *who, bool need_y)
     }
     GFS3D_REQUIRE(a->y_cf || !need_y, "%s: NULL y_cf", who);
     GFS3D_REQUIRE(a->workspace, "%s: NULL workspace", who);
+    GFS3D_REQUIRE(a->compute == GFS3D_COMPUTE_F32 || a->compute == GFS3D_COMPUTE_BF16 || a->compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
     return GFS3D_OK;
 }
 
@@ -906,7 +927,8 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
         fill_a(rg, a, l, l ? a->h[l - 1] : nullptr);
         rg.w = a->w[l];
         rg.w3 = ws + p.off_w3[l];
-        if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st)) return rc;
+        rg.prec = prec_of(a->compute, false);
+        if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st, rg.prec)) return rc;
         rg.M = M;
         rg.Nc = C;
         rg.slope = a->slope;
@@ -994,6 +1016,7 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
         wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
         wg.slope = a->slope;
         wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
+        wg.prec = prec_of(a->compute, true);
         int rc;
         if (l == 0) {
             for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
@@ -1007,11 +1030,12 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
         }
         if (rc) return rc;
         // dA_{l-1} = dH_l W_l
-        if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st)) return rc2;      // pieces of W_l^T (Ci, C)
+        if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st, prec_of(a->compute, true))) return rc2;      // pieces of W_l^T (Ci, C)
         RowGemm rg{};
         rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
         rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
         rg.w3 = w3t;
+        rg.prec = prec_of(a->compute, true);
         rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
         if (l == 0) {
             for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];

@@ -213,13 +213,14 @@ constexpr int PX_THREADS = 512;
 //                     valid: the wave reads its 32 x 32 chunk as 128-B row pieces (8 lanes per row) and turns it
 //                     through a wave-private LDS tile `wtile` [32][XS_LD] so that lane (j, h) gets point j's channels
 constexpr int XS_LD = 36;            // floats per row of that tile (144 B: 16-B aligned, 9 slots = odd)
-template <int NT, bool ROWMAJOR>
+template <int NT, bool ROWMAJOR, int PREC = PREC_X6>
 __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t cstride, int nrows, float *wtile,
                                           const float *__restrict__ pb, int C, int K,
                                           unsigned char *img, float *gsq_out, f32x16 (&acc)[NT], float &fsq)
 {
     constexpr int NROW = NT * 32;
     constexpr int NU = NROW * 8 / PX_THREADS;            // float4 units of a prototype chunk per thread (NT / 2)
+    constexpr int NP = Mx<PREC>::NP;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -259,19 +260,20 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
     auto stage = [&](unsigned char *dst_img) {
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            unsigned hh[4], mm[4], ll[4];
+            float v4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                split3(pr[u][e], hh[e], mm[e], ll[e]);
+                v4[e] = pr[u][e];
                 gsq[u] = fmaf(pr[u][e], pr[u][e], gsq[u]);
             }
+            uint2 pc[NP];
+            mm_pieces4<PREC>(v4, pc);
             unsigned char *dst = dst_img + (row0 + 64 * u) * PX_ROW + c4 * 8;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(pack_hi16(hh[0], hh[1]), pack_hi16(hh[2], hh[3]));
-            *reinterpret_cast<uint2 *>(dst + 64) = make_uint2(pack_hi16(mm[0], mm[1]), pack_hi16(mm[2], mm[3]));
-            *reinterpret_cast<uint2 *>(dst + 128) = make_uint2(pack_hi16(ll[0], ll[1]), pack_hi16(ll[2], ll[3]));
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
         }
     };
-    uint4 bp[2][3];                                      // this lane's point: pieces of 8 channels per K-step
+    uint4 bp[2][NP];                                     // this lane's point: pieces of 8 channels per K-step
     auto split_point = [&]() {
         if (ROWMAJOR) {                                // row pieces -> tile -> this lane's 16 channels of point j
 #pragma unroll
@@ -291,15 +293,9 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            unsigned ph[8], pm[8], pl[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                split3(fr[8 * s + e], ph[e], pm[e], pl[e]);
-                fsq = fmaf(fr[8 * s + e], fr[8 * s + e], fsq);
-            }
-            bp[s][0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
-            bp[s][1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
-            bp[s][2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+            for (int e = 0; e < 8; ++e) fsq = fmaf(fr[8 * s + e], fr[8 * s + e], fsq);
+            mm_pieces8<PREC>(fr + 8 * s, bp[s]);
         }
     };
     load(0);
@@ -307,7 +303,6 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
     split_point();
     __syncthreads();
 
-    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
     const int nchunk = C / 32;
     for (int c = 0; c < nchunk; ++c) {
         const unsigned char *cur = img + (c & 1) * NROW * PX_ROW;
@@ -317,13 +312,11 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int wt = 0; wt < NT; ++wt) {
-                bf16x8 af[3];
+                uint4 af[NP];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pa + wt * 32 * PX_ROW + pl * 64 + s * 32));
-#pragma unroll
-                for (int term = 0; term < 6; ++term)
-                    acc[wt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]], __builtin_bit_cast(bf16x8, bp[s][PB[term]]), acc[wt], 0, 0, 0);
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const uint4 *>(pa + wt * 32 * PX_ROW + pl * 64 + s * 32);
+                mm_mac<PREC>(af, bp[s], acc[wt]);
             }
         }
         if (c + 1 < nchunk) {
@@ -342,7 +335,7 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
     __syncthreads();
 }
 
-template <int NT, int MODE>
+template <int NT, int MODE, int PREC>
 __global__ void __launch_bounds__(PX_THREADS)
 proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
                 const float *__restrict__ proto, int P, int K, float scale,
@@ -358,8 +351,8 @@ proto_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, i
     const int n = blockIdx.x * 256 + wv * 32 + j;
     f32x16 acc[NT];
     float fsq;
-    x6_scores<NT, false>(feat + (size_t)b * feat_bstride + min(n, N - 1), (size_t)N, 0, nullptr,
-                         proto + (P > 1 ? (size_t)b * K * C : 0), C, K, img, ginv, acc, fsq);
+    x6_scores<NT, false, PREC>(feat + (size_t)b * feat_bstride + min(n, N - 1), (size_t)N, 0, nullptr,
+                               proto + (P > 1 ? (size_t)b * K * C : 0), C, K, img, ginv, acc, fsq);
     if (tid < NROW) ginv[tid] = 1.0f / fmaxf(sqrtf(ginv[tid]), NORM_EPS);
     __syncthreads();
     fsq += __shfl_xor(fsq, 32, 64);
@@ -381,30 +374,39 @@ static int launch_proto(const float *feat, long long bs, int B, int C, int N, co
     return GFS3D_OK;
 }
 
-template <int NT, int MODE>
-static int launch_proto_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
-                           float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
+template <int NT, int MODE, int PREC>
+static int launch_proto_x6p(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
+                            float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)2 * NT * 32 * PX_ROW + sizeof(float) * NT * 32;
-    GFS3D_ENSURE_LDS((proto_x6_kernel<NT, MODE>), lds, who);
+    GFS3D_ENSURE_LDS((proto_x6_kernel<NT, MODE, PREC>), lds, who);
     dim3 grid((N + 255) / 256, B);
     ProfScope prof(3, st);
-    hipLaunchKernelGGL((proto_x6_kernel<NT, MODE>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale,
+    hipLaunchKernelGGL((proto_x6_kernel<NT, MODE, PREC>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale,
                        out, assign, onehot);
     GFS3D_LAUNCH_CHECK(who);
     return GFS3D_OK;
 }
+template <int NT, int MODE>
+static int launch_proto_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
+                           float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who, int prec)
+{
+    if (prec == PREC_BF16) return launch_proto_x6p<NT, MODE, PREC_BF16>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    if (prec == PREC_F16) return launch_proto_x6p<NT, MODE, PREC_F16>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+    return launch_proto_x6p<NT, MODE, PREC_X6>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+}
 
 template <int MODE>
 static int dispatch_proto(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K,
-                          float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who)
+                          float scale, float *out, int32_t *assign, float *onehot, hipStream_t st, const char *who,
+                          int prec = PREC_X6)
 {
     const int nt = (K + 31) / 32;
     static const bool x6 = [] { const char *e = getenv("GFS3D_PROTO_X6"); return !(e && e[0] == '0'); }();     // tuning / A-B only
     if (x6 && nt >= 2 && C % 32 == 0 && (reinterpret_cast<uintptr_t>(proto) & 15) == 0) {
-        if (nt <= 2) return launch_proto_x6<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
-        if (nt <= 4) return launch_proto_x6<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
-        return launch_proto_x6<8, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
+        if (nt <= 2) return launch_proto_x6<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
+        if (nt <= 4) return launch_proto_x6<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
+        return launch_proto_x6<8, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
     }
     if (nt <= 1) return launch_proto<1, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
     if (nt <= 2) return launch_proto<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
@@ -559,7 +561,7 @@ static int launch_proto_bwd(const float *feat, long long bs, int B, int C, int N
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int px_kpos(int u) { return 8 * ((u >> 2) & 1) + (u & 3) + 4 * (u >> 3); }   // word u of a 16-group -> K index
 
-template <int NT, int CT, int MODE>
+template <int NT, int CT, int MODE, int PREC>
 __global__ void __launch_bounds__(PX_THREADS)
 proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N,
                     const float *__restrict__ proto, int P, int K, float scale,
@@ -630,32 +632,23 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
             if (wl < 32) {
                 unsigned short *dst = reinterpret_cast<unsigned short *>(dst_img + (4 * cq) * PX_ROW) + 16 * (wl >> 4) + px_kpos(wl & 15);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    unsigned hh, mm, ll;
-                    split3(pr[u][e], hh, mm, ll);
-                    unsigned short *row = dst + e * (PX_ROW / 2);
-                    row[0] = (unsigned short)(hh >> 16);
-                    row[32] = (unsigned short)(mm >> 16);
-                    row[64] = (unsigned short)(ll >> 16);
-                }
+                for (int e = 0; e < 4; ++e) mm_store1<PREC>(pr[u][e], dst + e * (PX_ROW / 2), 32);
             }
         }
     };
-    uint4 bp[2][3];                                      // pieces of d[t]: K-step s <-> registers 8 s .. 8 s + 7
+    constexpr int NP = Mx<PREC>::NP;
+    uint4 bp[2][NP];                                     // pieces of d[t]: K-step s <-> registers 8 s .. 8 s + 7
     auto split_d = [&](int t) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            unsigned ph[8], pm[8], pl[8];
+            float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int r = 8 * s + e, w = t * 32 + acc_row(r, h);
-                float v = (MODE == MODE_SOFTMAX) ? sv[r] * (uv[r] - dot) : uv[r];
-                v *= scale * ginv[min(w, NT * 32 - 1)];
-                split3(v, ph[e], pm[e], pl[e]);
+                const float v = (MODE == MODE_SOFTMAX) ? sv[r] * (uv[r] - dot) : uv[r];
+                v8[e] = v * (scale * ginv[min(w, NT * 32 - 1)]);
             }
-            bp[s][0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
-            bp[s][1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
-            bp[s][2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+            mm_pieces8<PREC>(v8, bp[s]);
         }
     };
 
@@ -669,7 +662,6 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
     stage(img);
     split_d(0);
     __syncthreads();
-    constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
     for (int t = 0; t < ntile; ++t) {
         const unsigned char *cur = img + (t & 1) * NROW * PX_ROW;
         if (t + 1 < ntile) load(t + 1);
@@ -678,13 +670,11 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                bf16x8 af[3];
+                uint4 af[NP];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pa + ct * 32 * PX_ROW + pl * 64 + s * 32));
-#pragma unroll
-                for (int term = 0; term < 6; ++term)
-                    G[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[term]], __builtin_bit_cast(bf16x8, bp[s][PB[term]]), G[ct], 0, 0, 0);
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const uint4 *>(pa + ct * 32 * PX_ROW + pl * 64 + s * 32);
+                mm_mac<PREC>(af, bp[s], G[ct]);
             }
         }
         if (t + 1 < ntile) {
@@ -721,27 +711,35 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
         }
 }
 
-template <int NT, int CT, int MODE>
-static int launch_proto_bwd_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
-                               const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
+template <int NT, int CT, int MODE, int PREC>
+static int launch_proto_bwd_x6p(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
+                                const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)2 * CT * 32 * PX_ROW + sizeof(float) * NT * 32;
-    GFS3D_ENSURE_LDS((proto_bwd_x6_kernel<NT, CT, MODE>), lds, who);
+    GFS3D_ENSURE_LDS((proto_bwd_x6_kernel<NT, CT, MODE, PREC>), lds, who);
     dim3 grid((N + 255) / 256, B);
     ProfScope prof(3, st);
-    hipLaunchKernelGGL((proto_bwd_x6_kernel<NT, CT, MODE>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale, soft, dup, dfeat);
+    hipLaunchKernelGGL((proto_bwd_x6_kernel<NT, CT, MODE, PREC>), grid, dim3(PX_THREADS), lds, st, feat, bs, C, N, proto, P, K, scale, soft, dup, dfeat);
     GFS3D_LAUNCH_CHECK(who);
     return GFS3D_OK;
+}
+template <int NT, int CT, int MODE>
+static int launch_proto_bwd_x6(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
+                               const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who, int prec)
+{
+    if (prec != PREC_X6)       // gradients: bf16 operands in both reduced modes
+        return launch_proto_bwd_x6p<NT, CT, MODE, PREC_BF16>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
+    return launch_proto_bwd_x6p<NT, CT, MODE, PREC_X6>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
 }
 
 template <int MODE>
 static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
-                              const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who)
+                              const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who, int prec = PREC_X6)
 {
     const int nt = (K + 31) / 32, ct = (C + 63) / 64 * 2;
     static const bool x6 = [] { const char *e = getenv("GFS3D_PROTO_X6"); return !(e && e[0] == '0'); }();     // tuning / A-B only
     if (x6 && nt >= 2 && C % 64 == 0 && C <= 192 && (reinterpret_cast<uintptr_t>(proto) & 15) == 0) {
-#define GFS3D_PX(NT_, CT_) return launch_proto_bwd_x6<NT_, CT_, MODE>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who)
+#define GFS3D_PX(NT_, CT_) return launch_proto_bwd_x6<NT_, CT_, MODE>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who, prec)
         if (C == 64) { if (nt <= 2) GFS3D_PX(2, 2); if (nt <= 4) GFS3D_PX(4, 2); GFS3D_PX(8, 2); }
         if (C == 128) { if (nt <= 2) GFS3D_PX(2, 4); if (nt <= 4) GFS3D_PX(4, 4); GFS3D_PX(8, 4); }
         if (nt <= 2) GFS3D_PX(2, 6); if (nt <= 4) GFS3D_PX(4, 6); GFS3D_PX(8, 6);
@@ -1092,7 +1090,16 @@ extern "C" int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, 
                                      const float *words, int Kw, float scale,
                                      float *soft, int32_t *assign, float *onehot, void *stream)
 {
+    return gfs3d_word_assign_mixed(feat, feat_bstride, B, C, N, words, Kw, scale, soft, assign, onehot, GFS3D_COMPUTE_F32, stream);
+}
+
+extern "C" int gfs3d_word_assign_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
+                                       const float *words, int Kw, float scale,
+                                       float *soft, int32_t *assign, float *onehot, int compute, void *stream)
+{
     using namespace gfs3d;
+    GFS3D_REQUIRE(compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16,
+                  "gfs3d_word_assign_mixed: compute must be one of GFS3D_COMPUTE_*");
     GFS3D_REQUIRE(feat && words, "gfs3d_word_assign_f32: NULL input");
     GFS3D_REQUIRE(soft || assign || onehot, "gfs3d_word_assign_f32: no output requested");
     GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, "gfs3d_word_assign_f32: bad shape B=%d C=%d N=%d", B, C, N);
@@ -1100,7 +1107,7 @@ extern "C" int gfs3d_word_assign_f32(const float *feat, long long feat_bstride, 
     GFS3D_REQUIRE(Kw >= 1 && Kw <= 256, "gfs3d_word_assign_f32: need 1 <= Kw <= 256, got %d", Kw);
     GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "gfs3d_word_assign_f32: bad feat_bstride");
     return dispatch_proto<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, words, 1, Kw, scale, soft, assign, onehot,
-                                        static_cast<hipStream_t>(stream), "gfs3d_word_assign_f32");
+                                        static_cast<hipStream_t>(stream), "gfs3d_word_assign_f32", prec_of(compute, false));
 }
 
 extern "C" int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int C, int N,
@@ -1146,8 +1153,18 @@ extern "C" int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_b
                                              const float *proto, int P, int K, float scale,
                                              const float *soft, const float *dup, float *dfeat, void *stream)
 {
+    return gfs3d_proto_backward_feat_mixed(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, GFS3D_COMPUTE_F32, stream);
+}
+
+extern "C" int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
+                                               const float *proto, int P, int K, float scale,
+                                               const float *soft, const float *dup, float *dfeat, int compute, void *stream)
+{
     using namespace gfs3d;
     const char *who = "gfs3d_proto_backward_feat_f32";
+    GFS3D_REQUIRE(compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
+    const int prec = prec_of(compute, true);
     GFS3D_REQUIRE(feat && proto && dup && dfeat, "%s: NULL pointer", who);
     GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && C <= 192 && N >= 1, "%s: bad shape B=%d C=%d N=%d (C <= 192)", who, B, C, N);
     GFS3D_REQUIRE(K >= 1 && K <= 256, "%s: need 1 <= K <= 256, got %d", who, K);
@@ -1155,6 +1172,6 @@ extern "C" int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_b
     GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "%s: bad feat_bstride", who);
     GFS3D_REQUIRE((long long)N * 256 * 4 < 0x7fffffffll, "%s: N=%d too large for 32-bit plane offsets", who, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
-    return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who);
+    if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who, prec);
+    return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who, prec);
 }

@@ -34,6 +34,7 @@ class EdgeConvArgs(Structure):
         ("x_pm", c_void_p),
         ("Pp", c_void_p), ("Qp", c_void_p),
         ("y_sqnorm", c_void_p),
+        ("compute", c_int),
     ]
 
 
@@ -49,6 +50,7 @@ class EdgeConvBwdArgs(Structure):
 
 
 PW_MAX_LAYERS, PW_MAX_SEGS, PW_SEG_WIDTH = 4, 4, 64
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2          # include/gfs3d.h: GFS3D_COMPUTE_*
 
 
 class PointwiseArgs(Structure):
@@ -64,6 +66,7 @@ class PointwiseArgs(Structure):
         ("h", c_void_p * PW_MAX_LAYERS), ("stats", c_void_p * PW_MAX_LAYERS),
         ("y_cf", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("compute", c_int),
     ]
 
 
@@ -106,6 +109,10 @@ SYMBOLS = {
                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_kmeans_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "gfs3d_word_assign_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gfs3d_proto_backward_feat_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                                c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 

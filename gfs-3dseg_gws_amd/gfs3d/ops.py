@@ -18,6 +18,44 @@ from ._lib import PointwiseArgs, PointwiseBwdArgs, PW_MAX_LAYERS, PW_MAX_SEGS, P
 EC_WIDTH = 64
 MAX_K = 32
 
+# --------------------------------------------------------------------------
+# arithmetic of the GEMM-shaped kernels (include/gfs3d.h: GFS3D_COMPUTE_*)
+# --------------------------------------------------------------------------
+_COMPUTE_IDS = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f16": _lib.COMPUTE_F16}
+_compute = _lib.COMPUTE_F32
+
+
+def set_compute(mode: str) -> str:
+    """Select the matrix-core operand form of every following call: "f32" (default: fp32 accuracy, exact 3-way bf16
+    split), "bf16" (one bf16 product per fp32 product) or "f16" (half operands forward, bf16 backward) - BASELINE
+    configs[4]'s reduced-precision mode.  Tensors stay fp32; kNN, BatchNorm statistics and reductions are unaffected.
+    A backward pass uses the mode its forward ran in.  Returns the previous mode."""
+    global _compute
+    if mode not in _COMPUTE_IDS:
+        raise ValueError(f"gfs3d.set_compute: mode must be one of {sorted(_COMPUTE_IDS)}, got {mode!r}")
+    prev = get_compute()
+    _compute = _COMPUTE_IDS[mode]
+    return prev
+
+
+def get_compute() -> str:
+    return next(k for k, v in _COMPUTE_IDS.items() if v == _compute)
+
+
+class compute:
+    """`with ops.compute("bf16"): ...` - scoped set_compute()."""
+
+    def __init__(self, mode: str):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_compute(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_compute(self.prev)
+        return False
+
 
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -114,6 +152,7 @@ class EdgeConvRun:
             raise RuntimeError("gfs3d.edgeconv: x_pm must be the contiguous (B,N,C) fp32 point-major copy of x")
         self.x_pm = x_pm
         self.training = bool(training)
+        self.compute = _compute                      # the backward of this run uses the same mode
         self.scalars = (float(eps), float(momentum), float(slope))
         self.w1, self.w2 = w1.contiguous(), w2.contiguous()
         self.g1, self.b1, self.g2, self.b2 = g1, b1, g2, b2
@@ -145,6 +184,7 @@ class EdgeConvRun:
         eps, momentum, slope = self.scalars
         a.B, a.C, a.N, a.k = self.B, self.C, self.N, self.k
         a.training = 1 if self.training else 0
+        a.compute = self.compute
         a.eps, a.momentum, a.slope = eps, momentum, slope
         a.x, a.idx, a.w1 = self.x.data_ptr(), self.idx.data_ptr(), self.w1.data_ptr()
         a.bn1_w, a.bn1_b = self.g1.data_ptr(), self.b1.data_ptr()
@@ -327,6 +367,7 @@ class PointwiseRun:
                 raise NotImplementedError("gfs3d.pointwise: layer widths must be multiples of 64 (<= 1024) and chain")
             prev = c
         self.training = bool(training)
+        self.compute = _compute
         self.scalars = (float(eps), float(momentum), float(slope))
         dev = self.xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -342,6 +383,7 @@ class PointwiseRun:
         eps, momentum, slope = self.scalars
         a.B, a.N, a.n_seg, a.n_layers = self.B, self.N, len(self.xs), len(self.layers)
         a.training = 1 if self.training else 0
+        a.compute = self.compute
         a.eps, a.momentum, a.slope = eps, momentum, slope
         for s_, t in enumerate(self.xs):
             a.x_seg[s_] = t.data_ptr()
@@ -509,7 +551,7 @@ def _bstride(t: torch.Tensor) -> int:
 
 
 def word_assign_raw(feat: torch.Tensor, words: torch.Tensor, scale: float = 10.0,
-                    want_soft: bool = True, want_onehot: bool = True):
+                    want_soft: bool = True, want_onehot: bool = True, compute: Optional[int] = None):
     """softmax(scale*cos(word, point)) over words, arg-max word and its one-hot
     (model/capl.py:344-353).  No autograd here - see WordAssignFunction."""
     _need_gpu(feat, "feat")
@@ -522,9 +564,9 @@ def word_assign_raw(feat: torch.Tensor, words: torch.Tensor, scale: float = 10.0
     onehot = torch.empty((B, Kw, N), dtype=torch.float32, device=dev) if want_onehot else None
     assign = torch.empty((B, N), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().gfs3d_word_assign_f32(_p(feat), _bstride(feat), B, C, N, _p(words), Kw, float(scale),
-                                              _p(soft), _p(assign), _p(onehot), _stream())
-    _lib.check(rc, "gfs3d_word_assign_f32")
+        rc = _lib.lib().gfs3d_word_assign_mixed(_p(feat), _bstride(feat), B, C, N, _p(words), Kw, float(scale),
+                                                _p(soft), _p(assign), _p(onehot), _compute if compute is None else compute, _stream())
+    _lib.check(rc, "gfs3d_word_assign_mixed")
     return soft, assign, onehot
 
 
@@ -546,7 +588,7 @@ def proto_cosine_raw(feat: torch.Tensor, proto: torch.Tensor, scale: float = 10.
 
 
 def proto_backward_feat(feat: torch.Tensor, proto: torch.Tensor, scale: float, dup: torch.Tensor,
-                        soft: Optional[torch.Tensor] = None) -> torch.Tensor:
+                        soft: Optional[torch.Tensor] = None, compute: Optional[int] = None) -> torch.Tensor:
     """Gradient of a cosine head w.r.t. the point features: `dup` is the gradient of the logits (get_pred) or, with
     `soft` given, of the softmax over the words (word assignment).  One fused HIP kernel (softmax backward,
     (C x K).(K x points) contraction on MFMA, normalisation backward)."""
@@ -557,9 +599,10 @@ def proto_backward_feat(feat: torch.Tensor, proto: torch.Tensor, scale: float, d
     dup = dup.contiguous()
     dfeat = torch.empty((B, C, N), dtype=torch.float32, device=feat.device)
     with torch.cuda.device(feat.device):
-        rc = _lib.lib().gfs3d_proto_backward_feat_f32(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
-                                                      _p(soft), _p(dup), _p(dfeat), _stream())
-    _lib.check(rc, "gfs3d_proto_backward_feat_f32")
+        rc = _lib.lib().gfs3d_proto_backward_feat_mixed(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
+                                                        _p(soft), _p(dup), _p(dfeat), _compute if compute is None else compute,
+                                                        _stream())
+    _lib.check(rc, "gfs3d_proto_backward_feat_mixed")
     return dfeat
 
 
@@ -571,6 +614,7 @@ class WordAssignFunction(torch.autograd.Function):
     def forward(ctx, feat, words, scale):
         soft, assign, onehot = word_assign_raw(feat, words, scale)
         ctx.scale = scale
+        ctx.compute = _compute
         ctx.save_for_backward(feat, words, soft)
         ctx.mark_non_differentiable(onehot, assign)
         return soft, onehot, assign
@@ -580,7 +624,7 @@ class WordAssignFunction(torch.autograd.Function):
         feat, words, soft = ctx.saved_tensors
         if feat.shape[1] > 192:
             raise NotImplementedError("gfs3d.word_assign: the backward kernel handles up to 192 feature channels")
-        return proto_backward_feat(feat, words, ctx.scale, dsoft, soft), None, None
+        return proto_backward_feat(feat, words, ctx.scale, dsoft, soft, compute=ctx.compute), None, None
 
 
 class ProtoCosineFunction(torch.autograd.Function):

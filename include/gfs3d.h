@@ -32,6 +32,19 @@ extern "C" {
 #define GFS3D_ERR_WORKSPACE 2    /* workspace too small */
 #define GFS3D_ERR_HIP 3          /* a HIP runtime call or launch failed */
 
+/* Arithmetic of the GEMM-shaped kernels (EdgeConv conv2, point-wise stack, word / prototype matching, k-means),
+ * chosen per call.  Tensors in HBM are fp32 in every mode; what changes is the matrix-core operand form:
+ *   GFS3D_COMPUTE_F32   fp32 accuracy (default): every fp32 operand enters the bf16 matrix cores as the exact sum of
+ *                       three bf16 pieces, six piece products per fp32 product - within 1e-4 of the fp32 reference
+ *   GFS3D_COMPUTE_BF16  ONE bf16 product per fp32 product (operands rounded to nearest-even), fp32 accumulate:
+ *                       BASELINE configs[4]'s reduced-precision mode; tolerance vs the fp32 oracle in DESIGN.md
+ *   GFS3D_COMPUTE_F16   the same with IEEE half operands in the FORWARD passes (11 significand bits instead of 8);
+ *                       backward passes use bf16 operands (gradients of a mean loss underflow in half)
+ * kNN (bit-exact contract), BatchNorm statistics and all reductions stay fp32 / fp64 in every mode. */
+#define GFS3D_COMPUTE_F32 0
+#define GFS3D_COMPUTE_BF16 1
+#define GFS3D_COMPUTE_F16 2
+
 #define GFS3D_EC_WIDTH 64        /* EdgeConv block widths supported: [64, 64] */
 #define GFS3D_MAX_K 32           /* neighbours per point supported by the EdgeConv kernels */
 
@@ -105,6 +118,7 @@ typedef struct gfs3d_edgeconv_args {
     float *y_sqnorm;              /* optional out (B*N floats + 16 floats of slack): |y_n|^2 summed over the 64 channels in the kNN
                                      kernel's order (sequential c, rounded squares) - hand it to gfs3d_knn_topk_norms_f32 for
                                      the next layer's graph instead of a norm pass */
+    int compute;                  /* GFS3D_COMPUTE_*: arithmetic of conv2 (heavy kernels) and of the point-major projection GEMM */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);
@@ -173,6 +187,7 @@ typedef struct gfs3d_pointwise_args {
     float *y_cf;
     void *workspace;
     size_t workspace_bytes;
+    int compute;                  /* GFS3D_COMPUTE_*: arithmetic of the row GEMMs and weight-gradient GEMMs */
 } gfs3d_pointwise_args;
 
 typedef struct gfs3d_pointwise_bwd_args {
@@ -232,6 +247,15 @@ int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_bstride, int
                                   const float *soft, const float *dup, float *dfeat, void *stream);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
+/* gfs3d_word_assign_f32 / gfs3d_proto_backward_feat_f32 with the matrix-core operand form chosen by the caller
+ * (`compute` = GFS3D_COMPUTE_*; tensors stay fp32).  The reduced forms apply to the geometric-word shapes (more than 32
+ * prototypes, C % 32 == 0); get_pred-sized calls (<= 32 prototypes) are HBM-bound on fp32 MFMAs and ignore it. */
+int gfs3d_word_assign_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
+                            const float *words, int Kw, float scale,
+                            float *soft, int32_t *assign, float *onehot, int compute, void *stream);
+int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
+                                    const float *proto, int P, int K, float scale,
+                                    const float *soft, const float *dup, float *dfeat, int compute, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,226 @@
+"""GPU tests of the reduced-precision modes (BASELINE configs[4]: "fp16 EdgeConv + MFMA prototype distance").
+
+`ops.compute("f16")`: half operands in the forward GEMMs, bf16 operands in the backward GEMMs (gradients of a mean loss
+underflow in half); `ops.compute("bf16")`: bf16 operands everywhere.  One 16-bit product per fp32 product, fp32
+accumulate; tensors, kNN, BatchNorm statistics and reductions stay fp32 / fp64.  The reference is fp32 only (SURVEY 7
+"Hard parts"), so the tolerance of these modes is DEFINED here, against the fp32 oracle / the reference goldens, from
+what one operand rounding does (relative 2^-12 for half, 2^-9 for bf16):
+
+  per kernel, forward     half: max error <= 1e-3 of the tensor's max      bf16: <= 1e-2
+  model level, forward    features: half <= 1e-3 / bf16 <= 1e-2 of max; geometric words agree on >= 99.5 % / 98 % of the
+                          points; eval predictions (arg-max over classes) agree on >= 99.5 % / 99 %
+  training                loss within 1e-3 (half) / 2e-3 (bf16) relative of the golden
+  gradients               direction, not elements: a forward difference of 1e-3 moves ~0.03 % (half) / ~0.3 % (bf16) of
+                          the LeakyReLU pre-activations across the kink, and each flipped unit changes its gradient by
+                          80 % - an rms error of sqrt(fraction) * 0.8 (1.5 % / 5 %) that no arithmetic can avoid.  Per
+                          kernel: cosine with the fp32-accurate gradient >= 0.999 (half) / 0.99 (bf16); whole model:
+                          >= 0.95 / 0.8 for every parameter tensor.
+The fp32-accurate mode (default) is untouched by all this: tests/test_gpu_parity.py runs in it.
+"""
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_dict_from
+from oracle import c_oracle, ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = {"f16": 1e-3, "bf16": 1e-2}
+KERNEL_COS = {"f16": 0.999, "bf16": 0.99}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from gfs3d import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def relmax(a, b):
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((torch.as_tensor(a).detach().cpu().double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def cosine(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double().flatten(), torch.as_tensor(b).detach().cpu().double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def test_compute_mode_api(dev):
+    from gfs3d import ops
+    assert ops.get_compute() == "f32"
+    with ops.compute("bf16"):
+        assert ops.get_compute() == "bf16"
+        with ops.compute("f16"):
+            assert ops.get_compute() == "f16"
+        assert ops.get_compute() == "bf16"
+    assert ops.get_compute() == "f32"
+    with pytest.raises(ValueError):
+        ops.set_compute("fp8")
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (2, 64, 300, 20), (1, 64, 77, 7)])
+def test_edgeconv_reduced_vs_oracle(dev, mode, B, C, N, k):
+    """K2 in a reduced mode against the fp32 oracle (autograd on the materialised edge tensor), eval and training."""
+    from gfs3d import ops
+    from test_gpu_parity import _block_params, _make_block, _force_routing
+    p = _block_params(C, 400 + C)
+    g = torch.Generator().manual_seed(N + k)
+    x = torch.randn(B, C, N, generator=g)
+    cot = torch.randn(B, 64, N, generator=g)
+    idx = torch.from_numpy(c_oracle.knn(x.numpy(), k))
+    ref_eval = R.conv_stack(R.edge_feature(x, k, idx), p, "b", 2, training=False).max(dim=-1)[0]
+    pr = {kk: v.clone().requires_grad_("running" not in kk) for kk, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr, jr = R.conv_stack(R.edge_feature(xr, k, idx), pr, "b", 2, training=True, new_stats={}).max(dim=-1)
+    (yr * cot).sum().backward()
+    with ops.compute(mode):
+        blk = _make_block(p, C, dev).eval()
+        c1, bn1, c2, bn2 = blk.fused_parts()
+        with torch.no_grad():
+            y = ops.edgeconv_block(x.to(dev), idx.int().to(dev), c1.weight, bn1, c2.weight, bn2, False)
+        assert relmax(y, ref_eval) < FWD_TOL[mode]
+        blk.train()
+        xg = x.to(dev).requires_grad_(True)
+        yt = ops.edgeconv_block(xg, idx.int().to(dev), c1.weight, bn1, c2.weight, bn2, True)
+        assert yt.grad_fn.c.compute == {"f16": 2, "bf16": 1}[mode]
+    # outside the context: the backward still runs in the mode of its forward
+    (yt * cot.to(dev)).sum().backward()
+    assert relmax(yt, yr) < FWD_TOL[mode]
+    assert cosine(xg.grad, xr.grad) > KERNEL_COS[mode]
+    assert cosine(c2.weight.grad, pr["b.layer.3.weight"].grad) > KERNEL_COS[mode]
+    assert cosine(c1.weight.grad, pr["b.layer.0.weight"].grad) > KERNEL_COS[mode]
+    assert cosine(bn2.weight.grad, pr["b.layer.4.weight"].grad) > KERNEL_COS[mode]
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("B,N,nseg,widths", [(2, 200, 3, [512, 256]), (1, 130, 1, [64]), (2, 96, 2, [192, 128, 64])])
+def test_pointwise_stack_reduced_vs_torch(dev, mode, B, N, nseg, widths):
+    from gfs3d import ops
+    from model.dgcnn import conv1d
+    from test_gpu_parity import _pw_reference
+    torch.manual_seed(B * 100 + N + nseg)
+    conv = conv1d(64 * nseg, widths).to(dev).train()
+    xs = [torch.randn(B, N, 64, device=dev).requires_grad_(True) for _ in range(nseg)]
+    cot = torch.randn(B, widths[-1], N, device=dev)
+    ref, y_ref, gx_ref = _pw_reference(conv, xs, cot, True)
+    with ops.compute(mode):
+        y = ops.pointwise_stack(xs, conv.fused_parts(), True)
+        y.backward(cot)
+        conv.eval()
+        with torch.no_grad():
+            ye = ops.pointwise_stack([t.detach() for t in xs], conv.fused_parts(), False)
+    assert relmax(y, y_ref) < FWD_TOL[mode]
+    assert relmax(ye, ref.eval()(torch.cat([t.detach().double().transpose(1, 2) for t in xs], dim=1))) < FWD_TOL[mode]
+    for t, gr in zip(xs, gx_ref):
+        assert cosine(t.grad, gr) > KERNEL_COS[mode]
+    for (n1, p1), (_, p2) in zip(conv.named_parameters(), ref.named_parameters()):
+        if float(p2.grad.abs().max()) > 1e-9:
+            assert cosine(p1.grad, p2.grad) > KERNEL_COS[mode], n1
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("B,C,N,Kw", [(2, 192, 256, 200), (1, 192, 100, 180), (2, 64, 130, 40)])
+def test_word_assign_reduced_vs_oracle(dev, mode, B, C, N, Kw):
+    """K3 (more than 32 prototypes: the matrix-core form) in a reduced mode: softmax within 1e-3 / 1e-2 of its max,
+    arg-max words equal wherever the two best cosines are separated by more than the operand rounding, gradient direction."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(Kw + N)
+    feat = torch.randn(B, C, N, generator=g)
+    gp = torch.randn(Kw, C, generator=g)
+    cot = torch.randn(B, Kw, N, generator=g)
+    fr = feat.clone().requires_grad_(True)
+    soft_r, oh_r = R.geometric_word_assign(gp, fr)
+    (soft_r * cot).sum().backward()
+    with ops.compute(mode):
+        fd = feat.to(dev).requires_grad_(True)
+        soft, onehot, assign = ops.WordAssignFunction.apply(fd, gp.to(dev), 10.0)
+        (soft * cot.to(dev)).sum().backward()
+    assert relmax(soft, soft_r) < FWD_TOL[mode]
+    cosm = torch.nn.functional.normalize(gp, dim=1) @ torch.nn.functional.normalize(feat, dim=1)       # (B,Kw,N)
+    top2 = cosm.topk(2, dim=1)[0]
+    clear = (top2[:, 0] - top2[:, 1]) > 4 * FWD_TOL[mode]
+    agree = assign.cpu().long() == oh_r.argmax(1)
+    assert bool(agree[clear].all()) and float(agree.float().mean()) > 0.97
+    assert bool((onehot.sum(1) == 1).all())
+    assert cosine(fd.grad, fr.grad) > KERNEL_COS[mode]
+
+
+def _capl(g, dev, classes, base):
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                              base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=classes, criterion=torch.nn.CrossEntropyLoss(ignore_index=255), args=a,
+                                      base_num=base, gp=torch.from_numpy(g["gp"]).to(dev), energy=0.9)
+    m.load_state_dict(state_dict_from(g))
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("mode,word_agree,pred_agree", [("f16", 0.995, 0.995), ("bf16", 0.98, 0.99)])
+def test_capl_scannet_reduced_vs_reference_golden(dev, mode, word_agree, pred_agree):
+    """BASELINE configs[4] shapes (ScanNet: 21 + 1 classes, base_num 15, K_w = 180) in the reduced modes against the
+    reference's fp32 outputs: getFeatures and the eval forward (capl.py:324-362, 170-192)."""
+    from gfs3d import ops
+    g = load_golden("capl_scannet")
+    m = _capl(g, dev, 21, 15).eval()
+    coding = torch.from_numpy(g["gw_coding"]).to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with ops.compute(mode), torch.no_grad():
+        pf, sem, oh = m.getFeatures(x)
+        lg, acc, nacc = m(x, y=torch.from_numpy(g["gw_lab21"]).to(dev), gened_proto=torch.from_numpy(g["fe_gened"]).to(dev).unsqueeze(0),
+                          eval_model=True, base_class_coding=coding[:15], novel_class_coding=coding[15:])
+    assert relmax(pf, g["gf_point"]) < FWD_TOL[mode] and relmax(sem, g["gf_sem"]) < FWD_TOL[mode]
+    same_word = oh.argmax(1).cpu().numpy() == g["gf_word"]
+    assert float(same_word.mean()) >= word_agree
+    ref = torch.from_numpy(g["fe_logits"])
+    assert float((lg.argmax(1).cpu() == ref.argmax(1)).float().mean()) >= pred_agree
+    # where the geometric word is the reference's, the re-weighted logits are within the forward tolerance of 10 * cosine
+    err = (lg.cpu() - ref).abs().amax(1)[torch.from_numpy(same_word)]
+    assert float(err.max()) < 20 * FWD_TOL[mode] * 1.2
+
+
+@pytest.mark.parametrize("mode,loss_tol,min_cos", [("f16", 1e-3, 0.95), ("bf16", 2e-3, 0.8)])
+def test_capl_train_step_reduced_vs_reference_golden(dev, mode, loss_tol, min_cos):
+    """A whole CAPL training step (capl.py:194-242) in a reduced mode: loss, predictions and the direction of every
+    parameter gradient against the reference's fp32 step."""
+    from gfs3d import ops
+    g = load_golden("capl")
+    m = _capl(g, dev, 13, 7).train()
+    mask = np.unpackbits(g["ft_mask"])[: int(np.prod(g["ft_mask_shape"]))].reshape(g["ft_mask_shape"])
+    m.att_learner._forced_keep_mask = torch.from_numpy(mask.astype(bool)).to(dev)
+    random.seed(0)
+    with ops.compute(mode):
+        pred, loss = m(torch.from_numpy(g["x"]).to(dev), y=torch.from_numpy(g["y"]).to(dev))
+        loss.backward()
+    assert abs(float(loss.detach()) - float(g["ft_loss"])) <= loss_tol * abs(float(g["ft_loss"]))
+    assert float((pred.cpu().numpy() == g["ft_pred"]).mean()) > 0.9
+    checked = 0
+    for n, p in m.named_parameters():
+        key = "ft_grad." + n
+        if p.grad is None or key not in g.files or float(np.abs(g[key]).max()) < 1e-6:
+            continue
+        assert bool(torch.isfinite(p.grad).all()), n
+        assert cosine(p.grad, g[key]) >= min_cos, n
+        checked += 1
+    assert checked >= 30
+
+
+def test_reduced_modes_full_size_step_is_finite(dev):
+    """B = 64 x 2048 (configs[4] batch) DGCNN training step in both reduced modes: finite outputs and gradients."""
+    from gfs3d import ops
+    from model.dgcnn import DGCNN
+    x = R.synthetic_blocks(64, 2048, seed=2).to(dev)
+    for mode in ("f16", "bf16"):
+        torch.manual_seed(0)
+        net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev).train()
+        with ops.compute(mode):
+            feats, out = net(x)
+            out.mean().backward()
+        assert bool(torch.isfinite(out).all())
+        assert all(bool(torch.isfinite(q.grad).all()) and float(q.grad.abs().max()) > 0 for q in net.parameters())
