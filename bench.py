@@ -8,15 +8,27 @@ over synthetic B x 2048 x 9 blocks, k = 20 (config 2: B = 32 per GPU), blocks/s.
 
 One process per GPU; ranks own disjoint shards of the block batch (weak scaling:
 32 blocks per GPU); the only data-path collective is one flat-bucket gradient
-all-reduce (RCCL) per step.  A step = zero grads, DGCNN train-mode forward
-(BatchNorm batch statistics), backward, gradient all-reduce, Adam update.
-Rank 0 prints ONE JSON line.
+all-reduce (RCCL) per step.  A step = zero grads, train-mode forward (BatchNorm
+batch statistics), backward, gradient all-reduce, Adam update.  Rank 0 prints ONE JSON line.
+
+--workload c2 (default)  BASELINE configs[1]: DGCNN + EdgeConv fwd/bwd, B = 32 per GPU, fp32 accuracy
+--workload c4            configs[3]: the whole CAPL training step (S3DIS shapes, 13 + 1 classes, K_w = 200), B = 32 per GPU
+--workload c5            configs[4]: CAPL step with ScanNet shapes (21 + 1 classes, K_w = 180), B = 64 per GPU, reduced
+                         precision (half forward / bf16 backward operands; --dtype bf16 for bf16 everywhere)
+
+The timed region runs un-instrumented; the per-kernel times come from a second pass of the same K steps with the
+library's hipEvent brackets on (events on the launch stream, from a pool: no allocation inside).  With the default
+workload rank 0 afterwards measures the other kernels of the path on their BASELINE shapes (`extra`: word assignment,
+get_pred, one Lloyd step of configs[2], attention, the configs[3] / configs[4] steps), each against its binding roof.
 """
 import argparse
+import ctypes
 import json
 import os
+import random
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "gfs-3dseg_gws_amd")):
@@ -25,11 +37,23 @@ for p in (ROOT, os.path.join(ROOT, "gfs-3dseg_gws_amd")):
 
 import torch  # noqa: E402
 
-B_PER_GPU, NPTS, KNN, CIN = 32, 2048, 20, 9
-PEAK_FP32_TFLOPS = 157.3       # MI355X dense fp32 (vector == matrix) peak, MI355X_MICROARCH.md
+NPTS, KNN, CIN = 2048, 20, 9
+PEAK_FP32_TFLOPS = 157.3       # MI355X dense fp32 (vector == fp32 MFMA) peak, MI355X_MICROARCH.md
+PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
-KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_kernel", 3: "proto_mfma_kernel",
-           4: "ec_stats1_kernel", 5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd"}
+KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_kernel", 3: "proto_kernels", 4: "ec_stats1_kernel",
+           5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd", 8: "attention_fwd", 9: "attention_bwd"}
+WORKLOADS = {
+    "c2": dict(model="dgcnn", B=32, dtype="f32", classes=0, base=0, Kw=0,
+               text="configs[1]: S3DIS-shaped blocks, batch=32x2048x9 per GPU, k=20, DGCNN+EdgeConv fwd/bwd (train mode, BN batch stats) "
+                    "+ grad all-reduce + Adam"),
+    "c4": dict(model="capl", B=32, dtype="f32", classes=13, base=7, Kw=200,
+               text="configs[3]: S3DIS S0 CAPL training step (DGCNN + attention + geometric words K_w=200 + prototype matching, 13+1 "
+                    "classes), batch=32x2048x9 per GPU, k=20, fwd/bwd + grad all-reduce + Adam"),
+    "c5": dict(model="capl", B=64, dtype="f16", classes=21, base=15, Kw=180,
+               text="configs[4]: ScanNet S0 CAPL training step (21+1 classes, K_w=180), batch=64x2048x9 per GPU, k=20, reduced precision "
+                    "(16-bit matrix-core operands, fp32 accumulate and storage; kNN fp32 bit-exact), fwd/bwd + grad all-reduce + Adam"),
+}
 
 
 def algorithmic_flops(kid, B):
@@ -48,18 +72,27 @@ def algorithmic_flops(kid, B):
         return B * N * mlp, 1
     if kid == 7:
         return B * N * 2 * mlp, 1
+    if kid == 8:
+        return B * 4 * N * N * 64, 1           # S = q^T k and O = P v
+    if kid == 9:
+        return B * 10 * N * N * 64, 1          # five N x N x 64 products (S and dP recomputed for both sides counted once)
     return 0, 0
 
 
-def hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/r01_e_hbm_traffic.json:
+def hbm_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/<tag>_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note;
-    scripts/collect_profiles.py)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")) as f:
-            return json.load(f).get(kernel, {}).get("traffic_bytes_per_launch")
-    except OSError:
-        return None
+    scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
+    for t in (tag, "r01_e"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
+                d = json.load(f)
+            for k, v in d.items():
+                if k.startswith(kernel) and isinstance(v, dict):
+                    return v.get("traffic_bytes_per_launch"), f"profiles/{t}_hbm_traffic.json"
+        except OSError:
+            continue
+    return None, None
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -80,15 +113,183 @@ def cpu_baseline(seconds_budget=25.0):
         _, out = R.dgcnn_forward(p, x, k=KNN, training=True, new_stats={})
         out.mean().backward()
     one()
-    t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget * 0.6 and n < 10):
+    times = []
+    t_start = time.time()
+    while len(times) < 3 or (time.time() - t_start < seconds_budget * 0.6 and len(times) < 10):
+        t0 = time.time()
         one()
-        n += 1
-    dt = (time.time() - t0) / n
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     torch.set_num_threads(prev_threads)
-    return {"value": round(Bc / dt, 3), "unit": "blocks/s", "cores": cores, "kind": "port",
-            "sample": f"{n} iterations of B={Bc} x {NPTS} x {CIN}, k={KNN}, DGCNN fwd+bwd (torch CPU oracle)"}
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": round(Bc / dt, 3), "unit": "blocks/s", "cores": cores, "kind": "port", "cpu": model,
+            "sample": f"median of {len(times)} iterations of B={Bc} x {NPTS} x {CIN}, k={KNN}, DGCNN fwd+bwd (torch CPU oracle)"}
+
+
+def capl_args():
+    return types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=CIN, dgcnn_k=KNN,
+                                 base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+
+
+def build_step(cfg, dev, rank, world, sync_bn, gdist):
+    """-> (step(), net, bucket, x): one training step of the workload on this rank's shard."""
+    from gfs3d import ops
+    from gfs3d.synthetic import synthetic_blocks    # input recipe (SURVEY 8d); oracle/ is used by cpu_baseline() only
+    torch.manual_seed(0)
+    x = synthetic_blocks(cfg["B"], NPTS, seed=rank).to(dev)
+    if cfg["model"] == "dgcnn":
+        from model.dgcnn import DGCNN
+        net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev).train()
+        early = list(net.conv.parameters())           # 88 % of the parameters, first in backward order
+        y = None
+    else:
+        import contextlib
+        import io
+        from model.capl import mpti_net_Point_GeoAsWeight_v2
+        gp = torch.randn(cfg["Kw"], 192, generator=torch.Generator().manual_seed(2)).to(dev)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = mpti_net_Point_GeoAsWeight_v2(classes=cfg["classes"], args=capl_args(), base_num=cfg["base"], gp=gp, energy=0.9)
+        net = net.to(dev).train()
+        edge = {id(p) for p in net.encoder.edge_convs.parameters()}
+        early = [p for p in net.parameters() if id(p) not in edge]      # everything that is complete before the EdgeConv backward
+        y = torch.randint(0, cfg["base"] + 1, (cfg["B"], NPTS), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    if sync_bn and world > 1:
+        net = gdist.enable_sync_batchnorm(net)
+    # the early slice is exchanged under the EdgeConv backward - unless synchronised BatchNorm puts other collectives inside
+    # backward (then every rank must issue them in one fixed order)
+    bucket = gdist.FlatGradBucket(net.parameters(), early=early, overlap=not (sync_bn and world > 1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    mode = cfg["dtype"]
+
+    if cfg["model"] == "dgcnn":
+        def step():
+            bucket.zero()
+            with ops.compute(mode):
+                _, out = net(x)
+                out.mean().backward()
+            bucket.all_reduce_mean()
+            opt.step()
+    else:
+        def step():
+            bucket.zero()
+            random.seed(0)                            # rank-identical fake-novel draw (train.py seeds every rank alike)
+            with ops.compute(mode):
+                _, loss = net(x, y=y)
+                loss.backward()
+            bucket.all_reduce_mean()
+            opt.step()
+    return step, net, bucket, x
+
+
+def read_profile(L):
+    prof = {}
+    for kid in KERNELS:
+        ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
+        L.gfs3d_profile_read(kid, ctypes.byref(ms), ctypes.byref(n))
+        if n.value:
+            prof[kid] = (ms.value, n.value)
+    return prof
+
+
+def timed_ms(fn, iters, warm=3):
+    """Device time per call on the current stream (the stream the library launches on)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def extras(dev, L, gdist):
+    """The other kernels of the path on their BASELINE shapes, each against its BINDING roof (word cosine,
+    get_pred and the Lloyd step are HBM-bound, attention is bound by the fp32 matrix rate)."""
+    from gfs3d import ops
+    out = {}
+    B, N = 32, NPTS
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        feat = torch.randn(B, 192, N, generator=g).to(dev)
+        words = torch.randn(200, 192, generator=g).to(dev)
+        for mode in ("f32", "f16"):
+            with ops.compute(mode):
+                ms = timed_ms(lambda: ops.word_assign_raw(feat, words, 10.0), 20)
+            byts = 4.0 * B * N * (192 + 200 + 200 + 1)              # features in; softmax, one-hot and word id out
+            out["word_assign_" + mode] = {"shape": "B=32x2048, C=192, K_w=200", "ms": round(ms, 4), "bound": "hbm",
+                                          "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                                          "algorithmic_TFLOPps": round(2.0 * B * N * 192 * 200 / ms / 1e9, 2)}
+        f2 = torch.randn(B, 128, N, generator=g).to(dev)
+        pr = torch.randn(14, 128, generator=g).to(dev)
+        ms = timed_ms(lambda: ops.proto_cosine_raw(f2, pr, 10.0), 50)
+        byts = 4.0 * B * N * (128 + 14)
+        out["get_pred"] = {"shape": "B=32x2048, C=128, K=13+1", "ms": round(ms, 4), "bound": "hbm",
+                           "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
+        # configs[2]: one Lloyd step over the full S3DIS base split (7 classes x 300 000 points, 192-d, 200 centroids)
+        M = 7 * 300000
+        pts = torch.randn(M, 192, generator=g).to(dev)
+        cent = pts[torch.randperm(M, generator=g)[:200].to(dev)].contiguous()
+        ms = timed_ms(lambda: ops.kmeans_assign(pts, cent), 5, warm=2)
+        byts = 4.0 * M * (192 + 1)                                   # every point read once, its label written
+        out["lloyd_step"] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3), "bound": "hbm",
+                             "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                             "algorithmic_TFLOPps": round(2.0 * M * 192 * 200 / ms / 1e9, 2),
+                             "note": "assignment + centroid sums: the points are read twice (two kernels)"}
+        del pts
+    q, k_, v = (torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
+    cot = torch.randn(B, 64, N, generator=g).to(dev)
+
+    def att():
+        q.grad = k_.grad = v.grad = None
+        ops.attention(q, k_, v, 0.125, 0.1, 1234).backward(cot)
+    read_profile(L)
+    for _ in range(3):
+        att()
+    torch.cuda.synchronize()
+    L.gfs3d_profile_enable(1)
+    for _ in range(10):
+        att()
+    torch.cuda.synchronize()
+    L.gfs3d_profile_enable(0)
+    prof = read_profile(L)
+    for kid, key in ((8, "attention_fwd"), (9, "attention_bwd")):
+        if kid in prof:
+            ms = prof[kid][0] / prof[kid][1]
+            fl = algorithmic_flops(kid, B)[0]
+            out[key] = {"shape": "B=32x2048, d=64, dropout 0.1", "ms": round(ms, 4), "bound": "mfma (fp32)",
+                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4)}
+    del q, k_, v, cot
+    for name in ("c4", "c5"):
+        cfg = WORKLOADS[name]
+        step, net, bucket, x = build_step(cfg, dev, 0, 1, False, gdist)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        L.gfs3d_profile_enable(1)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        L.gfs3d_profile_enable(0)
+        prof = read_profile(L)
+        out["step_" + name] = {"workload": cfg["text"], "dtype": cfg["dtype"], "ms_per_step": round(dt * 1e3, 3),
+                               "blocks_per_s": round(cfg["B"] / dt, 1),
+                               "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / 3, 4) for k, v in prof.items()}}
+        del step, net, bucket, x
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -96,7 +297,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--dtype", choices=["f32", "f16", "bf16"], default=None, help="override the workload's arithmetic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements of the other kernels (rank 0, N = 1)")
     ap.add_argument("--sync-bn", action="store_true", help="whole-batch BatchNorm statistics across ranks (N>1)")
     args = ap.parse_args()
 
@@ -120,26 +324,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from gfs3d import _lib, dist as gdist
-    from model.dgcnn import DGCNN
-    from gfs3d.synthetic import synthetic_blocks    # input recipe; oracle/ is used by cpu_baseline() only
     L = _lib.lib()
-
-    torch.manual_seed(0)
-    net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev).train()
-    if args.sync_bn and world > 1:
-        net = gdist.enable_sync_batchnorm(net)
-    # conv: 88 % of the parameters, first in backward: its slice is exchanged under the EdgeConv backward - unless synchronised
-    # BatchNorm puts other collectives inside backward (then every rank must issue them in one fixed order)
-    bucket = gdist.FlatGradBucket(net.parameters(), early=net.conv.parameters(), overlap=not (args.sync_bn and world > 1))
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
-    x = synthetic_blocks(B_PER_GPU, NPTS, seed=rank).to(dev)
-
-    def step():
-        bucket.zero()
-        _, out = net(x)
-        out.mean().backward()
-        bucket.all_reduce_mean()
-        opt.step()
+    cfg = dict(WORKLOADS[args.workload])
+    if args.dtype:
+        cfg["dtype"] = args.dtype
+    B = cfg["B"]
+    step, net, bucket, x = build_step(cfg, dev, rank, world, args.sync_bn, gdist)
 
     if world > 1:          # communicator set-up and the first-use costs of both message sizes stay out of the timed region for any W
         dist.all_reduce(torch.zeros_like(bucket.flat))
@@ -150,7 +340,6 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    L.gfs3d_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -159,78 +348,87 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    L.gfs3d_profile_enable(0)
     elapsed = gdist.max_over_ranks(elapsed, dev)
+
+    # second pass, outside the timed region: the same K steps with the library's hipEvent brackets on (all ranks: the
+    # steps hold collectives)
+    L.gfs3d_profile_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    L.gfs3d_profile_enable(0)
+    prof = read_profile(L)
+    if world > 1:
+        dist.barrier()
 
     # north-star side figure (BASELINE.json: "kNN + EdgeConv forward at B=32 x 2048"): the three kNN + EdgeConv
     # blocks alone, eval mode (running statistics), after and outside the timed region
     fwd_ms = None
-    if rank == 0:
+    if rank == 0 and cfg["model"] == "dgcnn":
+        from gfs3d import ops
         net.eval()
-        with torch.no_grad():
-            for _ in range(3):
-                net.edgeconv_features(x)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                net.edgeconv_features(x)
-            e1.record()
-            torch.cuda.synchronize()
-            fwd_ms = e0.elapsed_time(e1) / 20
+        with torch.no_grad(), ops.compute(cfg["dtype"]):
+            fwd_ms = timed_ms(lambda: net.edgeconv_features(x), 20)
         net.train()
 
-    # per-kernel device time from the in-library hipEvent brackets (same stream as the launches)
-    import ctypes
-    prof = {}
-    for kid, name in KERNELS.items():
-        ms, n = ctypes.c_double(0), ctypes.c_longlong(0)
-        L.gfs3d_profile_read(kid, ctypes.byref(ms), ctypes.byref(n))
-        if n.value:
-            prof[kid] = (ms.value, n.value)
     if rank == 0:
-        dom = max((k for k in prof if k in (0, 1, 2)), key=lambda k: prof[k][0])
-        ms, n = prof[dom]
-        flops_step, launches_step = algorithmic_flops(dom, B_PER_GPU)
-        avg_ms = ms / n
-        achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": hbm_traffic(KERNELS[dom]),
-                "avg_launch_ms": round(avg_ms, 4), "launches": n,
-                "note": "achieved = algorithmic fp32 flops / time against the fp32 (vector == fp32-MFMA) peak; the EdgeConv and "
-                        "point-wise GEMMs run on the bf16 matrix cores at fp32 accuracy (exact 3-way bf16 split, 6 piece "
-                        "products per fp32 product); kNN stays on the bit-exact fp32 MFMA chain",
-                "per_kernel_ms_per_step": {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}}
-        # the point-wise stack runs on the bf16 matrix cores at fp32 accuracy (6 bf16 products per fp32 product):
-        # algorithmic fp32 TFLOP/s of its two launch groups (all kernels of a pass), against the same fp32 peak
-        for kid in (6, 7):
+        reduced = cfg["dtype"] != "f32"
+        heavy = [k for k in prof if k in (0, 1, 2)]
+        roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+        if heavy:
+            dom = max(heavy, key=lambda k: prof[k][0])
+            ms, n = prof[dom]
+            flops_step, launches_step = algorithmic_flops(dom, B)
+            avg_ms = ms / n
+            achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
+            peak = PEAK_16BIT_TFLOPS if (reduced and dom in (1, 2)) else PEAK_FP32_TFLOPS
+            traffic, src = hbm_traffic(KERNELS[dom], "r02")
+            roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
+                         "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
+        roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass). f32 mode: against "
+                        "the fp32 (vector == fp32-MFMA) peak; the EdgeConv / point-wise GEMMs run on the bf16 matrix cores at fp32 accuracy "
+                        "(exact 3-way bf16 split, 6 piece products per fp32 product); kNN stays on the bit-exact fp32 MFMA chain. Reduced "
+                        "modes: conv2 kernels against the dense 16-bit MFMA peak")
+        roof["per_kernel_ms_per_step"] = {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}
+        for kid in (6, 7, 8, 9):
             if kid in prof:
-                fl, _ = algorithmic_flops(kid, B_PER_GPU)
+                fl, _ = algorithmic_flops(kid, B)
                 roof[KERNELS[kid]] = {"ms_per_step": round(prof[kid][0] / args.steps, 4),
                                       "algorithmic_TFLOPps": round(fl / (prof[kid][0] / args.steps * 1e-3) / 1e12, 2)}
         if 0 in prof:       # "kNN HBM GB/s" of the metric: algorithmic bytes 4CN + 8Nk per block and layer
-            kb = B_PER_GPU * sum(4 * C * NPTS + 8 * NPTS * KNN for C in (CIN, 64, 64))
+            kb = B * sum(4 * C * NPTS + 8 * NPTS * KNN for C in (CIN, 64, 64))
             kms = prof[0][0] / args.steps
+            kfl = algorithmic_flops(0, B)[0] / (kms * 1e-3) / 1e12
             roof["knn"] = {"ms_per_step": round(kms, 4), "algorithmic_GBps": round(kb / (kms * 1e-3) / 1e9, 2),
-                           "algorithmic_TFLOPps": round(algorithmic_flops(0, B_PER_GPU)[0] / (kms * 1e-3) / 1e12, 2)}
+                           "algorithmic_TFLOPps": round(kfl, 2), "frac_of_fp32_peak": round(kfl / PEAK_FP32_TFLOPS, 4)}
         if fwd_ms:
-            # SURVEY 8(d) per block: kNN 1.19 GF + EdgeConv fwd 2.44 GF; compulsory bytes 2.10 MB + 3.80 MB.
+            # SURVEY 8(d) per block: kNN 1.19 GF + EdgeConv fwd 2.44 GF (conv1 counted on the N k edges); compulsory bytes 2.10 MB + 3.80 MB.
+            # The kernels run conv1 on the N points (P / Q algebra): executed-equivalent 1.19 + 3 x 0.336 (conv2) + 0.05 (projections) GF.
             # 565-640 flop/B: the fp32 roof binds, not HBM (the north star's "HBM roofline" cannot: 189 MB is 24 us at 8 TB/s)
-            gf, mb = B_PER_GPU * (1.19 + 2.44), B_PER_GPU * (2.10 + 3.80)
-            roof["fwd_knn_edgeconv_eval"] = {"ms": round(fwd_ms, 4), "blocks_per_s": round(B_PER_GPU / (fwd_ms * 1e-3), 1),
+            gf, mb = B * (1.19 + 2.44), B * (2.10 + 3.80)
+            gf_exec = B * (1.19 + 3 * NPTS * KNN * 2 * 64 * 64 / 1e9 + 2 * NPTS * 64 * (2 * CIN + 4 * 64) / 1e9)
+            roof["fwd_knn_edgeconv_eval"] = {"ms": round(fwd_ms, 4), "blocks_per_s": round(B / (fwd_ms * 1e-3), 1),
                                              "algorithmic_TFLOPps": round(gf / fwd_ms, 2),
                                              "frac_of_fp32_peak": round(gf / fwd_ms / PEAK_FP32_TFLOPS, 4),
+                                             "executed_equivalent_TFLOPps": round(gf_exec / fwd_ms, 2),
+                                             "frac_of_fp32_peak_executed": round(gf_exec / fwd_ms / PEAK_FP32_TFLOPS, 4),
                                              "algorithmic_GBps": round(mb / fwd_ms, 1)}
         ms_step = elapsed / args.steps * 1e3
+        metric = "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd" if cfg["model"] == "dgcnn" else \
+                 "point-cloud blocks/sec (2048 pts, k=20) CAPL training step"
         line = {
-            "metric": "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd", "value": round(world * B_PER_GPU / (elapsed / args.steps), 2),
+            "metric": metric, "value": round(world * B / (elapsed / args.steps), 2),
             "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: S3DIS-shaped blocks, batch=32x2048x9 per GPU, k=20, DGCNN+EdgeConv fwd/bwd "
-                                   "(train mode, BN batch stats) + grad all-reduce + Adam",
-                       "blocks_per_gpu": B_PER_GPU, "points": NPTS, "k": KNN, "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and world > 1 else "")},
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["text"], "blocks_per_gpu": B, "points": NPTS, "k": KNN,
+                       "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and world > 1 else "")},
             "roofline": roof,
         }
+        if world == 1 and not args.no_extras and args.workload == "c2":
+            del step, net, bucket
+            torch.cuda.empty_cache()
+            line["extra"] = extras(dev, L, gdist)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
