@@ -40,8 +40,9 @@ with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w") as f:
 
 fa, fn = counters(fetch_db)
 wa, wn = counters(write_db)
-traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 2`, B=32x2048, "
-                    "per-launch averages. Units KB in the tool; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of "
+traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --no-cpu-baseline --steps 3 --warmup 2` "
+                    "(timed workload configs[1] B=32x2048 + the side measurements: K3 / k-means / attention / CAPL steps c4, c5), "
+                    "per-launch averages over ALL launches of a kernel name. Units KB in the tool; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of "
                     "coalesced reads). WRITE_SIZE is exact for stores and float atomics."}
 for k in fa:
     n = max(fn.get(k, 1), 1)
@@ -54,7 +55,7 @@ json.dump(traffic, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), inde
 sa, sn = counters(sq_db)
 with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as f:
     names = sorted({c for k in sa for c in sa[k]})
-    f.write("rocprofv3 --pmc " + " ".join(names) + "\non `python3 bench.py --steps 3 --warmup 2` (B=32x2048, k=20); per-launch averages\n")
+    f.write("rocprofv3 --pmc " + " ".join(names) + "\non `python3 bench.py --no-cpu-baseline --steps 3 --warmup 2` (configs[1] B=32x2048, k=20 + side measurements); per-launch averages\n")
     f.write("kernel".ljust(34) + "".join(n.replace("SQ_", "")[:15].rjust(16) for n in names) + "\n")
     for k in sorted(sa, key=lambda k: -sa[k].get("SQ_WAVE_CYCLES", 0)):
         if sa[k].get("SQ_WAVE_CYCLES", 0) / max(sn[k], 1) < 1e6:
