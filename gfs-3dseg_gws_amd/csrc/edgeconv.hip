@@ -700,6 +700,9 @@ constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+#ifndef GFS3D_ABL          // ablation builds only (scripts/build_ablation.sh): 1 no G_P atomics, 2 gather one fixed row, 4 no dW2 product
+#define GFS3D_ABL 0
+#endif
 constexpr int BWD_WAVES = 4;
 constexpr int BWD_WROW = 3 * 2 * EC + 16;                          // bytes per row of a W2 piece image
 constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES * BWD_WAVE_LDS + 192);
@@ -762,7 +765,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = 2 * tt + h;
-            if (t < T) mall[t * 32 + i] = bA * N + idx[(size_t)ptA * k + min(4 * t + jjA, k - 1)];
+            if (t < T) mall[t * 32 + i] = (GFS3D_ABL & 2) ? bA * N : bA * N + idx[(size_t)ptA * k + min(4 * t + jjA, k - 1)];
         }
         __builtin_amdgcn_wave_barrier();
         auto gather = [&](int t) {                     // lane (edge row i, half h): 8 x 16 B of P'[m][32h..32h+31]
@@ -782,6 +785,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
         for (int t = 0; t < T; ++t) {
             // tile 0: everything older (ids, Q', P' gather); later tiles: all but the previous tile's 32 atomics
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (GFS3D_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             const int *mrow = mall + t * 32;
             float a[32];
@@ -867,7 +871,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]   (register r <-> the same edge in both operands)
             // (K-block kb = registers 8kb..8kb+7 of both lane halves: the same 16 edges in both operands)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < ((GFS3D_ABL & 4) ? 0 : 2); ++kb) {
                 float v8[8];
                 uint4 d[NP], x0[NP], x1[NP];
                 pieces(aD0 + 8 * kb, x0);
@@ -931,8 +935,10 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 gq0[q] += dy0;
                 gq1[q] += dy1;
                 const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;
-                atomicAdd(&GP[row], dy0);
-                atomicAdd(&GP[row + 32], dy1);
+                if (!(GFS3D_ABL & 1)) {
+                    atomicAdd(&GP[row], dy0);
+                    atomicAdd(&GP[row + 32], dy1);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
