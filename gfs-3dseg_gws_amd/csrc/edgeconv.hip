@@ -34,6 +34,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // stats rows
 enum { ST_MEAN1 = 0, ST_RSTD1, ST_SCALE1, ST_SHIFT1, ST_MEAN2, ST_RSTD2, ST_SCALE2, ST_SHIFT2 };
 
+// Where a block's [2][64] fp64 partial sums go: float64 atomics on the 128 accumulators (fast; the order of the adds can
+// move the double sum in its last bit), or - gfs3d_set_deterministic(1) - row `blk` of a partial table that
+// bn_reduce_rows_kernel / bn_reduce_final_kernel then add in a fixed order.
+struct BnAcc {
+    double *acc;        // [2][64] accumulators (atomics mode: zeroed by the launcher)
+    double *rows;       // ordered mode: [nblocks][2][64], else NULL
+};
+__device__ __forceinline__ void bn_acc_add(const BnAcc &a, int blk, int which, int c, double v)
+{
+    if (a.rows) a.rows[(size_t)blk * 2 * GFS3D_EC_WIDTH + which * GFS3D_EC_WIDTH + c] = v;
+    else atomicAdd(&a.acc[which * GFS3D_EC_WIDTH + c], v);
+}
+// ordered mode, level 1: block g adds rows g R .. g R + R - 1 (thread = (row slot, element): coalesced 1-KB rows)
+constexpr int BNR_GROUPS = 16;
+__global__ void __launch_bounds__(1024)
+bn_reduce_rows_kernel(const double *__restrict__ rows, int nrows, double *__restrict__ mid)
+{
+    __shared__ double red[8][128];
+    const int e = threadIdx.x & 127, slot = threadIdx.x >> 7;
+    const int per = (nrows + BNR_GROUPS - 1) / BNR_GROUPS;
+    const int r0 = blockIdx.x * per, r1 = min(nrows, r0 + per);
+    double s = 0.0;
+    for (int r = r0 + slot; r < r1; r += 8) s += rows[(size_t)r * 128 + e];
+    red[slot][e] = s;
+    __syncthreads();
+    if (slot == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][e];
+        mid[blockIdx.x * 128 + e] = t;
+    }
+}
+__global__ void bn_reduce_final_kernel(const double *__restrict__ mid, double *__restrict__ acc)
+{
+    const int e = threadIdx.x;
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < BNR_GROUPS; ++g) t += mid[g * 128 + e];
+    acc[e] = t;
+}
+
 // ---------------------------------------------------------------------------
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
@@ -41,7 +82,7 @@ enum { ST_MEAN1 = 0, ST_RSTD1, ST_SCALE1, ST_SHIFT1, ST_MEAN2, ST_RSTD2, ST_SCAL
 constexpr int ST1_WAVES = 16;       // every block ends in 128 same-address fp64 atomics (~14 ns each, serialised): few big blocks
 __global__ void __launch_bounds__(64 * ST1_WAVES)
 ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ idx,
-                 int BN, int N, int k, float *__restrict__ SP, double *__restrict__ partial)
+                 int BN, int N, int k, float *__restrict__ SP, const BnAcc partial)
 {
     __shared__ double red[ST1_WAVES][2][EC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -80,7 +121,7 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < ST1_WAVES; ++w) t += red[w][which][lane];
-        atomicAdd(&partial[which * EC + lane], t);          // 128 fp64 accumulators (zeroed by the launcher)
+        bn_acc_add(partial, blockIdx.x, which, lane, t);
     }
 }
 
@@ -189,6 +230,156 @@ rev_overflow_kernel(const float *__restrict__ Q, const int *__restrict__ ovf_cnt
     for (int o = blockIdx.x * 4 + wv; o < n; o += gridDim.x * 4) {
         const int2 en = ovf[o];
         atomicAdd(&SQ[(size_t)en.x * EC + lane], Q[(size_t)en.y * EC + lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The reverse graph in CSR form, one workgroup per point-cloud block (N k <= 65536 edges and the tables below within
+// LDS): for every target m its in-edges in ASCENDING edge order (edge e = n k + j), so that everything summed over the
+// in-edges of a point - SQ here, G_P in the backward - has a FIXED order: bit-reproducible, and no float atomics.
+//   rowptr[b N + m]      first row of target m in the global CSR order (rows b N k .. (b+1) N k - 1 belong to block b);
+//                        rowptr[B N] = B N k
+//   csr_src[row]         global source point (b N + n) of that in-edge
+//   pos[(b N + n) k + j] the CSR row of edge (n, j)   - where the backward stores that edge's dy1 row
+// A counting sort by (target, source) without a sort: the workgroup's 16 waves own 16 consecutive source ranges.
+//   A  per (source range w, target m) counts, any thread, LDS atomics on packed u16 pairs (order-free);
+//   B  a thread per target turns them into exclusive prefixes over the ranges and the in-degree; block-wide scan -> ptr;
+//   C  wave w walks ITS sources in ascending order, one source (k distinct targets = k lanes, no conflict) per step:
+//      row = ptr[m] + cursor[w][m]++ - the wave is the only writer of its cursors, its LDS operations stay in program
+//      order, so the ranks follow the source order exactly.  A hub's in-edges are spread over the steps like any others.
+// ---------------------------------------------------------------------------
+constexpr int CSR_THREADS = 1024, CSR_WAVES = CSR_THREADS / 64;
+static inline size_t csr_lds_bytes(int N, int k) { (void)k; return sizeof(unsigned) * (CSR_WAVES / 2) * (size_t)N + sizeof(int) * (size_t)N + sizeof(int) * 64; }
+__global__ void __launch_bounds__(CSR_THREADS)
+csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__restrict__ rowptr, int *__restrict__ csr_src,
+                 int *__restrict__ pos)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr_smem[];
+    unsigned *cw = reinterpret_cast<unsigned *>(csr_smem);                 // [8][N]: ranges 2 q (low half) and 2 q + 1 (high half)
+    int *ptr = reinterpret_cast<int *>(cw + (CSR_WAVES / 2) * (size_t)N);  // [N] in-degree, then exclusive scan
+    int *wsum = ptr + N;                                                   // [64] scan scratch
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
+    const int ne = N * k;
+    const int span = (N + CSR_WAVES - 1) / CSR_WAVES;                      // sources per range
+    const int32_t *ib = idx + (size_t)b * ne;
+    for (int q = tid; q < (CSR_WAVES / 2) * N; q += CSR_THREADS) cw[q] = 0u;
+    __syncthreads();
+    // A: edges tid, tid + 1024, ... (N k <= 65536 -> at most 64): all loads in flight at once
+    {
+        int tg[64];
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            const int e = tid + q * CSR_THREADS;
+            tg[q] = e < ne ? ib[e] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < 64; ++q)
+            if (tg[q] >= 0) {
+                const int w = ((tid + q * CSR_THREADS) / k) / span;
+                atomicAdd(&cw[(size_t)(w >> 1) * N + tg[q]], (w & 1) ? 0x10000u : 1u);
+            }
+    }
+    __syncthreads();
+    // B: exclusive prefix over the ranges, per target; thread t owns the `per` consecutive targets t per ..
+    const int per = (N + CSR_THREADS - 1) / CSR_THREADS;
+    int loc = 0;
+    for (int q = 0; q < per; ++q) {
+        const int m = tid * per + q;
+        if (m < N) {
+            unsigned run = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < CSR_WAVES / 2; ++w2) {
+                const unsigned v = cw[(size_t)w2 * N + m];
+                const unsigned lo = v & 0xffffu, hi = v >> 16;
+                cw[(size_t)w2 * N + m] = run | ((run + lo) << 16);
+                run += lo + hi;
+            }
+            ptr[m] = (int)run;
+            loc += (int)run;
+        }
+    }
+    int inc = loc;                                          // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        int v = lane < CSR_WAVES ? wsum[lane] : 0, w = v;
+#pragma unroll
+        for (int o = 1; o < CSR_WAVES; o <<= 1) { const int u = __shfl_up(w, o, 64); if (lane >= o) w += u; }
+        if (lane < CSR_WAVES) wsum[lane] = w - v;           // exclusive wave offsets
+    }
+    __syncthreads();
+    int run = wsum[wv] + inc - loc;
+    for (int q = 0; q < per; ++q) {
+        const int m = tid * per + q;
+        if (m < N) { const int c = ptr[m]; ptr[m] = run; rowptr[(size_t)b * N + m] = b * ne + run; run += c; }
+    }
+    if (b == B - 1 && tid == 0) rowptr[(size_t)B * N] = B * ne;
+    __syncthreads();
+    // C: ordered placement
+    unsigned *cur = cw + (size_t)(wv >> 1) * N;             // this wave's cursors: the low (even wave) or high half of word m
+    const unsigned one = (wv & 1) ? 0x10000u : 1u;
+    const int sh = (wv & 1) ? 16 : 0;
+    const int n_lo = wv * span, n_hi = min(N, n_lo + span);
+    for (int n0 = n_lo; n0 < n_hi; n0 += 8) {               // the neighbour lists of 8 sources in flight
+        int tg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tg[u] = (lane < k && n0 + u < n_hi) ? ib[(size_t)(n0 + u) * k + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (tg[u] >= 0) {
+                // (an atomic, so that a caller's list with a repeated neighbour still gets distinct rows; one wave's LDS
+                // operations on an address are served in issue order, which is the source order)
+                const int c = (int)((atomicAdd(&cur[tg[u]], one) >> sh) & 0xffffu);
+                const int row = b * ne + ptr[tg[u]] + c;
+                csr_src[row] = b * N + n0 + u;
+                pos[(size_t)b * ne + (size_t)(n0 + u) * k + lane] = row;
+            }
+        }
+    }
+}
+// SQ[m] = sum over the in-edges of m, in CSR (= ascending source) order, of Q[source]; in-degree.
+// lane = (row slot sub = lane >> 4, channel quad c4 = lane & 15): a wave instruction gathers 4 rows of 256 B as 16-byte
+// pieces, 8 of them in flight; a wave owns 8 consecutive targets (one load brings their row pointers).
+__global__ void __launch_bounds__(256)
+csr_gather_kernel(const float *__restrict__ Q, const int *__restrict__ rowptr, const int *__restrict__ csr_src,
+                  int BN, float *__restrict__ SQ, float *__restrict__ indeg)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane >> 4, c4 = lane & 15;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    constexpr int TPW = 8;
+    const int nchunk = (BN + TPW - 1) / TPW;
+    for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
+        const int t0 = ch * TPW;
+        const int myptr = rowptr[min(t0 + min(lane, TPW), BN)];
+#pragma unroll 2
+        for (int q = 0; q < TPW; ++q) {
+            const int tm = t0 + q;
+            if (tm >= BN) break;
+            const int p0 = __shfl(myptr, q, 64), p1 = __shfl(myptr, q + 1, 64);
+            f32x4 acc = zero;
+            for (int p = p0 + sub; p < p1; p += 32) {
+                int src[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) src[u] = (p + 4 * u < p1) ? csr_src[p + 4 * u] : -1;
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[u] >= 0 ? *reinterpret_cast<const f32x4 *>(Q + (size_t)src[u] * EC + 4 * c4) : zero;
+                acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                acc[e] = t;
+            }
+            if (sub == 0) *reinterpret_cast<f32x4 *>(SQ + (size_t)tm * EC + 4 * c4) = acc;
+            if (lane == 0) indeg[tm] = (float)(p1 - p0);
+        }
     }
 }
 
@@ -377,7 +568,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    const float *__restrict__ w2, const float *__restrict__ gamma2,
                    int BN, int N, int k, float slope,
                    float *__restrict__ hsel, uint8_t *__restrict__ jsel,
-                   double *__restrict__ partial)
+                   const BnAcc partial)
 {
     constexpr int WROW = 3 * 2 * EC + 16;               // bytes per W2 row image
     __shared__ __attribute__((aligned(16))) unsigned char sW3[EC * WROW];
@@ -518,7 +709,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             double tsum = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) tsum += red[w][0][which][c] + red[w][1][which][c];
-            atomicAdd(&partial[which * EC + c], tsum);
+            bn_acc_add(partial, blockIdx.x, which, c, tsum);
         }
     }
 }
@@ -577,7 +768,7 @@ __global__ void __launch_bounds__(256)
 ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const float *__restrict__ dy_pm,
                    const float *__restrict__ y_pm,
                    const float *__restrict__ hsel, const float *__restrict__ stats, int N, float slope,
-                   float *__restrict__ g_pm, double *__restrict__ partial)
+                   float *__restrict__ g_pm, const BnAcc partial)
 {
     __shared__ float tile[64][65];
     __shared__ double red[4][2][EC];
@@ -629,7 +820,7 @@ ec_bwd_prep_kernel(const float *__restrict__ dy_cf, long long dy_bstride, const 
     if (tid < 128) {
         const int which = tid >> 6;
         const double t = red[0][which][co] + red[1][which][co] + red[2][which][co] + red[3][which][co];
-        atomicAdd(&partial[which * EC + co], t);
+        bn_acc_add(partial, blockIdx.y * gridDim.x + blockIdx.x, which, co, t);
     }
 }
 
@@ -695,7 +886,7 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, const void *lds_dst_
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char *)lds_dst_wave_uniform);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc) : "memory");
 }
-constexpr int BWD_WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC;      // floats per wave: transpose tile | ids | Q' tile
+constexpr int BWD_WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC + 8 * 32;      // floats per wave: transpose tile | ids | Q' tile | CSR rows
 constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -707,13 +898,18 @@ constexpr int BWD_WAVES = 4;
 constexpr int BWD_WROW = 3 * 2 * EC + 16;                          // bytes per row of a W2 piece image
 constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES * BWD_WAVE_LDS + 192);
 
-template <int PREC>
+// CSR = true: the dy1 row of every edge is STORED to row pos[edge] of `dyb` (the edge's place in its target's CSR
+// segment; masked rows go to a per-wave scratch row behind the B N k real ones) and ec_bwd_segsum_kernel sums the
+// segments: plain stores at ~5x the float-atomic rate, a fixed summation order, no memset of G_P.  CSR = false: float
+// atomics into G_P (shapes beyond csr_build_kernel's LDS tables).
+template <int PREC, bool CSR>
 __global__ void __launch_bounds__(64 * BWD_WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2, const CoefIn cin,
                    const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
                    int BN, int N, int k, float slope,
-                   float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial)
+                   float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial,
+                   const int *__restrict__ pos, float *__restrict__ dyb)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] bf16 pieces of W2
@@ -724,6 +920,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     float *tr = wbase + (size_t)wv * BWD_WAVE_LDS;              // [32][TLD] transpose tile == [8][64 lanes][4] DMA image
     int *mall = reinterpret_cast<int *>(tr + 32 * TLD);         // [8][32] neighbour id of each row of each tile
     float *qt = reinterpret_cast<float *>(mall + 8 * 32);       // [8][64] Q' rows of the super-tile's points
+    int *pall = reinterpret_cast<int *>(qt + 8 * EC);           // [8][32] CSR row of each row of each tile (CSR mode)
+    const int trash_row = BN * k + (int)(blockIdx.x * BWD_WAVES + wv);     // where masked rows are stored (never read)
 
     for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
         const int co = e >> 6, ci = e & 63;
@@ -765,7 +963,11 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = 2 * tt + h;
-            if (t < T) mall[t * 32 + i] = (GFS3D_ABL & 2) ? bA * N : bA * N + idx[(size_t)ptA * k + min(4 * t + jjA, k - 1)];
+            if (t < T) {
+                const int jc = 4 * t + jjA;
+                mall[t * 32 + i] = (GFS3D_ABL & 2) ? bA * N : bA * N + idx[(size_t)ptA * k + min(jc, k - 1)];
+                if (CSR) pall[t * 32 + i] = (jc < k && n0 + pA < BN) ? pos[(size_t)ptA * k + jc] : trash_row;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         auto gather = [&](int t) {                     // lane (edge row i, half h): 8 x 16 B of P'[m][32h..32h+31]
@@ -787,7 +989,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (GFS3D_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            const int *mrow = mall + t * 32;
+            const int *mrow = CSR ? pall + t * 32 : mall + t * 32;
             float a[32];
             {
                 const float4 *p4 = reinterpret_cast<const float4 *>(tr) + lane;              // DMA image [v][lane]
@@ -935,7 +1137,10 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 gq0[q] += dy0;
                 gq1[q] += dy1;
                 const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;
-                if (!(GFS3D_ABL & 1)) {
+                if (CSR) {                                  // (a masked row's values are 0 and its row is the wave's scratch row)
+                    dyb[row] = dy0;
+                    dyb[row + 32] = dy1;
+                } else if (!(GFS3D_ABL & 1)) {
                     atomicAdd(&GP[row], dy0);
                     atomicAdd(&GP[row + 32], dy1);
                 }
@@ -951,22 +1156,92 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             }
         }
     }
-    // block-level sum of the four waves' dW2 accumulators, then one partial per block
+    // block-level sum of the four waves' dW2 accumulators in a FIXED order (one [64][64] image per wave: 64 KB of the
+    // 99 KB this block owns), then one partial per block
     __syncthreads();
-    float *sD = smem;                                   // reuse: [64][64]
-    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) sD[e] = 0.f;
-    __syncthreads();
+    float *sD = smem + (size_t)wv * EC * EC;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = drow(r, h);                     // C/D layout: row = co (within half), col = ci = i
-        atomicAdd(&sD[row * EC + i], dW00[r]);
-        atomicAdd(&sD[row * EC + 32 + i], dW01[r]);
-        atomicAdd(&sD[(32 + row) * EC + i], dW10[r]);
-        atomicAdd(&sD[(32 + row) * EC + 32 + i], dW11[r]);
+        sD[row * EC + i] = dW00[r];
+        sD[row * EC + 32 + i] = dW01[r];
+        sD[(32 + row) * EC + i] = dW10[r];
+        sD[(32 + row) * EC + 32 + i] = dW11[r];
     }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * BWD_PART;
-    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) out[e] = sD[e];
+    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES)
+        out[e] = ((smem[e] + smem[EC * EC + e]) + smem[2 * EC * EC + e]) + smem[3 * EC * EC + e];
+}
+
+// B4 (CSR mode): G_P[m] = sum of the dy1 rows of m's in-edges - one contiguous CSR segment of `dyb`, read as a stream
+// and summed in a fixed order - fused with the BN1-backward reductions of ec_bwd_bn1_reduce_kernel (which it replaces):
+//     sum_n GQ  and  sum_e dy1 xhat1 = sum_m P''[m] GP[m] + sum_n Q''[n] GQ[n]
+// wave per target, lane = channel; partial[2][64] doubles.
+__global__ void __launch_bounds__(256)
+ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowptr,
+                     const float *__restrict__ P, const float *__restrict__ Q, const float *__restrict__ GQ,
+                     const float *__restrict__ stats, int BN, float *__restrict__ GP, const BnAcc partial)
+{
+    // lane = (row slot sub = lane >> 4, channel quad c4 = lane & 15): one wave instruction reads 4 rows of 256 B as 16-byte
+    // pieces; 4 of them in flight = 16 rows per step.  The four row slots are added in a fixed tree at the end.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ double red[4][2][EC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane >> 4, c4 = lane & 15;
+    const f32x4 mean1 = *reinterpret_cast<const f32x4 *>(stats + ST_MEAN1 * EC + 4 * c4);
+    const f32x4 rstd1 = *reinterpret_cast<const f32x4 *>(stats + ST_RSTD1 * EC + 4 * c4);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, sx[4] = {0.0, 0.0, 0.0, 0.0};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // a wave owns SEG_TPW consecutive targets = one contiguous run of CSR rows; their row pointers come in with one load
+    constexpr int SEG_TPW = 8;
+    const int nchunk = (BN + SEG_TPW - 1) / SEG_TPW;
+    for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
+        const int t0 = ch * SEG_TPW;
+        const int myptr = rowptr[min(t0 + min(lane, SEG_TPW), BN)];
+#pragma unroll 2
+        for (int q = 0; q < SEG_TPW; ++q) {
+            const int tm = t0 + q;
+            if (tm >= BN) break;
+            const int p0 = __shfl(myptr, q, 64), p1 = __shfl(myptr, q + 1, 64);
+            const size_t o = (size_t)tm * EC + 4 * c4;
+            const f32x4 gq = *reinterpret_cast<const f32x4 *>(GQ + o), pv = *reinterpret_cast<const f32x4 *>(P + o),
+                        qv = *reinterpret_cast<const f32x4 *>(Q + o);
+            f32x4 acc = zero;
+            for (int p = p0 + sub; p < p1; p += 32) {          // 32 rows of 256 B in flight per wave and step
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (p + 4 * u < p1) ? *reinterpret_cast<const f32x4 *>(dyb + (size_t)(p + 4 * u) * EC + 4 * c4) : zero;
+                acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[e];
+                t += __shfl_xor(t, 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                acc[e] = t;
+            }
+            if (sub == 0) {
+                *reinterpret_cast<f32x4 *>(GP + o) = acc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[e] += (double)gq[e];
+                    sx[e] += (double)(pv[e] * rstd1[e] * acc[e]) + (double)((qv[e] - mean1[e]) * rstd1[e] * gq[e]);
+                }
+            }
+        }
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[wv][0][4 * c4 + e] = s[e]; red[wv][1][4 * c4 + e] = sx[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6;
+        bn_acc_add(partial, blockIdx.x, which, lane,
+                   red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
+    }
 }
 
 // B5: BN1 backward reductions: sum_n GQ (= sum_e dy1) and
@@ -974,7 +1249,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 __global__ void __launch_bounds__(256)
 ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ Q,
                          const float *__restrict__ GP, const float *__restrict__ GQ,
-                         const float *__restrict__ stats, int BN, double *__restrict__ partial)
+                         const float *__restrict__ stats, int BN, const BnAcc partial)
 {
     __shared__ double red[4][2][EC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1000,8 +1275,8 @@ ec_bwd_bn1_reduce_kernel(const float *__restrict__ P, const float *__restrict__ 
     __syncthreads();
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6;
-        atomicAdd(&partial[which * EC + lane],
-                  red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
+        bn_acc_add(partial, blockIdx.x, which, lane,
+                   red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
     }
 }
 struct Bn1Fin {
@@ -1212,6 +1487,9 @@ struct Plan {
     size_t off_acc;                                                      // 4 x 64 fp64 atomic accumulators (BN sums)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
     size_t off_cnt, off_slot, off_ovf;                                       // reverse graph (cnt[BN] | ovf_cnt)
+    size_t off_csrsrc, off_dyb;                                              // CSR mode: sources in CSR order; per-edge dy1 rows
+    bool csr_ok;                                                             // the shape fits csr_build_kernel's LDS tables
+    size_t part_rows;                                                        // rows of the ordered-reduction table at off_part
     size_t total;
 };
 
@@ -1236,7 +1514,13 @@ static Plan make_plan(int B, int C, int N, int k)
     if (p.g_mfma > maxparts) maxparts = p.g_mfma;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    p.off_part = take(sizeof(double) * 2 * EC * (size_t)maxparts);
+    {   // ordered BN reductions: one [2][64] row per producer block (the largest grid is the segment-sum kernel's) + level-1 sums
+        size_t rows = (size_t)maxparts > 2048 ? (size_t)maxparts : 2048;
+        const size_t prep = (size_t)(((N + 63) / 64 + 3) / 4) * B;
+        if (prep > rows) rows = prep;
+        p.off_part = take(sizeof(double) * 2 * EC * (rows + BNR_GROUPS));
+        p.part_rows = rows;
+    }
     {
         size_t w = BWD_PART;
         const size_t CPp = (size_t)((C + 31) / 32) * 32;
@@ -1258,6 +1542,9 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_slot = take(sizeof(int) * BN * (size_t)REV_CAP);
     p.off_ovf = take(sizeof(int2) * BN * (size_t)k);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)(((C + 31) / 32) * 32) * p.g_pq);
+    p.csr_ok = (size_t)N * k <= 65536 && csr_lds_bytes(N, k) <= 160 * 1024 && (BN * k + 4096) < (size_t)(1u << 24);
+    p.off_csrsrc = take(p.csr_ok ? sizeof(int) * BN * k : 0);
+    p.off_dyb = take(p.csr_ok ? sizeof(float) * EC * (BN * k + (size_t)p.g_bwd * BWD_WAVES) : 0);
     p.total = o;
     return p;
 }
@@ -1291,6 +1578,17 @@ extern "C" size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k)
 }
 
 namespace gfs3d {
+static bool g_deterministic = false;
+// after a producer launched with `nblocks` blocks: in ordered mode add its partial rows into acc[0:128] in a fixed order
+static int bn_finish(const BnAcc &ba, int nblocks, hipStream_t st, double *mid)
+{
+    if (!ba.rows) return GFS3D_OK;
+    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(BNR_GROUPS), dim3(1024), 0, st, ba.rows, nblocks, mid);
+    GFS3D_LAUNCH_CHECK("bn_reduce_rows_kernel");
+    hipLaunchKernelGGL(bn_reduce_final_kernel, dim3(1), dim3(128), 0, st, mid, ba.acc);
+    GFS3D_LAUNCH_CHECK("bn_reduce_final_kernel");
+    return GFS3D_OK;
+}
 // accumulator block (fp64): [0:128] stage-A sums, [128:256] stage-B sums, [256:384] / [384:512] this
 // rank's copies of A / B taken before the caller all-reduces A / B across ranks (synchronised BN)
 constexpr int ACC_DOUBLES = 8 * EC;
@@ -1346,6 +1644,16 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
 {
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
+    if (p.csr_ok && a->csr_rowptr && a->csr_pos) {           // CSR form: fixed in-edge order, no float atomics anywhere
+        int *csr_src = reinterpret_cast<int *>(ws + p.off_csrsrc);
+        const size_t lds = csr_lds_bytes(a->N, a->k);
+        GFS3D_ENSURE_LDS(csr_build_kernel, lds, who);
+        hipLaunchKernelGGL(csr_build_kernel, dim3(a->B), dim3(CSR_THREADS), lds, rs, a->idx, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
+        GFS3D_LAUNCH_CHECK("csr_build_kernel");
+        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, 2048)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->SQ, a->indeg);
+        GFS3D_LAUNCH_CHECK("csr_gather_kernel");
+        return GFS3D_OK;
+    }
     int *cnt = reinterpret_cast<int *>(ws + p.off_cnt), *ovf_cnt = cnt + BN;
     int *slot = reinterpret_cast<int *>(ws + p.off_slot);
     int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
@@ -1386,6 +1694,8 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     double *acc1 = acc, *acc2 = acc + 2 * EC;
+    double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_part) : nullptr;      // ordered BN reductions
+    double *mid = reinterpret_cast<double *>(ws + p.off_part) + 2 * EC * p.part_rows;
     float *Pp = a->Pp ? a->Pp : reinterpret_cast<float *>(ws + p.off_Pp), *Qp = a->Qp ? a->Qp : reinterpret_cast<float *>(ws + p.off_Qp);
     dim3 tgrid((a->N + 63) / 64, a->B);
     // eval mode: BatchNorm1 (running statistics) is folded into the projection kernels, P / Q are never written and
@@ -1420,14 +1730,17 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
                 lane->pending = true;                  // joined in phase 2, or by side_join() on any error return
             }
             if (int rc = reverse_graph(a, p, rs, who)) return rc;
-            if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+            if (!rows && hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
                 set_error("%s: hipMemsetAsync failed", who);
                 return GFS3D_ERR_HIP;
             }
-            ProfScope prof(4, st);
-            hipLaunchKernelGGL(ec_stats1_kernel, dim3((p.g_heavy + 3) / 4), dim3(64 * ST1_WAVES), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
-                               a->SP, acc1);
-            GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
+            {
+                ProfScope prof(4, st);
+                hipLaunchKernelGGL(ec_stats1_kernel, dim3((p.g_heavy + 3) / 4), dim3(64 * ST1_WAVES), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
+                                   a->SP, BnAcc{acc1, rows});
+                GFS3D_LAUNCH_CHECK("ec_stats1_kernel");
+            }
+            if (int rc = bn_finish(BnAcc{acc1, rows}, (p.g_heavy + 3) / 4, st, mid)) return rc;
         }
     } else if (phase == 1) {
         const BnFin fin1{acc1, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training};
@@ -1441,7 +1754,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         const int prec = prec_of(a->compute, false);
 #define GFS3D_FWD_LAUNCH(STATS_, PREC_, GRID_)                                                                                \
         hipLaunchKernelGGL((ec_main_fwd_kernel<STATS_, PREC_>), GRID_, dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,     \
-                           BN, a->N, a->k, a->slope, hmax, jmax, acc2)
+                           BN, a->N, a->k, a->slope, hmax, jmax, BnAcc{acc2, rows})
         if (a->training) {
             if (prec == PREC_BF16) GFS3D_FWD_LAUNCH(true, PREC_BF16, dim3(p.g_mfma));
             else if (prec == PREC_F16) GFS3D_FWD_LAUNCH(true, PREC_F16, dim3(p.g_mfma));
@@ -1453,6 +1766,8 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         }
 #undef GFS3D_FWD_LAUNCH
         GFS3D_LAUNCH_CHECK("ec_main_fwd_kernel");
+        if (a->training)
+            if (int rc = bn_finish(BnAcc{acc2, rows}, p.g_mfma, st, mid)) return rc;
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
         hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, jmax, fin2, a->stats, a->N, a->slope,
@@ -1480,22 +1795,28 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     // monolithic call: this rank's sums ARE the global sums, no local copies needed
     double *acc1 = acc, *acc2 = acc + 2 * EC, *loc1 = acc_user ? acc + 4 * EC : acc1, *loc2 = acc_user ? acc + 6 * EC : acc2;
+    double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_part) : nullptr;      // ordered BN reductions
+    double *mid = reinterpret_cast<double *>(ws + p.off_part) + 2 * EC * p.part_rows;
     dim3 tgrid((a->N + 63) / 64, a->B);
     if (phase == 0) {
-        if (hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
+        if (!rows && hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
-        hipLaunchKernelGGL(ec_bwd_prep_kernel, dim3(((a->N + 63) / 64 + PREP_TILES - 1) / PREP_TILES, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
-                           a->N, a->slope, g, acc1);
+        const dim3 pgrid(((a->N + 63) / 64 + PREP_TILES - 1) / PREP_TILES, a->B);
+        hipLaunchKernelGGL(ec_bwd_prep_kernel, pgrid, dim3(256), 0, st, ba->dy_cf, ba->dy_bstride, ba->dy_pm, a->y_pm, a->hsel, a->stats,
+                           a->N, a->slope, g, BnAcc{acc1, rows});
         GFS3D_LAUNCH_CHECK("ec_bwd_prep_kernel");
+        if (int rc = bn_finish(BnAcc{acc1, rows}, (int)(pgrid.x * pgrid.y), st, mid)) return rc;
         if (acc_user && hipMemcpyAsync(loc1, acc1, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("%s: hipMemcpyAsync failed", who);
             return GFS3D_ERR_HIP;
         }
     } else if (phase == 1) {
         const CoefIn cin{acc1, loc1, count, a->stats, ba->dbn2_w, ba->dbn2_b};
-        if (hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
+        const bool csr = p.csr_ok && a->csr_rowptr && a->csr_pos;
+        float *dyb = reinterpret_cast<float *>(ws + p.off_dyb);
+        if (!csr && hipMemsetAsync(GP, 0, sizeof(float) * (size_t)BN * EC, st) != hipSuccess) {
             set_error("%s: hipMemsetAsync failed", who);
             return GFS3D_ERR_HIP;
         }
@@ -1508,22 +1829,33 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
             }
             const bool reduced = prec_of(a->compute, true) != PREC_X6;           // gradients: bf16 operands in both reduced modes
-            if (reduced) GFS3D_ENSURE_LDS(ec_main_bwd_kernel<PREC_BF16>, BWD_LDS_BYTES, who);
-            else GFS3D_ENSURE_LDS(ec_main_bwd_kernel<PREC_X6>, BWD_LDS_BYTES, who);
-            ProfScope prof(2, st);
-            if (reduced)
-                hipLaunchKernelGGL(ec_main_bwd_kernel<PREC_BF16>, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
-                                   g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
-            else
-                hipLaunchKernelGGL(ec_main_bwd_kernel<PREC_X6>, dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin,
-                                   g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart);
+#define GFS3D_BWD_LAUNCH(PREC_, CSR_)                                                                                              \
+            do {                                                                                                                   \
+                GFS3D_ENSURE_LDS((ec_main_bwd_kernel<PREC_, CSR_>), BWD_LDS_BYTES, who);                                           \
+                ProfScope prof(2, st);                                                                                             \
+                hipLaunchKernelGGL((ec_main_bwd_kernel<PREC_, CSR_>), dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, \
+                                   a->w2, cin, g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart, a->csr_pos, dyb);              \
+            } while (0)
+            if (reduced) { if (csr) GFS3D_BWD_LAUNCH(PREC_BF16, true); else GFS3D_BWD_LAUNCH(PREC_BF16, false); }
+            else { if (csr) GFS3D_BWD_LAUNCH(PREC_X6, true); else GFS3D_BWD_LAUNCH(PREC_X6, false); }
+#undef GFS3D_BWD_LAUNCH
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
         hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred, ba->dw2);
         GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
-        // every block ends in 128 same-address fp64 atomics: few, long-running blocks
-        hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(p.g_heavy < 256 ? p.g_heavy : 256), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, acc2);
-        GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
+        if (csr) {
+            const int sg = min((BN + 31) / 32, 2048);
+            hipLaunchKernelGGL(ec_bwd_segsum_kernel, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
+                               a->stats, BN, GP, BnAcc{acc2, rows});
+            GFS3D_LAUNCH_CHECK("ec_bwd_segsum_kernel");
+            if (int rc = bn_finish(BnAcc{acc2, rows}, sg, st, mid)) return rc;
+        } else {
+            // every block ends in 128 same-address fp64 atomics: few, long-running blocks
+            const int rg = p.g_heavy < 256 ? p.g_heavy : 256;
+            hipLaunchKernelGGL(ec_bwd_bn1_reduce_kernel, dim3(rg), dim3(256), 0, st, a->P, a->Q, GP, GQ, a->stats, BN, BnAcc{acc2, rows});
+            GFS3D_LAUNCH_CHECK("ec_bwd_bn1_reduce_kernel");
+            if (int rc = bn_finish(BnAcc{acc2, rows}, rg, st, mid)) return rc;
+        }
         if (acc_user && hipMemcpyAsync(loc2, acc2, sizeof(double) * 2 * EC, hipMemcpyDeviceToDevice, st) != hipSuccess) {
             set_error("%s: hipMemcpyAsync failed", who);
             return GFS3D_ERR_HIP;
@@ -1571,6 +1903,12 @@ static int check_bwd(const gfs3d_edgeconv_bwd_args *ba, const char *who)
     return GFS3D_OK;
 }
 }  // namespace gfs3d
+
+extern "C" int gfs3d_set_deterministic(int on)
+{
+    gfs3d::g_deterministic = on != 0;
+    return GFS3D_OK;
+}
 
 extern "C" int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *stream)
 {

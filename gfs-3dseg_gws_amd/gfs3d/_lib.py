@@ -35,6 +35,7 @@ class EdgeConvArgs(Structure):
         ("Pp", c_void_p), ("Qp", c_void_p),
         ("y_sqnorm", c_void_p),
         ("compute", c_int),
+        ("csr_rowptr", c_void_p), ("csr_pos", c_void_p),
     ]
 
 
@@ -89,6 +90,7 @@ SYMBOLS = {
     "gfs3d_knn_topk_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfs3d_knn_topk_norms_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfs3d_set_deterministic": (c_int, [c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),
     "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),
     "gfs3d_edgeconv_forward_phase_f32": (c_int, [POINTER(EdgeConvArgs), c_int, c_void_p, c_double, c_void_p]),

@@ -42,6 +42,12 @@ def get_compute() -> str:
     return next(k for k, v in _COMPUTE_IDS.items() if v == _compute)
 
 
+def set_deterministic(on: bool) -> None:
+    """Bit-reproducible EdgeConv forward / backward (include/gfs3d.h: gfs3d_set_deterministic): the BatchNorm reductions
+    are added in a fixed order instead of with float64 atomics.  Process-wide."""
+    _lib.check(_lib.lib().gfs3d_set_deterministic(1 if on else 0), "gfs3d_set_deterministic")
+
+
 class compute:
     """`with ops.compute("bf16"): ...` - scoped set_compute()."""
 
@@ -170,8 +176,11 @@ class EdgeConvRun:
             self.jsel = torch.empty((B, N, EC_WIDTH), dtype=torch.uint8, device=dev)
             self.Pp = torch.empty((B, N, EC_WIDTH), **f32)        # BN-folded projections, reused by the backward
             self.Qp = torch.empty((B, N, EC_WIDTH), **f32)
+            # reverse kNN graph in CSR form (fixed in-edge order: no float atomics in the backward)
+            self.csr_rowptr = torch.empty(B * N + 1, dtype=torch.int32, device=dev)
+            self.csr_pos = torch.empty((B, N, k), dtype=torch.int32, device=dev)
         else:
-            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.Pp = self.Qp = None
+            self.SP = self.SQ = self.indeg = self.hsel = self.jsel = self.Pp = self.Qp = self.csr_rowptr = self.csr_pos = None
         self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)      # point-major copy: input of the point-wise stack (K4)
         self.y_sq = torch.empty(B * N + 16, **f32)            # |y_n|^2 for the next layer's kNN (+ the slack its 16-B reads need)
         self.y = torch.empty((B, EC_WIDTH, N), **f32)
@@ -196,7 +205,7 @@ class EdgeConvRun:
         a.bn2_rm = rm2.data_ptr() if rm2 is not None else None
         a.bn2_rv = rv2.data_ptr() if rv2 is not None else None
         a.P, a.Q, a.stats = self.P.data_ptr(), self.Q.data_ptr(), self.stats.data_ptr()
-        for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm", "Pp", "Qp"):
+        for name in ("SP", "SQ", "indeg", "hsel", "jsel", "y_pm", "Pp", "Qp", "csr_rowptr", "csr_pos"):
             t = getattr(self, name)
             setattr(a, name, t.data_ptr() if t is not None else None)
         a.y_cf, a.y_cf_bstride = (self.y.data_ptr() if self.y is not None else None), EC_WIDTH * self.N

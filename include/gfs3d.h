@@ -119,9 +119,21 @@ typedef struct gfs3d_edgeconv_args {
                                      kernel's order (sequential c, rounded squares) - hand it to gfs3d_knn_topk_norms_f32 for
                                      the next layer's graph instead of a norm pass */
     int compute;                  /* GFS3D_COMPUTE_*: arithmetic of conv2 (heavy kernels) and of the point-major projection GEMM */
+    int32_t *csr_rowptr;          /* optional, saved for backward: (B*N + 1) first CSR row of every target point's in-edges */
+    int32_t *csr_pos;             /* optional, saved for backward: (B, N, k) CSR row of every edge.  Both given (and N k <= 65536
+                                     edges per block): the training forward builds the reverse kNN graph in CSR form and the
+                                     backward stores per-edge rows + sums CSR segments instead of float atomics - every sum over
+                                     the in-edges of a point then has a fixed order.  NULL: slot table + float atomics */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);
+
+/* Reproducibility of the EdgeConv entry points.  With csr_rowptr / csr_pos given, every sum over the in-edges of a point
+ * (SQ, the input-gradient scatter) and the conv2 weight gradient have a fixed order.  What remains are the 128-wide
+ * BatchNorm reductions: by default float64 atomics (the order of the adds can change a double sum in its last bit);
+ * gfs3d_set_deterministic(1) makes the producers write per-block rows that are added in a fixed order (two small extra
+ * launches per reduction): forward and backward are then bit-reproducible from run to run.  Process-wide switch. */
+int gfs3d_set_deterministic(int on);
 int gfs3d_edgeconv_forward_f32(const gfs3d_edgeconv_args *a, void *stream);
 
 /* Backward of the block above (autograd of dgcnn.py:116-118 in the reference).

@@ -182,6 +182,40 @@ def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     assert relerr(bn2.bias.grad, pr["b.layer.4.bias"].grad) < TOL
 
 
+
+def test_edgeconv_forward_backward_bit_reproducible(dev):
+    """SURVEY 5 determinism test.  With the reverse kNN graph in CSR form every sum over the in-edges of a point has a
+    fixed order (no float atomics), the conv2 weight gradient is reduced in a fixed order, and
+    gfs3d_set_deterministic(1) orders the 128-wide BatchNorm reductions too: forward outputs, saved statistics and ALL
+    gradients of a full-size block (B = 16 x 2048, hubs included) are bit-identical from run to run, with other work
+    perturbing the schedule in between."""
+    from gfs3d import ops
+    B, C, N, k = 16, 64, 2048, 20
+    p = _block_params(C, 808)
+    g = torch.Generator().manual_seed(8)
+    x0 = torch.randn(B, C, N, generator=g).to(dev)
+    cot = torch.randn(B, 64, N, generator=g).to(dev)
+    idx = ops.knn_topk(x0, k, want_i64=False, want_i32=True)
+    runs = []
+    ops.set_deterministic(True)
+    try:
+        for it in range(3):
+            blk = _make_block(p, C, dev).train()
+            c1, bn1, c2, bn2 = blk.fused_parts()
+            x = x0.clone().requires_grad_(True)
+            if it:      # disturb: other kernels in flight, different allocator state
+                junk = torch.randn(1 << (20 + it), device=dev).sin_().sum()
+            y = ops.edgeconv_block(x, idx, c1.weight, bn1, c2.weight, bn2, True)
+            (y * cot).sum().backward()
+            runs.append([y.detach().clone(), x.grad.clone(), bn1.running_var.clone(), bn2.running_mean.clone()]
+                        + [q.grad.clone() for q in blk.parameters()])
+    finally:
+        ops.set_deterministic(False)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_edgeconv_backward_hub_point_overflows_slot_table(dev):
     """A hub: one point is a neighbour of every other point (in-degree N-1 > the 64-entry slot
     table of the reverse graph), so the overflow path of the backward runs."""
