@@ -460,6 +460,388 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Screened kNN for wide C (16 <= C <= 64, k <= 32): the exact fp32 chain is evaluated ONLY for the few candidates that can
+// reach the result.  The fp32 MFMA chain of knn_mfma_kernel sits at its roof (32 MFMAs of 64 cycles per 32 x 32 tile, and
+// the chip lowers its clock to ~1.4-1.6 GHz under that load); 98 % of those exact distances are far from the k-th best.
+//   S  knn_screen_kernel: ALL distances once more cheaply - operands as hi + mid bf16 pairs (16 significant bits; one bf16
+//      alone leaves an error of 2^-8 |x||y|, larger than the neighbour gaps of real feature maps whose norms dwarf their
+//      distances), v_mfma_f32_32x32x16_bf16: 12 MFMAs of 32 cycles per tile instead of 32 of 64 - with a RIGOROUS bound E
+//      of the approximation (KNN_SCREEN_*).  Sweep 0 takes, per query,
+//      the K-th largest of the per-(lane half, tile) bucket maxima: K distinct candidates reach it approximately, hence
+//      exactly within E, so the exact K-th best is >= tau - E and every member of the exact top-K has an approximate
+//      value >= tau - 2 E.  Sweep 1 writes the ids of those candidates (about K + 5 per query) to `cand`.
+//   E  knn_exact_kernel: for every query the bit-exact distances of its candidates (sequential fp32 fma chain over the
+//      channels of the point-major rows, pd = fl(fl(2 dot - |xj|^2) - |xi|^2): oracle/knn_oracle.c) and a bitonic sort by
+//      (distance desc, index asc) across 32 lanes; a query whose candidate list overflowed (ties, tiny N) is scanned
+//      exhaustively in chunks of 32 with a running merged top-32.  Two queries per wave.
+// Bit-exactness does not depend on the screen being tight - only on E being a true bound; a loose E costs candidates.
+// ---------------------------------------------------------------------------
+// operands enter as hi + mid, two bf16 roundings to nearest: x = hi + mid + lo with |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; the
+// three products hi hi + hi mid + mid hi miss x lo_y + y lo_x + mid mid: <= 3 2^-18 |x||y| per dot, twice that per distance
+constexpr float KNN_SCREEN_REL = 4.0e-5f;      // > 2 (3 2^-18) + fp32 accumulation of 3 x 64 and 64 terms (both chains: 2 (256 2^-24))
+constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
+constexpr int KS_QS = 32;                      // queue slots per lane (= per query half)
+constexpr int KS_CAP = 64;                     // candidate ids kept per query
+constexpr int KS_TC = 32;                      // candidates per LDS stage (64 = two MFMA tiles per barrier was measured: 110 -> 153 us)
+constexpr int KS_CPT = KS_TC / 8;              // candidates per staging thread
+constexpr int KS_TLD = 272;                    // bytes per candidate row of the tile image: [hi 64 x bf16 | mid | 16 B pad] (17 slots: conflict-free ds_read_b128)
+
+// two fp32 values -> their hi and mid bf16 pieces (both roundings to nearest-even), each pair packed in one dword (a low)
+__device__ __forceinline__ void split2_rne(float a, float b, unsigned &hi, unsigned &mid)
+{
+    hi = mm_pack2<PREC_BF16>(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);   // exact
+    mid = mm_pack2<PREC_BF16>(ra, rb);
+}
+
+// x (B, C, N) channel-first -> xpm (B, N, 64) point-major, channels >= C zero
+__global__ void __launch_bounds__(256)
+knn_pm_kernel(const float *__restrict__ x, int C, int N, float *__restrict__ xpm)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
+    const int p = tid & 63, wv = tid >> 6;
+    for (int c = wv; c < 64; c += 4) tile[p][c] = (c < C && n0 + p < N) ? x[((size_t)b * C + c) * N + n0 + p] : 0.f;
+    __syncthreads();
+    for (int q = wv; q < 64; q += 4)
+        if (n0 + q < N) xpm[((size_t)b * N + n0 + q) * 64 + p] = tile[q][p];
+}
+
+template <int K>
+__global__ void __launch_bounds__(256, 3)
+knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int B, int C, int N,
+                  int *__restrict__ cand, int *__restrict__ ccnt)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
+    unsigned char *timg = ks_smem;                                              // [2][KS_TC][KS_TLD] bf16 candidate stages
+    float *tsq = reinterpret_cast<float *>(timg + 2 * KS_TC * KS_TLD);          // [2][KS_TC] their norms
+    float *red = tsq + 2 * KS_TC;                                               // [4]
+    unsigned *queue = reinterpret_cast<unsigned *>(red + 4);                    // [4 waves][KS_QS + 1][64] candidate ids (+ one scratch row)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    // blocks b and b + 8 share an XCD (round-robin dispatch): keep the blocks of one point cloud on one XCD, so that its
+    // 512 KB of rows stay in that XCD's L2 for all of its query blocks (speed only)
+    const int nq = (N + 127) / 128;
+    const int slot = blockIdx.x >> 3;
+    const int b = (slot / nq) * 8 + (blockIdx.x & 7), qblk = slot % nq;
+    if (b >= B) return;
+    const int q0 = qblk * 128 + w * 32;
+    const float *xb = x + (size_t)b * C * N;
+    const float *sqb = sqg + (size_t)b * N;
+    unsigned *myq = queue + (size_t)w * (KS_QS + 1) * 64 + lane;
+
+    // largest norm of the block (the bound E needs max_j |x_j|)
+    float mx = 0.f;
+    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, sqb[n]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[w] = mx;
+    // query operand: K-block kb, element e <-> channel 16 kb + 8 h + e of query q0 + j
+    uint4 qph[4], qpm[4];
+    {
+        const int qi = min(q0 + j, N - 1);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 16 * kb + 8 * h + e;
+                v8[e] = c < C ? xb[(size_t)c * N + qi] : 0.f;
+            }
+            unsigned hh[4], mm[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2_rne(v8[2 * e], v8[2 * e + 1], hh[e], mm[e]);
+            qph[kb] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+            qpm[kb] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+        }
+    }
+    const float sqq = sqb[min(q0 + j, N - 1)];
+    __syncthreads();
+    const float sqmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float E = KNN_SCREEN_REL * sqrtf(sqq * sqmax) + KNN_SCREEN_ABS * (sqq + sqmax);
+
+    // staging of one stage (KS_TC candidates): thread (channel pair cp, candidate group cq) loads 2 channels x KS_CPT
+    // candidates and writes KS_CPT dwords of 2 bf16
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const int cp = tid >> 3, cq = tid & 7;
+    const int ns = (N + KS_TC - 1) / KS_TC;
+    // (branch-free: N % 4 == 0 is a precondition of this path; a ragged last stage reads the last KS_CPT valid columns
+    // instead - its rows past N are never scored - and channels past C read row C - 1 and are zeroed by a select)
+    const int ch0 = min(2 * cp, C - 1), ch1 = min(2 * cp + 1, C - 1);
+    const bool z0 = 2 * cp >= C, z1 = 2 * cp + 1 >= C;
+    auto fetch = [&](int st, float (&gv0)[KS_CPT], float (&gv1)[KS_CPT], float &gsq) {
+        const int jb = min(KS_TC * st + KS_CPT * cq, N - KS_CPT);
+        const f32x4_ *r0 = reinterpret_cast<const f32x4_ *>(xb + (size_t)ch0 * N + jb);
+        const f32x4_ *r1 = reinterpret_cast<const f32x4_ *>(xb + (size_t)ch1 * N + jb);
+#pragma unroll
+        for (int u = 0; u < KS_CPT / 4; ++u) {
+            const f32x4_ a0 = r0[u], b0 = r1[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gv0[4 * u + e] = z0 ? 0.f : a0[e]; gv1[4 * u + e] = z1 ? 0.f : b0[e]; }
+        }
+        gsq = sqb[min(KS_TC * st + (tid & (KS_TC - 1)), N - 1)];
+    };
+    auto put = [&](int buf, const float (&gv0)[KS_CPT], const float (&gv1)[KS_CPT], float gsq) {
+        unsigned char *img = timg + buf * KS_TC * KS_TLD;
+#pragma unroll
+        for (int e = 0; e < KS_CPT; ++e) {
+            unsigned hh, mm;
+            split2_rne(gv0[e], gv1[e], hh, mm);
+            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 4 * cp) = hh;
+            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 128 + 4 * cp) = mm;
+        }
+        if (tid < KS_TC) tsq[buf * KS_TC + tid] = gsq;
+    };
+    // one 32-candidate tile (rows 32 sub .. of stage image buf): approximate t_r = 2 <x_j, x_q> - |x_j|^2 for the 16
+    // candidate rows this lane sees (C/D layout of the MFMA)
+    auto tile_scores = [&](int buf, int sub, float (&tv)[16]) {
+        const unsigned char *img = timg + (buf * KS_TC + 32 * sub + j) * KS_TLD + 16 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const uint4 ah = *reinterpret_cast<const uint4 *>(img + 32 * kb);
+            const uint4 am = *reinterpret_cast<const uint4 *>(img + 128 + 32 * kb);
+            acc = mm_mfma<PREC_BF16>(am, qph[kb], acc);         // smallest products first
+            acc = mm_mfma<PREC_BF16>(ah, qpm[kb], acc);
+            acc = mm_mfma<PREC_BF16>(ah, qph[kb], acc);
+        }
+        const float *sq = tsq + buf * KS_TC + 32 * sub + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 s4 = *reinterpret_cast<const float4 *>(sq + 8 * g);
+            tv[4 * g + 0] = __builtin_fmaf(2.0f, acc[4 * g + 0], -s4.x);
+            tv[4 * g + 1] = __builtin_fmaf(2.0f, acc[4 * g + 1], -s4.y);
+            tv[4 * g + 2] = __builtin_fmaf(2.0f, acc[4 * g + 2], -s4.z);
+            tv[4 * g + 3] = __builtin_fmaf(2.0f, acc[4 * g + 3], -s4.w);
+        }
+    };
+
+    float bm[K];                                          // sweep 0: the K largest bucket maxima of this lane (query half)
+#pragma unroll
+    for (int t = 0; t < K; ++t) bm[t] = -__builtin_inff();
+    auto bm_insert = [&](float m) {
+#pragma unroll
+        for (int t = K - 1; t >= 1; --t) bm[t] = __builtin_amdgcn_fmed3f(bm[t - 1], m, bm[t]);
+        bm[0] = fmaxf(bm[0], m);
+    };
+    float thr = -__builtin_inff(), thr2 = -__builtin_inff();
+    int cnt = 0;
+    float a0[KS_CPT], a1[KS_CPT], b0[KS_CPT], b1[KS_CPT], aq = 0.f, bq = 0.f;      // two stages in flight: s + 1 and s + 2
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        fetch(0, a0, a1, aq);
+        __syncthreads();                                   // (the previous sweep's last stage has been read by every wave)
+        put(0, a0, a1, aq);
+        if (ns > 1) fetch(1, a0, a1, aq);
+        __syncthreads();
+        // stage s is computed from image s & 1 while stage s + 1 (registers, requested one stage ago) is written to the other
+        // image and stage s + 2 is requested: a request has a whole stage of work to land
+        auto one_stage = [&](int st, float (&c0r)[KS_CPT], float (&c1r)[KS_CPT], float &cqr, float (&n0r)[KS_CPT], float (&n1r)[KS_CPT], float &nqr) {
+            if (st + 2 < ns) fetch(st + 2, n0r, n1r, nqr);
+#pragma unroll
+            for (int sub = 0; sub < KS_TC / 32; ++sub) {
+                const int t = st * (KS_TC / 32) + sub;     // 32-candidate tile index
+                if (32 * t >= N) break;
+                float tv[16];
+                tile_scores(st & 1, sub, tv);
+                const int cbase = 32 * t + 4 * h;
+                if (32 * t + 32 > N) {                     // ragged last tile: rows past N can never be candidates
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cbase + (r & 3) + 8 * (r >> 2) >= N) tv[r] = -__builtin_inff();
+                }
+                if (sweep == 0) {
+                    float mt = fmaxf(fmaxf(tv[0], tv[1]), tv[2]);
+#pragma unroll
+                    for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, tv[r]), tv[r + 1]);       // v_max3_f32
+                    mt = fmaxf(mt, tv[15]);
+                    bm_insert(__fsub_rn(mt, sqq));
+                } else {
+                    // candidates are rare (~12 of a lane's 1024 elements): one compare + one add-with-carry per element builds
+                    // a 16-bit mask (element r at bit 15 - r), the queue is touched only for its set bits.  The compare is on
+                    // tv against thr2 = thr + |xq|^2 lowered by the roundings of both forms: a superset of {pd >= thr}.
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) bits = bits + bits + (tv[r] >= thr2 ? 1u : 0u);
+                    while (__any(bits != 0)) {
+                        if (bits != 0) {
+                            const int hb = 31 - __builtin_clz(bits);            // highest set bit <-> smallest r = 15 - hb
+                            const int r = 15 - hb;
+                            bits &= ~(1u << hb);
+                            myq[(cnt < KS_QS ? cnt : KS_QS) * 64] = (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+            if (st + 1 < ns) put((st + 1) & 1, c0r, c1r, cqr);
+            __syncthreads();
+        };
+        int st = 0;
+        for (; st + 2 <= ns; st += 2) {
+            one_stage(st, a0, a1, aq, b0, b1, bq);
+            one_stage(st + 1, b0, b1, bq, a0, a1, aq);
+        }
+        if (st < ns) one_stage(st, a0, a1, aq, b0, b1, bq);
+        if (sweep == 0) {
+            float other[K];
+#pragma unroll
+            for (int t = 0; t < K; ++t) other[t] = __shfl_xor(bm[t], 32, 64);
+#pragma unroll
+            for (int t = 0; t < K; ++t) bm_insert(other[t]);
+            // K candidates have an approximate value >= bm[K-1]; all members of the exact top-K are >= bm[K-1] - 2 E approximately
+            const float lo = bm[K - 1] - 2.0f * E * 1.0001f;
+            thr = (bm[K - 1] == -__builtin_inff()) ? -__builtin_inff() : next_below(next_below(lo));
+            // pd = fl(tv - |xq|^2) >= thr  implies  tv >= thr + |xq|^2 - (roundings of the subtraction and of this sum)
+            thr2 = (thr == -__builtin_inff()) ? thr : (thr + sqq) - 4.8e-7f * (fabsf(thr) + fabsf(sqq)) - 1e-37f;
+        }
+    }
+    // ---- publish: the two halves of a query one after the other; overflow (or more than KS_CAP) -> exhaustive scan
+    const int c0 = __shfl(cnt, j, 64), c1 = __shfl(cnt, j + 32, 64);
+    const bool bad = c0 > KS_QS || c1 > KS_QS || c0 + c1 > KS_CAP;
+    const int q = q0 + j;
+    if (q < N) {
+        const size_t gq = (size_t)b * N + q;
+        if (h == 0) ccnt[gq] = bad ? -1 : c0 + c1;
+        if (!bad) {
+            int *dst = cand + gq * KS_CAP + (h ? c0 : 0);
+            for (int s = 0; s < cnt; ++s) dst[s] = (int)myq[s * 64];
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, const int *__restrict__ cand,
+                 const int *__restrict__ ccnt, int B, int N, int k, int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
+{
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float qrow[4][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hq = lane >> 5, l = lane & 31;
+    // (same XCD-aware block -> point cloud map as the screen kernel: the gathered rows of a cloud stay in one L2)
+    const int bpc = (N + 7) / 8;                               // blocks per cloud: 8 queries each
+    const int slot = blockIdx.x >> 3;
+    const int bb = (slot / bpc) * 8 + (blockIdx.x & 7);
+    const int qi_raw = (slot % bpc) * 8 + w * 2 + hq;
+    const bool qok = bb < B && qi_raw < N;
+    const int b = min(bb, B - 1);
+    const size_t gq = (size_t)b * N + min(qi_raw, N - 1);
+    const float *sqb = sqg + (size_t)b * N;
+    if (l < 16) *reinterpret_cast<f32x4_ *>(&qrow[w][hq][4 * l]) = *reinterpret_cast<const f32x4_ *>(xpm + gq * 64 + 4 * l);
+    const float sqq = sqg[gq];
+    const int n = ccnt[gq];
+    const int count = n >= 0 ? n : N;                        // -1: exhaustive
+    const int nch_mine = (count + 31) / 32;
+    const int nch = max(nch_mine, __shfl_xor(nch_mine, 32, 64));
+    __builtin_amdgcn_wave_barrier();
+    auto before = [](float a, int ai, float bb, int bi) { return a > bb || (a == bb && ai < bi); };
+    float tv = -__builtin_inff();
+    int ti = 0x7fffffff;                                      // sorted best-first across the 32 lanes of the half
+    for (int c = 0; c < nch; ++c) {
+        const int pos = c * 32 + l;
+        const bool valid = pos < count;
+        const int id = valid ? (n >= 0 ? cand[gq * KS_CAP + pos] : pos) : 0;
+        const float *row = xpm + ((size_t)b * N + id) * 64;
+        f32x4_ xr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xr[u] = *reinterpret_cast<const f32x4_ *>(row + 4 * u);
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const f32x4_ qv = *reinterpret_cast<const f32x4_ *>(&qrow[w][hq][4 * u]);
+            dot = __builtin_fmaf(qv[0], xr[u][0], dot);
+            dot = __builtin_fmaf(qv[1], xr[u][1], dot);
+            dot = __builtin_fmaf(qv[2], xr[u][2], dot);
+            dot = __builtin_fmaf(qv[3], xr[u][3], dot);
+        }
+        float v = valid ? __fsub_rn(__fsub_rn(2.0f * dot, sqb[id]), sqq) : -__builtin_inff();
+        int vi = valid ? id : 0x7fffffff;
+        // bitonic sort of the chunk, best first
+#pragma unroll
+        for (int sz = 2; sz <= 32; sz <<= 1) {
+#pragma unroll
+            for (int st = sz >> 1; st > 0; st >>= 1) {
+                const float ov = __shfl_xor(v, st, 64);
+                const int oi = __shfl_xor(vi, st, 64);
+                const bool want_better = (((l & st) == 0) == ((l & sz) == 0));
+                const bool take = want_better ? before(ov, oi, v, vi) : before(v, vi, ov, oi);
+                v = take ? ov : v;
+                vi = take ? oi : vi;
+            }
+        }
+        // merge with the running list: max(top[i], chunk[31 - i]) is bitonic and holds the best 32 of the union
+        {
+            const int src = (lane & 32) | (31 - l);
+            const float rv = __shfl(v, src, 64);
+            const int ri = __shfl(vi, src, 64);
+            const bool take = before(rv, ri, tv, ti);
+            tv = take ? rv : tv;
+            ti = take ? ri : ti;
+#pragma unroll
+            for (int st = 16; st > 0; st >>= 1) {
+                const float ov = __shfl_xor(tv, st, 64);
+                const int oi = __shfl_xor(ti, st, 64);
+                const bool want_better = (l & st) == 0;
+                const bool tk = want_better ? before(ov, oi, tv, ti) : before(tv, ti, ov, oi);
+                tv = tk ? ov : tv;
+                ti = tk ? oi : ti;
+            }
+        }
+    }
+    if (qok && l < k) {
+        if (idx64) idx64[gq * k + l] = (int64_t)ti;
+        if (idx32) idx32[gq * k + l] = ti;
+    }
+}
+
+struct KnnWs { size_t off_sq, off_pm, off_cand, off_cnt, total; };
+static KnnWs knn_ws(int B, int C, int N, int k)
+{
+    (void)k;
+    KnnWs w{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    w.off_sq = take(sizeof(float) * (size_t)B * N + 64);                 // norms + slack for 16-byte reads at the end
+    const bool screened = C >= 16 && C <= 64;
+    w.off_pm = take(screened ? sizeof(float) * (size_t)B * N * 64 : 0);
+    w.off_cand = take(screened ? sizeof(int) * (size_t)B * N * KS_CAP : 0);
+    w.off_cnt = take(screened ? sizeof(int) * (size_t)B * N : 0);
+    w.total = o;
+    return w;
+}
+
+template <int K>
+static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, bool have_norms, int B, int C, int N, int k,
+                               int64_t *idx64, int32_t *idx32, char *ws, const KnnWs &lay, hipStream_t st)
+{
+    const char *who = "gfs3d_knn_topk_f32(screened)";
+    ProfScope prof(0, st);
+    if (!have_norms) {
+        hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
+        GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
+    }
+    const float *xpm = xpm_in;
+    if (!xpm || C != 64) {                                  // the exact pass reads zero-padded 64-channel rows
+        float *t = reinterpret_cast<float *>(ws + lay.off_pm);
+        hipLaunchKernelGGL(knn_pm_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, C, N, t);
+        GFS3D_LAUNCH_CHECK("knn_pm_kernel");
+        xpm = t;
+    }
+    int *cand = reinterpret_cast<int *>(ws + lay.off_cand), *ccnt = reinterpret_cast<int *>(ws + lay.off_cnt);
+    const size_t lds = 2 * KS_TC * KS_TLD + sizeof(float) * (2 * KS_TC + 4) + sizeof(unsigned) * 4 * (KS_QS + 1) * 64;
+    GFS3D_ENSURE_LDS(knn_screen_kernel<K>, lds, who);
+    hipLaunchKernelGGL(knn_screen_kernel<K>, dim3(((N + 127) / 128) * ((B + 7) / 8) * 8), dim3(256), lds, st, x, sq, B, C, N, cand, ccnt);
+    GFS3D_LAUNCH_CHECK("knn_screen_kernel");
+    const long long nq = (long long)B * N;
+    (void)nq;
+    hipLaunchKernelGGL(knn_exact_kernel<K>, dim3((unsigned)(((N + 7) / 8) * ((B + 7) / 8) * 8)), dim3(256), 0, st, xpm, sq, cand, ccnt, B, N, k, idx64, idx32);
+    GFS3D_LAUNCH_CHECK("knn_exact_kernel");
+    return GFS3D_OK;
+}
+
 template <int CS, int K>
 static int launch_knn_mfma(const float *x, float *sq, bool have_norms, int B, int C, int N, int k, int64_t *idx64, int32_t *idx32,
                            hipStream_t st)
@@ -503,11 +885,10 @@ static int launch_knn(const float *x, int B, int C, int N, int k, int64_t *idx64
 
 extern "C" size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k)
 {
-    (void)C; (void)k;
-    return (B < 1 || N < 1) ? 0 : sizeof(float) * (size_t)B * N + 64;    // norms + slack for 16-byte reads at the end
+    return (B < 1 || N < 1 || C < 1) ? 0 : gfs3d::knn_ws(B, C, N, k).total;
 }
 
-static int knn_entry(const char *who, const float *x, const float *norms, int B, int C, int N, int k,
+static int knn_entry(const char *who, const float *x, const float *x_pm, const float *norms, int B, int C, int N, int k,
                      int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace gfs3d;
@@ -518,16 +899,25 @@ static int knn_entry(const char *who, const float *x, const float *norms, int B,
     GFS3D_REQUIRE(B <= 65535, "%s: B=%d exceeds grid.y", who, B);
     if (B == 0) return GFS3D_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (C <= 64 && k <= 32) {          // MFMA path; the point norms come from the caller or are computed into the workspace
+    if (C <= 64 && k <= 32) {          // matrix paths; the point norms come from the caller or are computed into the workspace
         GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "%s: C*N too large for 32-bit buffer offsets", who);
+        const KnnWs lay = knn_ws(B, C, N, k);
+        static const bool screen_on = [] { const char *e = getenv("GFS3D_KNN_SCREEN"); return !(e && e[0] == '0'); }();     // A-B only
+        const bool screened = screen_on && C >= 16 && (N & 3) == 0 && N >= 8 && workspace != nullptr && workspace_bytes >= lay.total &&
+                              (long long)B * N * KS_CAP < (1ll << 31);
         float *sq = const_cast<float *>(norms);
         if (!norms) {
             GFS3D_REQUIRE(workspace != nullptr, "%s: NULL workspace", who);
-            if (workspace_bytes < gfs3d_knn_workspace_bytes(B, C, N, k)) {
-                set_error("%s: workspace %zu < required %zu", who, workspace_bytes, gfs3d_knn_workspace_bytes(B, C, N, k));
+            if (workspace_bytes < lay.off_pm) {              // at least the norms
+                set_error("%s: workspace %zu < required %zu", who, workspace_bytes, lay.total);
                 return GFS3D_ERR_WORKSPACE;
             }
-            sq = static_cast<float *>(workspace);
+            sq = reinterpret_cast<float *>(static_cast<char *>(workspace) + lay.off_sq);
+        }
+        if (screened) {
+            char *ws = static_cast<char *>(workspace);
+            if (k <= 20) return launch_knn_screened<20>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            return launch_knn_screened<32>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
         }
         if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
         if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
@@ -542,7 +932,7 @@ static int knn_entry(const char *who, const float *x, const float *norms, int B,
 extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
                                   int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return knn_entry("gfs3d_knn_topk_f32", x, nullptr, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
+    return knn_entry("gfs3d_knn_topk_f32", x, nullptr, nullptr, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, int N, int k,
@@ -550,5 +940,11 @@ extern "C" int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(sqnorm != nullptr, "gfs3d_knn_topk_norms_f32: sqnorm is NULL");
-    return knn_entry("gfs3d_knn_topk_norms_f32", x, sqnorm, B, C, N, k, idx64, idx32, nullptr, 0, stream);
+    return knn_entry("gfs3d_knn_topk_norms_f32", x, nullptr, sqnorm, B, C, N, k, idx64, idx32, nullptr, 0, stream);
+}
+
+extern "C" int gfs3d_knn_topk_pm_f32(const float *x, const float *x_pm, const float *sqnorm, int B, int C, int N, int k,
+                                     int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return knn_entry("gfs3d_knn_topk_pm_f32", x, x_pm, sqnorm, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
 }

@@ -89,6 +89,8 @@ SYMBOLS = {
     "gfs3d_knn_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_knn_topk_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfs3d_knn_topk_norms_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gfs3d_knn_topk_pm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_set_deterministic": (c_int, [c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),

@@ -95,10 +95,13 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # K1
 # --------------------------------------------------------------------------
-def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False, sqnorm: Optional[torch.Tensor] = None):
+def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False, sqnorm: Optional[torch.Tensor] = None,
+             x_pm: Optional[torch.Tensor] = None):
     """x (B,C,N) channel-first -> neighbour indices (B,N,k), nearest first.
     Replaces knn() of model/dgcnn.py:17-23.  `sqnorm`: the point norms if the caller has them in the kernel's
-    summation order (the third output of `edgeconv_block(..., want_sq=True)` for the previous block's features)."""
+    summation order (the third output of `edgeconv_block(..., want_sq=True)` for the previous block's features);
+    `x_pm`: the (B,N,64) point-major values of x when C == 64 (the previous block's second output) - the screened
+    path's exact pass reads point rows."""
     _need_gpu(x, "x")
     if x.dim() != 3:
         raise RuntimeError("gfs3d.knn_topk: x must be (B,C,N)")
@@ -106,16 +109,16 @@ def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = Fa
     B, C, N = x.shape
     i64 = torch.empty((B, N, k), dtype=torch.int64, device=x.device) if want_i64 else None
     i32 = torch.empty((B, N, k), dtype=torch.int32, device=x.device) if want_i32 else None
+    if sqnorm is not None and (sqnorm.dtype != torch.float32 or not sqnorm.is_contiguous() or sqnorm.numel() < B * N + 16
+                               or sqnorm.device != x.device):
+        raise RuntimeError("gfs3d.knn_topk: sqnorm must be a contiguous fp32 tensor of B*N + 16 elements on x's device")
+    if x_pm is not None and (C != 64 or tuple(x_pm.shape) != (B, N, 64) or not x_pm.is_contiguous() or x_pm.dtype != torch.float32):
+        raise RuntimeError("gfs3d.knn_topk: x_pm must be the contiguous (B,N,64) fp32 point-major copy of a 64-channel x")
     with torch.cuda.device(x.device):
         L = _lib.lib()
-        if sqnorm is not None:
-            if sqnorm.dtype != torch.float32 or not sqnorm.is_contiguous() or sqnorm.numel() < B * N + 16 or sqnorm.device != x.device:
-                raise RuntimeError("gfs3d.knn_topk: sqnorm must be a contiguous fp32 tensor of B*N + 16 elements on x's device")
-            rc = L.gfs3d_knn_topk_norms_f32(_p(x), _p(sqnorm), B, C, N, int(k), _p(i64), _p(i32), _stream())
-        else:
-            ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
-            rc = L.gfs3d_knn_topk_f32(_p(x), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
-    _lib.check(rc, "gfs3d_knn_topk_f32")
+        ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
+        rc = L.gfs3d_knn_topk_pm_f32(_p(x), _p(x_pm), _p(sqnorm), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "gfs3d_knn_topk_pm_f32")
     if want_i64 and want_i32:
         return i64, i32
     return i64 if want_i64 else i32

@@ -130,7 +130,8 @@ class DGCNN(nn.Module):
         x_pm = x_sq = None
         for block in self.edge_convs:
             c1, bn1, c2, bn2 = block.fused_parts()
-            idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True, sqnorm=x_sq)
+            idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True, sqnorm=x_sq,
+                                 x_pm=x_pm.detach() if (x_pm is not None and x.shape[1] == 64) else None)
             x, x_pm, x_sq = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
                                                sync=self.bn_sync, x_pm=x_pm, track=False, want_sq=True)
             bns += [bn1, bn2]

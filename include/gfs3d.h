@@ -70,7 +70,7 @@ int gfs3d_profile_read(int kernel_id, double *total_ms, long long *launches);
  * Numerics contract (oracle/knn_oracle.c): dot = fp32 fma chain over c,
  * pd = fl(fl(2 dot - |xj|^2) - |xi|^2), ties -> lower index first.
  * Requires 1 <= k <= min(N, 64), C >= 1.  workspace: gfs3d_knn_workspace_bytes() bytes of
- * device scratch (the per-point squared norms). */
+ * device scratch (the per-point squared norms; for 16 <= C <= 64 also the candidate lists of the screened path). */
 size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k);
 int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
                        int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
@@ -81,6 +81,14 @@ int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
  * needs no workspace either). */
 int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, int N, int k,
                              int64_t *idx64, int32_t *idx32, void *stream);
+
+/* The general form: x_pm, if not NULL, is the point-major copy (B, N, 64) of x with C == 64 (what the EdgeConv entry points
+ * leave in y_pm) and sqnorm, if not NULL, the point norms as above.  With 16 <= C <= 64, k <= 32 and the full workspace
+ * (gfs3d_knn_workspace_bytes) the graph is built by the SCREENED path: all distances approximately on the bf16 matrix
+ * cores with a rigorous error bound, the exact fp32 chain only for the ~k + 5 candidates per point that can reach the
+ * result - the same indices bit for bit, about a third of the time of the exhaustive fp32 chain. */
+int gfs3d_knn_topk_pm_f32(const float *x, const float *x_pm, const float *sqnorm, int B, int C, int N, int k,
+                          int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ K2 --
  * One EdgeConv block = get_edge_feature (dgcnn.py:26-42) + conv2d block
