@@ -46,6 +46,11 @@ def relerr(a, b):
     # wide-C path (lazy selection): every distance tied, exact twins, heavily tied integer features, ragged last tile
     (1, 64, 256, 20, "same"), (2, 64, 512, 20, "twins"), (2, 16, 1000, 20, "ints"), (1, 32, 2048, 12, "ints"),
     (1, 64, 77, 20, "randn"),
+    # screened path (16 <= C <= 64, N % 4 == 0): feature maps whose norms dwarf their distances (the error bound of the
+    # screen scales with |x||y|), post-ReLU features, a spread so small that every query overflows its candidate list and
+    # is scanned exhaustively, a ragged last 32-candidate tile, k = 32, C below 64 (zero-padded point rows)
+    (2, 64, 1024, 20, "offset"), (2, 64, 2048, 20, "relu"), (1, 64, 512, 20, "tiny_spread"), (2, 64, 1000, 20, "offset"),
+    (1, 64, 300, 32, "relu"), (2, 24, 516, 20, "offset"), (1, 48, 2048, 9, "randn"),
 ])
 def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
     from gfs3d import ops
@@ -61,6 +66,12 @@ def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
         x[:, :, N // 2:] = x[:, :, :N // 2]
     elif kind == "ints":
         x = torch.randint(0, 3, (B, C, N), generator=g).float()
+    elif kind == "offset":
+        x = torch.randn(B, C, N, generator=g) * 0.3 + torch.randn(1, C, 1, generator=g) * 4.0
+    elif kind == "relu":
+        x = torch.nn.functional.leaky_relu(torch.randn(B, C, N, generator=g) + 0.8, 0.2)
+    elif kind == "tiny_spread":
+        x = torch.randn(B, C, N, generator=g) * 1e-3 + 50.0
     else:
         x = torch.randn(B, C, N, generator=g)
     i64, i32 = ops.knn_topk(x.to(dev), k, want_i64=True, want_i32=True)
