@@ -715,8 +715,10 @@ __global__ void pw_bn_finalize_kernel(const double *__restrict__ acc, int C, dou
 }
 
 // BatchNorm backward coefficients: dh = a g + b + c h; parameter gradients
-__global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, int C, double count, const float *__restrict__ stats,
-                                   float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta)
+// acc: sums over the whole (possibly multi-rank) batch -> coefficients; loc: this rank's sums -> its parameter gradients
+__global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, const double *__restrict__ loc, int C, double count,
+                                   const float *__restrict__ stats, float *__restrict__ coef, float *__restrict__ dgamma,
+                                   float *__restrict__ dbeta)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -726,8 +728,8 @@ __global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, int C, double
     coef[c] = (float)a;
     coef[C + c] = (float)(-a * S1 / count - cc * mean);
     coef[2 * C + c] = (float)cc;
-    dgamma[c] = (float)S2;
-    dbeta[c] = (float)S1;
+    dgamma[c] = (float)(rstd * (loc[C + c] - mean * loc[c]));
+    dbeta[c] = (float)loc[c];
 }
 
 // ------------------------------------------------------------------ host side
@@ -902,26 +904,29 @@ extern "C" size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n
     return pw_plan(B, N, n_seg, n_layers, width).total;
 }
 
-extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream)
+// Forward in phases 0 .. L (L = n_layers); training mode: phase p < L runs the GEMM of layer p (after finalising the
+// BatchNorm of layer p - 1 from the sums in acc row p - 1) and leaves the column sums of layer p in acc row p; phase L
+// finalises the last BatchNorm and writes the channel-first result.  acc: [L][2][maxw] doubles - the caller's buffer under
+// synchronised BatchNorm (it all-reduces row p between phases p and p + 1), else workspace.
+static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *acc_user, double stat_count, hipStream_t st, const char *who)
 {
-    const char *who = "gfs3d_pointwise_forward_f32";
-    if (int rc = pw_check(a, who, true)) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
-    if (a->workspace_bytes < p.total) {
-        set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
-        return GFS3D_ERR_WORKSPACE;
-    }
     char *ws = static_cast<char *>(a->workspace);
-    double *acc = reinterpret_cast<double *>(ws + p.off_acc);
+    double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     const int L = a->n_layers, M = p.M;
-    ProfScope prof(6, st);
-    if (a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
+    const double count = stat_count > 0.0 ? stat_count : (double)M;
+    if (phase == 0 && a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
         set_error("%s: hipMemsetAsync failed", who);
         return GFS3D_ERR_HIP;
     }
-    for (int l = 0; l < L; ++l) {
-        const int C = a->width[l];
+    if (a->training && phase > 0) {                      // BatchNorm of layer phase - 1: batch statistics are complete (and global)
+        const int l = phase - 1, C = a->width[l];
+        hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc + (size_t)2 * p.maxw * l, C, count, a->bn_w[l], a->bn_b[l],
+                           a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l]);
+        GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
+    }
+    if (phase < L) {
+        const int l = phase, C = a->width[l];
         double *acc_l = acc + (size_t)2 * p.maxw * l;
         RowGemm rg{};
         fill_a(rg, a, l, l ? a->h[l - 1] : nullptr);
@@ -944,9 +949,6 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
                 rc = rowgemm<PRO_BNACT, EPI_RAW_STATS, false>(rg, st, who);
             }
             if (rc) return rc;
-            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc_l, C, (double)M, a->bn_w[l], a->bn_b[l],
-                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l]);
-            GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
         } else {
             hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
                                a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l]);
@@ -961,8 +963,7 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
                 rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, false>(rg, st, who);
             if (rc) return rc;
         }
-    }
-    if (a->training) {
+    } else if (a->training) {
         const int C = a->width[L - 1];
         hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->h[L - 1], a->stats[L - 1], a->N, C,
                            a->slope, a->y_cf);
@@ -971,9 +972,122 @@ extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *
     return GFS3D_OK;
 }
 
-extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, void *stream)
+static int pw_fwd_common(const gfs3d_pointwise_args *a, const char *who)
 {
-    const char *who = "gfs3d_pointwise_backward_f32";
+    if (int rc = pw_check(a, who, true)) return rc;
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    if (a->workspace_bytes < p.total) {
+        set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
+        return GFS3D_ERR_WORKSPACE;
+    }
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream)
+{
+    const char *who = "gfs3d_pointwise_forward_f32";
+    if (int rc = pw_fwd_common(a, who)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(6, st);
+    for (int ph = 0; ph <= a->n_layers; ++ph)
+        if (int rc = pw_forward_phase(a, ph, nullptr, 0.0, st, who)) return rc;
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_pointwise_forward_phase_f32(const gfs3d_pointwise_args *a, int phase, double *acc, double stat_count, void *stream)
+{
+    const char *who = "gfs3d_pointwise_forward_phase_f32";
+    if (int rc = pw_fwd_common(a, who)) return rc;
+    GFS3D_REQUIRE(phase >= 0 && phase <= a->n_layers, "%s: phase must be 0 .. n_layers", who);
+    GFS3D_REQUIRE(acc != nullptr, "%s: NULL acc", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(6, st);
+    return pw_forward_phase(a, phase, acc, stat_count, st, who);
+}
+
+// Backward in phases 0 .. L: phase 0 turns dy into the gradient of the last pre-activation and its BatchNorm-backward sums
+// (acc row L - 1); phase q >= 1 handles layer l = L - q: BatchNorm-backward coefficients from acc row l (global sums;
+// the parameter gradients use this rank's own sums, kept in loc row l), dW_l, and the gradient of layer l - 1 with ITS sums
+// (acc row l - 1) - or dx for l = 0.  acc / loc: [L][2][maxw] doubles each.
+static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, double *acc_user, double stat_count, hipStream_t st, const char *who)
+{
+    const gfs3d_pointwise_args *a = &ba->f;
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    char *ws = static_cast<char *>(a->workspace);
+    const int L = a->n_layers, M = p.M;
+    double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
+    double *loc = acc_user ? acc_user + (size_t)2 * p.maxw * L : acc;          // monolithic: this rank's sums are the global sums
+    float *coef = reinterpret_cast<float *>(ws + p.off_coef);
+    const double count = stat_count > 0.0 ? stat_count : (double)M;
+    auto keep_local = [&](int l) -> int {
+        if (!acc_user) return GFS3D_OK;
+        if (hipMemcpyAsync(loc + (size_t)2 * p.maxw * l, acc + (size_t)2 * p.maxw * l, sizeof(double) * 2 * p.maxw, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            set_error("%s: hipMemcpyAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
+        return GFS3D_OK;
+    };
+    if (phase == 0) {
+        const int C = a->width[L - 1];
+        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
+                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]),
+                           acc + (size_t)2 * p.maxw * (L - 1));
+        GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
+        return keep_local(L - 1);
+    }
+    const int l = L - phase;
+    const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
+    float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
+    void *w3t = ws + p.off_w3[l];
+    hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc + (size_t)2 * p.maxw * l, loc + (size_t)2 * p.maxw * l, C, count,
+                       a->stats[l], coef, ba->dbn_w[l], ba->dbn_b[l]);
+    GFS3D_LAUNCH_CHECK("pw_bwd_coef_kernel");
+    // dW_l
+    if (hipMemsetAsync(ba->dw[l], 0, sizeof(float) * (size_t)C * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+    WGrad wg{};
+    wg.u = gl; wg.u2 = a->h[l]; wg.ldu = C;
+    wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
+    wg.slope = a->slope;
+    wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
+    wg.prec = prec_of(a->compute, true);
+    int rc;
+    if (l == 0) {
+        for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
+        wg.v_segw = GFS3D_PW_SEG_WIDTH; wg.ldv = GFS3D_PW_SEG_WIDTH;
+        // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once
+        rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
+    } else {
+        wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
+        wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
+        rc = (Ci % 128 == 0) ? launch_wgrad<128, PRO_BNACT>(wg, st, who) : launch_wgrad<64, PRO_BNACT>(wg, st, who);
+    }
+    if (rc) return rc;
+    // dA_{l-1} = dH_l W_l
+    if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st, prec_of(a->compute, true))) return rc2;      // pieces of W_l^T (Ci, C)
+    RowGemm rg{};
+    rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
+    rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
+    rg.w3 = w3t;
+    rg.prec = prec_of(a->compute, true);
+    rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
+    if (l == 0) {
+        for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
+        rg.o_segw = GFS3D_PW_SEG_WIDTH;
+        return launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
+    }
+    rg.out[0] = reinterpret_cast<float *>(ws + p.off_g[l - 1]);
+    rg.o_segw = Ci;
+    rg.ea = a->stats[l - 1] + PST_SCALE * Ci;
+    rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
+    rg.eh = a->h[l - 1];
+    rg.acc = acc + (size_t)2 * p.maxw * (l - 1);
+    if (int rc3 = rowgemm<PRO_BWD, EPI_BWD_ACT, false>(rg, st, who)) return rc3;
+    return keep_local(l - 1);
+}
+
+static int pw_bwd_common(const gfs3d_pointwise_bwd_args *ba, const char *who)
+{
     GFS3D_REQUIRE(ba, "%s: NULL args", who);
     const gfs3d_pointwise_args *a = &ba->f;
     if (int rc = pw_check(a, who, false)) return rc;
@@ -982,75 +1096,32 @@ extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, 
     for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(ba->dx_seg[s], "%s: NULL dx_seg[%d]", who, s);
     for (int l = 0; l < a->n_layers; ++l)
         GFS3D_REQUIRE(ba->dw[l] && ba->dbn_w[l] && ba->dbn_b[l], "%s: NULL gradient buffer of layer %d", who, l);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
     if (a->workspace_bytes < p.total) {
         set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
         return GFS3D_ERR_WORKSPACE;
     }
-    char *ws = static_cast<char *>(a->workspace);
-    double *acc = reinterpret_cast<double *>(ws + p.off_acc);
-    float *coef = reinterpret_cast<float *>(ws + p.off_coef);
-    const int L = a->n_layers, M = p.M;
-    ProfScope prof(7, st);
-    {
-        const int C = a->width[L - 1];
-        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
-        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
-                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]),
-                           acc + (size_t)2 * p.maxw * (L - 1));
-        GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
-    }
-    for (int l = L - 1; l >= 0; --l) {
-        const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
-        float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
-        void *w3t = ws + p.off_w3[l];
-        double *acc_l = acc + (size_t)2 * p.maxw * l;
-        hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc_l, C, (double)M, a->stats[l], coef,
-                           ba->dbn_w[l], ba->dbn_b[l]);
-        GFS3D_LAUNCH_CHECK("pw_bwd_coef_kernel");
-        // dW_l
-        if (hipMemsetAsync(ba->dw[l], 0, sizeof(float) * (size_t)C * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
-        WGrad wg{};
-        wg.u = gl; wg.u2 = a->h[l]; wg.ldu = C;
-        wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
-        wg.slope = a->slope;
-        wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
-        wg.prec = prec_of(a->compute, true);
-        int rc;
-        if (l == 0) {
-            for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
-            wg.v_segw = GFS3D_PW_SEG_WIDTH; wg.ldv = GFS3D_PW_SEG_WIDTH;
-            // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once
-            rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
-        } else {
-            wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
-            wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
-            rc = (Ci % 128 == 0) ? launch_wgrad<128, PRO_BNACT>(wg, st, who) : launch_wgrad<64, PRO_BNACT>(wg, st, who);
-        }
-        if (rc) return rc;
-        // dA_{l-1} = dH_l W_l
-        if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st, prec_of(a->compute, true))) return rc2;      // pieces of W_l^T (Ci, C)
-        RowGemm rg{};
-        rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
-        rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
-        rg.w3 = w3t;
-        rg.prec = prec_of(a->compute, true);
-        rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
-        if (l == 0) {
-            for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
-            rg.o_segw = GFS3D_PW_SEG_WIDTH;
-            rc = launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
-        } else {
-            rg.out[0] = reinterpret_cast<float *>(ws + p.off_g[l - 1]);
-            rg.o_segw = Ci;
-            rg.ea = a->stats[l - 1] + PST_SCALE * Ci;
-            rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
-            rg.eh = a->h[l - 1];
-            rg.acc = acc + (size_t)2 * p.maxw * (l - 1);
-            rc = rowgemm<PRO_BWD, EPI_BWD_ACT, false>(rg, st, who);
-        }
-        if (rc) return rc;
-    }
     return GFS3D_OK;
+}
+
+extern "C" int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *ba, void *stream)
+{
+    const char *who = "gfs3d_pointwise_backward_f32";
+    if (int rc = pw_bwd_common(ba, who)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(7, st);
+    for (int ph = 0; ph <= ba->f.n_layers; ++ph)
+        if (int rc = pw_backward_phase(ba, ph, nullptr, 0.0, st, who)) return rc;
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_pointwise_backward_phase_f32(const gfs3d_pointwise_bwd_args *ba, int phase, double *acc, double stat_count, void *stream)
+{
+    const char *who = "gfs3d_pointwise_backward_phase_f32";
+    if (int rc = pw_bwd_common(ba, who)) return rc;
+    GFS3D_REQUIRE(phase >= 0 && phase <= ba->f.n_layers, "%s: phase must be 0 .. n_layers", who);
+    GFS3D_REQUIRE(acc != nullptr, "%s: NULL acc", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(7, st);
+    return pw_backward_phase(ba, phase, acc, stat_count, st, who);
 }

@@ -100,6 +100,8 @@ SYMBOLS = {
     "gfs3d_pointwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
     "gfs3d_pointwise_forward_f32": (c_int, [POINTER(PointwiseArgs), c_void_p]),
     "gfs3d_pointwise_backward_f32": (c_int, [POINTER(PointwiseBwdArgs), c_void_p]),
+    "gfs3d_pointwise_forward_phase_f32": (c_int, [POINTER(PointwiseArgs), c_int, c_void_p, c_double, c_void_p]),
+    "gfs3d_pointwise_backward_phase_f32": (c_int, [POINTER(PointwiseBwdArgs), c_int, c_void_p, c_double, c_void_p]),
     "gfs3d_attention_forward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_void_p,
                                             c_void_p, c_void_p, c_void_p]),
     "gfs3d_attention_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

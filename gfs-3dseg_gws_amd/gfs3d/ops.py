@@ -362,7 +362,7 @@ class PointwiseRun:
     """One invocation of the point-wise stack [Conv1d 1x1 -> BatchNorm1d -> LeakyReLU] x L on point-major
     64-channel segments (model/dgcnn.py:64-80, 121-122)."""
 
-    def __init__(self, xs, layers, training, eps, momentum, slope):
+    def __init__(self, xs, layers, training, eps, momentum, slope, private_workspace: bool = False):
         if not 1 <= len(xs) <= PW_MAX_SEGS or not 1 <= len(layers) <= PW_MAX_LAYERS:
             raise NotImplementedError("gfs3d.pointwise: 1..4 input segments and 1..4 layers are implemented in HIP")
         for t in xs:
@@ -390,6 +390,7 @@ class PointwiseRun:
         self.y = torch.empty((self.B, self.widths[-1], self.N), **f32)
         arr = (ctypes.c_int * L)(*self.widths)
         self._nbytes = _lib.lib().gfs3d_pointwise_workspace_bytes(self.B, self.N, len(xs), L, arr)
+        self._private_ws = torch.empty(self._nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
 
     def _args(self, a: PointwiseArgs):
         eps, momentum, slope = self.scalars
@@ -407,20 +408,58 @@ class PointwiseRun:
             a.h[l] = self.h[l].data_ptr() if self.h[l] is not None else None
             a.stats[l] = self.stats[l].data_ptr()
         a.y_cf = self.y.data_ptr() if self.y is not None else None      # not needed by the backward
-        ws = _workspace(self.xs[0].device, self._nbytes)
+        ws = self._private_ws if self._private_ws is not None else _workspace(self.xs[0].device, self._nbytes)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         return ws
 
-    def forward(self):
+    def _acc(self):
+        """(acc buffer, doubles per row): rows [l][2][maxw] of global sums + the library's copies of this rank's sums."""
+        row = 2 * max(self.widths)
+        return torch.zeros(2 * len(self.layers) * row, dtype=torch.float64, device=self.xs[0].device), row
+
+    def forward_phase(self, phase: int, acc: torch.Tensor, stat_count: float):
+        """One phase of the forward (tests / custom exchanges); needs private_workspace=True if other calls run between phases."""
         a = PointwiseArgs()
         ws = self._args(a)
         with torch.cuda.device(self.xs[0].device):
-            rc = _lib.lib().gfs3d_pointwise_forward_f32(ctypes.byref(a), _stream())
-        _lib.check(rc, "gfs3d_pointwise_forward_f32")
+            rc = _lib.lib().gfs3d_pointwise_forward_phase_f32(ctypes.byref(a), phase, _p(acc), float(stat_count), _stream())
+        _lib.check(rc, "gfs3d_pointwise_forward_phase_f32")
+        del ws
+
+    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None):
+        if phase == 0:
+            self._ba = self._bwd_args(dy)
+        ba, ws = self._ba
+        with torch.cuda.device(self.xs[0].device):
+            rc = _lib.lib().gfs3d_pointwise_backward_phase_f32(ctypes.byref(ba), phase, _p(acc), float(stat_count), _stream())
+        _lib.check(rc, "gfs3d_pointwise_backward_phase_f32")
+        if phase == len(self.layers):
+            del self._ba
+            out = (self.dxs, self.dws, self.dgs, self.dbs)
+            self.dxs = self.dws = self.dgs = self.dbs = self.dy = None
+            return out
+        return None
+
+    def forward(self, sync: Optional["BNSync"] = None):
+        a = PointwiseArgs()
+        ws = self._args(a)
+        L = _lib.lib()
+        with torch.cuda.device(self.xs[0].device):
+            if sync is None or not self.training:
+                rc = L.gfs3d_pointwise_forward_f32(ctypes.byref(a), _stream())
+                _lib.check(rc, "gfs3d_pointwise_forward_f32")
+            else:       # synchronised BatchNorm: the column sums of every layer are all-reduced between the phases
+                acc, row = self._acc()
+                count = float(self.B) * self.N * sync.world_size
+                for ph in range(len(self.layers) + 1):
+                    rc = L.gfs3d_pointwise_forward_phase_f32(ctypes.byref(a), ph, _p(acc), count, _stream())
+                    _lib.check(rc, "gfs3d_pointwise_forward_phase_f32")
+                    if ph < len(self.layers):
+                        sync.all_reduce(acc[ph * row:(ph + 1) * row])
         del ws
         return self.y
 
-    def backward(self, dy):
+    def _bwd_args(self, dy):
         dev = self.xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         self.dy = dy.contiguous()
@@ -438,9 +477,25 @@ class PointwiseRun:
             ba.dx_seg[s_] = t.data_ptr()
         for l in range(len(self.layers)):
             ba.dw[l], ba.dbn_w[l], ba.dbn_b[l] = self.dws[l].data_ptr(), self.dgs[l].data_ptr(), self.dbs[l].data_ptr()
+        return ba, ws
+
+    def backward(self, dy, sync: Optional["BNSync"] = None):
+        dev = self.xs[0].device
+        ba, ws = self._bwd_args(dy)
         with torch.cuda.device(dev):
-            rc = _lib.lib().gfs3d_pointwise_backward_f32(ctypes.byref(ba), _stream())
-        _lib.check(rc, "gfs3d_pointwise_backward_f32")
+            if sync is None:
+                rc = _lib.lib().gfs3d_pointwise_backward_f32(ctypes.byref(ba), _stream())
+                _lib.check(rc, "gfs3d_pointwise_backward_f32")
+            else:
+                acc, row = self._acc()
+                count = float(self.B) * self.N * sync.world_size
+                nl = len(self.layers)
+                for ph in range(nl + 1):
+                    rc = _lib.lib().gfs3d_pointwise_backward_phase_f32(ctypes.byref(ba), ph, _p(acc), count, _stream())
+                    _lib.check(rc, "gfs3d_pointwise_backward_phase_f32")
+                    if ph < nl:                       # phase ph leaves the sums of layer nl - 1 - ph
+                        l = nl - 1 - ph
+                        sync.all_reduce(acc[l * row:(l + 1) * row])
         del ws
         out = (self.dxs, self.dws, self.dgs, self.dbs)
         self.dxs = self.dws = self.dgs = self.dbs = self.dy = None          # see EdgeConvRun._take_grads
@@ -451,16 +506,17 @@ class PointwiseStackFunction(torch.autograd.Function):
     """act(bn_L(... act(bn_1(W_1 cat(xs))) ...)) -> (B, C_L, N); tensors = xs + [w, gamma, beta] * L + [rm, rv] * L."""
 
     @staticmethod
-    def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, *tensors):
+    def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, sync, *tensors):
         xs = tensors[:n_seg]
         par = tensors[n_seg:n_seg + 3 * n_layers]
         run_ = tensors[n_seg + 3 * n_layers:]
         layers = [(par[3 * l], par[3 * l + 1], par[3 * l + 2], run_[2 * l], run_[2 * l + 1]) for l in range(n_layers)]
         run = PointwiseRun(xs, layers, training, eps, momentum, slope)
-        y = run.forward()
+        y = run.forward(sync)
         run.y = None
         if training:
             ctx.c = run
+            ctx.sync = sync
         ctx.n = (n_seg, n_layers)
         return y
 
@@ -469,15 +525,16 @@ class PointwiseStackFunction(torch.autograd.Function):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.pointwise: backward is implemented for training mode (batch statistics) only")
         n_seg, n_layers = ctx.n
-        dxs, dws, dgs, dbs = ctx.c.backward(dy)
+        dxs, dws, dgs, dbs = ctx.c.backward(dy, ctx.sync)
         par = []
         for l in range(n_layers):
             par += [dws[l], dgs[l], dbs[l]]
-        return (None,) * 6 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers)
+        return (None,) * 7 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers)
 
 
-def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: bool = True):
-    """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64) segments."""
+def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: bool = True, sync: Optional[BNSync] = None):
+    """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64) segments.  `sync`: share the batch
+    statistics between the ranks of a block-sharded batch (phased C ABI, one all-reduce per layer and pass)."""
     if training and track:
         for _c, bn in parts:
             if bn.num_batches_tracked is not None:
@@ -488,7 +545,7 @@ def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: boo
     for conv, bn in parts:
         par += [conv.weight, bn.weight, bn.bias]
         run_ += [bn.running_mean, bn.running_var]
-    return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope),
+    return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope), sync,
                                         *xs_pm, *par, *run_)
 
 

@@ -97,7 +97,9 @@ class conv1d(nn.Module):
         parts = []
         for i in range(0, len(m), 3):
             c, bn, act = m[i], m[i + 1], m[i + 2]
-            ok = (isinstance(c, nn.Conv1d) and type(bn) is nn.BatchNorm1d and isinstance(act, nn.LeakyReLU)
+            # (convert_sync_batchnorm() swaps the class and keeps weights / buffers: the HIP stack then shares its statistics
+            # through gfs3d.ops.BNSync instead)
+            ok = (isinstance(c, nn.Conv1d) and type(bn) in (nn.BatchNorm1d, nn.SyncBatchNorm) and isinstance(act, nn.LeakyReLU)
                   and c.bias is None and c.kernel_size == (1,) and c.out_channels % 64 == 0 and c.out_channels <= 1024
                   and bn.affine and bn.track_running_stats and abs(act.negative_slope - _LRELU) < 1e-12)
             if not ok:
@@ -145,9 +147,9 @@ class DGCNN(nn.Module):
 
     def forward(self, x):
         feats, feats_pm = self.edgeconv_features(x, with_point_major=True)
-        parts = self.conv.fused_parts() if self.bn_sync is None and len(feats) <= ops.PW_MAX_SEGS else None
+        parts = self.conv.fused_parts() if len(feats) <= ops.PW_MAX_SEGS else None
         if parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats):
-            out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU)       # K4: no cat, no transposes
+            out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync)       # K4: no cat, no transposes
         else:
             out = self.conv(torch.cat(feats, dim=1))
         if self.return_edgeconvs:

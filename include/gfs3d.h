@@ -45,7 +45,12 @@ extern "C" {
 #define GFS3D_COMPUTE_BF16 1
 #define GFS3D_COMPUTE_F16 2
 
-#define GFS3D_EC_WIDTH 64        /* EdgeConv block widths supported: [64, 64] */
+#define GFS3D_EC_WIDTH 64        /* EdgeConv block widths supported: [64, 64] - the reference's only configuration
+                                    (train.py:776 `--edgeconv_widths [[64,64],[64,64],[64,64]]`, never overridden by its scripts).
+                                    The heavy kernels are built around it: one point's 64 channels are one 256-B row (one
+                                    coalesced load / store per wave), conv2 is exactly two 32x32 MFMA tiles per lane half, and the
+                                    max over k, the BatchNorm sums and G_Q are in-lane reductions over the accumulator registers
+                                    of that tile shape.  Other widths return GFS3D_ERR_INVALID (Python: NotImplementedError). */
 #define GFS3D_MAX_K 32           /* neighbours per point supported by the EdgeConv kernels */
 
 int gfs3d_version(void);
@@ -222,6 +227,17 @@ typedef struct gfs3d_pointwise_bwd_args {
 size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width);
 int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream);
 int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream);
+
+/* Phased variants for SYNCHRONISED BatchNorm (see the EdgeConv phases above).  L = n_layers, maxw = the largest layer
+ * width, `acc` a caller-owned device buffer of 2 * L * 2 * maxw doubles: rows [l][2][maxw] of global sums, followed by
+ * the library's copies of this rank's own sums (parameter gradients).  `stat_count`: the GLOBAL number of points.
+ *   forward   phase p < L: GEMM of layer p -> column sums in row p (the caller all-reduces row p, 2 * maxw doubles,
+ *             before phase p + 1); phase L: last BatchNorm + the channel-first output
+ *   backward  phase 0: gradient of the last pre-activation -> sums in row L - 1; phase q = 1 .. L: layer l = L - q from
+ *             the all-reduced row l: BatchNorm backward, dW_l, gradient of layer l - 1 -> sums in row l - 1 (dx for l = 0)
+ * Phases 0 .. L in order are exactly the monolithic calls. */
+int gfs3d_pointwise_forward_phase_f32(const gfs3d_pointwise_args *a, int phase, double *acc, double stat_count, void *stream);
+int gfs3d_pointwise_backward_phase_f32(const gfs3d_pointwise_bwd_args *a, int phase, double *acc, double stat_count, void *stream);
 
 /* ------------------------------------------------------------------ K5 --
  * Fused self-attention over the points of a block.  Replaces SelfAttention.forward after the three 1x1 projections,

@@ -839,6 +839,60 @@ def test_edgeconv_synchronised_batchnorm_two_shards_equal_whole_batch(dev):
         assert relerr(gs[0][j] + gs[1][j], gw[j]) < TOL, name
 
 
+
+def test_pointwise_synchronised_batchnorm_two_shards_equal_whole_batch(dev):
+    """Phased K4 C ABI (gfs3d_pointwise_*_phase_f32): two block shards whose fp64 column sums are added between the phases
+    reproduce the single-device whole-batch stack - outputs, running statistics, input gradients; shard parameter
+    gradients add up to the whole-batch ones (SURVEY 8(e)-2 for the point-wise stack)."""
+    import copy
+    from gfs3d import ops
+    from model.dgcnn import conv1d
+    torch.manual_seed(21)
+    conv = conv1d(192, [512, 256]).to(dev).train()
+    B, N = 4, 200
+    xs = [torch.randn(B, N, 64, device=dev) for _ in range(3)]
+    cot = torch.randn(B, 256, N, device=dev)
+    whole = copy.deepcopy(conv)
+    xw = [t.clone().requires_grad_(True) for t in xs]
+    yw = ops.pointwise_stack(xw, whole.fused_parts(), True)
+    yw.backward(cot)
+
+    mods = [copy.deepcopy(conv), copy.deepcopy(conv)]
+    runs = []
+    for r, m in enumerate(mods):
+        layers = [(c.weight.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var) for c, bn in m.fused_parts()]
+        runs.append(ops.PointwiseRun([t[2 * r:2 * r + 2].contiguous() for t in xs], layers, True, 1e-5, 0.1, 0.2, private_workspace=True))
+    row = 2 * 512
+    accs = [torch.zeros(2 * 2 * row, dtype=torch.float64, device=dev) for _ in runs]
+    count = float(B * N)
+
+    def exchange(l):
+        tot = accs[0][l * row:(l + 1) * row] + accs[1][l * row:(l + 1) * row]
+        for a_ in accs:
+            a_[l * row:(l + 1) * row] = tot
+    for ph in range(3):
+        for run, a_ in zip(runs, accs):
+            run.forward_phase(ph, a_, count)
+        if ph < 2:
+            exchange(ph)
+    assert maxerr(torch.cat([r_.y for r_ in runs], 0), yw) < 1e-5
+    gs = [None, None]
+    for ph in range(3):
+        for i, (run, a_) in enumerate(zip(runs, accs)):
+            gs[i] = run.backward_phase(ph, a_, count, cot[2 * i:2 * i + 2] if ph == 0 else None)
+        if ph < 2:
+            exchange(1 - ph)
+    for s_ in range(3):
+        assert relerr(torch.cat([gs[0][0][s_], gs[1][0][s_]], 0), xw[s_].grad) < TOL
+    parts = whole.fused_parts()
+    for l, (c, bn) in enumerate(parts):
+        assert relerr(gs[0][1][l] + gs[1][1][l], c.weight.grad.reshape(gs[0][1][l].shape)) < TOL
+        assert relerr(gs[0][2][l] + gs[1][2][l], bn.weight.grad) < TOL
+        assert relerr(gs[0][3][l] + gs[1][3][l], bn.bias.grad) < TOL
+    for (c0, bn0), (cw, bnw) in zip(mods[0].fused_parts(), parts):
+        assert maxerr(bn0.running_mean, bnw.running_mean) < 1e-6 and maxerr(bn0.running_var, bnw.running_var) < 1e-6
+
+
 # ------------------------------------------------------------------ K4: point-wise stack
 def _pw_reference(conv, xs_pm, cot, train):
     """fp64 torch reference of conv1d(cat(xs)) on the module's own (copied) parameters."""

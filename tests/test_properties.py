@@ -1,0 +1,162 @@
+"""Property tests: hypothesis-driven checks of the kNN graph and of EdgeConv's permutation
+invariance, on the CPU oracle (always) and on the HIP path (`-m gpu`).
+
+  * kNN: for random shapes / k / data with ties and duplicated points, every row of the C oracle is sorted by
+    (distance desc, index asc) under the oracle's own fp32 distance formula, holds k distinct ids and contains the true
+    nearest neighbours wherever the fp64 gap at the k-th boundary is clear; the HIP kernel equals the oracle bit for bit.
+  * EdgeConv: max over the neighbours is invariant to the ORDER of a point's neighbour list, and relabelling the points
+    of a block (a permutation applied to points and graph alike) permutes the output - on the oracle, and on the HIP
+    kernel against itself.
+"""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import c_oracle, ref_ops as R
+
+CPU_SETTINGS = dict(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+GPU_SETTINGS = dict(max_examples=20, deadline=None, suppress_health_check=list(HealthCheck))
+
+
+def _points(seed, B, C, N, kind):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "randn":
+        x = torch.randn(B, C, N, generator=g)
+    elif kind == "ints":                      # heavy ties
+        x = torch.randint(0, 3, (B, C, N), generator=g).float()
+    elif kind == "dups":                      # exact twins: the second half repeats the first
+        x = torch.randn(B, C, N, generator=g)
+        x[:, :, N // 2:] = x[:, :, :N - N // 2]
+    else:                                     # features with a large common offset (norms >> distances)
+        x = torch.randn(B, C, N, generator=g) * 0.2 + 3.0
+    return x
+
+
+def _oracle_pd(x):
+    """The oracle's fp32 distance matrix, same operand order: fl(fl(2 dot - sq_j) - sq_i), dot = fma chain over c."""
+    B, C, N = x.shape
+    out = np.empty((B, N, N), dtype=np.float32)
+    for b in range(B):
+        xb = x[b].numpy()
+        sq = np.zeros(N, dtype=np.float32)
+        for c in range(C):
+            sq = (sq + (xb[c] * xb[c]).astype(np.float32)).astype(np.float32)
+        dot = np.zeros((N, N), dtype=np.float64)
+        acc = np.zeros((N, N), dtype=np.float32)
+        for c in range(C):      # fma chain: exact product + one rounding per step == float64 product-sum rounded to float32
+            acc = (acc.astype(np.float64) + xb[c][:, None].astype(np.float64) * xb[c][None, :].astype(np.float64)).astype(np.float32)
+        t = (np.float32(2.0) * acc - sq[None, :]).astype(np.float32)
+        out[b] = (t - sq[:, None]).astype(np.float32)
+        del dot
+    return out
+
+
+def _check_knn_rows(x, idx, k):
+    B, C, N = x.shape
+    pd = _oracle_pd(x)
+    x64 = x.double()
+    d64 = -((x64[:, :, :, None] - x64[:, :, None, :]) ** 2).sum(1).numpy()
+    for b in range(B):
+        for i in range(N):
+            row = idx[b, i]
+            assert len(set(row.tolist())) == k and row.min() >= 0 and row.max() < N
+            v = pd[b, i, row]
+            for t in range(k - 1):            # (value desc, index asc)
+                assert v[t] > v[t + 1] or (v[t] == v[t + 1] and row[t] < row[t + 1])
+            # nothing outside the row beats the row's last entry under the oracle's arithmetic
+            mask = np.ones(N, dtype=bool)
+            mask[row] = False
+            if mask.any():
+                best_out = pd[b, i][mask].max()
+                assert best_out < v[-1] or (best_out == v[-1] and np.nonzero(mask & (pd[b, i] == best_out))[0].min() > row[-1])
+            srt = np.sort(d64[b, i])[::-1]
+            if k < N and srt[k - 1] - srt[k] > 1e-4 * (abs(srt[k - 1]) + 1.0):
+                assert set(row.tolist()) == set(np.argsort(-d64[b, i], kind="stable")[:k].tolist())
+
+
+@settings(**CPU_SETTINGS)
+@given(seed=st.integers(0, 2 ** 20), B=st.integers(1, 2), C=st.sampled_from([1, 3, 9, 16, 64]), N=st.integers(2, 70),
+       kind=st.sampled_from(["randn", "ints", "dups", "offset"]), data=st.data())
+def test_knn_oracle_rows_are_sorted_exact_topk(seed, B, C, N, kind, data):
+    k = data.draw(st.integers(1, min(N, 32)))
+    x = _points(seed, B, C, N, kind)
+    _check_knn_rows(x, c_oracle.knn(x.numpy(), k), k)
+
+
+@settings(**CPU_SETTINGS)
+@given(seed=st.integers(0, 2 ** 20), C=st.sampled_from([3, 9]), N=st.integers(6, 40), k=st.integers(1, 6))
+def test_edgeconv_oracle_is_invariant_to_neighbour_order_and_point_relabelling(seed, C, N, k):
+    from test_gpu_parity import _block_params
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, C, N, generator=g)
+    idx = torch.from_numpy(c_oracle.knn(x.numpy(), k))
+    p = _block_params(C, seed % 97)
+    y = R.conv_stack(R.edge_feature(x, k, idx), p, "b", 2, training=False).max(dim=-1)[0]
+    # shuffle every point's neighbour list
+    perm_k = torch.stack([torch.randperm(k, generator=g) for _ in range(N)])
+    idx2 = torch.gather(idx, 2, perm_k.unsqueeze(0))
+    y2 = R.conv_stack(R.edge_feature(x, k, idx2), p, "b", 2, training=False).max(dim=-1)[0]
+    assert torch.equal(y, y2)
+    # relabel the points
+    perm = torch.randperm(N, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(N)
+    xp = x[:, :, perm]
+    idxp = inv[idx[:, perm, :]]
+    yp = R.conv_stack(R.edge_feature(xp, k, idxp), p, "b", 2, training=False).max(dim=-1)[0]
+    assert float((yp - y[:, :, perm]).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------ the same on the device
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from gfs3d import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@settings(**GPU_SETTINGS)
+@given(seed=st.integers(0, 2 ** 20), B=st.integers(1, 3), C=st.sampled_from([1, 3, 9, 10, 16, 24, 64, 65]),
+       N=st.sampled_from([8, 20, 33, 64, 100, 128, 257, 512]), kind=st.sampled_from(["randn", "ints", "dups", "offset"]), data=st.data())
+def test_knn_hip_equals_oracle_on_random_shapes(dev, seed, B, C, N, kind, data):
+    """Every kernel variant (VALU C > 64, MFMA with and without the bound pass, the screened path for 16 <= C <= 64 with
+    N % 4 == 0 and its exhaustive fallback) against the C oracle, bit for bit, ties and twins included."""
+    from gfs3d import ops
+    k = data.draw(st.integers(1, min(N, 32)))
+    x = _points(seed, B, C, N, kind)
+    got = ops.knn_topk(x.to(dev), k).cpu().numpy()
+    assert np.array_equal(got, c_oracle.knn(x.numpy(), k))
+
+
+@pytest.mark.gpu
+@settings(**GPU_SETTINGS)
+@given(seed=st.integers(0, 2 ** 20), C=st.sampled_from([3, 9, 64]), N=st.sampled_from([16, 70, 256]), k=st.sampled_from([1, 5, 20]),
+       training=st.booleans())
+def test_edgeconv_hip_is_invariant_to_neighbour_order_and_point_relabelling(dev, seed, C, N, k, training):
+    from gfs3d import ops
+    from test_gpu_parity import _block_params, _make_block
+    k = min(k, N)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(2, C, N, generator=g)
+    idx = torch.from_numpy(c_oracle.knn(x.numpy(), k))
+    p = _block_params(C, seed % 89)
+
+    def run(xx, ii):
+        blk = _make_block(p, C, dev).train(training)
+        c1, bn1, c2, bn2 = blk.fused_parts()
+        with torch.no_grad():
+            return ops.edgeconv_block(xx.to(dev), ii.int().contiguous().to(dev), c1.weight, bn1, c2.weight, bn2, training).cpu()
+    y = run(x, idx)
+    perm_k = torch.stack([torch.stack([torch.randperm(k, generator=g) for _ in range(N)]) for _ in range(2)])
+    y2 = run(x, torch.gather(idx, 2, perm_k))
+    # the max over the neighbours does not see their order; in training mode the batch statistics are sums over the
+    # same multiset of edges in another order (fp64 accumulators): equal to rounding
+    assert float((y - y2).abs().max()) <= (0.0 if not training else 2e-6)
+    perm = torch.randperm(N, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(N)
+    yp = run(x[:, :, perm].contiguous(), inv[idx[:, perm, :]])
+    assert float((yp - y[:, :, perm]).abs().max()) < 2e-6
