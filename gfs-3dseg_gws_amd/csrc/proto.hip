@@ -753,6 +753,117 @@ static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int
 }
 
 // ---------------------------------------------------------------------------
+// Backward of get_pred with respect to the PROTOTYPES (the autograd of capl.py:308-322 for `proto`):
+//   dphat[k][c] = scale * sum_n dout[k][n] fhat[c][n]      fhat = f / max(|f|, eps), per point
+//   dproto[k]   = (dphat[k] - phat[k] <phat[k], dphat[k]>) / max(|proto[k]|, eps)
+// a (K x points) . (points x C) contraction with K <= 32, C <= 192: v_mfma_f32_32x32x2_f32, A = dout rows (k), B = fhat
+// (channel columns), the points are the K dimension.  A block walks PB_STAGES stages of 64 points of one batch item
+// (both operands staged through LDS, the point norms taken from the staged columns) and writes ONE partial (32 x C);
+// proto_bwd_proto_reduce_kernel adds the partials of a prototype set in a fixed order (bit-reproducible, no atomics)
+// and applies the normalisation backward.
+// ---------------------------------------------------------------------------
+constexpr int PB_NP = 64, PB_LD = 68, PB_STAGES = 8;
+__global__ void __launch_bounds__(256)
+proto_bwd_proto_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N, int K, float scale,
+                       const float *__restrict__ dout, float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *dt = smem;                          // [32][PB_LD]  scale * dout rows (k >= K: zero)
+    float *ft = dt + 32 * PB_LD;               // [CT * 32][PB_LD] feature rows, normalised in place
+    const int CT = (C + 31) / 32;
+    float *finv = ft + CT * 32 * PB_LD;        // [64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float *fb = feat + (size_t)b * feat_bstride;
+    const float *db = dout + (size_t)b * K * N;
+    f32x16 acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    for (int st = 0; st < PB_STAGES; ++st) {
+        const int n0 = (chunk * PB_STAGES + st) * PB_NP;
+        if (n0 >= N) break;
+        __syncthreads();
+        for (int e = tid; e < 32 * PB_NP; e += 256) {
+            const int k = e >> 6, n = e & 63;
+            dt[k * PB_LD + n] = (k < K && n0 + n < N) ? scale * db[(size_t)k * N + n0 + n] : 0.f;
+        }
+        for (int e = tid; e < CT * 32 * PB_NP; e += 256) {
+            const int c = e >> 6, n = e & 63;
+            ft[c * PB_LD + n] = (c < C && n0 + n < N) ? fb[(size_t)c * N + n0 + n] : 0.f;
+        }
+        __syncthreads();
+        if (tid < PB_NP) {
+            float sq = 0.f;
+            for (int c = 0; c < C; ++c) sq = fmaf(ft[c * PB_LD + tid], ft[c * PB_LD + tid], sq);
+            finv[tid] = 1.0f / fmaxf(sqrtf(sq), NORM_EPS);
+        }
+        __syncthreads();
+        for (int e = tid; e < CT * 32 * PB_NP; e += 256) {
+            const int c = e >> 6, n = e & 63;
+            ft[c * PB_LD + n] *= finv[n];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ct = w + 4 * u;
+            if (ct < CT) {
+                const float *arow = dt + i * PB_LD, *brow = ft + (ct * 32 + i) * PB_LD;
+#pragma unroll
+                for (int q = 0; q < PB_NP / 4; ++q) {
+                    const float4 a4 = *reinterpret_cast<const float4 *>(arow + 4 * q);
+                    const float4 b4 = *reinterpret_cast<const float4 *>(brow + 4 * q);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.y : a4.x, h ? b4.y : b4.x, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.w : a4.z, h ? b4.w : b4.z, acc[u], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout: column = channel ct * 32 + i, rows = prototypes acc_row(r, h)
+    float *out = part + ((size_t)b * gridDim.x + chunk) * 32 * CT * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ct = w + 4 * u;
+        if (ct < CT)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)acc_row(r, h) * CT * 32 + ct * 32 + i] = acc[u][r];
+    }
+}
+// one block per (prototype set p, prototype k): fixed-order sum of the partials, then the normalisation backward
+__global__ void __launch_bounds__(256)
+proto_bwd_proto_reduce_kernel(const float *__restrict__ part, int nchunk, int B, int P, int K, int C, const float *__restrict__ proto,
+                              float *__restrict__ dproto)
+{
+    __shared__ float red[256];
+    const int k = blockIdx.x, p = blockIdx.y, c = threadIdx.x;
+    const int CT = (C + 31) / 32, LDC = CT * 32;
+    float s = 0.f;
+    if (c < C) {
+        const int b0 = P > 1 ? p : 0, b1 = P > 1 ? p + 1 : B;
+        for (int b = b0; b < b1; ++b)
+            for (int q = 0; q < nchunk; ++q) s += part[(((size_t)b * nchunk + q) * 32 + k) * LDC + c];
+    }
+    const float pv = c < C ? proto[((size_t)p * K + k) * C + c] : 0.f;
+    auto block_sum = [&](float v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        const float t = red[0];
+        __syncthreads();
+        return t;
+    };
+    const float pn = fmaxf(sqrtf(block_sum(pv * pv)), NORM_EPS);
+    const float ph = pv / pn;
+    const float dotv = block_sum(ph * s);
+    if (c < C) dproto[((size_t)p * K + k) * C + c] = (s - ph * dotv) / pn;
+}
+
+// ---------------------------------------------------------------------------
 // k-means assignment (Lloyd step), first version: 64 points per workgroup in LDS,
 // centroids streamed through LDS in tiles of 64; thread (p, q) scores point p
 // against centroids q, q+4, ... of the tile.  sums/counts accumulate with float
@@ -1174,4 +1285,40 @@ extern "C" int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who, prec);
     return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who, prec);
+}
+
+extern "C" size_t gfs3d_proto_backward_proto_workspace_bytes(int B, int C, int N)
+{
+    if (B < 1 || C < 1 || N < 1) return 0;
+    const int nchunk = (N + gfs3d::PB_NP * gfs3d::PB_STAGES - 1) / (gfs3d::PB_NP * gfs3d::PB_STAGES);
+    return sizeof(float) * (size_t)B * nchunk * 32 * ((C + 31) / 32) * 32;
+}
+
+extern "C" int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                              const float *proto, int P, int K, float scale, const float *dout, float *dproto,
+                                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace gfs3d;
+    const char *who = "gfs3d_proto_backward_proto_f32";
+    GFS3D_REQUIRE(feat && proto && dout && dproto && workspace, "%s: NULL pointer", who);
+    GFS3D_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && C <= 192 && N >= 1, "%s: bad shape B=%d C=%d N=%d (C <= 192)", who, B, C, N);
+    GFS3D_REQUIRE(K >= 1 && K <= 32, "%s: need 1 <= K <= 32 prototypes, got %d", who, K);
+    GFS3D_REQUIRE(P == 1 || P == B, "%s: P must be 1 or B (got %d)", who, P);
+    GFS3D_REQUIRE(feat_bstride >= (long long)C * N, "%s: bad feat_bstride", who);
+    if (workspace_bytes < gfs3d_proto_backward_proto_workspace_bytes(B, C, N)) {
+        set_error("%s: workspace too small", who);
+        return GFS3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int CT = (C + 31) / 32;
+    const int nchunk = (N + PB_NP * PB_STAGES - 1) / (PB_NP * PB_STAGES);
+    const size_t lds = sizeof(float) * ((size_t)(32 + CT * 32) * PB_LD + 64);
+    GFS3D_ENSURE_LDS(proto_bwd_proto_kernel, lds, who);
+    float *part = static_cast<float *>(workspace);
+    ProfScope prof(3, st);
+    hipLaunchKernelGGL(proto_bwd_proto_kernel, dim3(nchunk, B), dim3(256), lds, st, feat, feat_bstride, C, N, K, scale, dout, part);
+    GFS3D_LAUNCH_CHECK("proto_bwd_proto_kernel");
+    hipLaunchKernelGGL(proto_bwd_proto_reduce_kernel, dim3(K, P), dim3(256), 0, st, part, nchunk, B, P, K, C, proto, dproto);
+    GFS3D_LAUNCH_CHECK("proto_bwd_proto_reduce_kernel");
+    return GFS3D_OK;
 }

@@ -675,6 +675,23 @@ def proto_backward_feat(feat: torch.Tensor, proto: torch.Tensor, scale: float, d
     return dfeat
 
 
+def proto_backward_proto(feat: torch.Tensor, proto: torch.Tensor, scale: float, dout: torch.Tensor) -> torch.Tensor:
+    """Gradient of get_pred's logits w.r.t. the prototypes (shared (K,C) or per-sample (B,K,C)); HIP, bit-reproducible."""
+    B, C, N = feat.shape
+    proto = proto.contiguous()
+    P = 1 if proto.dim() == 2 else proto.shape[0]
+    K = proto.shape[-2]
+    dout = dout.contiguous()
+    dproto = torch.empty_like(proto)
+    with torch.cuda.device(feat.device):
+        L = _lib.lib()
+        ws = _workspace(feat.device, L.gfs3d_proto_backward_proto_workspace_bytes(B, C, N))
+        rc = L.gfs3d_proto_backward_proto_f32(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale), _p(dout), _p(dproto),
+                                              _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "gfs3d_proto_backward_proto_f32")
+    return dproto
+
+
 class WordAssignFunction(torch.autograd.Function):
     """Differentiable wrt the point features (the words `gp` carry no grad,
     capl.py:49-50).  Backward: one fused HIP kernel (proto_backward_feat)."""
@@ -716,15 +733,10 @@ class ProtoCosineFunction(torch.autograd.Function):
                 raise NotImplementedError("gfs3d.proto_cosine: the backward kernel handles up to 192 feature channels")
             dfeat = proto_backward_feat(feat, proto, s, dout)                    # fused HIP kernel
         if ctx.needs_input_grad[1]:                                              # (K, C) / (B, K, C): a skinny reduction over the points
-            fhat = torch.nn.functional.normalize(feat, p=2, dim=1, eps=1e-12)    # (B,C,N)
-            pnorm = proto.norm(p=2, dim=-1, keepdim=True).clamp_min(1e-12)
-            phat = proto / pnorm
-            d = dout * s
-            if proto.dim() == 2:
-                dphat = torch.einsum("bkn,bcn->kc", d, fhat)
+            if proto.shape[-2] <= 32 and feat.shape[1] <= 192:
+                dproto = proto_backward_proto(feat, proto, s, dout)              # MFMA partials + fixed-order reduction
             else:
-                dphat = torch.matmul(d, fhat.transpose(1, 2))                    # (B,K,C)
-            dproto = (dphat - phat * (phat * dphat).sum(dim=-1, keepdim=True)) / pnorm
+                raise NotImplementedError("gfs3d.proto_cosine: the prototype gradient handles up to 32 prototypes of <= 192 channels")
         return dfeat, dproto, None
 
 

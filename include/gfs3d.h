@@ -281,6 +281,12 @@ int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int
 int gfs3d_proto_backward_feat_f32(const float *feat, long long feat_bstride, int B, int C, int N,
                                   const float *proto, int P, int K, float scale,
                                   const float *soft, const float *dup, float *dfeat, void *stream);
+/* Backward of gfs3d_proto_cosine_f32 with respect to the prototypes (get_pred, capl.py:308-322): dout (B, K, N) ->
+ * dproto (P, K, C); K <= 32, C <= 192.  Partial sums per block + a fixed-order reduction (bit-reproducible). */
+size_t gfs3d_proto_backward_proto_workspace_bytes(int B, int C, int N);
+int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_bstride, int B, int C, int N,
+                                   const float *proto, int P, int K, float scale, const float *dout, float *dproto,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
 /* gfs3d_word_assign_f32 / gfs3d_proto_backward_feat_f32 with the matrix-core operand form chosen by the caller
