@@ -83,7 +83,9 @@ def hbm_traffic(kernel, tag):
     """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/<tag>_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note;
     scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
-    for t in (tag, "r01_e"):
+    import glob
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_hbm_traffic.json")))
+    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r01_e"]:
         try:
             with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
                 d = json.load(f)

@@ -762,7 +762,8 @@ static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int
 // proto_bwd_proto_reduce_kernel adds the partials of a prototype set in a fixed order (bit-reproducible, no atomics)
 // and applies the normalisation backward.
 // ---------------------------------------------------------------------------
-constexpr int PB_NP = 64, PB_LD = 68, PB_STAGES = 8;
+constexpr int PB_NP = 64, PB_LD = 68, PB_STAGES = 2;
+typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256)
 proto_bwd_proto_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N, int K, float scale,
                        const float *__restrict__ dout, float *__restrict__ part)
@@ -772,6 +773,7 @@ proto_bwd_proto_kernel(const float *__restrict__ feat, long long feat_bstride, i
     float *ft = dt + 32 * PB_LD;               // [CT * 32][PB_LD] feature rows, normalised in place
     const int CT = (C + 31) / 32;
     float *finv = ft + CT * 32 * PB_LD;        // [64]
+    float *psq = finv + 64;                    // [4][64] partial column sums of squares
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -786,20 +788,46 @@ proto_bwd_proto_kernel(const float *__restrict__ feat, long long feat_bstride, i
         const int n0 = (chunk * PB_STAGES + st) * PB_NP;
         if (n0 >= N) break;
         __syncthreads();
-        for (int e = tid; e < 32 * PB_NP; e += 256) {
-            const int k = e >> 6, n = e & 63;
-            dt[k * PB_LD + n] = (k < K && n0 + n < N) ? scale * db[(size_t)k * N + n0 + n] : 0.f;
-        }
-        for (int e = tid; e < CT * 32 * PB_NP; e += 256) {
-            const int c = e >> 6, n = e & 63;
-            ft[c * PB_LD + n] = (c < C && n0 + n < N) ? fb[(size_t)c * N + n0 + n] : 0.f;
+        // staging: 16-byte loads where the rows allow it (N % 4 == 0: every row start is 16-byte aligned), all of a thread's
+        // loads in flight before the first LDS store; the point norms from 4 partial column sums per point
+        const bool vec = (N & 3) == 0 && n0 + PB_NP <= N;
+        if (vec) {
+            const int q = tid & 15, r0 = tid >> 4;                 // float4 column q of rows r0, r0 + 16, ...
+            pb_f32x4 dv[2], fv[12];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = r0 + 16 * u;
+                dv[u] = k < K ? *reinterpret_cast<const pb_f32x4 *>(db + (size_t)k * N + n0 + 4 * q) : pb_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int c = r0 + 16 * u;
+                fv[u] = (u < 2 * CT && c < C) ? *reinterpret_cast<const pb_f32x4 *>(fb + (size_t)c * N + n0 + 4 * q) : pb_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<pb_f32x4 *>(dt + (r0 + 16 * u) * PB_LD + 4 * q) = dv[u] * scale;
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (u < 2 * CT) *reinterpret_cast<pb_f32x4 *>(ft + (r0 + 16 * u) * PB_LD + 4 * q) = fv[u];
+        } else {
+            for (int e = tid; e < 32 * PB_NP; e += 256) {
+                const int k = e >> 6, n = e & 63;
+                dt[k * PB_LD + n] = (k < K && n0 + n < N) ? scale * db[(size_t)k * N + n0 + n] : 0.f;
+            }
+            for (int e = tid; e < CT * 32 * PB_NP; e += 256) {
+                const int c = e >> 6, n = e & 63;
+                ft[c * PB_LD + n] = (c < C && n0 + n < N) ? fb[(size_t)c * N + n0 + n] : 0.f;
+            }
         }
         __syncthreads();
-        if (tid < PB_NP) {
+        {
+            const int n = tid & 63, part = tid >> 6;               // channels part, part + 4, ...
             float sq = 0.f;
-            for (int c = 0; c < C; ++c) sq = fmaf(ft[c * PB_LD + tid], ft[c * PB_LD + tid], sq);
-            finv[tid] = 1.0f / fmaxf(sqrtf(sq), NORM_EPS);
+            for (int c = part; c < C; c += 4) sq = fmaf(ft[c * PB_LD + n], ft[c * PB_LD + n], sq);
+            psq[part * 64 + n] = sq;
         }
+        __syncthreads();
+        if (tid < PB_NP) finv[tid] = 1.0f / fmaxf(sqrtf((psq[tid] + psq[64 + tid]) + (psq[128 + tid] + psq[192 + tid])), NORM_EPS);
         __syncthreads();
         for (int e = tid; e < CT * 32 * PB_NP; e += 256) {
             const int c = e >> 6, n = e & 63;
@@ -831,25 +859,33 @@ proto_bwd_proto_kernel(const float *__restrict__ feat, long long feat_bstride, i
             for (int r = 0; r < 16; ++r) out[(size_t)acc_row(r, h) * CT * 32 + ct * 32 + i] = acc[u][r];
     }
 }
-// one block per (prototype set p, prototype k): fixed-order sum of the partials, then the normalisation backward
-__global__ void __launch_bounds__(256)
+// one block per (prototype set p, prototype k): fixed-order sum of the partials (G thread groups take every G-th partial,
+// the groups are added in order), then the normalisation backward
+__global__ void __launch_bounds__(1024)
 proto_bwd_proto_reduce_kernel(const float *__restrict__ part, int nchunk, int B, int P, int K, int C, const float *__restrict__ proto,
                               float *__restrict__ dproto)
 {
-    __shared__ float red[256];
-    const int k = blockIdx.x, p = blockIdx.y, c = threadIdx.x;
+    __shared__ float red[1024];
+    const int k = blockIdx.x, p = blockIdx.y;
     const int CT = (C + 31) / 32, LDC = CT * 32;
+    const int G = 1024 / LDC, g = threadIdx.x / LDC, c = threadIdx.x - g * LDC;
+    const int b0 = P > 1 ? p : 0, nb = P > 1 ? 1 : B;
+    const int total = nb * nchunk;                     // partial (b0 + q / nchunk, q % nchunk), q = 0 .. total - 1
     float s = 0.f;
-    if (c < C) {
-        const int b0 = P > 1 ? p : 0, b1 = P > 1 ? p + 1 : B;
-        for (int b = b0; b < b1; ++b)
-            for (int q = 0; q < nchunk; ++q) s += part[(((size_t)b * nchunk + q) * 32 + k) * LDC + c];
-    }
-    const float pv = c < C ? proto[((size_t)p * K + k) * C + c] : 0.f;
+    if (g < G)
+        for (int q = g; q < total; q += G) s += part[(((size_t)(b0 + q / nchunk) * nchunk + q % nchunk) * 32 + k) * LDC + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    float tot = 0.f;
+    if ((int)threadIdx.x < LDC)
+        for (int gg = 0; gg < G; ++gg) tot += red[gg * LDC + threadIdx.x];
+    __syncthreads();
+    const bool own = (int)threadIdx.x < C;             // thread c < C owns channel c from here on
+    const float pv = own ? proto[((size_t)p * K + k) * C + threadIdx.x] : 0.f;
     auto block_sum = [&](float v) {
         red[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = 512; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
@@ -859,8 +895,8 @@ proto_bwd_proto_reduce_kernel(const float *__restrict__ part, int nchunk, int B,
     };
     const float pn = fmaxf(sqrtf(block_sum(pv * pv)), NORM_EPS);
     const float ph = pv / pn;
-    const float dotv = block_sum(ph * s);
-    if (c < C) dproto[((size_t)p * K + k) * C + c] = (s - ph * dotv) / pn;
+    const float dotv = block_sum(own ? ph * tot : 0.f);
+    if (own) dproto[((size_t)p * K + k) * C + threadIdx.x] = (tot - ph * dotv) / pn;
 }
 
 // ---------------------------------------------------------------------------
@@ -1312,13 +1348,13 @@ extern "C" int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int CT = (C + 31) / 32;
     const int nchunk = (N + PB_NP * PB_STAGES - 1) / (PB_NP * PB_STAGES);
-    const size_t lds = sizeof(float) * ((size_t)(32 + CT * 32) * PB_LD + 64);
+    const size_t lds = sizeof(float) * ((size_t)(32 + CT * 32) * PB_LD + 64 + 256);
     GFS3D_ENSURE_LDS(proto_bwd_proto_kernel, lds, who);
     float *part = static_cast<float *>(workspace);
     ProfScope prof(3, st);
     hipLaunchKernelGGL(proto_bwd_proto_kernel, dim3(nchunk, B), dim3(256), lds, st, feat, feat_bstride, C, N, K, scale, dout, part);
     GFS3D_LAUNCH_CHECK("proto_bwd_proto_kernel");
-    hipLaunchKernelGGL(proto_bwd_proto_reduce_kernel, dim3(K, P), dim3(256), 0, st, part, nchunk, B, P, K, C, proto, dproto);
+    hipLaunchKernelGGL(proto_bwd_proto_reduce_kernel, dim3(K, P), dim3(1024), 0, st, part, nchunk, B, P, K, C, proto, dproto);
     GFS3D_LAUNCH_CHECK("proto_bwd_proto_reduce_kernel");
     return GFS3D_OK;
 }

@@ -56,9 +56,9 @@ sa, sn = counters(sq_db)
 with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as f:
     names = sorted({c for k in sa for c in sa[k]})
     f.write("rocprofv3 --pmc " + " ".join(names) + "\non `python3 bench.py --no-cpu-baseline --steps 3 --warmup 2` (configs[1] B=32x2048, k=20 + side measurements); per-launch averages\n")
-    f.write("kernel".ljust(34) + "".join(n.replace("SQ_", "")[:15].rjust(16) for n in names) + "\n")
+    f.write("kernel".ljust(46) + "".join(n.replace("SQ_", "")[:15].rjust(16) for n in names) + "\n")
     for k in sorted(sa, key=lambda k: -sa[k].get("SQ_WAVE_CYCLES", 0)):
         if sa[k].get("SQ_WAVE_CYCLES", 0) / max(sn[k], 1) < 1e6:
             continue
-        f.write(k[:33].ljust(34) + "".join(f"{sa[k].get(n, 0) / sn[k]:16.4g}" for n in names) + "\n")
+        f.write(k[:45].ljust(46) + "".join(f"{sa[k].get(n, 0) / sn[k]:16.4g}" for n in names) + "\n")
 print("wrote", tag)
