@@ -15,4 +15,5 @@ rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o r -- python3 bench.py --no-cpu-bas
 python3 scripts/collect_profiles.py "$tag" "$out/trace/r_results.db" "$out/sq/r_results.db" "$out/fetch/r_results.db" "$out/write/r_results.db"
 mkdir -p "gpurun_out/profiles_$tag" && cp profiles/${tag}_* "gpurun_out/profiles_$tag/"
 rm -rf "$out/trace" "$out/sq" "$out/fetch" "$out/write"      # the rocpd databases exceed what gpurun copies back (64 MiB); the summaries are what is kept
-tail -1 "$out/trace.log" | cut -c1-200
+grep -h '^{"metric' "$out/trace.log" > "profiles/${tag}_bench_line.json" && cp "profiles/${tag}_bench_line.json" "gpurun_out/profiles_$tag/"
+cut -c1-300 "profiles/${tag}_bench_line.json"

@@ -160,3 +160,58 @@ def test_edgeconv_hip_is_invariant_to_neighbour_order_and_point_relabelling(dev,
     inv[perm] = torch.arange(N)
     yp = run(x[:, :, perm].contiguous(), inv[idx[:, perm, :]])
     assert float((yp - y[:, :, perm]).abs().max()) < 2e-6
+
+
+# ---------------------------------------------------------------------------
+# the error bound of the screened kNN (csrc/knn.hip: knn_screen_kernel).  Bit-exactness of the screened path rests on
+#   | approximate score - oracle fp32 score |  <=  E_i = REL sqrt(sq_i sqmax) + ABS (sq_i + sqmax)
+# for every pair; this restates the screen's arithmetic in numpy (hi + mid round-to-nearest bf16 pieces, the three products
+# hi hi + hi mid + mid hi, fp32 accumulation) and measures the worst pair.  The constants are the kernel's.
+# ---------------------------------------------------------------------------
+KNN_SCREEN_REL, KNN_SCREEN_ABS = 4.0e-5, 4e-6
+_WORST = {}
+
+
+def _bf16_rne(a):
+    u = a.astype(np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _knn_screen_constants_from_source():
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gfs-3dseg_gws_amd", "csrc", "knn.hip")).read()
+    rel = float(re.search(r"KNN_SCREEN_REL\s*=\s*([0-9.e+-]+)f", src).group(1))
+    ab = float(re.search(r"KNN_SCREEN_ABS\s*=\s*([0-9.e+-]+)f", src).group(1))
+    return rel, ab
+
+
+@settings(**CPU_SETTINGS)
+@given(seed=st.integers(0, 2 ** 31 - 1), C=st.sampled_from([16, 33, 64]), N=st.sampled_from([64, 160]),
+       kind=st.sampled_from(["randn", "ints", "dups", "offset", "relu", "scaled"]))
+def test_knn_screen_error_bound_holds(seed, C, N, kind):
+    assert _knn_screen_constants_from_source() == (KNN_SCREEN_REL, KNN_SCREEN_ABS)
+    if kind == "relu":
+        x = torch.relu(_points(seed, 1, C, N, "randn")) * 4.0 + 0.5
+    elif kind == "scaled":
+        x = _points(seed, 1, C, N, "randn") * 1e3
+    else:
+        x = _points(seed, 1, C, N, kind)
+    pd = _oracle_pd(x)[0].astype(np.float64)                     # [i][j]: query i, candidate j
+    xb = x[0].numpy()
+    hi = _bf16_rne(xb)
+    mid = _bf16_rne((xb - hi).astype(np.float32))                # exact residual, rounded again
+    acc = np.zeros((N, N), dtype=np.float32)
+    for c0 in range(0, C, 16):                                   # one MFMA K-step = 16 channels; smallest products first
+        for a, b in ((mid, hi), (hi, mid), (hi, hi)):
+            part = a[c0:c0 + 16].astype(np.float64).T @ b[c0:c0 + 16].astype(np.float64)
+            acc = (acc.astype(np.float64) + part).astype(np.float32)
+    sq = np.zeros(N, dtype=np.float32)
+    for c in range(C):
+        sq = (sq + (xb[c] * xb[c]).astype(np.float32)).astype(np.float32)
+    approx = ((np.float32(2.0) * acc - sq[None, :]).astype(np.float32) - sq[:, None]).astype(np.float32).astype(np.float64)
+    sqmax = float(sq.max())
+    E = KNN_SCREEN_REL * np.sqrt(sq.astype(np.float64) * sqmax) + KNN_SCREEN_ABS * (sq.astype(np.float64) + sqmax)
+    worst = (np.abs(approx - pd) / np.maximum(E[:, None], 1e-300)).max()
+    _WORST[kind] = max(_WORST.get(kind, 0.0), float(worst))
+    assert worst <= 0.75, worst                                  # a quarter of the bound is kept as margin for the MFMA's internal order
