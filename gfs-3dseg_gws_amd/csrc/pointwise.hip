@@ -38,7 +38,9 @@ struct RowGemm {
     float slope;
     float *out[4];            // point-major output, column segments of width o_segw (row stride o_segw)
     int o_segw;
-    float *out_cf;            // OUT_CF: (B, Nc, npts) channel-first
+    float *out_cf;            // OUT_CF: (B, Nc, npts) channel-first ...
+    float *out_cfs[4];        // ... or, cf_segw > 0: Nc / cf_segw tensors (B, cf_segw, npts)
+    int cf_segw;
     int npts;
     const float *ea, *eb;     // epilogue scale / shift per output channel
     const float *eh;          // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc)
@@ -66,8 +68,13 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = col0 + wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float z = fmaf(acc[i][j][r], g.ea[ch], g.eb[ch]);
-                    g.out_cf[((size_t)b * g.Nc + ch) * g.npts + n] = lrelu(z, g.slope);
+                    if (EPI == EPI_PLAIN) {
+                        const int sg = ch / g.cf_segw, cc = ch - sg * g.cf_segw;
+                        g.out_cfs[sg][((size_t)b * g.cf_segw + cc) * g.npts + n] = acc[i][j][r];
+                    } else {
+                        const float z = fmaf(acc[i][j][r], g.ea[ch], g.eb[ch]);
+                        g.out_cf[((size_t)b * g.Nc + ch) * g.npts + n] = lrelu(z, g.slope);
+                    }
                 }
         }
         return;
@@ -621,16 +628,20 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 
 // y_cf(b, c, n) = act(scale h(b n, c) + shift): 64 points x 64 channels per block, grid (ceil(N/64), C/64, B)
 __global__ void __launch_bounds__(256)
-pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf)
+pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf,
+              float *__restrict__ y_pm)
 {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int c = tid & 63, wv = tid >> 6;
-    const float sc = stats[PST_SCALE * C + c0 + c], sh = stats[PST_SHIFT * C + c0 + c];
+    const float sc = stats ? stats[PST_SCALE * C + c0 + c] : 1.f, sh = stats ? stats[PST_SHIFT * C + c0 + c] : 0.f;   // NULL: plain transpose
     for (int p = wv; p < 64; p += 4) {
         const int n = n0 + p;
-        tile[p][c] = n < N ? lrelu(fmaf(h[((size_t)b * N + n) * C + c0 + c], sc, sh), slope) : 0.f;
+        const float v = n < N ? lrelu(fmaf(h[((size_t)b * N + n) * C + c0 + c], sc, sh), slope) : 0.f;
+        tile[p][c] = v;
+        if (y_pm && n < N) y_pm[((size_t)b * N + n) * C + c0 + c] = v;
     }
+    if (!y_cf) return;
     __syncthreads();
     const int p = tid & 63;
     if (n0 + p < N)
@@ -642,8 +653,8 @@ pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int 
 // same-address fp64 atomics per block)
 constexpr int PW_IN_TILES = 4;
 __global__ void __launch_bounds__(256)
-pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ h, const float *__restrict__ stats, int N, int C,
-                 float slope, float *__restrict__ gout, double *__restrict__ acc)
+pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_pm, const float *__restrict__ h,
+                 const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ gout, double *__restrict__ acc)
 {
     __shared__ float tile[64][65];
     __shared__ float red[4][2][64];
@@ -661,17 +672,21 @@ pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ h, c
         {
             const int p = tid & 63;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rt[j] = n0 + p < N ? dy_cf[((size_t)b * C + c0 + wv + 4 * j) * N + n0 + p] : 0.f;
+            for (int j = 0; j < 16; ++j) rt[j] = (dy_cf && n0 + p < N) ? dy_cf[((size_t)b * C + c0 + wv + 4 * j) * N + n0 + p] : 0.f;
 #pragma unroll
             for (int j = 0; j < 16; ++j) tile[p][wv + 4 * j] = rt[j];
         }
         __syncthreads();
+        float rp[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rp[j] = (dy_pm && n0 + wv + 4 * j < N) ? dy_pm[((size_t)b * N + n0 + wv + 4 * j) * C + c0 + c] : 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int p = wv + 4 * j, n = n0 + p;
             if (n < N) {
                 const float hv = rh[j];
-                const float gv = fmaf(hv, sc, sh) > 0.f ? tile[p][c] : tile[p][c] * slope;
+                const float gin = tile[p][c] + rp[j];
+                const float gv = fmaf(hv, sc, sh) > 0.f ? gin : gin * slope;
                 gout[((size_t)b * N + n) * C + c0 + c] = gv;
                 s += gv;
                 sx = fmaf(gv, hv, sx);
@@ -691,19 +706,23 @@ pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ h, c
 // batch statistics -> (scale, shift, mean, rstd) and the running-statistics update of nn.BatchNorm1d
 __global__ void pw_bn_finalize_kernel(const double *__restrict__ acc, int C, double count, const float *__restrict__ gamma,
                                       const float *__restrict__ beta, float *__restrict__ rm, float *__restrict__ rv,
-                                      float eps, float momentum, int training, float *__restrict__ stats)
+                                      float eps, float momentum, int training, float *__restrict__ stats,
+                                      const float *__restrict__ bias)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    // h is stored without the convolution's bias b: BatchNorm(h + b) with batch statistics does not depend on b (only the
+    // running mean does); with running statistics it is scale (h - (rm - b)) + beta
+    const double bc = bias ? (double)bias[c] : 0.0;
     double mean, var;
     if (training) {
         mean = acc[c] / count;
         var = acc[C + c] / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+        if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * (mean + bc));
         if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * var * (count > 1.0 ? count / (count - 1.0) : 1.0));
     } else {
-        mean = rm[c];
+        mean = (double)rm[c] - bc;
         var = rv[c];
     }
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -816,12 +835,15 @@ struct PwPlan {
     size_t off_acc, off_coef, off_w3[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], total;
 };
 
-PwPlan pw_plan(int B, int N, int n_seg, int n_layers, const int *width)
+inline int pw_segw(int seg_width) { return seg_width > 0 ? seg_width : GFS3D_PW_SEG_WIDTH; }
+inline float pw_slope(const gfs3d_pointwise_args *a, int l) { return a->per_layer_slope ? a->slope_l[l] : a->slope; }
+
+PwPlan pw_plan(int B, int N, int n_seg, int seg_width, int n_layers, const int *width)
 {
     PwPlan p{};
     p.L = n_layers;
     p.M = B * N;
-    p.in_width = GFS3D_PW_SEG_WIDTH * n_seg;
+    p.in_width = pw_segw(seg_width) * n_seg;
     p.maxw = 0;
     for (int l = 0; l < n_layers; ++l) p.maxw = width[l] > p.maxw ? width[l] : p.maxw;
     size_t o = 0;
@@ -844,6 +866,8 @@ int pw_check(const gfs3d_pointwise_args *a, const char *who, bool need_y)
     GFS3D_REQUIRE(a->n_seg >= 1 && a->n_seg <= GFS3D_PW_MAX_SEGS, "%s: n_seg=%d unsupported (1..%d)", who, a->n_seg, GFS3D_PW_MAX_SEGS);
     GFS3D_REQUIRE(a->n_layers >= 1 && a->n_layers <= GFS3D_PW_MAX_LAYERS, "%s: n_layers=%d unsupported (1..%d)", who, a->n_layers,
                   GFS3D_PW_MAX_LAYERS);
+    GFS3D_REQUIRE(a->seg_width >= 0 && pw_segw(a->seg_width) % 64 == 0 && pw_segw(a->seg_width) * a->n_seg <= 1024,
+                  "%s: seg_width=%d unsupported (multiple of 64, seg_width * n_seg <= 1024)", who, a->seg_width);
     for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(a->x_seg[s], "%s: NULL x_seg[%d]", who, s);
     for (int l = 0; l < a->n_layers; ++l) {
         GFS3D_REQUIRE(a->width[l] >= 64 && a->width[l] % 64 == 0 && a->width[l] <= 1024,
@@ -852,7 +876,7 @@ int pw_check(const gfs3d_pointwise_args *a, const char *who, bool need_y)
         GFS3D_REQUIRE(a->training || (a->bn_rm[l] && a->bn_rv[l]), "%s: eval mode needs running statistics (layer %d)", who, l);
         GFS3D_REQUIRE(a->h[l] || (!a->training && l == a->n_layers - 1), "%s: NULL h[%d]", who, l);
     }
-    GFS3D_REQUIRE(a->y_cf || !need_y, "%s: NULL y_cf", who);
+    GFS3D_REQUIRE(a->y_cf || a->y_pm || !need_y, "%s: NULL y_cf and y_pm", who);
     GFS3D_REQUIRE(a->workspace, "%s: NULL workspace", who);
     GFS3D_REQUIRE(a->compute == GFS3D_COMPUTE_F32 || a->compute == GFS3D_COMPUTE_BF16 || a->compute == GFS3D_COMPUTE_F16,
                   "%s: compute must be one of GFS3D_COMPUTE_*", who);
@@ -863,9 +887,9 @@ void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev
 {
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) rg.a[s] = a->x_seg[s];
-        rg.a_segw = GFS3D_PW_SEG_WIDTH;
-        rg.lda = GFS3D_PW_SEG_WIDTH;
-        rg.K = GFS3D_PW_SEG_WIDTH * a->n_seg;
+        rg.a_segw = pw_segw(a->seg_width);
+        rg.lda = pw_segw(a->seg_width);
+        rg.K = pw_segw(a->seg_width) * a->n_seg;
     } else {
         rg.a[0] = prev;
         rg.a_segw = a->width[l - 1];
@@ -901,7 +925,14 @@ using namespace gfs3d;
 extern "C" size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width)
 {
     if (B < 1 || N < 1 || n_seg < 1 || n_seg > GFS3D_PW_MAX_SEGS || n_layers < 1 || n_layers > GFS3D_PW_MAX_LAYERS || !width) return 0;
-    return pw_plan(B, N, n_seg, n_layers, width).total;
+    return pw_plan(B, N, n_seg, 0, n_layers, width).total;
+}
+
+extern "C" size_t gfs3d_pointwise_workspace_bytes_ex(int B, int N, int n_seg, int seg_width, int n_layers, const int *width)
+{
+    if (B < 1 || N < 1 || n_seg < 1 || n_seg > GFS3D_PW_MAX_SEGS || n_layers < 1 || n_layers > GFS3D_PW_MAX_LAYERS || !width) return 0;
+    if (seg_width < 0 || pw_segw(seg_width) % 64 || pw_segw(seg_width) * n_seg > 1024) return 0;
+    return pw_plan(B, N, n_seg, seg_width, n_layers, width).total;
 }
 
 // Forward in phases 0 .. L (L = n_layers); training mode: phase p < L runs the GEMM of layer p (after finalising the
@@ -910,7 +941,7 @@ extern "C" size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n
 // synchronised BatchNorm (it all-reduces row p between phases p and p + 1), else workspace.
 static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *acc_user, double stat_count, hipStream_t st, const char *who)
 {
-    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->seg_width, a->n_layers, a->width);
     char *ws = static_cast<char *>(a->workspace);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     const int L = a->n_layers, M = p.M;
@@ -922,7 +953,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
     if (a->training && phase > 0) {                      // BatchNorm of layer phase - 1: batch statistics are complete (and global)
         const int l = phase - 1, C = a->width[l];
         hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc + (size_t)2 * p.maxw * l, C, count, a->bn_w[l], a->bn_b[l],
-                           a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l]);
+                           a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 1, a->stats[l], a->bias[l]);
         GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
     }
     if (phase < L) {
@@ -936,7 +967,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st, rg.prec)) return rc;
         rg.M = M;
         rg.Nc = C;
-        rg.slope = a->slope;
+        rg.slope = a->training ? (l ? pw_slope(a, l - 1) : 1.f) : pw_slope(a, l);    // training: the prologue's activation; eval: the epilogue's
         rg.out[0] = a->h[l];
         rg.o_segw = C;
         rg.acc = acc_l;
@@ -951,11 +982,19 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
             if (rc) return rc;
         } else {
             hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
-                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l]);
+                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l], a->bias[l]);
             GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
             rg.ea = a->stats[l] + PST_SCALE * C;
             rg.eb = a->stats[l] + PST_SHIFT * C;
-            if (l == L - 1) {
+            if (l == L - 1 && a->y_pm) {                 // point-major result (+ a transposed copy if both are wanted)
+                rg.out[0] = a->y_pm;
+                rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, false>(rg, st, who);
+                if (!rc && a->y_cf) {
+                    hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->y_pm, (const float *)nullptr, a->N, C,
+                                       1.f, a->y_cf, (float *)nullptr);
+                    GFS3D_LAUNCH_CHECK("pw_out_kernel");
+                }
+            } else if (l == L - 1) {
                 rg.out_cf = a->y_cf;
                 rg.npts = a->N;
                 rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, true>(rg, st, who);
@@ -966,7 +1005,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
     } else if (a->training) {
         const int C = a->width[L - 1];
         hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->h[L - 1], a->stats[L - 1], a->N, C,
-                           a->slope, a->y_cf);
+                           pw_slope(a, L - 1), a->y_cf, a->y_pm);
         GFS3D_LAUNCH_CHECK("pw_out_kernel");
     }
     return GFS3D_OK;
@@ -975,7 +1014,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
 static int pw_fwd_common(const gfs3d_pointwise_args *a, const char *who)
 {
     if (int rc = pw_check(a, who, true)) return rc;
-    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->seg_width, a->n_layers, a->width);
     if (a->workspace_bytes < p.total) {
         set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
         return GFS3D_ERR_WORKSPACE;
@@ -1012,7 +1051,7 @@ extern "C" int gfs3d_pointwise_forward_phase_f32(const gfs3d_pointwise_args *a, 
 static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, double *acc_user, double stat_count, hipStream_t st, const char *who)
 {
     const gfs3d_pointwise_args *a = &ba->f;
-    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->seg_width, a->n_layers, a->width);
     char *ws = static_cast<char *>(a->workspace);
     const int L = a->n_layers, M = p.M;
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
@@ -1030,8 +1069,8 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     if (phase == 0) {
         const int C = a->width[L - 1];
         if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
-        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, a->h[L - 1],
-                           a->stats[L - 1], a->N, C, a->slope, reinterpret_cast<float *>(ws + p.off_g[L - 1]),
+        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_pm, a->h[L - 1],
+                           a->stats[L - 1], a->N, C, pw_slope(a, L - 1), reinterpret_cast<float *>(ws + p.off_g[L - 1]),
                            acc + (size_t)2 * p.maxw * (L - 1));
         GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
         return keep_local(L - 1);
@@ -1048,15 +1087,16 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     WGrad wg{};
     wg.u = gl; wg.u2 = a->h[l]; wg.ldu = C;
     wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
-    wg.slope = a->slope;
+    wg.slope = l ? pw_slope(a, l - 1) : 1.f;
     wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
     wg.prec = prec_of(a->compute, true);
     int rc;
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
-        wg.v_segw = GFS3D_PW_SEG_WIDTH; wg.ldv = GFS3D_PW_SEG_WIDTH;
+        wg.v_segw = pw_segw(a->seg_width); wg.ldv = pw_segw(a->seg_width);
         // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once
-        rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
+        rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who)
+           : (Ci % 128 == 0) ? launch_wgrad<128, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
     } else {
         wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
         wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
@@ -1070,10 +1110,10 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
     rg.w3 = w3t;
     rg.prec = prec_of(a->compute, true);
-    rg.M = M; rg.Nc = Ci; rg.slope = a->slope;
+    rg.M = M; rg.Nc = Ci; rg.slope = l ? pw_slope(a, l - 1) : 1.f;
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
-        rg.o_segw = GFS3D_PW_SEG_WIDTH;
+        rg.o_segw = pw_segw(a->seg_width);
         return launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
     }
     rg.out[0] = reinterpret_cast<float *>(ws + p.off_g[l - 1]);
@@ -1092,11 +1132,11 @@ static int pw_bwd_common(const gfs3d_pointwise_bwd_args *ba, const char *who)
     const gfs3d_pointwise_args *a = &ba->f;
     if (int rc = pw_check(a, who, false)) return rc;
     GFS3D_REQUIRE(a->training, "%s: backward is implemented for training mode (batch statistics)", who);
-    GFS3D_REQUIRE(ba->dy_cf, "%s: NULL dy_cf", who);
+    GFS3D_REQUIRE(ba->dy_cf || ba->dy_pm, "%s: NULL dy_cf and dy_pm", who);
     for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(ba->dx_seg[s], "%s: NULL dx_seg[%d]", who, s);
     for (int l = 0; l < a->n_layers; ++l)
         GFS3D_REQUIRE(ba->dw[l] && ba->dbn_w[l] && ba->dbn_b[l], "%s: NULL gradient buffer of layer %d", who, l);
-    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->n_layers, a->width);
+    const PwPlan p = pw_plan(a->B, a->N, a->n_seg, a->seg_width, a->n_layers, a->width);
     if (a->workspace_bytes < p.total) {
         set_error("%s: workspace too small (%zu < %zu)", who, a->workspace_bytes, p.total);
         return GFS3D_ERR_WORKSPACE;
@@ -1124,4 +1164,185 @@ extern "C" int gfs3d_pointwise_backward_phase_f32(const gfs3d_pointwise_bwd_args
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope prof(7, st);
     return pw_backward_phase(ba, phase, acc, stat_count, st, who);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Channel concatenation into one point-major matrix (and its adjoint): 64 points x 64 columns per block through an LDS
+// tile, so that both the channel-first side (lanes along the points) and the point-major side (lanes along the columns)
+// are coalesced.  grid (ceil(N / 64), column tiles, B); the column tiles enumerate (source, 64-channel slice) pairs and
+// then the zero padding up to dst_ld.
+// ---------------------------------------------------------------------------------------------------------
+namespace gfs3d {
+namespace {
+struct PackPlan {
+    int n_src, tiles[GFS3D_PACK_MAX_SRC + 1], off[GFS3D_PACK_MAX_SRC + 1], total_tiles, used;
+};
+
+template <bool UNPACK>
+__global__ void __launch_bounds__(256)
+pw_pack_kernel(const gfs3d_pack_args a, const PackPlan pl)
+{
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, n0 = blockIdx.x * 64, b = blockIdx.z, N = a.N;
+    int s = 0, ty = blockIdx.y;
+    while (s < pl.n_src && ty >= pl.tiles[s]) { ty -= pl.tiles[s]; ++s; }
+    const int lane = tid & 63, wv = tid >> 6;
+    if (s == pl.n_src) {                                   // padding columns
+        if (UNPACK) return;
+        const int col = pl.used + ty * 64 + lane;
+        if (col < a.dst_ld)
+            for (int p = wv; p < 64; p += 4)
+                if (n0 + p < N) a.dst[((size_t)b * N + n0 + p) * a.dst_ld + col] = 0.f;
+        return;
+    }
+    const int W = a.width[s], c0 = ty * 64, cw = min(64, W - c0), dcol = pl.off[s] + c0;
+    float *src = a.src[s];
+    if (!UNPACK) {
+        if (a.channel_first[s]) {
+            for (int cc = wv; cc < cw; cc += 4) tile[lane][cc] = n0 + lane < N ? src[((size_t)b * W + c0 + cc) * N + n0 + lane] : 0.f;
+        } else {
+            for (int p = wv; p < 64; p += 4) tile[p][lane] = (lane < cw && n0 + p < N) ? src[((size_t)b * N + n0 + p) * W + c0 + lane] : 0.f;
+        }
+        __syncthreads();
+        if (lane < cw)
+            for (int p = wv; p < 64; p += 4)
+                if (n0 + p < N) a.dst[((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane] = tile[p][lane];
+    } else {
+        for (int p = wv; p < 64; p += 4) tile[p][lane] = (lane < cw && n0 + p < N) ? a.dst[((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane] : 0.f;
+        __syncthreads();
+        if (a.channel_first[s]) {
+            if (n0 + lane < N)
+                for (int cc = wv; cc < cw; cc += 4) src[((size_t)b * W + c0 + cc) * N + n0 + lane] = tile[lane][cc];
+        } else if (lane < cw) {
+            for (int p = wv; p < 64; p += 4)
+                if (n0 + p < N) src[((size_t)b * N + n0 + p) * W + c0 + lane] = tile[p][lane];
+        }
+    }
+}
+
+int pack_launch(const gfs3d_pack_args *a, bool unpack, hipStream_t st, const char *who)
+{
+    GFS3D_REQUIRE(a, "%s: NULL args", who);
+    GFS3D_REQUIRE(a->B >= 1 && a->N >= 1 && (long long)a->B * a->N < (1ll << 31), "%s: bad shape B=%d N=%d", who, a->B, a->N);
+    GFS3D_REQUIRE(a->n_src >= 1 && a->n_src <= GFS3D_PACK_MAX_SRC, "%s: n_src=%d unsupported (1..%d)", who, a->n_src, GFS3D_PACK_MAX_SRC);
+    GFS3D_REQUIRE(a->dst, "%s: NULL dst", who);
+    PackPlan pl{};
+    pl.n_src = a->n_src;
+    int off = 0, tiles = 0;
+    for (int s = 0; s < a->n_src; ++s) {
+        GFS3D_REQUIRE(a->src[s] && a->width[s] >= 1, "%s: NULL or empty source %d", who, s);
+        pl.off[s] = off;
+        pl.tiles[s] = (a->width[s] + 63) / 64;
+        off += a->width[s];
+        tiles += pl.tiles[s];
+    }
+    GFS3D_REQUIRE(a->dst_ld >= off, "%s: dst_ld=%d < total width %d", who, a->dst_ld, off);
+    pl.used = off;
+    pl.tiles[a->n_src] = (a->dst_ld - off + 63) / 64;
+    pl.total_tiles = tiles + (unpack ? 0 : pl.tiles[a->n_src]);
+    GFS3D_REQUIRE(pl.total_tiles <= 65535 && a->B <= 65535, "%s: too many tiles", who);
+    const dim3 grid((a->N + 63) / 64, pl.total_tiles, a->B);
+    if (unpack) hipLaunchKernelGGL(pw_pack_kernel<true>, grid, dim3(256), 0, st, *a, pl);
+    else hipLaunchKernelGGL(pw_pack_kernel<false>, grid, dim3(256), 0, st, *a, pl);
+    GFS3D_LAUNCH_CHECK("pw_pack_kernel");
+    return GFS3D_OK;
+}
+
+struct LinPlan { size_t off_w3, off_dy, total; };
+LinPlan lin_plan(int B, int N, int K, int Nc)
+{
+    LinPlan p{};
+    size_t o = 0;
+    p.off_w3 = o; o = align_up(o + 6 * (size_t)K * Nc, 256);
+    p.off_dy = o; o = align_up(o + sizeof(float) * (size_t)B * N * Nc, 256);
+    p.total = o;
+    return p;
+}
+
+int lin_check(const float *x, int B, int N, int K, const float *w, int Nc, const void *ws, size_t wsb, int compute, const char *who)
+{
+    GFS3D_REQUIRE(x && w && ws, "%s: NULL pointer", who);
+    GFS3D_REQUIRE(B >= 1 && N >= 1 && (long long)B * N < (1ll << 31), "%s: bad shape B=%d N=%d", who, B, N);
+    GFS3D_REQUIRE(K >= 64 && K % 64 == 0 && K <= 1024, "%s: K=%d unsupported (multiple of 64, <= 1024)", who, K);
+    GFS3D_REQUIRE(Nc >= 64 && Nc % 64 == 0 && Nc <= 256, "%s: Nc=%d unsupported (64, 128, 192, 256)", who, Nc);
+    GFS3D_REQUIRE(compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
+    if (wsb < lin_plan(B, N, K, Nc).total) {
+        set_error("%s: workspace too small (%zu < %zu)", who, wsb, lin_plan(B, N, K, Nc).total);
+        return GFS3D_ERR_WORKSPACE;
+    }
+    return GFS3D_OK;
+}
+}  // namespace
+}  // namespace gfs3d
+
+extern "C" int gfs3d_pack_rows_f32(const gfs3d_pack_args *a, void *stream)
+{
+    return pack_launch(a, false, static_cast<hipStream_t>(stream), "gfs3d_pack_rows_f32");
+}
+
+extern "C" int gfs3d_unpack_rows_f32(const gfs3d_pack_args *a, void *stream)
+{
+    return pack_launch(a, true, static_cast<hipStream_t>(stream), "gfs3d_unpack_rows_f32");
+}
+
+extern "C" size_t gfs3d_linear_workspace_bytes(int B, int N, int K, int Nc)
+{
+    if (B < 1 || N < 1 || K < 64 || K % 64 || K > 1024 || Nc < 64 || Nc % 64 || Nc > 256) return 0;
+    return lin_plan(B, N, K, Nc).total;
+}
+
+extern "C" int gfs3d_linear_forward_f32(const float *x_pm, int B, int N, int K, const float *w, int Nc, float *const *y_cf, int compute,
+                                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *who = "gfs3d_linear_forward_f32";
+    if (int rc = lin_check(x_pm, B, N, K, w, Nc, workspace, workspace_bytes, compute, who)) return rc;
+    GFS3D_REQUIRE(y_cf, "%s: NULL y_cf", who);
+    for (int s = 0; s < Nc / 64; ++s) GFS3D_REQUIRE(y_cf[s], "%s: NULL y_cf[%d]", who, s);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LinPlan p = lin_plan(B, N, K, Nc);
+    char *ws = static_cast<char *>(workspace);
+    RowGemm rg{};
+    rg.a[0] = x_pm; rg.a_segw = K; rg.lda = K; rg.K = K;
+    rg.w = w; rg.w3 = ws + p.off_w3; rg.prec = prec_of(compute, false);
+    if (int rc = split_weights(w, Nc, K, K, 1, ws + p.off_w3, st, rg.prec)) return rc;
+    rg.M = B * N; rg.Nc = Nc; rg.slope = 1.f;
+    for (int s = 0; s < Nc / 64; ++s) rg.out_cfs[s] = y_cf[s];
+    rg.cf_segw = 64; rg.npts = N;
+    return rowgemm<PRO_NONE, EPI_PLAIN, true>(rg, st, who);
+}
+
+extern "C" int gfs3d_linear_backward_f32(const float *x_pm, int B, int N, int K, const float *w, int Nc, const float *const *dy_cf,
+                                         float *dx_pm, float *dw, int compute, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const char *who = "gfs3d_linear_backward_f32";
+    if (int rc = lin_check(x_pm, B, N, K, w, Nc, workspace, workspace_bytes, compute, who)) return rc;
+    GFS3D_REQUIRE(dy_cf && dx_pm && dw, "%s: NULL pointer", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const LinPlan p = lin_plan(B, N, K, Nc);
+    char *ws = static_cast<char *>(workspace);
+    float *dy = reinterpret_cast<float *>(ws + p.off_dy);
+    gfs3d_pack_args pa{};
+    pa.B = B; pa.N = N; pa.n_src = Nc / 64; pa.dst = dy; pa.dst_ld = Nc;
+    for (int s = 0; s < Nc / 64; ++s) {
+        GFS3D_REQUIRE(dy_cf[s], "%s: NULL dy_cf[%d]", who, s);
+        pa.src[s] = const_cast<float *>(dy_cf[s]); pa.width[s] = 64; pa.channel_first[s] = 1;
+    }
+    if (int rc = pack_launch(&pa, false, st, who)) return rc;
+    const int prec = prec_of(compute, true);
+    // dW = dY^T X
+    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Nc * K, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+    WGrad wg{};
+    wg.u = dy; wg.ldu = Nc;
+    wg.v[0] = x_pm; wg.v_segw = K; wg.ldv = K;
+    wg.slope = 1.f; wg.M = B * N; wg.Co = Nc; wg.Ci = K; wg.dw = dw; wg.prec = prec;
+    if (int rc = (K % 128 == 0) ? launch_wgrad<128, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who)) return rc;
+    // dX = dY W
+    if (int rc = split_weights(w, K, Nc, 1, K, ws + p.off_w3, st, prec)) return rc;       // pieces of W^T (K, Nc)
+    RowGemm rg{};
+    rg.a[0] = dy; rg.a_segw = Nc; rg.lda = Nc; rg.K = Nc;
+    rg.w3 = ws + p.off_w3; rg.prec = prec;
+    rg.M = B * N; rg.Nc = K; rg.slope = 1.f;
+    rg.out[0] = dx_pm; rg.o_segw = K;
+    return rowgemm<PRO_NONE, EPI_PLAIN, false>(rg, st, who);
 }

@@ -68,6 +68,11 @@ class PointwiseArgs(Structure):
         ("y_cf", c_void_p),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("compute", c_int),
+        ("seg_width", c_int),
+        ("bias", c_void_p * PW_MAX_LAYERS),
+        ("per_layer_slope", c_int),
+        ("slope_l", c_float * PW_MAX_LAYERS),
+        ("y_pm", c_void_p),
     ]
 
 
@@ -77,6 +82,21 @@ class PointwiseBwdArgs(Structure):
         ("dy_cf", c_void_p),
         ("dx_seg", c_void_p * PW_MAX_SEGS),
         ("dw", c_void_p * PW_MAX_LAYERS), ("dbn_w", c_void_p * PW_MAX_LAYERS), ("dbn_b", c_void_p * PW_MAX_LAYERS),
+        ("dy_pm", c_void_p),
+    ]
+
+
+PACK_MAX_SRC = 8
+
+
+class PackArgs(Structure):
+    _fields_ = [
+        ("B", c_int), ("N", c_int), ("n_src", c_int),
+        ("src", c_void_p * PACK_MAX_SRC),
+        ("width", c_int * PACK_MAX_SRC),
+        ("channel_first", c_int * PACK_MAX_SRC),
+        ("dst", c_void_p),
+        ("dst_ld", c_int),
     ]
 
 
@@ -98,6 +118,14 @@ SYMBOLS = {
     "gfs3d_edgeconv_forward_phase_f32": (c_int, [POINTER(EdgeConvArgs), c_int, c_void_p, c_double, c_void_p]),
     "gfs3d_edgeconv_backward_phase_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_int, c_void_p, c_double, c_void_p]),
     "gfs3d_pointwise_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "gfs3d_pointwise_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "gfs3d_linear_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "gfs3d_linear_forward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_void_p), c_int, c_void_p, c_size_t,
+                                         c_void_p]),
+    "gfs3d_linear_backward_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, POINTER(c_void_p), c_void_p, c_void_p, c_int,
+                                          c_void_p, c_size_t, c_void_p]),
+    "gfs3d_pack_rows_f32": (c_int, [POINTER(PackArgs), c_void_p]),
+    "gfs3d_unpack_rows_f32": (c_int, [POINTER(PackArgs), c_void_p]),
     "gfs3d_pointwise_forward_f32": (c_int, [POINTER(PointwiseArgs), c_void_p]),
     "gfs3d_pointwise_backward_f32": (c_int, [POINTER(PointwiseBwdArgs), c_void_p]),
     "gfs3d_pointwise_forward_phase_f32": (c_int, [POINTER(PointwiseArgs), c_int, c_void_p, c_double, c_void_p]),

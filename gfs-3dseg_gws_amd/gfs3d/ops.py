@@ -359,45 +359,62 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
 # K4
 # --------------------------------------------------------------------------
 class PointwiseRun:
-    """One invocation of the point-wise stack [Conv1d 1x1 -> BatchNorm1d -> LeakyReLU] x L on point-major
-    64-channel segments (model/dgcnn.py:64-80, 121-122)."""
+    """One invocation of the point-wise stack [Conv1d 1x1 (+bias) -> BatchNorm1d -> LeakyReLU(slope_l)] x L on point-major
+    segments of equal width (a multiple of 64): the DGCNN stack (model/dgcnn.py:64-80, 121-122), BaseLearner
+    (dgcnn.py:130-152: ReLU between, nothing after) and the fusion layer (capl.py:64-65)."""
 
-    def __init__(self, xs, layers, training, eps, momentum, slope, private_workspace: bool = False):
+    def __init__(self, xs, layers, training, eps, momentum, slope, private_workspace: bool = False, biases=None, slopes=None,
+                 want_cf: bool = True, want_pm: bool = False):
         if not 1 <= len(xs) <= PW_MAX_SEGS or not 1 <= len(layers) <= PW_MAX_LAYERS:
             raise NotImplementedError("gfs3d.pointwise: 1..4 input segments and 1..4 layers are implemented in HIP")
+        segw = int(xs[0].shape[-1])
         for t in xs:
             _need_gpu(t, "x_seg")
-            if t.dim() != 3 or t.shape[-1] != PW_SEG_WIDTH or t.shape != xs[0].shape:
-                raise RuntimeError("gfs3d.pointwise: inputs must be equal-shape point-major (B,N,64) tensors")
+            if t.dim() != 3 or segw % PW_SEG_WIDTH or t.shape != xs[0].shape:
+                raise RuntimeError("gfs3d.pointwise: inputs must be equal-shape point-major (B,N,64 m) tensors")
+        if segw * len(xs) > 1024:
+            raise NotImplementedError("gfs3d.pointwise: at most 1024 input channels")
+        if not (want_cf or want_pm):
+            raise ValueError("gfs3d.pointwise: no output requested")
+        self.segw = segw
         self.xs = [t.contiguous() for t in xs]
         self.B, self.N = self.xs[0].shape[:2]
         self.layers = [(w.contiguous(), g, b, rm, rv) for (w, g, b, rm, rv) in layers]
         self.widths = [int(w.shape[0]) for (w, *_r) in self.layers]
-        prev = PW_SEG_WIDTH * len(xs)
+        prev = segw * len(xs)
         for (w, *_r), c in zip(self.layers, self.widths):
             if w.numel() != c * prev or c % 64 or c > 1024:
                 raise NotImplementedError("gfs3d.pointwise: layer widths must be multiples of 64 (<= 1024) and chain")
             prev = c
+        L = len(self.layers)
+        self.biases = list(biases) if biases is not None else [None] * L
+        self.slopes = [float(v) for v in slopes] if slopes is not None else None
+        if len(self.biases) != L or (self.slopes is not None and len(self.slopes) != L):
+            raise ValueError("gfs3d.pointwise: one bias / slope per layer")
         self.training = bool(training)
         self.compute = _compute
         self.scalars = (float(eps), float(momentum), float(slope))
         dev = self.xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         M = self.B * self.N
-        L = len(self.layers)
         self.h = [torch.empty((M, c), **f32) if (self.training or l < L - 1) else None for l, c in enumerate(self.widths)]
         self.stats = [torch.empty((4, c), **f32) for c in self.widths]
-        self.y = torch.empty((self.B, self.widths[-1], self.N), **f32)
+        self.y = torch.empty((self.B, self.widths[-1], self.N), **f32) if want_cf else None
+        self.y_pm = torch.empty((self.B, self.N, self.widths[-1]), **f32) if want_pm else None
         arr = (ctypes.c_int * L)(*self.widths)
-        self._nbytes = _lib.lib().gfs3d_pointwise_workspace_bytes(self.B, self.N, len(xs), L, arr)
+        self._nbytes = _lib.lib().gfs3d_pointwise_workspace_bytes_ex(self.B, self.N, len(xs), segw, L, arr)
+        if self._nbytes == 0:
+            raise RuntimeError("gfs3d.pointwise: unsupported shape")
         self._private_ws = torch.empty(self._nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
 
     def _args(self, a: PointwiseArgs):
         eps, momentum, slope = self.scalars
         a.B, a.N, a.n_seg, a.n_layers = self.B, self.N, len(self.xs), len(self.layers)
+        a.seg_width = self.segw
         a.training = 1 if self.training else 0
         a.compute = self.compute
         a.eps, a.momentum, a.slope = eps, momentum, slope
+        a.per_layer_slope = 0 if self.slopes is None else 1
         for s_, t in enumerate(self.xs):
             a.x_seg[s_] = t.data_ptr()
         for l, (w, g, b, rm, rv) in enumerate(self.layers):
@@ -407,7 +424,11 @@ class PointwiseRun:
             a.bn_rv[l] = rv.data_ptr() if rv is not None else None
             a.h[l] = self.h[l].data_ptr() if self.h[l] is not None else None
             a.stats[l] = self.stats[l].data_ptr()
+            a.bias[l] = self.biases[l].data_ptr() if self.biases[l] is not None else None
+            if self.slopes is not None:
+                a.slope_l[l] = self.slopes[l]
         a.y_cf = self.y.data_ptr() if self.y is not None else None      # not needed by the backward
+        a.y_pm = self.y_pm.data_ptr() if self.y_pm is not None else None
         ws = self._private_ws if self._private_ws is not None else _workspace(self.xs[0].device, self._nbytes)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         return ws
@@ -426,9 +447,9 @@ class PointwiseRun:
         _lib.check(rc, "gfs3d_pointwise_forward_phase_f32")
         del ws
 
-    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None):
+    def backward_phase(self, phase: int, acc: torch.Tensor, stat_count: float, dy=None, dy_pm=None):
         if phase == 0:
-            self._ba = self._bwd_args(dy)
+            self._ba = self._bwd_args(dy, dy_pm)
         ba, ws = self._ba
         with torch.cuda.device(self.xs[0].device):
             rc = _lib.lib().gfs3d_pointwise_backward_phase_f32(ctypes.byref(ba), phase, _p(acc), float(stat_count), _stream())
@@ -436,7 +457,7 @@ class PointwiseRun:
         if phase == len(self.layers):
             del self._ba
             out = (self.dxs, self.dws, self.dgs, self.dbs)
-            self.dxs = self.dws = self.dgs = self.dbs = self.dy = None
+            self.dxs = self.dws = self.dgs = self.dbs = self.dy = self.dy_pm = None
             return out
         return None
 
@@ -457,12 +478,15 @@ class PointwiseRun:
                     if ph < len(self.layers):
                         sync.all_reduce(acc[ph * row:(ph + 1) * row])
         del ws
-        return self.y
+        return self.y if self.y is not None else self.y_pm
 
-    def _bwd_args(self, dy):
+    def _bwd_args(self, dy, dy_pm=None):
         dev = self.xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
-        self.dy = dy.contiguous()
+        if dy is None and dy_pm is None:
+            raise RuntimeError("gfs3d.pointwise: backward without a gradient")
+        self.dy = dy.contiguous() if dy is not None else None
+        self.dy_pm = dy_pm.contiguous() if dy_pm is not None else None
         self.dxs = [torch.empty_like(t) for t in self.xs]
         self.dws = [torch.empty_like(w) for (w, *_r) in self.layers]
         self.dgs = [torch.empty(c, **f32) for c in self.widths]
@@ -472,16 +496,17 @@ class PointwiseRun:
         self.layers = [(w, g, b, None, None) for (w, g, b, rm, rv) in saved]      # running stats are not touched
         ws = self._args(ba.f)
         self.layers = saved
-        ba.dy_cf = self.dy.data_ptr()
+        ba.dy_cf = self.dy.data_ptr() if self.dy is not None else None
+        ba.dy_pm = self.dy_pm.data_ptr() if self.dy_pm is not None else None
         for s_, t in enumerate(self.dxs):
             ba.dx_seg[s_] = t.data_ptr()
         for l in range(len(self.layers)):
             ba.dw[l], ba.dbn_w[l], ba.dbn_b[l] = self.dws[l].data_ptr(), self.dgs[l].data_ptr(), self.dbs[l].data_ptr()
         return ba, ws
 
-    def backward(self, dy, sync: Optional["BNSync"] = None):
+    def backward(self, dy, sync: Optional["BNSync"] = None, dy_pm=None):
         dev = self.xs[0].device
-        ba, ws = self._bwd_args(dy)
+        ba, ws = self._bwd_args(dy, dy_pm)
         with torch.cuda.device(dev):
             if sync is None:
                 rc = _lib.lib().gfs3d_pointwise_backward_f32(ctypes.byref(ba), _stream())
@@ -498,55 +523,180 @@ class PointwiseRun:
                         sync.all_reduce(acc[l * row:(l + 1) * row])
         del ws
         out = (self.dxs, self.dws, self.dgs, self.dbs)
-        self.dxs = self.dws = self.dgs = self.dbs = self.dy = None          # see EdgeConvRun._take_grads
+        self.dxs = self.dws = self.dgs = self.dbs = self.dy = self.dy_pm = None          # see EdgeConvRun._take_grads
         return out
 
 
 class PointwiseStackFunction(torch.autograd.Function):
-    """act(bn_L(... act(bn_1(W_1 cat(xs))) ...)) -> (B, C_L, N); tensors = xs + [w, gamma, beta] * L + [rm, rv] * L."""
+    """act(bn_L(... act(bn_1(W_1 cat(xs))) ...)); tensors = xs + [w, gamma, beta] * L + [rm, rv] * L + [bias] * L (bias
+    entries may be None).  opts = (slopes or None, want_cf, want_pm); returns y_cf (B, C_L, N), y_pm (B, N, C_L) or both."""
 
     @staticmethod
-    def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, sync, *tensors):
+    def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, sync, opts, *tensors):
+        slopes, want_cf, want_pm = opts
         xs = tensors[:n_seg]
         par = tensors[n_seg:n_seg + 3 * n_layers]
-        run_ = tensors[n_seg + 3 * n_layers:]
+        run_ = tensors[n_seg + 3 * n_layers:n_seg + 5 * n_layers]
+        biases = tensors[n_seg + 5 * n_layers:]
         layers = [(par[3 * l], par[3 * l + 1], par[3 * l + 2], run_[2 * l], run_[2 * l + 1]) for l in range(n_layers)]
-        run = PointwiseRun(xs, layers, training, eps, momentum, slope)
-        y = run.forward(sync)
-        run.y = None
+        run = PointwiseRun(xs, layers, training, eps, momentum, slope, biases=list(biases) if biases else None, slopes=slopes,
+                           want_cf=want_cf, want_pm=want_pm)
+        run.forward(sync)
+        y, y_pm = run.y, run.y_pm
+        run.y = run.y_pm = None
         if training:
             ctx.c = run
             ctx.sync = sync
-        ctx.n = (n_seg, n_layers)
-        return y
+        ctx.n = (n_seg, n_layers, want_cf, want_pm, [b is not None for b in biases] if biases else [False] * n_layers)
+        if want_cf and want_pm:
+            return y, y_pm
+        return y if want_cf else y_pm
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *douts):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.pointwise: backward is implemented for training mode (batch statistics) only")
-        n_seg, n_layers = ctx.n
-        dxs, dws, dgs, dbs = ctx.c.backward(dy, ctx.sync)
+        n_seg, n_layers, want_cf, want_pm, has_bias = ctx.n
+        if want_cf and want_pm:
+            dy, dy_pm = douts
+        else:
+            dy, dy_pm = (douts[0], None) if want_cf else (None, douts[0])
+        dxs, dws, dgs, dbs = ctx.c.backward(dy, ctx.sync, dy_pm=dy_pm)
         par = []
         for l in range(n_layers):
             par += [dws[l], dgs[l], dbs[l]]
-        return (None,) * 7 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers)
+        # a bias in front of a training-mode BatchNorm has an exactly zero gradient (the batch mean absorbs it)
+        dbias = tuple(torch.zeros_like(dgs[l]) if has_bias[l] else None for l in range(n_layers))
+        return (None,) * 8 + tuple(dxs) + tuple(par) + (None,) * (2 * n_layers) + dbias
 
 
-def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: bool = True, sync: Optional[BNSync] = None):
-    """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64) segments.  `sync`: share the batch
-    statistics between the ranks of a block-sharded batch (phased C ABI, one all-reduce per layer and pass)."""
+def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: bool = True, sync: Optional[BNSync] = None,
+                    slopes=None, want_cf: bool = True, want_pm: bool = False):
+    """Run a conv1d stack given [(nn.Conv1d, nn.BatchNorm1d)] on point-major (B,N,64 m) segments.  `sync`: share the batch
+    statistics between the ranks of a block-sharded batch (phased C ABI, one all-reduce per layer and pass).  `slopes`: the
+    activation after each layer as a LeakyReLU slope (0 = ReLU, 1 = none), default `slope` everywhere.  Convolution biases
+    are honoured.  Returns the channel-first result, the point-major one, or (cf, pm)."""
     if training and track:
         for _c, bn in parts:
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
     bn0 = parts[0][1]
     mom = bn0.momentum if bn0.momentum is not None else 0.1
-    par, run_ = [], []
-    for conv, bn in parts:
-        par += [conv.weight, bn.weight, bn.bias]
+    par, run_, bias = [], [], []
+    for conv, bn in parts:                      # conv: an nn.Conv1d or a (weight, bias) pair (e.g. a K-padded weight)
+        w_, b_ = conv if isinstance(conv, tuple) else (conv.weight, conv.bias)
+        par += [w_, bn.weight, bn.bias]
         run_ += [bn.running_mean, bn.running_var]
-    return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope), sync,
-                                        *xs_pm, *par, *run_)
+        bias.append(b_)
+    opts = (tuple(float(v) for v in slopes) if slopes is not None else None, bool(want_cf), bool(want_pm))
+    return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope), sync, opts,
+                                        *xs_pm, *par, *run_, *bias)
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = x W^T for a bias-free 1x1 convolution without BatchNorm on a point-major input: x_pm (B, N, K), w (64 n, K) ->
+    n channel-first (B, 64, N) tensors (the q / k / v projections of model/attention.py:39-41 as one GEMM)."""
+
+    @staticmethod
+    def forward(ctx, x_pm, w):
+        _need_gpu(x_pm, "x_pm")
+        x_pm, w2 = x_pm.contiguous(), w.reshape(w.shape[0], -1).contiguous()
+        B, N, K = x_pm.shape
+        Nc = w2.shape[0]
+        L = _lib.lib()
+        nbytes = L.gfs3d_linear_workspace_bytes(B, N, K, Nc)
+        if nbytes == 0 or w2.shape[1] != K:
+            raise NotImplementedError("gfs3d.linear: K a multiple of 64 (<= 1024) and 64, 128, 192 or 256 outputs are implemented")
+        outs = [torch.empty((B, 64, N), dtype=torch.float32, device=x_pm.device) for _ in range(Nc // 64)]
+        ptrs = (ctypes.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+        ws = _workspace(x_pm.device, nbytes)
+        with torch.cuda.device(x_pm.device):
+            rc = L.gfs3d_linear_forward_f32(_p(x_pm), B, N, K, _p(w2), Nc, ptrs, _compute, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "gfs3d_linear_forward_f32")
+        ctx.save_for_backward(x_pm, w2)
+        ctx.compute = _compute
+        ctx.wshape = w.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x_pm, w2 = ctx.saved_tensors
+        B, N, K = x_pm.shape
+        Nc = w2.shape[0]
+        ds = [d.contiguous() if d is not None else torch.zeros((B, 64, N), dtype=torch.float32, device=x_pm.device) for d in douts]
+        ptrs = (ctypes.c_void_p * len(ds))(*[t.data_ptr() for t in ds])
+        dx, dw = torch.empty_like(x_pm), torch.empty_like(w2)
+        L = _lib.lib()
+        nbytes = L.gfs3d_linear_workspace_bytes(B, N, K, Nc)
+        ws = _workspace(x_pm.device, nbytes)
+        with torch.cuda.device(x_pm.device):
+            rc = L.gfs3d_linear_backward_f32(_p(x_pm), B, N, K, _p(w2), Nc, ptrs, _p(dx), _p(dw), ctx.compute, _p(ws), ws.numel(), _stream())
+        _lib.check(rc, "gfs3d_linear_backward_f32")
+        return dx, dw.reshape(ctx.wshape)
+
+
+def linear_cf(x_pm: torch.Tensor, w: torch.Tensor):
+    """x_pm (B, N, K) point-major, w (64 n, K[, 1]) -> tuple of n channel-first (B, 64, N) tensors."""
+    return LinearFunction.apply(x_pm, w)
+
+
+def _pack_args(B, N, tensors, cf_flags, dst):
+    a = _lib.PackArgs()
+    a.B, a.N, a.n_src = B, N, len(tensors)
+    for s_, (t, cf) in enumerate(zip(tensors, cf_flags)):
+        a.src[s_] = t.data_ptr()
+        a.width[s_] = int(t.shape[1] if cf else t.shape[2])
+        a.channel_first[s_] = 1 if cf else 0
+    a.dst, a.dst_ld = dst.data_ptr(), int(dst.shape[-1])
+    return a
+
+
+class PackRowsFunction(torch.autograd.Function):
+    """Concatenate along the channels into one point-major (B, N, ld) matrix; sources are channel-first (B, w, N) or
+    point-major (B, N, w); columns past the total width are zero (the torch.cat of model/capl.py:357-359 in the layout the
+    point-major GEMMs read)."""
+
+    @staticmethod
+    def forward(ctx, ld, cf_flags, *tensors):
+        if not 1 <= len(tensors) <= _lib.PACK_MAX_SRC:
+            raise NotImplementedError("gfs3d.pack_rows: 1..8 sources")
+        ts = []
+        for t in tensors:
+            _need_gpu(t, "src")
+            ts.append(t.contiguous())
+        B = ts[0].shape[0]
+        N = ts[0].shape[2] if cf_flags[0] else ts[0].shape[1]
+        for t, cf in zip(ts, cf_flags):
+            if t.dim() != 3 or t.shape[0] != B or (t.shape[2] if cf else t.shape[1]) != N:
+                raise RuntimeError("gfs3d.pack_rows: sources must be (B, w, N) channel-first or (B, N, w) point-major")
+        dst = torch.empty((B, N, int(ld)), dtype=torch.float32, device=ts[0].device)
+        a = _pack_args(B, N, ts, cf_flags, dst)
+        with torch.cuda.device(dst.device):
+            rc = _lib.lib().gfs3d_pack_rows_f32(ctypes.byref(a), _stream())
+        _lib.check(rc, "gfs3d_pack_rows_f32")
+        ctx.meta = (B, N, tuple(cf_flags), [tuple(t.shape) for t in ts])
+        return dst
+
+    @staticmethod
+    def backward(ctx, ddst):
+        B, N, cf_flags, shapes = ctx.meta
+        ddst = ddst.contiguous()
+        outs = [torch.empty(sh, dtype=torch.float32, device=ddst.device) if need else None
+                for sh, need in zip(shapes, ctx.needs_input_grad[2:])]
+        live = [(o, cf) for o, cf in zip(outs, cf_flags)]
+        # sources that need no gradient still occupy their columns: give them scratch so that offsets stay right
+        tmp = [o if o is not None else torch.empty(sh, dtype=torch.float32, device=ddst.device) for o, sh in zip(outs, shapes)]
+        a = _pack_args(B, N, tmp, cf_flags, ddst)
+        with torch.cuda.device(ddst.device):
+            rc = _lib.lib().gfs3d_unpack_rows_f32(ctypes.byref(a), _stream())
+        _lib.check(rc, "gfs3d_unpack_rows_f32")
+        del live
+        return (None, None) + tuple(outs)
+
+
+def pack_rows(tensors, cf_flags, ld: Optional[int] = None) -> torch.Tensor:
+    total = sum(int(t.shape[1] if cf else t.shape[2]) for t, cf in zip(tensors, cf_flags))
+    return PackRowsFunction.apply(int(ld if ld is not None else total), tuple(bool(c) for c in cf_flags), *tensors)
 
 
 # --------------------------------------------------------------------------

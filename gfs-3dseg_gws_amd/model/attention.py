@@ -31,6 +31,22 @@ class SelfAttention(nn.Module):
             # one draw from torch's generator per call: reproducible under torch.manual_seed like nn.Dropout
             seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and mask is None) else 0
             return ops.attention(q, k, v, 1.0 / self.temperature, p, seed, mask)
+        return self._attend_torch(q, k, v)
+
+    def forward_pm(self, x_pm):
+        """x_pm (B, N, in_channel) point-major -> (B, 64, N): the three projections as ONE HIP GEMM on the concatenated
+        weights (gfs3d_linear_forward_f32, channel-first q / k / v straight from its epilogue), then the fused K5 kernel."""
+        from gfs3d import ops
+        if self.out_channel != 64 or not x_pm.is_cuda:
+            raise NotImplementedError("SelfAttention.forward_pm: head size 64 on the GPU")
+        w = torch.cat((self.q_map.weight, self.k_map.weight, self.v_map.weight), dim=0)
+        q, k, v = ops.linear_cf(x_pm, w)
+        p = float(self.dropout.p) if self.training else 0.0
+        mask = self._forced_keep_mask if (self.training and self._forced_keep_mask is not None) else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and mask is None) else 0
+        return ops.attention(q, k, v, 1.0 / self.temperature, p, seed, mask)
+
+    def _attend_torch(self, q, k, v):
         attn = torch.bmm(q.transpose(1, 2) / self.temperature, k)
         attn = F.softmax(attn, dim=-1)
         if self._forced_keep_mask is not None and self.training:

@@ -74,17 +74,48 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
 
     def getFeatures(self, x, segment_label=None):
         """x (B,C_in,N) -> point_feat (B,128,N), semantic_feat (B,192,N), one_hot (B,K_w,N)."""
-        edge_feats, level2 = self.encoder(x)
-        semantic = torch.cat((edge_feats[0], self.att_learner(level2), self.base_learner(level2)), dim=1)
+        return self._features(x, want_semantic=True)
+
+    def _heads_fusable(self):
+        """The heads run on the HIP point-wise kernels (K4) when they have the reference's shapes: BaseLearner widths and the
+        fusion width multiples of 64, attention head size 64, Conv1d + BatchNorm1d + LeakyReLU fusion."""
+        f = self.fusion
+        return (self.base_learner.fused_parts() is not None and self.att_learner.out_channel == 64
+                and self.att_learner.in_channel % 64 == 0 and len(f) == 3 and isinstance(f[0], nn.Conv1d)
+                and type(f[1]) in (nn.BatchNorm1d, nn.SyncBatchNorm) and isinstance(f[2], nn.LeakyReLU)
+                and f[0].out_channels % 64 == 0 and f[0].in_channels <= 1024 and self.encoder.n_edgeconv <= ops.PW_MAX_SEGS
+                and self.encoder.conv.fused_parts() is not None)
+
+    def _features(self, x, want_semantic):
+        """capl.py:324-362.  On the GPU everything between the EdgeConv blocks and `point_feat` stays point-major and on the
+        library's kernels: level-2 stack -> {q|k|v GEMM -> K5 attention, BaseLearner stack} -> one packed (B,N,448) matrix
+        [soft words | edge feature | attention | base feature | zero pad] -> fusion stack (K padded from 392 to 448)."""
         words = self._words_on(x.device)
+        if not (x.is_cuda and self._heads_fusable()):
+            edge_feats, level2 = self.encoder(x)
+            semantic = torch.cat((edge_feats[0], self.att_learner(level2), self.base_learner(level2)), dim=1)
+            soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
+            point_feat = self.fusion(torch.cat([soft, semantic], dim=1))
+            return point_feat, semantic, one_hot
+        sync = self.encoder.bn_sync
+        edge_feats, edge_pm, level2_pm = self.encoder(x, point_major=True)
+        att = self.att_learner.forward_pm(level2_pm)                                        # (B,64,N)
+        base = self.base_learner.forward_pm(level2_pm, sync=sync, want_cf=want_semantic)
+        base_cf, base_pm = base if want_semantic else (None, base)
         soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
-        point_feat = self.fusion(torch.cat([soft, semantic], dim=1))
+        conv, bn, act = self.fusion[0], self.fusion[1], self.fusion[2]
+        k_in = conv.in_channels
+        k_pad = (k_in + 63) // 64 * 64
+        packed = ops.pack_rows([soft, edge_pm[0], att, base_pm], [True, False, True, False], ld=k_pad)
+        w = F.pad(conv.weight.squeeze(-1), (0, k_pad - k_in))
+        point_feat = ops.pointwise_stack([packed], [((w, conv.bias), bn)], self.training, float(act.negative_slope), sync=sync)
+        semantic = torch.cat((edge_feats[0], att, base_cf), dim=1) if want_semantic else None
         return point_feat, semantic, one_hot
 
     def Get_Fg_Feat(self, x, y):
         """x (1,d,N), y (1,N) binary mask -> foreground (n,128) features and (n,K_w) one-hot words."""
         keep = y[0] == 1
-        point_feat, _, word = self.getFeatures(x)
+        point_feat, _, word = self._features(x, want_semantic=False)
         return point_feat[0][:, keep].transpose(1, 0), word[0][:, keep].transpose(1, 0)
 
     # ------------------------------------------------------------------ heads
@@ -143,7 +174,7 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         """Training: returns (pred (B,N), loss).  eval_model=True: returns
         (logits (B,cls,N) re-weighted by the geometric-word coding, gp_acc, gp_novel_acc)."""
         nb = self.base_num
-        point_feat, _, word = self.getFeatures(x, segment_label=segment_label)
+        point_feat, _, word = self._features(x, want_semantic=False)
 
         if eval_model:
             if gened_proto.dim() == 3:

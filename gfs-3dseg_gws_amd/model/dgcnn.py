@@ -145,10 +145,18 @@ class DGCNN(nn.Module):
                 torch._foreach_add_(counters, 1)
         return (feats, feats_pm) if with_point_major else feats
 
-    def forward(self, x):
+    def forward(self, x, point_major=False):
+        """point_major=True (the fused CAPL heads): returns (block outputs, their (B,N,64) copies, level-2 feature as a
+        point-major (B,N,C) tensor) - no channel-first copy of the level-2 feature is written."""
         feats, feats_pm = self.edgeconv_features(x, with_point_major=True)
         parts = self.conv.fused_parts() if len(feats) <= ops.PW_MAX_SEGS else None
-        if parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats):
+        fused = parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats)
+        if point_major:
+            if not fused:
+                raise NotImplementedError("DGCNN(point_major=True): the point-wise stack is not in the HIP-fusable form")
+            out_pm = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync, want_cf=False, want_pm=True)
+            return feats, feats_pm, out_pm
+        if fused:
             out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync)       # K4: no cat, no transposes
         else:
             out = self.conv(torch.cat(feats, dim=1))
@@ -176,6 +184,32 @@ class BaseLearner(nn.Module):
             if i != last:
                 x = F.relu(x)
         return x
+
+    def fused_parts(self):
+        """[(conv, bn)] when the HIP point-wise stack implements this learner (1x1 convolutions to multiples of 64
+        channels from a multiple of 64, BatchNorm1d with running statistics; at most 4 layers) - else None."""
+        if not 1 <= self.num_convs <= ops.PW_MAX_LAYERS:
+            return None
+        parts = []
+        for blk in self.convs:
+            c, bn = blk[0], blk[1]
+            ok = (isinstance(c, nn.Conv1d) and type(bn) in (nn.BatchNorm1d, nn.SyncBatchNorm) and c.kernel_size == (1,)
+                  and c.in_channels % 64 == 0 and c.in_channels <= 1024 and c.out_channels % 64 == 0
+                  and c.out_channels <= 1024 and bn.affine and bn.track_running_stats)
+            if not ok:
+                return None
+            parts.append((c, bn))
+        return parts
+
+    def forward_pm(self, x_pm, sync=None, want_cf=False):
+        """x_pm (B, N, C) point-major -> (B, N, C_out) point-major [and (B, C_out, N)]: the whole learner as ONE K4 stack
+        (ReLU = LeakyReLU(0) between the layers, slope 1 = no activation after the last; the conv biases only move the
+        running means)."""
+        parts = self.fused_parts()
+        if parts is None:
+            raise NotImplementedError("BaseLearner.forward_pm: widths outside the HIP point-wise stack")
+        slopes = [0.0] * (self.num_convs - 1) + [1.0]
+        return ops.pointwise_stack([x_pm], parts, self.training, 0.0, sync=sync, slopes=slopes, want_cf=want_cf, want_pm=True)
 
 
 class DGCNNSeg_att(nn.Module):

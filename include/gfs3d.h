@@ -213,6 +213,15 @@ typedef struct gfs3d_pointwise_args {
     void *workspace;
     size_t workspace_bytes;
     int compute;                  /* GFS3D_COMPUTE_*: arithmetic of the row GEMMs and weight-gradient GEMMs */
+    /* ---- generalisations for the CAPL heads; all zero / NULL = the DGCNN stack described above ----
+     * BaseLearner (model/dgcnn.py:130-152: Conv1d WITH bias + BatchNorm1d, ReLU between the layers, none after the last)
+     * and the fusion layer (model/capl.py:64-65, 359: Conv1d(392 -> 128, bias) + BatchNorm1d + LeakyReLU(0.2)). */
+    int seg_width;                /* width of every input segment (0 = 64); a multiple of 64, seg_width * n_seg <= 1024 */
+    const float *bias[GFS3D_PW_MAX_LAYERS];   /* Conv1d bias of layer l or NULL.  In front of a BatchNorm it only moves the
+                                     running mean (training) / the shift (eval); h[l] is stored WITHOUT it */
+    int per_layer_slope;          /* != 0: layer l ends in LeakyReLU(slope_l[l]) (0 = ReLU, 1 = no activation) instead of `slope` */
+    float slope_l[GFS3D_PW_MAX_LAYERS];
+    float *y_pm;                  /* optional (B*N, width[last]) point-major copy of the result; y_cf may be NULL when it is given */
 } gfs3d_pointwise_args;
 
 typedef struct gfs3d_pointwise_bwd_args {
@@ -222,9 +231,12 @@ typedef struct gfs3d_pointwise_bwd_args {
     float *dw[GFS3D_PW_MAX_LAYERS];
     float *dbn_w[GFS3D_PW_MAX_LAYERS];
     float *dbn_b[GFS3D_PW_MAX_LAYERS];
+    const float *dy_pm;           /* optional (B*N, width[last]) gradient w.r.t. y_pm, ADDED to dy_cf (either may be NULL) */
 } gfs3d_pointwise_bwd_args;
 
 size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width);
+/* the same for segments of `seg_width` channels (0 = 64) */
+size_t gfs3d_pointwise_workspace_bytes_ex(int B, int N, int n_seg, int seg_width, int n_layers, const int *width);
 int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream);
 int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream);
 
@@ -238,6 +250,35 @@ int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream
  * Phases 0 .. L in order are exactly the monolithic calls. */
 int gfs3d_pointwise_forward_phase_f32(const gfs3d_pointwise_args *a, int phase, double *acc, double stat_count, void *stream);
 int gfs3d_pointwise_backward_phase_f32(const gfs3d_pointwise_bwd_args *a, int phase, double *acc, double stat_count, void *stream);
+
+/* Plain bias-free 1x1 convolution without BatchNorm: y = x W^T.  Replaces q_map / k_map / v_map of SelfAttention
+ * (model/attention.py:39-41) as ONE GEMM on the row-concatenated weights (Nc = 3 * 64).
+ *   x_pm (B*N, K) point-major, K a multiple of 64 (<= 1024);  w (Nc, K), Nc = 64 * n_out, n_out <= 4
+ *   y_cf[s] (B, 64, N) channel-first output s (q, k, v: the layout gfs3d_attention_* reads)
+ * backward: dy_cf[s] (B, 64, N) -> dx_pm (B*N, K), dw (Nc, K).  Workspace: gfs3d_linear_workspace_bytes(B, N, K, Nc). */
+size_t gfs3d_linear_workspace_bytes(int B, int N, int K, int Nc);
+int gfs3d_linear_forward_f32(const float *x_pm, int B, int N, int K, const float *w, int Nc, float *const *y_cf, int compute,
+                             void *workspace, size_t workspace_bytes, void *stream);
+int gfs3d_linear_backward_f32(const float *x_pm, int B, int N, int K, const float *w, int Nc, const float *const *dy_cf,
+                              float *dx_pm, float *dw, int compute, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Concatenation along the channels into ONE point-major matrix, and its adjoint.  Replaces the torch.cat of
+ * model/capl.py:357-359 (soft word assignment | edge feature | attention | base feature -> fusion) together with the
+ * layout change the point-major GEMMs need.
+ *   src[s]  width[s] channels, channel-first (B, width[s], N) if channel_first[s] else point-major (B*N, width[s])
+ *   dst     (B*N, dst_ld) point-major; columns [sum width, dst_ld) are written as zeros (K padding of the GEMM)
+ * gfs3d_unpack_rows_f32 is the adjoint: it scatters the columns of `dst` (read-only there) back into src[s] (written). */
+#define GFS3D_PACK_MAX_SRC 8
+typedef struct gfs3d_pack_args {
+    int B, N, n_src;
+    float *src[GFS3D_PACK_MAX_SRC];
+    int width[GFS3D_PACK_MAX_SRC];
+    int channel_first[GFS3D_PACK_MAX_SRC];
+    float *dst;
+    int dst_ld;
+} gfs3d_pack_args;
+int gfs3d_pack_rows_f32(const gfs3d_pack_args *a, void *stream);
+int gfs3d_unpack_rows_f32(const gfs3d_pack_args *a, void *stream);
 
 /* ------------------------------------------------------------------ K5 --
  * Fused self-attention over the points of a block.  Replaces SelfAttention.forward after the three 1x1 projections,

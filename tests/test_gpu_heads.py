@@ -1,0 +1,205 @@
+"""GPU parity of the CAPL heads on the HIP point-wise kernels (K4 generalised: conv bias, per-layer activation slopes,
+wide input segments, point-major outputs; the q/k/v GEMM; the channel packing) against torch in fp64 - through the C ABI.
+
+Reference code these replace: BaseLearner (model/dgcnn.py:130-152), q_map / k_map / v_map (model/attention.py:39-41), the
+fusion layer and its torch.cat (model/capl.py:64-65, 357-359).  Tolerance: 1e-4 of the tensor's max magnitude (fp32 contract).
+"""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from gfs3d import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def maxerr(a, b):
+    return float((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()).abs().max())
+
+
+def relerr(a, b):
+    b = torch.as_tensor(b).detach().cpu().double()
+    return maxerr(a, b) / max(float(b.abs().max()), 1e-12)
+
+
+# ------------------------------------------------------------------ pack / unpack
+@pytest.mark.parametrize("B,N,widths,cf,ld", [
+    (2, 100, [200, 64, 64, 64], [True, False, True, False], 448),      # the fusion input of capl.py:357-359, ragged N
+    (1, 64, [64], [True], 64),
+    (3, 257, [7, 130, 64], [False, True, False], 256),                 # odd widths, padding columns
+    (2, 2048, [180, 64, 64, 64], [True, False, True, False], 384),     # ScanNet words
+])
+def test_pack_rows_and_adjoint_match_torch(dev, B, N, widths, cf, ld):
+    from gfs3d import ops
+    torch.manual_seed(sum(widths) + N)
+    srcs = [(torch.randn(B, w, N, device=dev) if c else torch.randn(B, N, w, device=dev)).requires_grad_(True) for w, c in zip(widths, cf)]
+    out = ops.pack_rows(srcs, cf, ld=ld)
+    ref = torch.cat([t.transpose(1, 2) if c else t for t, c in zip(srcs, cf)], dim=2)
+    ref = F.pad(ref, (0, ld - sum(widths)))
+    assert out.shape == (B, N, ld)
+    assert torch.equal(out, ref)                                       # a copy: bit-exact
+    cot = torch.randn(B, N, ld, device=dev)
+    out.backward(cot)
+    g = [t.grad.clone() for t in srcs]
+    for t in srcs:
+        t.grad = None
+    ref.backward(cot)
+    for a, t in zip(g, srcs):
+        assert torch.equal(a, t.grad)
+
+
+# ------------------------------------------------------------------ q / k / v GEMM
+@pytest.mark.parametrize("B,N,K,n_out", [(2, 300, 256, 3), (1, 64, 64, 1), (3, 1000, 128, 4)])
+def test_linear_cf_forward_backward_matches_torch(dev, B, N, K, n_out):
+    from gfs3d import ops
+    torch.manual_seed(K + N)
+    x = torch.randn(B, N, K, device=dev).requires_grad_(True)
+    w = (torch.randn(64 * n_out, K, 1, device=dev) / K ** 0.5).requires_grad_(True)
+    outs = ops.linear_cf(x, w)
+    assert len(outs) == n_out
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    ref = F.conv1d(x64.transpose(1, 2), w64)                           # (B, 64 n, N)
+    cots = [torch.randn(B, 64, N, device=dev) for _ in range(n_out)]
+    for s, o in enumerate(outs):
+        assert o.shape == (B, 64, N)
+        assert relerr(o, ref[:, 64 * s:64 * s + 64]) < TOL
+    torch.autograd.backward(outs, cots)
+    ref.backward(torch.cat(cots, dim=1).double())
+    assert relerr(x.grad, x64.grad) < TOL
+    assert relerr(w.grad, w64.grad) < TOL
+
+
+# ------------------------------------------------------------------ BaseLearner on K4
+def _randomise_bn(mod):
+    for m in mod.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.5, 0.5)
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+
+
+@pytest.mark.parametrize("B,N,cin,widths", [(2, 500, 256, [128, 64]), (1, 77, 64, [64]), (2, 1024, 128, [192, 128, 64])])
+def test_base_learner_train_forward_backward_matches_torch(dev, B, N, cin, widths):
+    """Conv1d WITH bias + BatchNorm1d, ReLU between the layers, none after the last (reference dgcnn.py:130-152): outputs
+    in both layouts, running statistics (the bias moves the running mean) and every gradient (bias gradients are exactly
+    zero in front of a training-mode BatchNorm: torch's own are rounding noise)."""
+    from model.dgcnn import BaseLearner
+    torch.manual_seed(cin + N)
+    bl = BaseLearner(cin, widths).to(dev).train()
+    _randomise_bn(bl)
+    for blk in bl.convs:
+        blk[0].bias.data.normal_(0, 0.5)
+    ref = copy.deepcopy(bl).double()
+    x_pm = torch.randn(B, N, cin, device=dev).requires_grad_(True)
+    x64 = x_pm.detach().double().requires_grad_(True)
+    y_cf, y_pm = bl.forward_pm(x_pm, want_cf=True)
+    # fp64 reference
+    h = x64.transpose(1, 2)
+    for i, blk in enumerate(ref.convs):
+        h = blk(h)
+        if i != len(ref.convs) - 1:
+            h = F.relu(h)
+    assert y_cf.shape == (B, widths[-1], N) and y_pm.shape == (B, N, widths[-1])
+    assert relerr(y_cf, h) < TOL
+    assert torch.equal(y_pm, y_cf.transpose(1, 2).contiguous())
+    for (n1, b1), (_, b2) in zip(bl.named_buffers(), ref.named_buffers()):
+        assert maxerr(b1, b2) < 1e-5, n1
+    cot = torch.randn(B, widths[-1], N, device=dev)
+    # half of the gradient arrives through each view
+    torch.autograd.backward([y_cf, y_pm], [0.5 * cot, 0.5 * cot.transpose(1, 2).contiguous()])
+    h.backward(cot.double())
+    bad = ((x_pm.grad.double() - x64.grad).abs().amax(-1) > TOL * float(x64.grad.abs().max())).float().mean()
+    assert float(bad) <= 2e-3, float(bad)                           # points whose ReLU input sits within rounding of 0
+    for (n1, p1), (_, p2) in zip(bl.named_parameters(), ref.named_parameters()):
+        if n1.endswith("0.bias"):
+            assert float(p1.grad.abs().max()) == 0.0 and float(p2.grad.abs().max()) < 1e-6 * B * N
+        else:
+            assert relerr(p1.grad, p2.grad) < 2e-3, n1
+
+
+def test_base_learner_eval_matches_torch(dev):
+    from model.dgcnn import BaseLearner
+    torch.manual_seed(5)
+    bl = BaseLearner(256, [128, 64]).to(dev)
+    _randomise_bn(bl)
+    for blk in bl.convs:
+        blk[0].bias.data.normal_(0, 0.5)
+    bl.eval()
+    ref = copy.deepcopy(bl).double()
+    x_pm = torch.randn(3, 333, 256, device=dev)
+    with torch.no_grad():
+        y_pm = bl.forward_pm(x_pm)
+        y_cf, y_pm2 = bl.forward_pm(x_pm, want_cf=True)
+        y_ref = ref(x_pm.double().transpose(1, 2))
+    assert relerr(y_pm.transpose(1, 2), y_ref) < TOL
+    assert torch.equal(y_pm, y_pm2) and torch.equal(y_cf, y_pm.transpose(1, 2).contiguous())
+
+
+def test_attention_forward_pm_matches_module_forward(dev):
+    """SelfAttention.forward_pm (one q|k|v GEMM + K5) == SelfAttention.forward (three torch convolutions + K5), outputs and
+    gradients, with a forced dropout mask."""
+    from model.attention import SelfAttention
+    torch.manual_seed(2)
+    att = SelfAttention(256, 64).to(dev).train()
+    B, N = 2, 200
+    att._forced_keep_mask = torch.rand(B, N, N, device=dev) > 0.1
+    x = torch.randn(B, 256, N, device=dev).requires_grad_(True)
+    x_pm = x.detach().transpose(1, 2).contiguous().requires_grad_(True)
+    cot = torch.randn(B, 64, N, device=dev)
+    y1 = att(x)
+    y1.backward(cot)
+    g1 = [p.grad.clone() for p in att.parameters()]
+    for p in att.parameters():
+        p.grad = None
+    y2 = att.forward_pm(x_pm)
+    y2.backward(cot)
+    assert relerr(y2, y1) < TOL
+    assert relerr(x_pm.grad.transpose(1, 2), x.grad) < TOL
+    for a, p in zip(g1, att.parameters()):
+        assert relerr(p.grad, a) < TOL
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_fusion_layer_on_packed_input_matches_torch(dev, training):
+    """capl.py:357-359: Conv1d(392 -> 128, bias) + BatchNorm1d + LeakyReLU(0.2) on cat([soft, edge, att, base]) as one
+    packed point-major matrix with K padded to 448."""
+    from gfs3d import ops
+    torch.manual_seed(9)
+    B, N = 2, 300
+    fusion = torch.nn.Sequential(torch.nn.Conv1d(392, 128, 1), torch.nn.BatchNorm1d(128), torch.nn.LeakyReLU(0.2)).to(dev)
+    _randomise_bn(fusion)
+    fusion.train(training)
+    ref = copy.deepcopy(fusion).double()
+    soft = torch.softmax(torch.randn(B, 200, N, device=dev), 1).requires_grad_(True)
+    e0 = torch.randn(B, N, 64, device=dev).requires_grad_(True)
+    att = torch.randn(B, 64, N, device=dev).requires_grad_(True)
+    base = torch.randn(B, N, 64, device=dev).requires_grad_(True)
+    srcs = [soft, e0, att, base]
+    packed = ops.pack_rows(srcs, [True, False, True, False], ld=448)
+    w = F.pad(fusion[0].weight.squeeze(-1), (0, 56))
+    y = ops.pointwise_stack([packed], [((w, fusion[0].bias), fusion[1])], training, 0.2)
+    s64 = [t.detach().double().requires_grad_(True) for t in srcs]
+    y_ref = ref(torch.cat([s64[0], s64[1].transpose(1, 2), s64[2], s64[3].transpose(1, 2)], dim=1))
+    assert relerr(y, y_ref) < TOL
+    for (n1, b1), (_, b2) in zip(fusion.named_buffers(), ref.named_buffers()):
+        assert maxerr(b1, b2) < 1e-5, n1
+    if not training:
+        return
+    cot = torch.randn(B, 128, N, device=dev)
+    y.backward(cot)
+    y_ref.backward(cot.double())
+    for a, b in zip(srcs, s64):
+        assert relerr(a.grad, b.grad) < TOL
+    assert relerr(fusion[0].weight.grad, ref[0].weight.grad) < TOL
+    assert relerr(fusion[1].weight.grad, ref[1].weight.grad) < TOL and relerr(fusion[1].bias.grad, ref[1].bias.grad) < TOL
+    assert float(fusion[0].bias.grad.abs().max()) == 0.0

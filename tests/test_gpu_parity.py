@@ -637,12 +637,15 @@ def test_capl_train_heads_gradients_on_identical_backbone_outputs(dev):
     held = {}
     orig = m.encoder.forward
 
-    def spy(inp):
-        feats, out = orig(inp)
+    def spy(inp, point_major=False):
+        # the fused heads ask for the point-major views: (block outputs, their (B,N,64) copies, level-2 (B,N,256))
+        assert point_major, "the CAPL heads are expected on the fused HIP path"
+        feats, feats_pm, out_pm = orig(inp, point_major=True)
         feats = [f.detach().clone().requires_grad_(True) for f in feats]      # cut here: leaves of the head graph
-        out = out.detach().clone().requires_grad_(True)
-        held["feats"], held["out"] = feats, out
-        return feats, out
+        feats_pm = [f.detach().clone().requires_grad_(True) for f in feats_pm]
+        out_pm = out_pm.detach().clone().requires_grad_(True)
+        held["feats"], held["feats_pm"], held["out_pm"] = feats, feats_pm, out_pm
+        return feats, feats_pm, out_pm
     m.encoder.forward = spy
     fake = [int(v) for v in g["ft_fake_novel"]]
     random.seed(0)
@@ -655,16 +658,19 @@ def test_capl_train_heads_gradients_on_identical_backbone_outputs(dev):
         if v.dtype.is_floating_point and "running" not in k and not k.startswith("encoder."):
             v.requires_grad_(True)
     ecs = [f.detach().cpu().double().requires_grad_(True) for f in held["feats"]]
-    lvl2 = held["out"].detach().cpu().double().requires_grad_(True)
+    lvl2 = held["out_pm"].detach().transpose(1, 2).cpu().double().requires_grad_(True)
     dm = torch.from_numpy(mask.astype(np.float64)) / 0.9
     pr, lr, _ = R.capl_forward_train(p, torch.from_numpy(g["gp"]).double(), None, torch.from_numpy(g["y"]), base_num=7,
                                      fake_novel=fake, new_stats={}, dropout_mask=dm, encoder_out=(ecs, lvl2))
     lr.backward()
     assert abs(float(loss) - float(lr)) <= 1e-5 * abs(float(lr))
     assert float((pred.cpu() == pr).float().mean()) > 0.999
-    for i in range(3):
-        assert relerr(held["feats"][i].grad, ecs[i].grad) < TOL, f"d(edgeconv {i})"
-    assert relerr(held["out"].grad, lvl2.grad) < TOL, "d(level2)"
+    for i in range(3):      # a block output is consumed through both of its views: the gradients add
+        gi = held["feats"][i].grad
+        if held["feats_pm"][i].grad is not None:
+            gi = gi + held["feats_pm"][i].grad.transpose(1, 2)
+        assert relerr(gi, ecs[i].grad) < TOL, f"d(edgeconv {i})"
+    assert relerr(held["out_pm"].grad.transpose(1, 2), lvl2.grad) < TOL, "d(level2)"
     zero_grad = {"base_learner.convs.0.0.bias", "base_learner.convs.1.0.bias", "base_learner.convs.1.1.bias", "fusion.0.bias"}
     checked = 0
     for n, prm in m.named_parameters():
