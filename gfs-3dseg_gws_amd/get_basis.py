@@ -51,6 +51,17 @@ class DGCNNSeg(nn.Module):
 
     def forward(self, pc, return_feat=False):
         n = pc.shape[2]
+        from model.dgcnn import segmenter_fusable, segmenter_forward_pm
+        if pc.is_cuda and segmenter_fusable(self.segmenter) and self.encoder.conv.fused_parts() is not None:
+            # point-major throughout: the global max is taken over the points of the (B, N, C) level-2 feature and enters
+            # the packed classifier input as a broadcast channel-first source
+            feats, feats_pm, level2_pm = self.encoder(pc, point_major=True)
+            glob = level2_pm.max(dim=1, keepdim=True)[0].transpose(1, 2).expand(-1, -1, n)
+            packed = ops.pack_rows(list(feats_pm) + [glob], [False] * len(feats_pm) + [True])
+            logits = segmenter_forward_pm(self.segmenter, packed, self.training, self.encoder.bn_sync)
+            if return_feat:
+                return logits, torch.cat(feats, dim=1)
+            return logits
         feats, point_feat = self.encoder(pc)
         glob = point_feat.max(dim=-1, keepdim=True)[0].expand(-1, -1, n)
         logits = self.segmenter(torch.cat(feats + [glob], dim=1))

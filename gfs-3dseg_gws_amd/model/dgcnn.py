@@ -228,7 +228,38 @@ class DGCNNSeg_att(nn.Module):
             nn.Dropout(0.3), nn.Conv1d(128, num_classes, 1))
 
     def forward(self, pc, return_feat=False):
+        if pc.is_cuda and segmenter_fusable(self.segmenter) and self.base_learner.fused_parts() is not None \
+                and self.att_learner.out_channel == 64 and self.encoder.conv.fused_parts() is not None:
+            # everything after the EdgeConv blocks on the HIP point-wise kernels, point-major throughout
+            feats, feats_pm, level2_pm = self.encoder(pc, point_major=True)
+            att = self.att_learner.forward_pm(level2_pm)
+            base_pm = self.base_learner.forward_pm(level2_pm, sync=self.encoder.bn_sync)
+            packed = ops.pack_rows([feats_pm[0], att, base_pm], [False, True, False])
+            logits = segmenter_forward_pm(self.segmenter, packed, self.training, self.encoder.bn_sync)
+            return (logits, feats[0]) if return_feat else logits
         level1, level2 = self.encoder(pc)
         feat = torch.cat((level1, self.att_learner(level2), self.base_learner(level2)), dim=1)
         logits = self.segmenter(feat)
         return (logits, level1) if return_feat else logits
+
+
+def segmenter_fusable(seg):
+    """The point-wise classifier of the pre-training models (reference dgcnn.py:170-177, get_basis.py:84-93):
+    [Conv1d, BatchNorm1d, LeakyReLU] x 2, Dropout, Conv1d - the two BatchNorm layers run as one K4 stack."""
+    m = list(seg)
+    if len(m) != 8:
+        return False
+    c1, b1, a1, c2, b2, a2, dr, c3 = m
+    return (isinstance(c1, nn.Conv1d) and isinstance(c2, nn.Conv1d) and isinstance(c3, nn.Conv1d) and isinstance(dr, nn.Dropout)
+            and type(b1) in (nn.BatchNorm1d, nn.SyncBatchNorm) and type(b2) in (nn.BatchNorm1d, nn.SyncBatchNorm)
+            and isinstance(a1, nn.LeakyReLU) and isinstance(a2, nn.LeakyReLU)
+            and c1.in_channels % 64 == 0 and c1.in_channels <= 1024 and c1.out_channels % 64 == 0 and c2.out_channels % 64 == 0
+            and c1.kernel_size == (1,) and c2.kernel_size == (1,))
+
+
+def segmenter_forward_pm(seg, packed_pm, training, sync=None):
+    """packed_pm (B, N, C_in) point-major -> logits (B, num_classes, N)."""
+    c1, b1, a1, c2, b2, a2, dr, c3 = list(seg)
+    h = ops.pointwise_stack([packed_pm], [(c1, b1), (c2, b2)], training, _LRELU, sync=sync,
+                            slopes=[float(a1.negative_slope), float(a2.negative_slope)])
+    return c3(dr(h))

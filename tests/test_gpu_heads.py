@@ -203,3 +203,52 @@ def test_fusion_layer_on_packed_input_matches_torch(dev, training):
     assert relerr(fusion[0].weight.grad, ref[0].weight.grad) < TOL
     assert relerr(fusion[1].weight.grad, ref[1].weight.grad) < TOL and relerr(fusion[1].bias.grad, ref[1].bias.grad) < TOL
     assert float(fusion[0].bias.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_dgcnnseg_att_fused_heads_match_the_torch_heads(dev, training, monkeypatch):
+    """Pre-training model (reference dgcnn.py:155-202): attention + BaseLearner + segmenter on the HIP point-wise kernels
+    against the same module with its heads on torch (same HIP backbone), logits and every parameter gradient."""
+    import types
+    import model.dgcnn as D
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                              base_widths=[128, 64], output_dim=64)
+    torch.manual_seed(1)
+    m = D.DGCNNSeg_att(a, num_classes=13).to(dev)
+    _randomise_bn(m)
+    m.segmenter[6].p = 0.0                                          # the dropout draw is torch's in both paths; keep it out of the comparison
+    m.train(training)
+    B, N = 2, 256
+    if training:
+        m.att_learner._forced_keep_mask = torch.rand(B, N, N, device=dev) > 0.1
+    x = torch.rand(B, 9, N, device=dev)
+    cot = torch.randn(B, 13, N, device=dev)
+    sd = copy.deepcopy(m.state_dict())
+
+    def run(fused):
+        m.load_state_dict(sd)
+        for p in m.parameters():
+            p.grad = None
+        if not fused:
+            monkeypatch.setattr(D, "segmenter_fusable", lambda seg: False)
+        else:
+            monkeypatch.undo()
+        with torch.set_grad_enabled(training):
+            logits, l1 = m(x, return_feat=True)
+        if training:
+            logits.backward(cot)
+        return logits.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, copy.deepcopy(m.state_dict())
+
+    y0, g0, s0 = run(False)
+    y1, g1, s1 = run(True)
+    assert relerr(y1, y0) < TOL
+    for k in s0:
+        if "running" in k:
+            assert maxerr(s1[k], s0[k]) < 1e-5, k
+    if training:
+        assert set(g0) == set(g1)
+        for n in g0:
+            if float(g0[n].abs().max()) < 1e-4:      # constants a following BatchNorm removes (conv biases, the base learner's last beta): analytically zero
+                assert float(g1[n].abs().max()) < 1e-4, n
+            else:
+                assert relerr(g1[n], g0[n]) < 5e-4, n
