@@ -483,9 +483,12 @@ constexpr float KNN_SCREEN_REL = 4.0e-5f;      // > 2 (3 2^-18) + fp32 accumulat
 constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
 constexpr int KS_QS = 32;                      // queue slots per lane (= per query half)
 constexpr int KS_CAP = 64;                     // candidate ids kept per query
-constexpr int KS_TC = 32;                      // candidates per LDS stage (64 = two MFMA tiles per barrier was measured: 110 -> 153 us)
-constexpr int KS_CPT = KS_TC / 8;              // candidates per staging thread
-constexpr int KS_TLD = 272;                    // bytes per candidate row of the tile image: [hi 64 x bf16 | mid | 16 B pad] (17 slots: conflict-free ds_read_b128)
+// Stage geometry for NKB 16-channel K-blocks.  256 staging threads = (8 NKB channel pairs) x (candidate groups of 4):
+//   NKB = 4: 32 candidates per LDS stage (64 = two MFMA tiles per barrier was measured: 110 -> 153 us), rows of
+//            [hi 64 x bf16 | mid | 16 B pad] = 272 B (17 slots: conflict-free ds_read_b128)
+//   NKB = 1: 128 candidates per stage (four MFMA tiles per barrier), rows of [hi 16 x bf16 | mid | 16 B pad] = 80 B (5 slots)
+constexpr int ks_tc(int nkb) { return 4 * (256 / (8 * nkb)); }
+constexpr int ks_tld(int nkb) { return 64 * nkb + 16; }
 
 // two fp32 values -> their hi and mid bf16 pieces (both roundings to nearest-even), each pair packed in one dword (a low)
 __device__ __forceinline__ void split2_rne(float a, float b, unsigned &hi, unsigned &mid)
@@ -495,24 +498,27 @@ __device__ __forceinline__ void split2_rne(float a, float b, unsigned &hi, unsig
     mid = mm_pack2<PREC_BF16>(ra, rb);
 }
 
-// x (B, C, N) channel-first -> xpm (B, N, 64) point-major, channels >= C zero
+// x (B, C, N) channel-first -> xpm (B, N, RW) point-major (RW = 64 or 16), channels >= C zero
 __global__ void __launch_bounds__(256)
-knn_pm_kernel(const float *__restrict__ x, int C, int N, float *__restrict__ xpm)
+knn_pm_kernel(const float *__restrict__ x, int C, int N, int RW, float *__restrict__ xpm)
 {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
     const int p = tid & 63, wv = tid >> 6;
-    for (int c = wv; c < 64; c += 4) tile[p][c] = (c < C && n0 + p < N) ? x[((size_t)b * C + c) * N + n0 + p] : 0.f;
+    for (int c = wv; c < RW; c += 4) tile[p][c] = (c < C && n0 + p < N) ? x[((size_t)b * C + c) * N + n0 + p] : 0.f;
     __syncthreads();
-    for (int q = wv; q < 64; q += 4)
-        if (n0 + q < N) xpm[((size_t)b * N + n0 + q) * 64 + p] = tile[q][p];
+    if (p < RW)
+        for (int q = wv; q < 64; q += 4)
+            if (n0 + q < N) xpm[((size_t)b * N + n0 + q) * RW + p] = tile[q][p];
 }
 
-template <int K>
-__global__ void __launch_bounds__(256, 3)
+// NKB = 16-channel K-blocks of the operands: 4 (17..64 channels) or 1 (<= 16 channels: the xyz / colour input of layer 1)
+template <int K, int NKB>
+__global__ void __launch_bounds__(256, NKB == 1 ? 2 : 3)
 knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int B, int C, int N,
                   int *__restrict__ cand, int *__restrict__ ccnt)
 {
+    constexpr int KS_TC = ks_tc(NKB), KS_TLD = ks_tld(NKB), KS_CPT = 4, KS_NG = KS_TC / KS_CPT;     // stage geometry, see ks_tc()
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
     unsigned char *timg = ks_smem;                                              // [2][KS_TC][KS_TLD] bf16 candidate stages
     float *tsq = reinterpret_cast<float *>(timg + 2 * KS_TC * KS_TLD);          // [2][KS_TC] their norms
@@ -538,11 +544,11 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[w] = mx;
     // query operand: K-block kb, element e <-> channel 16 kb + 8 h + e of query q0 + j
-    uint4 qph[4], qpm[4];
+    uint4 qph[NKB], qpm[NKB];
     {
         const int qi = min(q0 + j, N - 1);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -564,7 +570,7 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     // staging of one stage (KS_TC candidates): thread (channel pair cp, candidate group cq) loads 2 channels x KS_CPT
     // candidates and writes KS_CPT dwords of 2 bf16
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const int cp = tid >> 3, cq = tid & 7;
+    const int cp = tid / KS_NG, cq = tid % KS_NG;
     const int ns = (N + KS_TC - 1) / KS_TC;
     // (branch-free: N % 4 == 0 is a precondition of this path; a ragged last stage reads the last KS_CPT valid columns
     // instead - its rows past N are never scored - and channels past C read row C - 1 and are zeroed by a select)
@@ -580,7 +586,8 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
 #pragma unroll
             for (int e = 0; e < 4; ++e) { gv0[4 * u + e] = z0 ? 0.f : a0[e]; gv1[4 * u + e] = z1 ? 0.f : b0[e]; }
         }
-        gsq = sqb[min(KS_TC * st + (tid & (KS_TC - 1)), N - 1)];
+        const int jr = KS_TC * st + (tid & (KS_TC - 1));
+        gsq = jr < N ? sqb[jr] : __builtin_inff();          // a row past N scores 2 dot - inf = -inf
     };
     auto put = [&](int buf, const float (&gv0)[KS_CPT], const float (&gv1)[KS_CPT], float gsq) {
         unsigned char *img = timg + buf * KS_TC * KS_TLD;
@@ -589,34 +596,57 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
             unsigned hh, mm;
             split2_rne(gv0[e], gv1[e], hh, mm);
             *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 4 * cp) = hh;
-            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 128 + 4 * cp) = mm;
+            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 32 * NKB + 4 * cp) = mm;
         }
         if (tid < KS_TC) tsq[buf * KS_TC + tid] = gsq;
     };
-    // one 32-candidate tile (rows 32 sub .. of stage image buf): approximate t_r = 2 <x_j, x_q> - |x_j|^2 for the 16
-    // candidate rows this lane sees (C/D layout of the MFMA)
-    auto tile_scores = [&](int buf, int sub, float (&tv)[16]) {
-        const unsigned char *img = timg + (buf * KS_TC + 32 * sub + j) * KS_TLD + 16 * h;
-        f32x16 acc;
+    // all KS_NT 32-candidate tiles of stage image buf: approximate t_r = 2 <x_j, x_q> - |x_j|^2 for the 16 candidate rows this
+    // lane sees of each (C/D layout of the MFMA).  Branch-free, every operand read issued first and the tiles' MFMA chains
+    // interleaved: with 2-3 waves per SIMD nothing else hides the LDS and MFMA latencies (one tile per basic block, as the
+    // first version had it, ran at ~830 cycles per tile for ~300 of issue).
+    constexpr int KS_NT = KS_TC / 32;
+    auto stage_scores = [&](int buf, float (&tv)[KS_NT][16]) {
+        float4 s4[KS_NT][4];
+        auto load_sq = [&]() {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int sub = 0; sub < KS_NT; ++sub) {
+                const float *sq = tsq + buf * KS_TC + 32 * sub + 4 * h;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const uint4 ah = *reinterpret_cast<const uint4 *>(img + 32 * kb);
-            const uint4 am = *reinterpret_cast<const uint4 *>(img + 128 + 32 * kb);
-            acc = mm_mfma<PREC_BF16>(am, qph[kb], acc);         // smallest products first
-            acc = mm_mfma<PREC_BF16>(ah, qpm[kb], acc);
-            acc = mm_mfma<PREC_BF16>(ah, qph[kb], acc);
+                for (int g = 0; g < 4; ++g) s4[sub][g] = *reinterpret_cast<const float4 *>(sq + 8 * g);
+            }
+        };
+        if (KS_NT > 1) load_sq();                           // (one tile per stage: after the chain, the registers are needed there)
+        f32x16 acc[KS_NT];
+#pragma unroll
+        for (int sub = 0; sub < KS_NT; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {                  // smallest products first
+            uint4 ah[KS_NT], am[KS_NT];
+#pragma unroll
+            for (int sub = 0; sub < KS_NT; ++sub) {
+                const unsigned char *img = timg + (buf * KS_TC + 32 * sub + j) * KS_TLD + 16 * h;
+                ah[sub] = *reinterpret_cast<const uint4 *>(img + 32 * kb);
+                am[sub] = *reinterpret_cast<const uint4 *>(img + 32 * NKB + 32 * kb);
+            }
+#pragma unroll
+            for (int sub = 0; sub < KS_NT; ++sub) acc[sub] = mm_mfma<PREC_BF16>(am[sub], qph[kb], acc[sub]);
+#pragma unroll
+            for (int sub = 0; sub < KS_NT; ++sub) acc[sub] = mm_mfma<PREC_BF16>(ah[sub], qpm[kb], acc[sub]);
+#pragma unroll
+            for (int sub = 0; sub < KS_NT; ++sub) acc[sub] = mm_mfma<PREC_BF16>(ah[sub], qph[kb], acc[sub]);
         }
-        const float *sq = tsq + buf * KS_TC + 32 * sub + 4 * h;
+        if (KS_NT == 1) load_sq();
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 s4 = *reinterpret_cast<const float4 *>(sq + 8 * g);
-            tv[4 * g + 0] = __builtin_fmaf(2.0f, acc[4 * g + 0], -s4.x);
-            tv[4 * g + 1] = __builtin_fmaf(2.0f, acc[4 * g + 1], -s4.y);
-            tv[4 * g + 2] = __builtin_fmaf(2.0f, acc[4 * g + 2], -s4.z);
-            tv[4 * g + 3] = __builtin_fmaf(2.0f, acc[4 * g + 3], -s4.w);
-        }
+        for (int sub = 0; sub < KS_NT; ++sub)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tv[sub][4 * g + 0] = __builtin_fmaf(2.0f, acc[sub][4 * g + 0], -s4[sub][g].x);
+                tv[sub][4 * g + 1] = __builtin_fmaf(2.0f, acc[sub][4 * g + 1], -s4[sub][g].y);
+                tv[sub][4 * g + 2] = __builtin_fmaf(2.0f, acc[sub][4 * g + 2], -s4[sub][g].z);
+                tv[sub][4 * g + 3] = __builtin_fmaf(2.0f, acc[sub][4 * g + 3], -s4[sub][g].w);
+            }
     };
 
     float bm[K];                                          // sweep 0: the K largest bucket maxima of this lane (query half)
@@ -640,36 +670,38 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
         // image and stage s + 2 is requested: a request has a whole stage of work to land
         auto one_stage = [&](int st, float (&c0r)[KS_CPT], float (&c1r)[KS_CPT], float &cqr, float (&n0r)[KS_CPT], float (&n1r)[KS_CPT], float &nqr) {
             if (st + 2 < ns) fetch(st + 2, n0r, n1r, nqr);
+            float tv[KS_NT][16];
+            stage_scores(st & 1, tv);
+            // (rows past N of a ragged last stage carry a norm of +inf - see fetch() - so their score is -inf: never a candidate)
+            if (sweep == 0) {
 #pragma unroll
-            for (int sub = 0; sub < KS_TC / 32; ++sub) {
-                const int t = st * (KS_TC / 32) + sub;     // 32-candidate tile index
-                if (32 * t >= N) break;
-                float tv[16];
-                tile_scores(st & 1, sub, tv);
-                const int cbase = 32 * t + 4 * h;
-                if (32 * t + 32 > N) {                     // ragged last tile: rows past N can never be candidates
+                for (int sub = 0; sub < KS_NT; ++sub) {
+                    float mt = fmaxf(fmaxf(tv[sub][0], tv[sub][1]), tv[sub][2]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (cbase + (r & 3) + 8 * (r >> 2) >= N) tv[r] = -__builtin_inff();
+                    for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, tv[sub][r]), tv[sub][r + 1]);       // v_max3_f32
+                    mt = fmaxf(mt, tv[sub][15]);
+                    bm_insert(__fsub_rn(mt, sqq));          // (a tile wholly past N inserts -inf: no change)
                 }
-                if (sweep == 0) {
-                    float mt = fmaxf(fmaxf(tv[0], tv[1]), tv[2]);
+            } else {
+                // candidates are rare (~12 of a lane's 1024 elements): one compare + one add-with-carry per element builds
+                // a 16-bit mask per tile (element r at bit 15 - r), the queue is touched only for its set bits.  The compare is
+                // on tv against thr2 = thr + |xq|^2 lowered by the roundings of both forms: a superset of {pd >= thr}.
+                unsigned bits[KS_NT];
 #pragma unroll
-                    for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, tv[r]), tv[r + 1]);       // v_max3_f32
-                    mt = fmaxf(mt, tv[15]);
-                    bm_insert(__fsub_rn(mt, sqq));
-                } else {
-                    // candidates are rare (~12 of a lane's 1024 elements): one compare + one add-with-carry per element builds
-                    // a 16-bit mask (element r at bit 15 - r), the queue is touched only for its set bits.  The compare is on
-                    // tv against thr2 = thr + |xq|^2 lowered by the roundings of both forms: a superset of {pd >= thr}.
-                    unsigned bits = 0;
+                for (int sub = 0; sub < KS_NT; ++sub) {
+                    bits[sub] = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) bits = bits + bits + (tv[r] >= thr2 ? 1u : 0u);
-                    while (__any(bits != 0)) {
-                        if (bits != 0) {
-                            const int hb = 31 - __builtin_clz(bits);            // highest set bit <-> smallest r = 15 - hb
+                    for (int r = 0; r < 16; ++r) bits[sub] = bits[sub] + bits[sub] + (tv[sub][r] >= thr2 ? 1u : 0u);
+                }
+#pragma unroll
+                for (int sub = 0; sub < KS_NT; ++sub) {
+                    const int cbase = KS_TC * st + 32 * sub + 4 * h;
+                    unsigned bt = bits[sub];
+                    while (__any(bt != 0)) {
+                        if (bt != 0) {
+                            const int hb = 31 - __builtin_clz(bt);              // highest set bit <-> smallest r = 15 - hb
                             const int r = 15 - hb;
-                            bits &= ~(1u << hb);
+                            bt &= ~(1u << hb);
                             myq[(cnt < KS_QS ? cnt : KS_QS) * 64] = (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
                             ++cnt;
                         }
@@ -700,7 +732,8 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     }
     // ---- publish: the two halves of a query one after the other; overflow (or more than KS_CAP) -> exhaustive scan
     const int c0 = __shfl(cnt, j, 64), c1 = __shfl(cnt, j + 32, 64);
-    const bool bad = c0 > KS_QS || c1 > KS_QS || c0 + c1 > KS_CAP;
+    // (no bound - fewer than K buckets in a tiny cloud - also means: rows past N of a ragged tile passed the -inf threshold)
+    const bool bad = c0 > KS_QS || c1 > KS_QS || c0 + c1 > KS_CAP || thr == -__builtin_inff();
     const int q = q0 + j;
     if (q < N) {
         const size_t gq = (size_t)b * N + q;
@@ -712,13 +745,13 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     }
 }
 
-template <int K>
+template <int K, int RW>
 __global__ void __launch_bounds__(256)
 knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, const int *__restrict__ cand,
                  const int *__restrict__ ccnt, int B, int N, int k, int64_t *__restrict__ idx64, int32_t *__restrict__ idx32)
 {
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) float qrow[4][2][64];
+    __shared__ __attribute__((aligned(16))) float qrow[4][2][RW];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hq = lane >> 5, l = lane & 31;
     // (same XCD-aware block -> point cloud map as the screen kernel: the gathered rows of a cloud stay in one L2)
@@ -730,7 +763,7 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
     const int b = min(bb, B - 1);
     const size_t gq = (size_t)b * N + min(qi_raw, N - 1);
     const float *sqb = sqg + (size_t)b * N;
-    if (l < 16) *reinterpret_cast<f32x4_ *>(&qrow[w][hq][4 * l]) = *reinterpret_cast<const f32x4_ *>(xpm + gq * 64 + 4 * l);
+    if (l < RW / 4) *reinterpret_cast<f32x4_ *>(&qrow[w][hq][4 * l]) = *reinterpret_cast<const f32x4_ *>(xpm + gq * RW + 4 * l);
     const float sqq = sqg[gq];
     const int n = ccnt[gq];
     const int count = n >= 0 ? n : N;                        // -1: exhaustive
@@ -744,13 +777,13 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
         const int pos = c * 32 + l;
         const bool valid = pos < count;
         const int id = valid ? (n >= 0 ? cand[gq * KS_CAP + pos] : pos) : 0;
-        const float *row = xpm + ((size_t)b * N + id) * 64;
-        f32x4_ xr[16];
+        const float *row = xpm + ((size_t)b * N + id) * RW;
+        f32x4_ xr[RW / 4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) xr[u] = *reinterpret_cast<const f32x4_ *>(row + 4 * u);
-        float dot = 0.f;
+        for (int u = 0; u < RW / 4; ++u) xr[u] = *reinterpret_cast<const f32x4_ *>(row + 4 * u);
+        float dot = 0.f;                                     // channels past C are zero in both rows: fma(0, 0, dot) == dot
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < RW / 4; ++u) {
             const f32x4_ qv = *reinterpret_cast<const f32x4_ *>(&qrow[w][hq][4 * u]);
             dot = __builtin_fmaf(qv[0], xr[u][0], dot);
             dot = __builtin_fmaf(qv[1], xr[u][1], dot);
@@ -805,7 +838,7 @@ static KnnWs knn_ws(int B, int C, int N, int k)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     w.off_sq = take(sizeof(float) * (size_t)B * N + 64);                 // norms + slack for 16-byte reads at the end
-    const bool screened = C >= 16 && C <= 64;
+    const bool screened = C <= 64;
     w.off_pm = take(screened ? sizeof(float) * (size_t)B * N * 64 : 0);
     w.off_cand = take(screened ? sizeof(int) * (size_t)B * N * KS_CAP : 0);
     w.off_cnt = take(screened ? sizeof(int) * (size_t)B * N : 0);
@@ -813,7 +846,7 @@ static KnnWs knn_ws(int B, int C, int N, int k)
     return w;
 }
 
-template <int K>
+template <int K, int NKB>
 static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, bool have_norms, int B, int C, int N, int k,
                                int64_t *idx64, int32_t *idx32, char *ws, const KnnWs &lay, hipStream_t st)
 {
@@ -823,21 +856,22 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
         hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
         GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
     }
-    const float *xpm = xpm_in;
-    if (!xpm || C != 64) {                                  // the exact pass reads zero-padded 64-channel rows
+    constexpr int RW = 16 * NKB, KS_TC = ks_tc(NKB), KS_TLD = ks_tld(NKB);
+    const float *xpm = (xpm_in && C == 64) ? xpm_in : nullptr;      // the caller's copy is used as it is for 64 channels only
+    if (!xpm) {                                             // the exact pass reads zero-padded RW-channel rows
         float *t = reinterpret_cast<float *>(ws + lay.off_pm);
-        hipLaunchKernelGGL(knn_pm_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, C, N, t);
+        hipLaunchKernelGGL(knn_pm_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, C, N, RW, t);
         GFS3D_LAUNCH_CHECK("knn_pm_kernel");
         xpm = t;
     }
     int *cand = reinterpret_cast<int *>(ws + lay.off_cand), *ccnt = reinterpret_cast<int *>(ws + lay.off_cnt);
     const size_t lds = 2 * KS_TC * KS_TLD + sizeof(float) * (2 * KS_TC + 4) + sizeof(unsigned) * 4 * (KS_QS + 1) * 64;
-    GFS3D_ENSURE_LDS(knn_screen_kernel<K>, lds, who);
-    hipLaunchKernelGGL(knn_screen_kernel<K>, dim3(((N + 127) / 128) * ((B + 7) / 8) * 8), dim3(256), lds, st, x, sq, B, C, N, cand, ccnt);
+    GFS3D_ENSURE_LDS((knn_screen_kernel<K, NKB>), lds, who);
+    hipLaunchKernelGGL((knn_screen_kernel<K, NKB>), dim3(((N + 127) / 128) * ((B + 7) / 8) * 8), dim3(256), lds, st, x, sq, B, C, N, cand, ccnt);
     GFS3D_LAUNCH_CHECK("knn_screen_kernel");
     const long long nq = (long long)B * N;
     (void)nq;
-    hipLaunchKernelGGL(knn_exact_kernel<K>, dim3((unsigned)(((N + 7) / 8) * ((B + 7) / 8) * 8)), dim3(256), 0, st, xpm, sq, cand, ccnt, B, N, k, idx64, idx32);
+    hipLaunchKernelGGL((knn_exact_kernel<K, RW>), dim3((unsigned)(((N + 7) / 8) * ((B + 7) / 8) * 8)), dim3(256), 0, st, xpm, sq, cand, ccnt, B, N, k, idx64, idx32);
     GFS3D_LAUNCH_CHECK("knn_exact_kernel");
     return GFS3D_OK;
 }
@@ -903,7 +937,7 @@ static int knn_entry(const char *who, const float *x, const float *x_pm, const f
         GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "%s: C*N too large for 32-bit buffer offsets", who);
         const KnnWs lay = knn_ws(B, C, N, k);
         static const bool screen_on = [] { const char *e = getenv("GFS3D_KNN_SCREEN"); return !(e && e[0] == '0'); }();     // A-B only
-        const bool screened = screen_on && C >= 16 && (N & 3) == 0 && N >= 8 && workspace != nullptr && workspace_bytes >= lay.total &&
+        const bool screened = screen_on && (N & 3) == 0 && N >= 8 && workspace != nullptr && workspace_bytes >= lay.total &&
                               (long long)B * N * KS_CAP < (1ll << 31);
         float *sq = const_cast<float *>(norms);
         if (!norms) {
@@ -916,8 +950,12 @@ static int knn_entry(const char *who, const float *x, const float *x_pm, const f
         }
         if (screened) {
             char *ws = static_cast<char *>(workspace);
-            if (k <= 20) return launch_knn_screened<20>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
-            return launch_knn_screened<32>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            if (C <= 16) {
+                if (k <= 20) return launch_knn_screened<20, 1>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+                return launch_knn_screened<32, 1>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            }
+            if (k <= 20) return launch_knn_screened<20, 4>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            return launch_knn_screened<32, 4>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
         }
         if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
         if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
