@@ -876,6 +876,8 @@ __device__ __forceinline__ void bwd_coef(const CoefIn &f, int c, bool writer, fl
 // through ds_add_f32 into a block-wide [64][64] image - 0.37 -> 1.02 ms per launch, the LDS float adds are that slow.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) char lds_char;
+typedef short s16x4_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
 // 16 B per lane, global -> LDS without a VGPR destination: lane l lands at lds_base + 16 l.  Issued as inline asm
 // on purpose: the compiler's own bookkeeping for the LDS-DMA builtin puts an `s_waitcnt vmcnt(0)` in front of the
 // next LDS read of ANY address (it cannot tell the regions apart), which would expose the whole gather latency
@@ -886,7 +888,8 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, const void *lds_dst_
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char *)lds_dst_wave_uniform);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(gsrc) : "memory");
 }
-constexpr int BWD_WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC + 8 * 32;      // floats per wave: transpose tile | ids | Q' tile | CSR rows
+constexpr int BWD_DIMG = 3 * EC * 64;                                       // bytes: bf16 piece planes of the dH2 tile, [plane][co][32 edges], swizzled
+constexpr int BWD_WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC + 8 * 32 + BWD_DIMG / 4;      // floats per wave: transpose tile | ids | Q' tile | CSR rows | dH2 pieces
 constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -921,6 +924,11 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     int *mall = reinterpret_cast<int *>(tr + 32 * TLD);         // [8][32] neighbour id of each row of each tile
     float *qt = reinterpret_cast<float *>(mall + 8 * 32);       // [8][64] Q' rows of the super-tile's points
     int *pall = reinterpret_cast<int *>(qt + 8 * EC);           // [8][32] CSR row of each row of each tile (CSR mode)
+    // dH2 as 16-bit operand PIECES, [plane][co][edge column], 64-byte rows.  Written from the C/D layout (a lane's 8 edges of
+    // one K-block are one 16-byte slot: column 16 kb + 8 h + e for register 8 kb + e), read back TRANSPOSED with
+    // ds_read_b64_tr_b16 as the A operand of (3): the split of (2) is reused, no fp32 transpose and no second split.
+    // Slot s of row co sits at physical slot s ^ ((co >> 1) & 3): conflict-free b128 writes (32 banks) and transposed reads.
+    unsigned char *dimg = reinterpret_cast<unsigned char *>(pall + 8 * 32);
     const int trash_row = BN * k + (int)(blockIdx.x * BWD_WAVES + wv);     // where masked rows are stored (never read)
 
     for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
@@ -1073,7 +1081,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]   (register r <-> the same edge in both operands)
             // (K-block kb = registers 8kb..8kb+7 of both lane halves: the same 16 edges in both operands)
 #pragma unroll
-            for (int kb = 0; kb < ((GFS3D_ABL & 4) ? 0 : 2); ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
                 float v8[8];
                 uint4 d[NP], x0[NP], x1[NP];
                 pieces(aD0 + 8 * kb, x0);
@@ -1081,28 +1089,22 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = acc0[8 * kb + e];
                 pieces(v8, d);
-                mac2(d, x0, x1, dW00, dW01);
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + i * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
+                if (!(GFS3D_ABL & 4)) mac2(d, x0, x1, dW00, dW01);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = acc1[8 * kb + e];
                 pieces(v8, d);
-                mac2(d, x0, x1, dW10, dW11);
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc)
+                    *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + (32 + i) * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
+                if (!(GFS3D_ABL & 4)) mac2(d, x0, x1, dW10, dW11);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // dH2: C/D layout -> A-layout through the transpose tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                tr[drow(r, h) * TLD + i] = acc0[r];
-                tr[drow(r, h) * TLD + 32 + i] = acc1[r];
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const float4 d4 = *reinterpret_cast<const float4 *>(tr + i * TLD + 32 * h + 4 * v);
-                a[4 * v + 0] = d4.x; a[4 * v + 1] = d4.y; a[4 * v + 2] = d4.z; a[4 * v + 3] = d4.w;
-            }
-            // the transpose tile is idle until the next tile's a1 write: start the next gather into it, ahead of this
-            // tile's atomics in issue order
+            // (dH2 reaches the A-layout of (3) as pieces, through dimg.)  The transpose tile is idle until the next tile's a1
+            // write: start the next gather into it, ahead of this tile's stores in issue order
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t + 1 < T) gather(t + 1);
@@ -1111,16 +1113,31 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             f32x16 e0, e1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
+            // A fragment of K-block kb = pieces of dH2[edge i][co = 32h + 8kb + e]: two transposed reads of 4 co rows each.  In
+            // its 16-lane group, lane 4q + pq supplies the address of row q, edge columns of chunk pq (edges 16 (g & 1) + 4 pq ..
+            // + 3, stored at column 16 (g & 1) + 8 (pq & 1) + 4 (pq >> 1)), and receives its own edge's column.
+            const int tq = (lane >> 2) & 3, tp = lane & 3, tslot = 2 * ((lane >> 4) & 1) + (tp & 1);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {                    // K = co: lane half h holds co 32h + 8kb ..
                 uint4 ap[NP], b0[NP], b1[NP];
 #pragma unroll
-                for (int pc = 0; pc < NP; ++pc) {              // issue the weight reads first: the split below hides them
+                for (int pc = 0; pc < NP; ++pc) {
                     b0[pc] = *reinterpret_cast<const uint4 *>(wt0 + pc * 128 + kb * 16);
                     b1[pc] = *reinterpret_cast<const uint4 *>(wt1 + pc * 128 + kb * 16);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                pieces(a + 8 * kb, ap);
+#pragma unroll
+                for (int pc = 0; pc < NP; ++pc) {
+                    unsigned w4[4];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int co = 32 * h + 8 * kb + 4 * hf + tq;
+                        const unsigned char *src = dimg + pc * (EC * 64) + co * 64 + 16 * (tslot ^ ((co >> 1) & 3)) + 8 * (tp >> 1);
+                        const s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)src);
+                        const uint2 u = __builtin_bit_cast(uint2, v);
+                        w4[2 * hf] = u.x; w4[2 * hf + 1] = u.y;
+                    }
+                    ap[pc] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
                 mac2(ap, b0, b1, e0, e1);
                 __builtin_amdgcn_sched_barrier(0);
             }
