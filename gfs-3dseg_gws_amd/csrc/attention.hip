@@ -4,12 +4,15 @@
 //     y    = attn v^T                                   -> (B, D, N) channel-first, D = 64
 //
 // The reference materialises the (B, N, N) score matrix three times (512 MiB each at B = 32, N = 2048).  Here a
-// wave owns 32 queries and streams over key tiles of 32 (flash-attention recurrence, fp32):
-//   S^T tile = K_tile Q^T on v_mfma_f32_32x32x2_f32 with the QUERY on the lane (C/D layout: column = query,
-//   registers = 16 keys per lane half) - the same orientation as the kNN kernel - so the running max / sum of a
-//   query, its dropout decisions and the rescaling of its output accumulators are in-lane work plus one
-//   cross-half shuffle per tile;   O^T += V^T P consumes the probabilities straight from the accumulator
-//   registers (register r of both lane halves = K index of one MFMA step), V from an LDS tile.
+// wave owns 32 queries and streams over key tiles of 32 (flash-attention recurrence, fp32 results):
+//   S^T tile = K_tile Q^T with the QUERY on the lane (C/D layout: column = query, registers = 16 keys per lane
+//   half) - the same orientation as the kNN kernel - so the running max / sum of a query, its dropout decisions
+//   and the rescaling of its output accumulators are in-lane work plus one cross-half shuffle per tile;
+//   O^T += V^T P consumes the probabilities straight from the accumulator registers (registers 8 s .. 8 s + 7 of
+//   both lane halves = the K index of MFMA step s), V^T from the staged tile through the transposed LDS read.
+// Arithmetic: bf16x6 on v_mfma_f32_32x32x16_bf16 (exact 3-way bf16 split of both operands, six piece products per
+// fp32 product - common.h): 48 MFMAs of 32 cycles per tile in the forward where the fp32 form (v_mfma_f32_32x32x2_f32)
+// took 64 of 64 cycles.
 // Dropout: keep(b, q, k) is a counter-based hash of (seed, b, q N + k), so the backward regenerates it; tests can
 // pass an explicit (B, N, N) byte mask instead.  The backward recomputes S and P from q, k and the saved
 // log-sum-exp (one kernel per side: dQ with the query on the lane, dK / dV with the key on the lane), no atomics.
@@ -50,59 +53,124 @@ struct AttnArgs {
     const uint8_t *mask;          // optional (B, N, N) keep mask
 };
 
-// stage a (64 channels x 32 positions) tile of a channel-first tensor: thread (pos = t & 31, c0 = t >> 5) holds rows c0 + 8p
-__device__ __forceinline__ void at_load(const float *base, int N, int p0, int t, float (&r)[8])
+// ---------------------------------------------------------------------------------------------------------
+// Operand images.  Every GEMM of the three kernels runs on v_mfma_f32_32x32x16_bf16 with both operands split exactly into
+// three bf16 pieces (six piece products = fp32 accuracy, common.h); a staged (32 positions x 64 channels) tile is split ONCE
+// per block while it is written to LDS as piece planes [plane][position][64 x bf16 | 16 B pad], and serves
+//   * as an A operand with rows = positions, k = channels   (ds_read_b128: lane (row j, half h) reads channels 16 kb + 8 h ..)
+//   * as an A operand with rows = channels, k = positions   (ds_read_b64_tr_b16, the hardware transpose read: no second image)
+// The B operand is always a register tile: the per-wave constant rows (q, dout / k, v: split once per wave) or a result of
+// the previous MFMA in its C/D layout (probabilities, dS) - k-step s takes registers 8 s .. 8 s + 7 of both lane halves, i.e.
+// positions at_drow(8 s + e, h), and the transposed read delivers the A operand in exactly that k order.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AT_PROW = 2 * AT_D + 16;             // bytes per position row of one piece plane
+constexpr int AT_PLANE = 32 * AT_PROW;
+typedef short at_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) at_s16x4 at_lds_s16x4;
+
+// thread (pos = t & 31, cg = t >> 5) stages channels 8 cg .. 8 cg + 7 of position p0 + pos (clamped: a tile past N repeats
+// the last position, whose scores are masked)
+__device__ __forceinline__ void at_load8(const float *base, int N, int p0, int t, float (&r)[8])
 {
-    const int pos = min(p0 + (t & 31), N - 1), c0 = t >> 5;
+    const int pos = min(p0 + (t & 31), N - 1), c0 = 8 * (t >> 5);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) r[p] = base[(size_t)(c0 + 8 * p) * N + pos];
+    for (int e = 0; e < 8; ++e) r[e] = base[(size_t)(c0 + e) * N + pos];
 }
-__device__ __forceinline__ void at_put_cf(float (*dst)[32], int t, const float (&r)[8], float s)      // [c][pos]
+template <int PREC>
+__device__ __forceinline__ void at_put(unsigned char *img, int t, const float (&r)[8], float s)
 {
+    float v[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dst[(t >> 5) + 8 * p][t & 31] = r[p] * s;
+    for (int e = 0; e < 8; ++e) v[e] = r[e] * s;
+    uint4 pc[Mx<PREC>::NP];
+    mm_pieces8<PREC>(v, pc);
+#pragma unroll
+    for (int p = 0; p < Mx<PREC>::NP; ++p) *reinterpret_cast<uint4 *>(img + p * AT_PLANE + (t & 31) * AT_PROW + 16 * (t >> 5)) = pc[p];
 }
-__device__ __forceinline__ void at_put_pm(float (*dst)[AT_D + 1], int t, const float (&r)[8], float s)  // [pos][c]
+// rows = positions: lane (row j, half h), K-block kb -> channels 16 kb + 8 h + e
+template <int PREC>
+__device__ __forceinline__ void at_rowfrag(const unsigned char *img, int j, int h, int kb, uint4 (&f)[Mx<PREC>::NP])
 {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dst[t & 31][(t >> 5) + 8 * p] = r[p] * s;
+    for (int p = 0; p < Mx<PREC>::NP; ++p) f[p] = *reinterpret_cast<const uint4 *>(img + p * AT_PLANE + j * AT_PROW + 32 * kb + 16 * h);
+}
+// rows = channels 32 dt + (lane & 31), k-step s: positions at_drow(8 s + e, h) = 16 s + 8 (e >> 2) + 4 h + (e & 3).  Two
+// transposed reads of 4 position rows each: in its 16-lane group, lane 4 q + p supplies the address of row q, channels
+// 16 (group & 1) + 4 p .. + 3, and receives the 4 rows of its own channel.  EXEC must be all ones here.
+template <int PREC>
+__device__ __forceinline__ void at_trfrag(const unsigned char *img, int lane, int dt, int s, uint4 (&f)[Mx<PREC>::NP])
+{
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p4 = lane & 3;
+    const unsigned char *base = img + (16 * s + 4 * h + q) * AT_PROW + 2 * (32 * dt + 16 * g1 + 4 * p4);
+#pragma unroll
+    for (int p = 0; p < Mx<PREC>::NP; ++p) {
+        const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4 *)(base + p * AT_PLANE));
+        const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_s16x4 *)(base + p * AT_PLANE + 8 * AT_PROW));
+        const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+        f[p] = make_uint4(a.x, a.y, b.x, b.y);
+    }
+}
+// the per-wave constant operand: lane (column j, half h) holds channels 16 kb + 8 h + e of its position, times s
+template <int PREC>
+__device__ __forceinline__ void at_colfrags(const float *base, int N, int pos, int h, float s, uint4 (&f)[4][Mx<PREC>::NP])
+{
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = base[(size_t)(16 * kb + 8 * h + e) * N + pos] * s;
+        mm_pieces8<PREC>(v, f[kb]);
+    }
+}
+template <int PREC>
+__device__ __forceinline__ void at_regfrag(const float (&v)[16], int s, uint4 (&f)[Mx<PREC>::NP])
+{
+    float v8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v8[e] = v[8 * s + e];
+    mm_pieces8<PREC>(v8, f);
 }
 
 // ------------------------------------------------------------------ forward
-template <bool HAS_MASK>
+template <bool HAS_MASK, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, float *__restrict__ out, float *__restrict__ lse)
 {
-    __shared__ float Ks[2][AT_D][32];          // [c][key]
-    __shared__ float Vs[2][32][AT_D + 1];      // [key][d]
+    constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
+    unsigned char *Kimg = at_smem, *Vimg = at_smem + 2 * IMG;          // [2 buffers] each
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, N = g.N, q0 = blockIdx.x * 128 + wv * 32;
-    const float *qb = g.q + (size_t)b * AT_D * N, *kb = g.k + (size_t)b * AT_D * N, *vb = g.v + (size_t)b * AT_D * N;
+    const float *qb = g.q + (size_t)b * AT_D * N, *kb_ = g.k + (size_t)b * AT_D * N, *vb = g.v + (size_t)b * AT_D * N;
     const int qi = min(q0 + j, N - 1);
     const unsigned sb = at_seed(g.seed, b);
     const bool drop = HAS_MASK || g.thresh != 0u;
-    float qreg[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) qreg[s] = qb[(size_t)(2 * s + h) * N + qi] * g.scale;
+    uint4 qp[4][NP];
+    at_colfrags<PREC>(qb, N, qi, h, g.scale, qp);
     float m = -__builtin_inff(), l = 0.f;
     f32x16 O0, O1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
 
     float rk[8], rv[8];
-    at_load(kb, N, 0, t, rk);
-    at_load(vb, N, 0, t, rv);
-    at_put_cf(Ks[0], t, rk, 1.f);
-    at_put_pm(Vs[0], t, rv, 1.f);
+    at_load8(kb_, N, 0, t, rk);
+    at_load8(vb, N, 0, t, rv);
+    at_put<PREC>(Kimg, t, rk, 1.f);
+    at_put<PREC>(Vimg, t, rv, 1.f);
     __syncthreads();
     const int nt = (N + 31) / 32;
     for (int tt = 0; tt < nt; ++tt) {
         const int cur = tt & 1, j0 = tt * 32;
-        if (tt + 1 < nt) { at_load(kb, N, j0 + 32, t, rk); at_load(vb, N, j0 + 32, t, rv); }
-        f32x16 acc;
+        const unsigned char *Kc = Kimg + cur * IMG, *Vc = Vimg + cur * IMG;
+        if (tt + 1 < nt) { at_load8(kb_, N, j0 + 32, t, rk); at_load8(vb, N, j0 + 32, t, rv); }
+        f32x16 acc;                                        // S^T tile: rows = keys, column = the lane's query
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[cur][2 * s + h][j], qreg[s], acc, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+            uint4 ak[NP];
+            at_rowfrag<PREC>(Kc, j, h, kb, ak);
+            mm_mac<PREC>(ak, qp[kb], acc);
+        }
         float tmax = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -131,13 +199,17 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, floa
                 pd[r] = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, key, N) ? pd[r] * g.inv_keep : 0.f;
             }
         }
+        // O^T += V^T P: rows = output channels (two tiles of 32), k = keys, B = the probabilities as they sit in the registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = at_drow(r, h);
-            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][row][j], pd[r], O0, 0, 0, 0);
-            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[cur][row][32 + j], pd[r], O1, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+            uint4 pp[NP], av[NP];
+            at_regfrag<PREC>(pd, s, pp);
+            at_trfrag<PREC>(Vc, lane, 0, s, av);
+            mm_mac<PREC>(av, pp, O0);
+            at_trfrag<PREC>(Vc, lane, 1, s, av);
+            mm_mac<PREC>(av, pp, O1);
         }
-        if (tt + 1 < nt) { at_put_cf(Ks[cur ^ 1], t, rk, 1.f); at_put_pm(Vs[cur ^ 1], t, rv, 1.f); }
+        if (tt + 1 < nt) { at_put<PREC>(Kimg + (cur ^ 1) * IMG, t, rk, 1.f); at_put<PREC>(Vimg + (cur ^ 1) * IMG, t, rv, 1.f); }
         __syncthreads();
     }
     if (q0 + j < N) {
@@ -166,47 +238,48 @@ __global__ void __launch_bounds__(256) attn_bwd_D_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------ backward, query side: dQ
-template <bool HAS_MASK>
+template <bool HAS_MASK, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, float *__restrict__ dq)
 {
-    extern __shared__ float at_smem[];
-    float (*Kc)[AT_D][32] = reinterpret_cast<float (*)[AT_D][32]>(at_smem);                              // [2][c][key]
-    float (*Vc)[AT_D][32] = reinterpret_cast<float (*)[AT_D][32]>(at_smem + 2 * AT_D * 32);               // [2][c][key]
-    float (*Km)[32][AT_D + 1] = reinterpret_cast<float (*)[32][AT_D + 1]>(at_smem + 4 * AT_D * 32);       // [2][key][d]
+    constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
+    unsigned char *Kimg = at_smem, *Vimg = at_smem + 2 * IMG;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, N = g.N, q0 = blockIdx.x * 128 + wv * 32;
     const size_t boff = (size_t)b * AT_D * N;
-    const float *kb = g.k + boff, *vb = g.v + boff;
+    const float *kb_ = g.k + boff, *vb = g.v + boff;
     const int qi = min(q0 + j, N - 1);
     const unsigned sb = at_seed(g.seed, b);
     const bool drop = HAS_MASK || g.thresh != 0u;
-    float qreg[32], doreg[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        qreg[s] = g.q[boff + (size_t)(2 * s + h) * N + qi] * g.scale;
-        doreg[s] = g.dout[boff + (size_t)(2 * s + h) * N + qi];
-    }
+    uint4 qp[4][NP], gp[4][NP];
+    at_colfrags<PREC>(g.q + boff, N, qi, h, g.scale, qp);
+    at_colfrags<PREC>(g.dout + boff, N, qi, h, 1.f, gp);
     const float Lq = g.lse[(size_t)b * N + qi], Dv = g.Dq[(size_t)b * N + qi];
     f32x16 G0, G1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { G0[r] = 0.f; G1[r] = 0.f; }
 
     float rk[8], rv[8];
-    at_load(kb, N, 0, t, rk);
-    at_load(vb, N, 0, t, rv);
-    at_put_cf(Kc[0], t, rk, 1.f); at_put_pm(Km[0], t, rk, 1.f); at_put_cf(Vc[0], t, rv, 1.f);
+    at_load8(kb_, N, 0, t, rk);
+    at_load8(vb, N, 0, t, rv);
+    at_put<PREC>(Kimg, t, rk, 1.f);
+    at_put<PREC>(Vimg, t, rv, 1.f);
     __syncthreads();
     const int nt = (N + 31) / 32;
     for (int tt = 0; tt < nt; ++tt) {
         const int cur = tt & 1, j0 = tt * 32;
-        if (tt + 1 < nt) { at_load(kb, N, j0 + 32, t, rk); at_load(vb, N, j0 + 32, t, rv); }
-        f32x16 acc, dp;
+        const unsigned char *Kc = Kimg + cur * IMG, *Vc = Vimg + cur * IMG;
+        if (tt + 1 < nt) { at_load8(kb_, N, j0 + 32, t, rk); at_load8(vb, N, j0 + 32, t, rv); }
+        f32x16 acc, dp;                                    // S^T and dP^T tiles: rows = keys, column = the lane's query
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kc[cur][2 * s + h][j], qreg[s], acc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[cur][2 * s + h][j], doreg[s], dp, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+            uint4 ak[NP], av[NP];
+            at_rowfrag<PREC>(Kc, j, h, kb, ak);
+            at_rowfrag<PREC>(Vc, j, h, kb, av);
+            mm_mac<PREC>(ak, qp[kb], acc);
+            mm_mac<PREC>(av, gp[kb], dp);
         }
         float ds[16];
 #pragma unroll
@@ -217,13 +290,17 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
             if (drop) dpv = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, min(key, N - 1), N) ? dpv * g.inv_keep : 0.f;
             ds[r] = p * (dpv - Dv);
         }
+        // dQ^T += K^T dS: rows = channels, k = keys
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = at_drow(r, h);
-            G0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Km[cur][row][j], ds[r], G0, 0, 0, 0);
-            G1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Km[cur][row][32 + j], ds[r], G1, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+            uint4 dsp[NP], ak[NP];
+            at_regfrag<PREC>(ds, s, dsp);
+            at_trfrag<PREC>(Kc, lane, 0, s, ak);
+            mm_mac<PREC>(ak, dsp, G0);
+            at_trfrag<PREC>(Kc, lane, 1, s, ak);
+            mm_mac<PREC>(ak, dsp, G1);
         }
-        if (tt + 1 < nt) { at_put_cf(Kc[cur ^ 1], t, rk, 1.f); at_put_pm(Km[cur ^ 1], t, rk, 1.f); at_put_cf(Vc[cur ^ 1], t, rv, 1.f); }
+        if (tt + 1 < nt) { at_put<PREC>(Kimg + (cur ^ 1) * IMG, t, rk, 1.f); at_put<PREC>(Vimg + (cur ^ 1) * IMG, t, rv, 1.f); }
         __syncthreads();
     }
     if (q0 + j < N) {
@@ -237,15 +314,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
 }
 
 // ------------------------------------------------------------------ backward, key side: dK, dV
-template <bool HAS_MASK>
+template <bool HAS_MASK, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, float *__restrict__ dk, float *__restrict__ dv)
 {
-    extern __shared__ float at_smem[];
-    float (*Qc)[AT_D][32] = reinterpret_cast<float (*)[AT_D][32]>(at_smem);                               // [2][c][query]  (scaled)
-    float (*Gc)[AT_D][32] = reinterpret_cast<float (*)[AT_D][32]>(at_smem + 2 * AT_D * 32);                // [2][c][query]  dout
-    float (*Qm)[32][AT_D + 1] = reinterpret_cast<float (*)[32][AT_D + 1]>(at_smem + 4 * AT_D * 32);        // [2][query][d] (scaled)
-    float (*Gm)[32][AT_D + 1] = reinterpret_cast<float (*)[32][AT_D + 1]>(at_smem + 4 * AT_D * 32 + 2 * 32 * (AT_D + 1));
-    float (*Ls)[32] = reinterpret_cast<float (*)[32]>(at_smem + 4 * AT_D * 32 + 4 * 32 * (AT_D + 1));       // [2][32]
+    constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
+    unsigned char *Qimg = at_smem, *Gimg = at_smem + 2 * IMG;                  // queries (scaled) and dout, [2 buffers] each
+    float (*Ls)[32] = reinterpret_cast<float (*)[32]>(at_smem + 4 * IMG);       // [2][32]
     float (*Ds)[32] = Ls + 2;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, j = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, N = g.N, k0 = blockIdx.x * 128 + wv * 32;
@@ -255,37 +330,38 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
     const bool kvalid = k0 + j < N;
     const unsigned sb = at_seed(g.seed, b);
     const bool drop = HAS_MASK || g.thresh != 0u;
-    float kreg[32], vreg[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        kreg[s] = g.k[boff + (size_t)(2 * s + h) * N + ki];
-        vreg[s] = g.v[boff + (size_t)(2 * s + h) * N + ki];
-    }
+    uint4 kp[4][NP], vp[4][NP];
+    at_colfrags<PREC>(g.k + boff, N, ki, h, 1.f, kp);
+    at_colfrags<PREC>(g.v + boff, N, ki, h, 1.f, vp);
     f32x16 K0, K1, V0, V1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { K0[r] = 0.f; K1[r] = 0.f; V0[r] = 0.f; V1[r] = 0.f; }
 
     float rq[8], rg[8];
     auto put = [&](int buf, int p0) {
-        at_put_cf(Qc[buf], t, rq, g.scale); at_put_pm(Qm[buf], t, rq, g.scale);
-        at_put_cf(Gc[buf], t, rg, 1.f); at_put_pm(Gm[buf], t, rg, 1.f);
+        at_put<PREC>(Qimg + buf * IMG, t, rq, g.scale);
+        at_put<PREC>(Gimg + buf * IMG, t, rg, 1.f);
         if (t < 32) { const int qq = min(p0 + t, N - 1); Ls[buf][t] = g.lse[(size_t)b * N + qq]; Ds[buf][t] = g.Dq[(size_t)b * N + qq]; }
     };
-    at_load(qb, N, 0, t, rq);
-    at_load(gb, N, 0, t, rg);
+    at_load8(qb, N, 0, t, rq);
+    at_load8(gb, N, 0, t, rg);
     put(0, 0);
     __syncthreads();
     const int nt = (N + 31) / 32;
     for (int tt = 0; tt < nt; ++tt) {
         const int cur = tt & 1, p0 = tt * 32;
-        if (tt + 1 < nt) { at_load(qb, N, p0 + 32, t, rq); at_load(gb, N, p0 + 32, t, rg); }
-        f32x16 acc, dp;
+        const unsigned char *Qc = Qimg + cur * IMG, *Gc = Gimg + cur * IMG;
+        if (tt + 1 < nt) { at_load8(qb, N, p0 + 32, t, rq); at_load8(gb, N, p0 + 32, t, rg); }
+        f32x16 acc, dp;                                    // S and dP tiles: rows = queries, column = the lane's key
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qc[cur][2 * s + h][j], kreg[s], acc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Gc[cur][2 * s + h][j], vreg[s], dp, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb) {
+            uint4 aq[NP], ag[NP];
+            at_rowfrag<PREC>(Qc, j, h, kb, aq);
+            at_rowfrag<PREC>(Gc, j, h, kb, ag);
+            mm_mac<PREC>(aq, kp[kb], acc);
+            mm_mac<PREC>(ag, vp[kb], dp);
         }
         float pd[16], ds[16];
 #pragma unroll
@@ -302,13 +378,20 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
             pd[r] = pk;
             ds[r] = p * (dpv - Ds[cur][row]);
         }
+        // dV^T += dout^T P and dK^T += Q^T dS: rows = channels, k = queries
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = at_drow(r, h);
-            V0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Gm[cur][row][j], pd[r], V0, 0, 0, 0);
-            V1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Gm[cur][row][32 + j], pd[r], V1, 0, 0, 0);
-            K0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Qm[cur][row][j], ds[r], K0, 0, 0, 0);
-            K1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Qm[cur][row][32 + j], ds[r], K1, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+            uint4 bp[NP], af[NP];
+            at_regfrag<PREC>(pd, s, bp);
+            at_trfrag<PREC>(Gc, lane, 0, s, af);
+            mm_mac<PREC>(af, bp, V0);
+            at_trfrag<PREC>(Gc, lane, 1, s, af);
+            mm_mac<PREC>(af, bp, V1);
+            at_regfrag<PREC>(ds, s, bp);
+            at_trfrag<PREC>(Qc, lane, 0, s, af);
+            mm_mac<PREC>(af, bp, K0);
+            at_trfrag<PREC>(Qc, lane, 1, s, af);
+            mm_mac<PREC>(af, bp, K1);
         }
         if (tt + 1 < nt) put(cur ^ 1, p0 + 32);
         __syncthreads();
@@ -334,8 +417,8 @@ __global__ void __launch_bounds__(256) attn_mask_kernel(int B, int N, unsigned t
     mask[e] = at_hash(qk ^ at_seed(seed, b)) >= thresh ? 1 : 0;
 }
 
-constexpr size_t AT_DQ_LDS = sizeof(float) * (4 * AT_D * 32 + 2 * 32 * (AT_D + 1));
-constexpr size_t AT_DKV_LDS = sizeof(float) * (4 * AT_D * 32 + 4 * 32 * (AT_D + 1) + 4 * 32);
+constexpr size_t AT_LDS = 4 * 3 * AT_PLANE;                          // two double-buffered tile images of three piece planes
+constexpr size_t AT_DKV_LDS = AT_LDS + sizeof(float) * 4 * 32;
 
 int at_check(const char *who, const float *q, const float *k, const float *v, int B, int D, int N, float p_drop)
 {
@@ -374,8 +457,8 @@ extern "C" int gfs3d_attention_forward_f32(const float *q, const float *k, const
     const AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
     dim3 grid((N + 127) / 128, B);
     ProfScope prof(8, st);
-    if (keep_mask) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, st, a, out, lse);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, st, a, out, lse);
+    if (keep_mask) hipLaunchKernelGGL((attn_fwd_kernel<true, PREC_X6>), grid, dim3(256), AT_LDS, st, a, out, lse);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, PREC_X6>), grid, dim3(256), AT_LDS, st, a, out, lse);
     GFS3D_LAUNCH_CHECK("attn_fwd_kernel");
     return GFS3D_OK;
 }
@@ -390,18 +473,16 @@ extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
     a.out = out; a.lse = lse; a.dout = dout; a.Dq = workspace;
-    GFS3D_ENSURE_LDS(attn_bwd_dkv_kernel<true>, AT_DKV_LDS, who);
-    GFS3D_ENSURE_LDS(attn_bwd_dkv_kernel<false>, AT_DKV_LDS, who);
     ProfScope prof(9, st);
     hipLaunchKernelGGL(attn_bwd_D_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, dout, out, N, workspace);
     GFS3D_LAUNCH_CHECK("attn_bwd_D_kernel");
     dim3 grid((N + 127) / 128, B);
     if (keep_mask) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), AT_DQ_LDS, st, a, dq);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, PREC_X6>), grid, dim3(256), AT_LDS, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, PREC_X6>), grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), AT_DQ_LDS, st, a, dq);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<false, PREC_X6>), grid, dim3(256), AT_LDS, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, PREC_X6>), grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
     }
     GFS3D_LAUNCH_CHECK("attn_bwd kernels");
     return GFS3D_OK;
