@@ -417,8 +417,6 @@ __global__ void __launch_bounds__(256) attn_mask_kernel(int B, int N, unsigned t
     mask[e] = at_hash(qk ^ at_seed(seed, b)) >= thresh ? 1 : 0;
 }
 
-constexpr size_t AT_LDS = 4 * 3 * AT_PLANE;                          // two double-buffered tile images of three piece planes
-constexpr size_t AT_DKV_LDS = AT_LDS + sizeof(float) * 4 * 32;
 
 int at_check(const char *who, const float *q, const float *k, const float *v, int B, int D, int N, float p_drop)
 {
@@ -447,29 +445,65 @@ AttnArgs at_args(const float *q, const float *k, const float *v, int B, int N, f
 
 using namespace gfs3d;
 
-extern "C" int gfs3d_attention_forward_f32(const float *q, const float *k, const float *v, int B, int D, int N, float scale, float p_drop,
-                                           unsigned long long seed, const uint8_t *keep_mask, float *out, float *lse, void *stream)
+template <int PREC>
+static int at_forward(const AttnArgs &a, bool has_mask, dim3 grid, float *out, float *lse, hipStream_t st)
 {
-    const char *who = "gfs3d_attention_forward_f32";
-    if (int rc = at_check(who, q, k, v, B, D, N, p_drop)) return rc;
-    GFS3D_REQUIRE(out && lse, "%s: NULL output", who);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
-    dim3 grid((N + 127) / 128, B);
-    ProfScope prof(8, st);
-    if (keep_mask) hipLaunchKernelGGL((attn_fwd_kernel<true, PREC_X6>), grid, dim3(256), AT_LDS, st, a, out, lse);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, PREC_X6>), grid, dim3(256), AT_LDS, st, a, out, lse);
+    const size_t lds = 4 * Mx<PREC>::NP * AT_PLANE;
+    if (has_mask) hipLaunchKernelGGL((attn_fwd_kernel<true, PREC>), grid, dim3(256), lds, st, a, out, lse);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, PREC>), grid, dim3(256), lds, st, a, out, lse);
     GFS3D_LAUNCH_CHECK("attn_fwd_kernel");
     return GFS3D_OK;
 }
 
-extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, const float *v, const float *out, const float *lse,
-                                            const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
-                                            const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, void *stream)
+template <int PREC>
+static int at_backward(const AttnArgs &a, bool has_mask, dim3 grid, float *dq, float *dk, float *dv, hipStream_t st)
+{
+    const size_t lds = 4 * Mx<PREC>::NP * AT_PLANE;
+    if (has_mask) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, PREC>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<false, PREC>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+    }
+    GFS3D_LAUNCH_CHECK("attn_bwd kernels");
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_attention_forward_mixed(const float *q, const float *k, const float *v, int B, int D, int N, float scale, float p_drop,
+                                             unsigned long long seed, const uint8_t *keep_mask, float *out, float *lse, int compute,
+                                             void *stream)
+{
+    const char *who = "gfs3d_attention_forward_f32";
+    if (int rc = at_check(who, q, k, v, B, D, N, p_drop)) return rc;
+    GFS3D_REQUIRE(out && lse, "%s: NULL output", who);
+    GFS3D_REQUIRE(compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
+    dim3 grid((N + 127) / 128, B);
+    ProfScope prof(8, st);
+    if (compute == GFS3D_COMPUTE_BF16) return at_forward<PREC_BF16>(a, keep_mask != nullptr, grid, out, lse, st);
+    if (compute == GFS3D_COMPUTE_F16) return at_forward<PREC_F16>(a, keep_mask != nullptr, grid, out, lse, st);
+    return at_forward<PREC_X6>(a, keep_mask != nullptr, grid, out, lse, st);
+}
+
+extern "C" int gfs3d_attention_forward_f32(const float *q, const float *k, const float *v, int B, int D, int N, float scale, float p_drop,
+                                           unsigned long long seed, const uint8_t *keep_mask, float *out, float *lse, void *stream)
+{
+    return gfs3d_attention_forward_mixed(q, k, v, B, D, N, scale, p_drop, seed, keep_mask, out, lse, GFS3D_COMPUTE_F32, stream);
+}
+
+extern "C" int gfs3d_attention_backward_mixed(const float *q, const float *k, const float *v, const float *out, const float *lse,
+                                              const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
+                                              const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, int compute,
+                                              void *stream)
 {
     const char *who = "gfs3d_attention_backward_f32";
     if (int rc = at_check(who, q, k, v, B, D, N, p_drop)) return rc;
     GFS3D_REQUIRE(out && lse && dout && dq && dk && dv && workspace, "%s: NULL buffer", who);
+    GFS3D_REQUIRE(compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16,
+                  "%s: compute must be one of GFS3D_COMPUTE_*", who);
     hipStream_t st = static_cast<hipStream_t>(stream);
     AttnArgs a = at_args(q, k, v, B, N, scale, p_drop, seed, keep_mask);
     a.out = out; a.lse = lse; a.dout = dout; a.Dq = workspace;
@@ -477,15 +511,17 @@ extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, cons
     hipLaunchKernelGGL(attn_bwd_D_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, dout, out, N, workspace);
     GFS3D_LAUNCH_CHECK("attn_bwd_D_kernel");
     dim3 grid((N + 127) / 128, B);
-    if (keep_mask) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, PREC_X6>), grid, dim3(256), AT_LDS, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, PREC_X6>), grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
-    } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<false, PREC_X6>), grid, dim3(256), AT_LDS, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, PREC_X6>), grid, dim3(256), AT_DKV_LDS, st, a, dk, dv);
-    }
-    GFS3D_LAUNCH_CHECK("attn_bwd kernels");
-    return GFS3D_OK;
+    // (gradients never run on half operands: prec_of)
+    if (prec_of(compute, true) == PREC_BF16) return at_backward<PREC_BF16>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
+    return at_backward<PREC_X6>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
+}
+
+extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, const float *v, const float *out, const float *lse,
+                                            const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
+                                            const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, void *stream)
+{
+    return gfs3d_attention_backward_mixed(q, k, v, out, lse, dout, B, D, N, scale, p_drop, seed, keep_mask, dq, dk, dv, workspace,
+                                          GFS3D_COMPUTE_F32, stream);
 }
 
 extern "C" int gfs3d_attention_dropout_mask(int B, int N, float p_drop, unsigned long long seed, uint8_t *mask, void *stream)

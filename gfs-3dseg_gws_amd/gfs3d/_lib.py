@@ -135,6 +135,10 @@ SYMBOLS = {
     "gfs3d_attention_backward_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                              c_float, c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_attention_dropout_mask": (c_int, [c_int, c_int, c_float, c_ulonglong, c_void_p, c_void_p]),
+    "gfs3d_attention_forward_mixed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_ulonglong, c_void_p,
+                                              c_void_p, c_void_p, c_int, c_void_p]),
+    "gfs3d_attention_backward_mixed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                               c_float, c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gfs3d_word_assign_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_proto_cosine_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,

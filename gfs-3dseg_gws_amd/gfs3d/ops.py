@@ -720,12 +720,13 @@ class AttentionFunction(torch.autograd.Function):
         out = torch.empty_like(q)
         lse = torch.empty((B, N), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
-            rc = _lib.lib().gfs3d_attention_forward_f32(_p(q), _p(k), _p(v), B, D, N, float(scale), float(p_drop), int(seed),
-                                                        _p(keep_mask), _p(out), _p(lse), _stream())
-        _lib.check(rc, "gfs3d_attention_forward_f32")
+            rc = _lib.lib().gfs3d_attention_forward_mixed(_p(q), _p(k), _p(v), B, D, N, float(scale), float(p_drop), int(seed),
+                                                          _p(keep_mask), _p(out), _p(lse), _compute, _stream())
+        _lib.check(rc, "gfs3d_attention_forward_mixed")
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.mask = keep_mask
         ctx.cfg = (float(scale), float(p_drop), int(seed))
+        ctx.compute = _compute
         return out
 
     @staticmethod
@@ -737,9 +738,9 @@ class AttentionFunction(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
         ws = torch.empty((B, N), dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
-            rc = _lib.lib().gfs3d_attention_backward_f32(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), B, D, N, scale, p_drop, seed,
-                                                         _p(ctx.mask), _p(dq), _p(dk), _p(dv), _p(ws), _stream())
-        _lib.check(rc, "gfs3d_attention_backward_f32")
+            rc = _lib.lib().gfs3d_attention_backward_mixed(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(dout), B, D, N, scale, p_drop, seed,
+                                                           _p(ctx.mask), _p(dq), _p(dk), _p(dv), _p(ws), ctx.compute, _stream())
+        _lib.check(rc, "gfs3d_attention_backward_mixed")
         return dq, dk, dv, None, None, None, None
 
 

@@ -296,6 +296,15 @@ int gfs3d_attention_backward_f32(const float *q, const float *k, const float *v,
                                  const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
                                  const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, void *stream);
 int gfs3d_attention_dropout_mask(int B, int N, float p_drop, unsigned long long seed, uint8_t *mask, void *stream);
+/* The same with the operand precision of the matrix products chosen per call (GFS3D_COMPUTE_*; _f32 above = GFS3D_COMPUTE_F32:
+ * exact 3-way bf16 split, fp32 accuracy).  Scores, softmax, dropout and all accumulators stay fp32; the backward of an F16
+ * forward runs on bf16 operands. */
+int gfs3d_attention_forward_mixed(const float *q, const float *k, const float *v, int B, int D, int N, float scale, float p_drop,
+                                  unsigned long long seed, const uint8_t *keep_mask, float *out, float *lse, int compute, void *stream);
+int gfs3d_attention_backward_mixed(const float *q, const float *k, const float *v, const float *out, const float *lse,
+                                   const float *dout, int B, int D, int N, float scale, float p_drop, unsigned long long seed,
+                                   const uint8_t *keep_mask, float *dq, float *dk, float *dv, float *workspace, int compute,
+                                   void *stream);
 
 /* ------------------------------------------------------------------ K3 --
  * Point x prototype cosine matching on MFMA (fp32-in / fp32-acc).

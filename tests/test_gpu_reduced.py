@@ -152,6 +152,32 @@ def test_word_assign_reduced_vs_oracle(dev, mode, B, C, N, Kw):
     assert cosine(fd.grad, fr.grad) > KERNEL_COS[mode]
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("B,N,p_drop", [(2, 300, 0.0), (1, 1024, 0.1)])
+def test_attention_reduced_vs_fp64(dev, mode, B, N, p_drop):
+    """K5 in a reduced mode (q, k, v, probabilities and gradients enter the matrix cores as one 16-bit operand; scores,
+    softmax and accumulators fp32) against torch in fp64 with the same dropout mask: output within 1e-3 / 1e-2 of its max,
+    gradient directions >= 0.999 / 0.99."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(N)
+    q, k, v = (torch.randn(B, 64, N, generator=g) for _ in range(3))
+    cot = torch.randn(B, 64, N, generator=g)
+    keep = (torch.rand(B, N, N, generator=g) >= p_drop) if p_drop > 0 else None
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    att = torch.softmax(torch.bmm(q64.transpose(1, 2), k64) / 8.0, dim=-1)
+    if keep is not None:
+        att = att * keep.double() / (1.0 - p_drop)
+    ref = torch.bmm(att, v64.transpose(1, 2)).transpose(1, 2)
+    ref.backward(cot.double())
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    with ops.compute(mode):
+        y = ops.attention(qd, kd, vd, 1.0 / 8.0, p_drop, 0, keep.to(dev) if keep is not None else None)
+        y.backward(cot.to(dev))
+    assert relmax(y, ref) < FWD_TOL[mode]
+    for a_, b_ in ((qd, q64), (kd, k64), (vd, v64)):
+        assert cosine(a_.grad, b_.grad) > KERNEL_COS[mode]
+
+
 def _capl(g, dev, classes, base):
     from model.capl import mpti_net_Point_GeoAsWeight_v2
     a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
