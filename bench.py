@@ -56,7 +56,7 @@ WORKLOADS = {
 }
 
 
-def algorithmic_flops(kid, B):
+def algorithmic_flops(kid, B, cfg=None):
     """Algorithmic flops of ONE step's launches of kernel `kid` (SURVEY.md 8(d) figures):
     kNN layer: 2 N^2 C + 3 N^2 per block; conv2 of an EdgeConv layer: N k 2*64*64 per block
     forward, 2x that (dgrad + wgrad) backward.  Returns (flops_per_step, launches_per_step)."""
@@ -68,6 +68,8 @@ def algorithmic_flops(kid, B):
     if kid == 2:
         return B * 3 * N * k * 2 * (2 * 64 * 64), 3
     mlp = 2 * (192 * 512 + 512 * 256)          # point-wise stack 192 -> 512 -> 256, flops per point (forward)
+    if cfg is not None and cfg.get("model") == "capl":      # + BaseLearner 256 -> 128 -> 64, q|k|v 256 -> 192, fusion (K_w + 192) -> 128
+        mlp += 2 * (256 * 128 + 128 * 64) + 2 * 256 * 192 + 2 * (cfg["Kw"] + 192) * 128
     if kid == 6:
         return B * N * mlp, 1
     if kid == 7:
@@ -265,8 +267,11 @@ def extras(dev, L, gdist):
         if kid in prof:
             ms = prof[kid][0] / prof[kid][1]
             fl = algorithmic_flops(kid, B)[0]
-            out[key] = {"shape": "B=32x2048, d=64, dropout 0.1", "ms": round(ms, 4), "bound": "mfma (fp32)",
-                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2), "frac": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4)}
+            # fp32 results on the bf16 matrix cores (6 piece products per fp32 product): roof = dense bf16 peak / 6
+            out[key] = {"shape": "B=32x2048, d=64, dropout 0.1", "ms": round(ms, 4), "bound": "mfma (bf16x6: dense bf16 peak / 6)",
+                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2), "peak": round(PEAK_16BIT_TFLOPS / 6, 1),
+                        "frac": round(fl / ms / 1e9 / (PEAK_16BIT_TFLOPS / 6), 4),
+                        "frac_of_fp32_peak": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4)}
     del q, k_, v, cot
     for name in ("c4", "c5"):
         cfg = WORKLOADS[name]
@@ -394,7 +399,7 @@ def main():
         roof["per_kernel_ms_per_step"] = {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}
         for kid in (6, 7, 8, 9):
             if kid in prof:
-                fl, _ = algorithmic_flops(kid, B)
+                fl, _ = algorithmic_flops(kid, B, cfg)
                 roof[KERNELS[kid]] = {"ms_per_step": round(prof[kid][0] / args.steps, 4),
                                       "algorithmic_TFLOPps": round(fl / (prof[kid][0] / args.steps * 1e-3) / 1e12, 2)}
         if 0 in prof:       # "kNN HBM GB/s" of the metric: algorithmic bytes 4CN + 8Nk per block and layer

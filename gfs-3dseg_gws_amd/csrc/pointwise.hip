@@ -1300,6 +1300,7 @@ extern "C" int gfs3d_linear_forward_f32(const float *x_pm, int B, int N, int K, 
     GFS3D_REQUIRE(y_cf, "%s: NULL y_cf", who);
     for (int s = 0; s < Nc / 64; ++s) GFS3D_REQUIRE(y_cf[s], "%s: NULL y_cf[%d]", who, s);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(6, st);
     const LinPlan p = lin_plan(B, N, K, Nc);
     char *ws = static_cast<char *>(workspace);
     RowGemm rg{};
@@ -1319,6 +1320,7 @@ extern "C" int gfs3d_linear_backward_f32(const float *x_pm, int B, int N, int K,
     if (int rc = lin_check(x_pm, B, N, K, w, Nc, workspace, workspace_bytes, compute, who)) return rc;
     GFS3D_REQUIRE(dy_cf && dx_pm && dw, "%s: NULL pointer", who);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(7, st);
     const LinPlan p = lin_plan(B, N, K, Nc);
     char *ws = static_cast<char *>(workspace);
     float *dy = reinterpret_cast<float *>(ws + p.off_dy);
