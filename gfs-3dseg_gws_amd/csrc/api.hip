@@ -7,6 +7,8 @@
 #include "common.h"
 
 namespace gfs3d {
+bool g_deterministic = false;
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char *fmt, ...)

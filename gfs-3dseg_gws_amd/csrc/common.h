@@ -13,6 +13,7 @@ namespace gfs3d {
 constexpr int WAVE = 64;
 
 void set_error(const char *fmt, ...);
+extern bool g_deterministic;      // gfs3d_set_deterministic: ordered reductions instead of fp64 atomics (api.hip)
 
 // measurement hooks (api.hip): no-ops unless gfs3d_profile_enable(1)
 int prof_begin(int kernel_id, hipStream_t st);

@@ -1595,7 +1595,6 @@ extern "C" size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k)
 }
 
 namespace gfs3d {
-static bool g_deterministic = false;
 // after a producer launched with `nblocks` blocks: in ordered mode add its partial rows into acc[0:128] in a fixed order
 static int bn_finish(const BnAcc &ba, int nblocks, hipStream_t st, double *mid)
 {

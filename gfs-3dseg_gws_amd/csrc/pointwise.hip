@@ -44,7 +44,8 @@ struct RowGemm {
     int npts;
     const float *ea, *eb;     // epilogue scale / shift per output channel
     const float *eh;          // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc)
-    double *acc;              // (2, Nc) column sums
+    double *acc;              // (2, Nc) column sums (fp64 atomics) ...
+    double *acc_rows;         // ... or, deterministic mode: [row block][2][Nc] partial sums, added in order by pw_colsum_reduce_kernel
     int prec;                 // PREC_* of the bf16-pipe kernel (common.h)
 };
 
@@ -141,7 +142,8 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
             double sum = 0.0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) sum += red[(q * 2 + which) * 128 + col];
-            atomicAdd(&g.acc[which * g.Nc + col0 + col], sum);
+            if (g.acc_rows) g.acc_rows[((size_t)(row0 / PW_BM) * 2 + which) * g.Nc + col0 + col] = sum;
+            else atomicAdd(&g.acc[which * g.Nc + col0 + col], sum);
         }
         return;
     }
@@ -191,7 +193,8 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) s += red[((m * TN + j) * 2 + which) * 32 + i];
             }
-            atomicAdd(&g.acc[which * g.Nc + col0 + col], s);
+            if (g.acc_rows) g.acc_rows[((size_t)(row0 / PW_BM) * 2 + which) * g.Nc + col0 + col] = s;
+            else atomicAdd(&g.acc[which * g.Nc + col0 + col], s);
         }
     }
 }
@@ -458,7 +461,8 @@ struct WGrad {
     const float *va, *vb;     // PRO_BNACT per-Ci scale / shift
     float slope;
     int M, Co, Ci, rows_per_split, nsplit;
-    float *dw;                // (Co, Ci) zeroed by the launcher, accumulated with fp32 atomics
+    float *dw;                // (Co, Ci)
+    float *part;              // [nsplit][Co][Ci] partial products of the point splits, added in split order by pw_wgrad_reduce_kernel
     int prec;                 // PREC_X6 or PREC_BF16 (gradients: no half operands)
 };
 
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * (BMU / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int ci = ci0 + wn * (BNV / 2) + j * 32 + li;
-                atomicAdd(&g.dw[(size_t)co * g.Ci + ci], acc[i][j][r]);
+                g.part[((size_t)split * g.Co + co) * g.Ci + ci] = acc[i][j][r];
             }
 }
 
@@ -654,7 +658,8 @@ pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int 
 constexpr int PW_IN_TILES = 4;
 __global__ void __launch_bounds__(256)
 pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_pm, const float *__restrict__ h,
-                 const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ gout, double *__restrict__ acc)
+                 const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ gout, double *__restrict__ acc,
+                 double *__restrict__ acc_rows)
 {
     __shared__ float tile[64][65];
     __shared__ float red[4][2][64];
@@ -699,8 +704,37 @@ pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_p
     if (tid < 128) {
         const int which = tid >> 6;
         const float tsum = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-        atomicAdd(&acc[which * C + c0 + c], (double)tsum);
+        if (acc_rows) acc_rows[((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 2 + which) * C + c0 + c] = (double)tsum;
+        else atomicAdd(&acc[which * C + c0 + c], (double)tsum);
     }
+}
+
+// deterministic mode: acc[e] = sum over the partial rows in index order, e < 2 C
+__global__ void __launch_bounds__(256)
+pw_colsum_reduce_kernel(const double *__restrict__ rows, int nrows, int C2, double *__restrict__ acc)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C2) return;
+    double s = 0.0;
+    for (int r = 0; r < nrows; ++r) s += rows[(size_t)r * C2 + e];
+    acc[e] = s;
+}
+
+// dW[e] = sum over the point splits in split order (a fixed order: the weight gradient is reproducible bit for bit)
+__global__ void __launch_bounds__(256)
+pw_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int n, float *__restrict__ dw)
+{
+    const int e = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (e >= n) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (; q + 4 <= nsplit; q += 4) {                         // four loads in flight, added in order
+        const f32x4 a = ldg4(part + (size_t)q * n + e), b = ldg4(part + (size_t)(q + 1) * n + e);
+        const f32x4 c = ldg4(part + (size_t)(q + 2) * n + e), d = ldg4(part + (size_t)(q + 3) * n + e);
+        s = (((s + a) + b) + c) + d;
+    }
+    for (; q < nsplit; ++q) s = s + ldg4(part + (size_t)q * n + e);
+    *reinterpret_cast<f32x4 *>(dw + e) = s;
 }
 
 // batch statistics -> (scale, shift, mean, rstd) and the running-statistics update of nn.BatchNorm1d
@@ -790,33 +824,61 @@ int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
     return launch_rowgemm<64, PRO, EPI, OUT_CF>(rg, st, who);
 }
 
+// split-K geometry of a weight-gradient GEMM: tile (bmu x bnv), point splits of `rows` rows (a multiple of 32)
+struct WgGeo { int bmu, bnv, nsplit, rows; };
+WgGeo wg_geo(int M, int Co, int Ci, bool allow192)
+{
+    WgGeo g{};
+    g.bmu = Co % 128 == 0 ? 128 : 64;
+    g.bnv = (allow192 && Ci == 192) ? 192 : (Ci % 128 == 0 ? 128 : 64);
+    const size_t lds = (size_t)(g.bmu + g.bnv) * PW6_ROW;
+    const int ntile = (Co / g.bmu) * (Ci / g.bnv);
+    // 2-3 blocks per CU; every split ends in a bmu x bnv partial tile, so no more splits than that
+    int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;
+    int rows = (M + nsplit - 1) / nsplit;
+    rows = (rows + 31) / 32 * 32;
+    if (rows < 256) rows = 256;
+    g.rows = rows;
+    g.nsplit = (M + rows - 1) / rows;
+    return g;
+}
+size_t wg_part_bytes(int M, int Co, int Ci, bool allow192)
+{
+    return sizeof(float) * (size_t)wg_geo(M, Co, Ci, allow192).nsplit * Co * Ci;
+}
+
 template <int BMU, int BNV, int VPRO>
-int launch_wgrad_t(WGrad wg, hipStream_t st, const char *who)
+int launch_wgrad_t(WGrad wg, const WgGeo &geo, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
     if (wg.prec != PREC_X6) GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), lds, who);
     else GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), lds, who);
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
-    // 2-3 blocks per CU; every split ends in BMU x BNV float atomics, so no more splits than that. A split is a multiple of 32 points
-    int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;
-    int rows = (wg.M + nsplit - 1) / nsplit;
-    rows = (rows + 31) / 32 * 32;
-    if (rows < 256) rows = 256;
-    nsplit = (wg.M + rows - 1) / rows;
-    wg.rows_per_split = rows;
-    wg.nsplit = nsplit;
-    const unsigned grid = 8u * ntile * ((nsplit + 7) / 8);
+    wg.rows_per_split = geo.rows;
+    wg.nsplit = geo.nsplit;
+    const unsigned grid = 8u * ntile * ((geo.nsplit + 7) / 8);
     if (wg.prec != PREC_X6) hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), dim3(grid), dim3(256), lds, st, wg);
     else hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), dim3(grid), dim3(256), lds, st, wg);
     GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
+    const int n = wg.Co * wg.Ci;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, wg.part, geo.nsplit, n, wg.dw);
+    GFS3D_LAUNCH_CHECK("pw_wgrad_reduce_kernel");
     return GFS3D_OK;
 }
 
-template <int BNV, int VPRO>
-int launch_wgrad(const WGrad &wg, hipStream_t st, const char *who)
+// dW = T(U)^T T(V) with the tile shape wg_geo() picks; VPRO = the prologue of V
+template <int VPRO>
+int wgrad(const WGrad &wg, bool allow192, hipStream_t st, const char *who)
 {
-    if (wg.Co % 128 == 0) return launch_wgrad_t<128, BNV, VPRO>(wg, st, who);
-    return launch_wgrad_t<64, BNV, VPRO>(wg, st, who);
+    const WgGeo geo = wg_geo(wg.M, wg.Co, wg.Ci, allow192);
+    if (geo.bmu == 128) {
+        if constexpr (VPRO == PRO_NONE) { if (geo.bnv == 192) return launch_wgrad_t<128, 192, VPRO>(wg, geo, st, who); }
+        if (geo.bnv == 128) return launch_wgrad_t<128, 128, VPRO>(wg, geo, st, who);
+        return launch_wgrad_t<128, 64, VPRO>(wg, geo, st, who);
+    }
+    if constexpr (VPRO == PRO_NONE) { if (geo.bnv == 192) return launch_wgrad_t<64, 192, VPRO>(wg, geo, st, who); }
+    if (geo.bnv == 128) return launch_wgrad_t<64, 128, VPRO>(wg, geo, st, who);
+    return launch_wgrad_t<64, 64, VPRO>(wg, geo, st, who);
 }
 
 int split_weights(const float *w, int Nc, int K, long long sn, long long sk, void *w3, hipStream_t st, int prec)
@@ -832,7 +894,8 @@ int split_weights(const float *w, int Nc, int K, long long sn, long long sk, voi
 
 struct PwPlan {
     int L, M, in_width, maxw;
-    size_t off_acc, off_coef, off_w3[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], total;
+    size_t off_acc, off_coef, off_w3[GFS3D_PW_MAX_LAYERS], off_g[GFS3D_PW_MAX_LAYERS], off_part, off_rows, total;
+    int nrows;                // partial rows of the ordered column sums (deterministic mode)
 };
 
 inline int pw_segw(int seg_width) { return seg_width > 0 ? seg_width : GFS3D_PW_SEG_WIDTH; }
@@ -854,6 +917,15 @@ PwPlan pw_plan(int B, int N, int n_seg, int seg_width, int n_layers, const int *
         p.off_w3[l] = o; o = align_up(o + 6 * (size_t)ci * width[l], 256);      // bf16x3 image of W_l (or of W_l^T)
     }
     for (int l = 0; l < n_layers; ++l) { p.off_g[l] = o; o = align_up(o + sizeof(float) * (size_t)p.M * width[l], 256); }
+    size_t part = 0;                                   // split-K partial tiles of the largest weight gradient
+    for (int l = 0; l < n_layers; ++l) {
+        const size_t b = wg_part_bytes(p.M, width[l], l ? width[l - 1] : p.in_width, l == 0);
+        part = b > part ? b : part;
+    }
+    p.off_part = o; o = align_up(o + part, 256);
+    const int nrb = (p.M + PW_BM - 1) / PW_BM, nin = B * (((N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES);
+    p.nrows = nrb > nin ? nrb : nin;
+    p.off_rows = o; o = align_up(o + sizeof(double) * (size_t)p.nrows * 2 * p.maxw, 256);
     p.total = o;
     return p;
 }
@@ -971,6 +1043,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         rg.out[0] = a->h[l];
         rg.o_segw = C;
         rg.acc = acc_l;
+        rg.acc_rows = (a->training && g_deterministic) ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
         int rc;
         if (a->training) {
             if (l == 0) rc = rowgemm<PRO_NONE, EPI_RAW_STATS, false>(rg, st, who);
@@ -980,6 +1053,10 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
                 rc = rowgemm<PRO_BNACT, EPI_RAW_STATS, false>(rg, st, who);
             }
             if (rc) return rc;
+            if (rg.acc_rows) {
+                hipLaunchKernelGGL(pw_colsum_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, rg.acc_rows, (M + PW_BM - 1) / PW_BM, 2 * C, acc_l);
+                GFS3D_LAUNCH_CHECK("pw_colsum_reduce_kernel");
+            }
         } else {
             hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
                                a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l], a->bias[l]);
@@ -1069,10 +1146,16 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     if (phase == 0) {
         const int C = a->width[L - 1];
         if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
-        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_pm, a->h[L - 1],
+        double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
+        const int gx = ((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES;
+        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(gx, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_pm, a->h[L - 1],
                            a->stats[L - 1], a->N, C, pw_slope(a, L - 1), reinterpret_cast<float *>(ws + p.off_g[L - 1]),
-                           acc + (size_t)2 * p.maxw * (L - 1));
+                           acc + (size_t)2 * p.maxw * (L - 1), rows);
         GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
+        if (rows) {
+            hipLaunchKernelGGL(pw_colsum_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, rows, gx * a->B, 2 * C, acc + (size_t)2 * p.maxw * (L - 1));
+            GFS3D_LAUNCH_CHECK("pw_colsum_reduce_kernel");
+        }
         return keep_local(L - 1);
     }
     const int l = L - phase;
@@ -1082,9 +1165,9 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc + (size_t)2 * p.maxw * l, loc + (size_t)2 * p.maxw * l, C, count,
                        a->stats[l], coef, ba->dbn_w[l], ba->dbn_b[l]);
     GFS3D_LAUNCH_CHECK("pw_bwd_coef_kernel");
-    // dW_l
-    if (hipMemsetAsync(ba->dw[l], 0, sizeof(float) * (size_t)C * Ci, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+    // dW_l: per-split partial tiles, added in split order (no atomics, no memset)
     WGrad wg{};
+    wg.part = reinterpret_cast<float *>(ws + p.off_part);
     wg.u = gl; wg.u2 = a->h[l]; wg.ldu = C;
     wg.ua = coef; wg.ub = coef + C; wg.uc = coef + 2 * C;
     wg.slope = l ? pw_slope(a, l - 1) : 1.f;
@@ -1095,12 +1178,11 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
         for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
         wg.v_segw = pw_segw(a->seg_width); wg.ldv = pw_segw(a->seg_width);
         // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once
-        rc = (Ci == 192) ? launch_wgrad<192, PRO_NONE>(wg, st, who)
-           : (Ci % 128 == 0) ? launch_wgrad<128, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who);
+        rc = wgrad<PRO_NONE>(wg, true, st, who);
     } else {
         wg.v[0] = a->h[l - 1]; wg.v_segw = Ci; wg.ldv = Ci;
         wg.va = a->stats[l - 1] + PST_SCALE * Ci; wg.vb = a->stats[l - 1] + PST_SHIFT * Ci;
-        rc = (Ci % 128 == 0) ? launch_wgrad<128, PRO_BNACT>(wg, st, who) : launch_wgrad<64, PRO_BNACT>(wg, st, who);
+        rc = wgrad<PRO_BNACT>(wg, false, st, who);
     }
     if (rc) return rc;
     // dA_{l-1} = dH_l W_l
@@ -1122,7 +1204,12 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
     rg.eh = a->h[l - 1];
     rg.acc = acc + (size_t)2 * p.maxw * (l - 1);
+    rg.acc_rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
     if (int rc3 = rowgemm<PRO_BWD, EPI_BWD_ACT, false>(rg, st, who)) return rc3;
+    if (rg.acc_rows) {
+        hipLaunchKernelGGL(pw_colsum_reduce_kernel, dim3((2 * Ci + 255) / 256), dim3(256), 0, st, rg.acc_rows, (M + PW_BM - 1) / PW_BM, 2 * Ci, rg.acc);
+        GFS3D_LAUNCH_CHECK("pw_colsum_reduce_kernel");
+    }
     return keep_local(l - 1);
 }
 
@@ -1248,13 +1335,14 @@ int pack_launch(const gfs3d_pack_args *a, bool unpack, hipStream_t st, const cha
     return GFS3D_OK;
 }
 
-struct LinPlan { size_t off_w3, off_dy, total; };
+struct LinPlan { size_t off_w3, off_dy, off_part, total; };
 LinPlan lin_plan(int B, int N, int K, int Nc)
 {
     LinPlan p{};
     size_t o = 0;
     p.off_w3 = o; o = align_up(o + 6 * (size_t)K * Nc, 256);
     p.off_dy = o; o = align_up(o + sizeof(float) * (size_t)B * N * Nc, 256);
+    p.off_part = o; o = align_up(o + wg_part_bytes(B * N, Nc, K, true), 256);
     p.total = o;
     return p;
 }
@@ -1333,12 +1421,12 @@ extern "C" int gfs3d_linear_backward_f32(const float *x_pm, int B, int N, int K,
     if (int rc = pack_launch(&pa, false, st, who)) return rc;
     const int prec = prec_of(compute, true);
     // dW = dY^T X
-    if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Nc * K, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
     WGrad wg{};
+    wg.part = reinterpret_cast<float *>(ws + p.off_part);
     wg.u = dy; wg.ldu = Nc;
     wg.v[0] = x_pm; wg.v_segw = K; wg.ldv = K;
     wg.slope = 1.f; wg.M = B * N; wg.Co = Nc; wg.Ci = K; wg.dw = dw; wg.prec = prec;
-    if (int rc = (K % 128 == 0) ? launch_wgrad<128, PRO_NONE>(wg, st, who) : launch_wgrad<64, PRO_NONE>(wg, st, who)) return rc;
+    if (int rc = wgrad<PRO_NONE>(wg, true, st, who)) return rc;
     // dX = dY W
     if (int rc = split_weights(w, K, Nc, 1, K, ws + p.off_w3, st, prec)) return rc;       // pieces of W^T (K, Nc)
     RowGemm rg{};

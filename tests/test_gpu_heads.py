@@ -252,3 +252,50 @@ def test_dgcnnseg_att_fused_heads_match_the_torch_heads(dev, training, monkeypat
                 assert float(g1[n].abs().max()) < 1e-4, n
             else:
                 assert relerr(g1[n], g0[n]) < 5e-4, n
+
+
+def test_whole_model_train_step_bit_reproducible_in_deterministic_mode(dev):
+    """set_deterministic(True) covers the point-wise kernels too: split-K weight gradients are partial tiles added in split
+    order (always), BatchNorm column sums are ordered partial rows (in this mode).  Three runs of a full CAPL training forward
+    + backward at B = 8 x 2048 - EdgeConv blocks, point-wise stack, BaseLearner, q|k|v GEMM, attention, fusion, word
+    assignment, prototype heads - give bit-identical loss, running statistics and gradients, with other work in between."""
+    import random
+    import types
+    from gfs3d import ops
+    from gfs3d.synthetic import synthetic_blocks
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                              base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(3)
+    gp = torch.randn(200, 192, generator=torch.Generator().manual_seed(2)).to(dev)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, criterion=torch.nn.CrossEntropyLoss(ignore_index=255), args=a, base_num=7, gp=gp,
+                                      energy=0.9).to(dev).train()
+    sd = copy.deepcopy(m.state_dict())
+    B, N = 8, 2048
+    x = synthetic_blocks(B, N, seed=4).to(dev)
+    y = torch.randint(0, 8, (B, N), generator=torch.Generator().manual_seed(6)).to(dev)
+    m.att_learner._forced_keep_mask = (torch.rand(B, N, N, generator=torch.Generator().manual_seed(7)) > 0.1).to(dev)
+    runs = []
+    ops.set_deterministic(True)
+    try:
+        for it in range(3):
+            m.load_state_dict(sd)
+            for p in m.parameters():
+                p.grad = None
+            if it:
+                junk = torch.randn(1 << (20 + it), device=dev).sin_().sum()      # disturb the schedule and the allocator
+            random.seed(0)
+            pred, loss = m(x, y=y)
+            loss.backward()
+            runs.append([loss.detach().clone(), pred.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+                        + [b.clone() for n, b in m.named_buffers() if "running" in n])
+    finally:
+        ops.set_deterministic(False)
+    assert len(runs[0]) > 40
+    for other in runs[1:]:
+        assert len(other) == len(runs[0])
+        # the scalar loss is torch's nll_loss2d forward, a float-atomic reduction (on PyTorch's own list of non-deterministic
+        # CUDA ops): equal to rounding; its gradient is element-wise, so everything downstream is exact
+        assert abs(float(other[0]) - float(runs[0][0])) <= 1e-6 * abs(float(runs[0][0]))
+        for a_, b_ in zip(runs[0][1:], other[1:]):
+            assert torch.equal(a_, b_)
