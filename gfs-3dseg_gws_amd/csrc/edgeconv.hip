@@ -614,6 +614,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             jx0[q] = jx1[q] = 0;
         }
         float s0 = 0.f, ss0 = 0.f, s1 = 0.f, ss1 = 0.f;
+        const bool full = (k & 3) == 0 && n0 + 8 <= BN;        // wave-uniform
         // software pipeline: rows of tile t+1 and the neighbour id of tile t+2 are in flight while
         // tile t runs on the matrix pipe (no dependent idx -> row load chain inside the loop)
         float4 pf[8];
@@ -670,21 +671,43 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 __builtin_amdgcn_sched_barrier(0);
             }
             m_next = myidx[min(4 * (t + 2) + jjA, k - 1)];
-            // branch-free epilogue: masked rows look like -inf / +inf / 0 to the reductions
+            if (full) {
+                // every row of the tile is a real edge (k a multiple of 4, all 8 points inside the batch - all tiles but those
+                // of the last super-tile when k = 20): no masks; the eval form needs no winner slot either (nothing is
+                // differentiated there), so its running maximum is one v_max per element
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = r >> 2;
-                const int j = 4 * t + (r & 3);
-                const bool ok = (j < k) && (n0 + 4 * h + q < BN);
-                const float v0 = acc0[r], v1 = acc1[r];
-                const bool gx0 = ok && v0 > mx0[q];
-                const bool gx1 = ok && v1 > mx1[q];
-                mx0[q] = gx0 ? v0 : mx0[q]; jx0[q] = gx0 ? j : jx0[q];
-                mx1[q] = gx1 ? v1 : mx1[q]; jx1[q] = gx1 ? j : jx1[q];
-                if (STATS) {
-                    const float u0 = ok ? v0 : 0.f, u1 = ok ? v1 : 0.f;
-                    s0 += u0; ss0 = fmaf(u0, u0, ss0);
-                    s1 += u1; ss1 = fmaf(u1, u1, ss1);
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r >> 2;
+                    const float v0 = acc0[r], v1 = acc1[r];
+                    if (STATS) {
+                        const int j = 4 * t + (r & 3);
+                        const bool gx0 = v0 > mx0[q], gx1 = v1 > mx1[q];
+                        mx0[q] = gx0 ? v0 : mx0[q]; jx0[q] = gx0 ? j : jx0[q];
+                        mx1[q] = gx1 ? v1 : mx1[q]; jx1[q] = gx1 ? j : jx1[q];
+                        s0 += v0; ss0 = fmaf(v0, v0, ss0);
+                        s1 += v1; ss1 = fmaf(v1, v1, ss1);
+                    } else {
+                        mx0[q] = fmaxf(mx0[q], v0);
+                        mx1[q] = fmaxf(mx1[q], v1);
+                    }
+                }
+            } else {
+                // masked rows look like -inf / +inf / 0 to the reductions
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r >> 2;
+                    const int j = 4 * t + (r & 3);
+                    const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                    const float v0 = acc0[r], v1 = acc1[r];
+                    const bool gx0 = ok && v0 > mx0[q];
+                    const bool gx1 = ok && v1 > mx1[q];
+                    mx0[q] = gx0 ? v0 : mx0[q]; jx0[q] = gx0 ? j : jx0[q];
+                    mx1[q] = gx1 ? v1 : mx1[q]; jx1[q] = gx1 ? j : jx1[q];
+                    if (STATS) {
+                        const float u0 = ok ? v0 : 0.f, u1 = ok ? v1 : 0.f;
+                        s0 += u0; ss0 = fmaf(u0, u0, ss0);
+                        s1 += u1; ss1 = fmaf(u1, u1, ss1);
+                    }
                 }
             }
         }
