@@ -294,6 +294,18 @@ def extras(dev, L, gdist):
         out["step_" + name] = {"workload": cfg["text"], "dtype": cfg["dtype"], "ms_per_step": round(dt * 1e3, 3),
                                "blocks_per_s": round(cfg["B"] / dt, 1),
                                "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / 3, 4) for k, v in prof.items()}}
+        if name == "c4":       # the testing path of the reference (train.py test loop): capl.forward(eval_model=True), fp32 results
+            net.eval()
+            ncls = cfg["classes"]
+            gened = torch.randn(ncls, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+            bc = (torch.rand(cfg["base"], cfg["Kw"], generator=torch.Generator().manual_seed(4)) > 0.5).float().to(dev)
+            nc = (torch.rand(ncls - cfg["base"], cfg["Kw"], generator=torch.Generator().manual_seed(5)) > 0.5).float().to(dev)
+            yy = torch.randint(0, ncls, (cfg["B"], NPTS), generator=torch.Generator().manual_seed(6)).to(dev)
+            with torch.no_grad():
+                ms = timed_ms(lambda: net(x, y=yy, gened_proto=gened, eval_model=True, base_class_coding=bc, novel_class_coding=nc), 10)
+            out["capl_eval_forward"] = {"workload": "configs[3] shapes, capl.forward(eval_model=True): backbone + heads + prototype "
+                                        "refinement + geometric-word re-weighting, B=32x2048", "ms": round(ms, 4),
+                                        "blocks_per_s": round(cfg["B"] / (ms * 1e-3), 1)}
         del step, net, bucket, x
         torch.cuda.empty_cache()
     return out

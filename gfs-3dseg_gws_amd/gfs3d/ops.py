@@ -864,6 +864,28 @@ class WordAssignFunction(torch.autograd.Function):
         return proto_backward_feat(feat, words, ctx.scale, dsoft, soft, compute=ctx.compute), None, None
 
 
+class WordSoftAssignFunction(torch.autograd.Function):
+    """The same without the one-hot tensor: (soft (B,Kw,N), arg-max word (B,N) int32).  For callers that look the coding up
+    by word index (capl.forward) or do not use the words at all (the training step): 4 B Kw N bytes less to write, and no
+    arg-max pass over a one-hot tensor afterwards."""
+
+    @staticmethod
+    def forward(ctx, feat, words, scale):
+        soft, assign, _ = word_assign_raw(feat, words, scale, want_onehot=False)
+        ctx.scale = scale
+        ctx.compute = _compute
+        ctx.save_for_backward(feat, words, soft)
+        ctx.mark_non_differentiable(assign)
+        return soft, assign
+
+    @staticmethod
+    def backward(ctx, dsoft, _d1):
+        feat, words, soft = ctx.saved_tensors
+        if feat.shape[1] > 192:
+            raise NotImplementedError("gfs3d.word_assign: the backward kernel handles up to 192 feature channels")
+        return proto_backward_feat(feat, words, ctx.scale, dsoft, soft, compute=ctx.compute), None, None
+
+
 class ProtoCosineFunction(torch.autograd.Function):
     """get_pred with gradients to both the point features and the prototypes."""
 

@@ -86,23 +86,27 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
                 and f[0].out_channels % 64 == 0 and f[0].in_channels <= 1024 and self.encoder.n_edgeconv <= ops.PW_MAX_SEGS
                 and self.encoder.conv.fused_parts() is not None)
 
-    def _features(self, x, want_semantic):
-        """capl.py:324-362.  On the GPU everything between the EdgeConv blocks and `point_feat` stays point-major and on the
+    def _features(self, x, want_semantic, want_onehot=True):
+        """capl.py:324-362.  Returns (point_feat, semantic or None, one-hot words - or, want_onehot=False, the (B,N) int32 word
+        index).  On the GPU everything between the EdgeConv blocks and `point_feat` stays point-major and on the
         library's kernels: level-2 stack -> {q|k|v GEMM -> K5 attention, BaseLearner stack} -> one packed (B,N,448) matrix
         [soft words | edge feature | attention | base feature | zero pad] -> fusion stack (K padded from 392 to 448)."""
         words = self._words_on(x.device)
         if not (x.is_cuda and self._heads_fusable()):
             edge_feats, level2 = self.encoder(x)
             semantic = torch.cat((edge_feats[0], self.att_learner(level2), self.base_learner(level2)), dim=1)
-            soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
+            soft, one_hot, word = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
             point_feat = self.fusion(torch.cat([soft, semantic], dim=1))
-            return point_feat, semantic, one_hot
+            return point_feat, semantic, (one_hot if want_onehot else word)
         sync = self.encoder.bn_sync
         edge_feats, edge_pm, level2_pm = self.encoder(x, point_major=True)
         att = self.att_learner.forward_pm(level2_pm)                                        # (B,64,N)
         base = self.base_learner.forward_pm(level2_pm, sync=sync, want_cf=want_semantic)
         base_cf, base_pm = base if want_semantic else (None, base)
-        soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
+        if want_onehot:
+            soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
+        else:
+            soft, one_hot = ops.WordSoftAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)       # the word index
         conv, bn, act = self.fusion[0], self.fusion[1], self.fusion[2]
         k_in = conv.in_channels
         k_pad = (k_in + 63) // 64 * 64
@@ -144,10 +148,10 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         return w * pooled + (1 - w) * proto.unsqueeze(0)
 
     def get_gp_weight(self, gp_classifier, gp_feat, use_bg_weight=False, gt_label=None, th=None):
-        """gp_classifier (n_cls,K_w) multi-hot coding, gp_feat (B,K_w,N) one-hot words.
+        """gp_classifier (n_cls,K_w) multi-hot coding, gp_feat (B,K_w,N) one-hot words (or their (B,N) index).
         score[b,c,n] = coding[c, word(b,n)] - a table lookup (the reference spends a
         (n_cls x K_w x N) matmul on it, capl.py:102).  Returns (weight, acc, novel_acc)."""
-        word = gp_feat.argmax(dim=1)                                     # (B,N)
+        word = gp_feat.long() if gp_feat.dim() == 2 else gp_feat.argmax(dim=1)     # (B,N): the word index itself, or one-hot words
         score = gp_classifier.t()[word].permute(0, 2, 1).contiguous()    # (B,n_cls,N)
         n_cls = score.shape[1]
         acc, novel_acc = 0., 0.
@@ -174,7 +178,7 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         """Training: returns (pred (B,N), loss).  eval_model=True: returns
         (logits (B,cls,N) re-weighted by the geometric-word coding, gp_acc, gp_novel_acc)."""
         nb = self.base_num
-        point_feat, _, word = self._features(x, want_semantic=False)
+        point_feat, _, word = self._features(x, want_semantic=False, want_onehot=False)      # word: (B,N) index
 
         if eval_model:
             if gened_proto.dim() == 3:
