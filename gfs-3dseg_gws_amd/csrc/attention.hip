@@ -281,14 +281,21 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
             mm_mac<PREC>(ak, qp[kb], acc);
             mm_mac<PREC>(av, gp[kb], dp);
         }
-        float ds[16];
+        float ds[16];                                      // element-wise part, branch-free (one uniform branch for the dropout)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int key = j0 + at_drow(r, h);
-            const float p = key < N ? __expf(acc[r] - Lq) : 0.f;
-            float dpv = dp[r];
-            if (drop) dpv = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, min(key, N - 1), N) ? dpv * g.inv_keep : 0.f;
-            ds[r] = p * (dpv - Dv);
+            const float pe = __expf(acc[r] - Lq);            // (a key past N is a clamped copy of the last one: finite)
+            ds[r] = j0 + at_drow(r, h) < N ? pe : 0.f;
+        }
+        if (drop) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, min(j0 + at_drow(r, h), N - 1), N);
+                ds[r] *= (keep ? dp[r] * g.inv_keep : 0.f) - Dv;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] *= dp[r] - Dv;
         }
         // dQ^T += K^T dS: rows = channels, k = keys
 #pragma unroll
@@ -363,20 +370,25 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
             mm_mac<PREC>(aq, kp[kb], acc);
             mm_mac<PREC>(ag, vp[kb], dp);
         }
+        // element-wise part, branch-free (ONE uniform branch for the dropout decisions: as a per-element `if` it became 16
+        // basic blocks with a wait each)
         float pd[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = at_drow(r, h), qq = p0 + row;
-            const bool ok = qq < N && kvalid;
-            const float p = ok ? __expf(acc[r] - Ls[cur][row]) : 0.f;
-            float pk = p, dpv = dp[r];
-            if (drop) {
-                const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, min(qq, N - 1), ki, N);
-                pk = keep ? p * g.inv_keep : 0.f;
-                dpv = keep ? dpv * g.inv_keep : 0.f;
+            const bool ok = p0 + at_drow(r, h) < N && kvalid;
+            const float pe = __expf(acc[r] - Ls[cur][at_drow(r, h)]);     // (a query past N is a clamped copy of the last one: finite)
+            pd[r] = ok ? pe : 0.f;
+        }
+        if (drop) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, min(p0 + at_drow(r, h), N - 1), ki, N);
+                ds[r] = pd[r] * ((keep ? dp[r] * g.inv_keep : 0.f) - Ds[cur][at_drow(r, h)]);
+                pd[r] = keep ? pd[r] * g.inv_keep : 0.f;
             }
-            pd[r] = pk;
-            ds[r] = p * (dpv - Ds[cur][row]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = pd[r] * (dp[r] - Ds[cur][at_drow(r, h)]);
         }
         // dV^T += dout^T P and dK^T += Q^T dS: rows = channels, k = queries
 #pragma unroll
