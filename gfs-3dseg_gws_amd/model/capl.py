@@ -178,6 +178,13 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         """Training: returns (pred (B,N), loss).  eval_model=True: returns
         (logits (B,cls,N) re-weighted by the geometric-word coding, gp_acc, gp_novel_acc)."""
         nb = self.base_num
+        half = x.size(0) // 2
+        fake_novel = None
+        if not eval_model:
+            # The fake-novel draw needs the set of classes present in the support half ON THE HOST (python RNG, as the
+            # reference): do it BEFORE the backbone is queued, so that the host waits for one tiny kernel on the labels and
+            # not for the whole forward pass (the same draw from the same RNG state: nothing else consumes `random` between)
+            fake_novel = self._draw_fake_novel(y[half:])
         point_feat, _, word = self._features(x, want_semantic=False, want_onehot=False)      # word: (B,N) index
 
         if eval_model:
@@ -191,8 +198,8 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             weight, gp_acc, gp_novel_acc = self.get_gp_weight(coding, word, gt_label=y, th=self.args.eval_weight)
             return logits * weight, gp_acc, gp_novel_acc
 
-        half = x.size(0) // 2
-        ori_proto, _ = self.generate_fake_proto(x=point_feat[half:], y=y[half:], main_proto=self.main_proto.clone())
+        ori_proto, _ = self.generate_fake_proto(x=point_feat[half:], y=y[half:], main_proto=self.main_proto.clone(),
+                                                fake_novel=fake_novel)
         loss_1 = self.criterion(self.get_pred(point_feat, ori_proto, use_bg_proto=True), y)
         refined = self.post_refine_proto_v2(proto=self.main_proto.clone(), x=point_feat, point_feat=point_feat,
                                             use_bg_proto=True)
@@ -211,17 +218,7 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         dp = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
         if fake_novel is None:
-            if dp:
-                # block-sharded batch: the class set is the union over ranks (one MAX all-reduce of a
-                # presence vector); every rank then draws the SAME sample (python RNG seeded alike
-                # on all ranks, as train.py does)
-                seen = torch.zeros(main_proto.size(0) + 1, dtype=torch.int32, device=y.device)
-                seen[labels.unique().long().clamp_max(main_proto.size(0))] = 1
-                torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
-                present = [int(v) for v in torch.nonzero(seen).flatten().tolist() if int(v) != 0]
-            else:
-                present = [int(v) for v in labels.unique().tolist() if int(v) != 0]
-            fake_novel = random.sample(present, len(present) // 2)
+            fake_novel = self._draw_fake_novel(y, n_cls=main_proto.size(0))
         proto = _unit(main_proto, 1)
         feat = _unit(x, 1)
         fake = [int(c) for c in fake_novel]
@@ -241,6 +238,22 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
                 mean = torch.stack([self.post_processing_hard_coding(row) for row in mean.unbind(0)])
             proto = proto.index_copy(0, cls_idx - 1, mean)
         return proto, fake_novel
+
+    def _draw_fake_novel(self, y, n_cls=None):
+        """Half of the foreground classes present in y (python RNG, reference capl.py:384-390).  Block-sharded batch: the
+        class set is the union over ranks (one MAX all-reduce of a presence vector); every rank then draws the SAME sample
+        (python RNG seeded alike on all ranks, as train.py does)."""
+        n_cls = self.main_proto.size(0) if n_cls is None else n_cls
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        if dp:
+            seen = torch.zeros(n_cls + 1, dtype=torch.int32, device=y.device)
+            seen[y.unique().long().clamp_max(n_cls)] = 1
+            torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
+            present = [int(v) for v in torch.nonzero(seen).flatten().tolist() if int(v) != 0]
+        else:
+            present = [int(v) for v in y.unique().tolist() if int(v) != 0]
+        return random.sample(present, len(present) // 2)
 
     def post_processing_hard_coding(self, coding):
         """(K_w,) probability vector -> multi-hot of the smallest descending prefix whose

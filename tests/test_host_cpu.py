@@ -52,16 +52,45 @@ def test_args_structs_match_header_field_order_and_size():
     from gfs3d import _lib
     header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
     pairs = [("gfs3d_edgeconv_args", _lib.EdgeConvArgs), ("gfs3d_edgeconv_bwd_args", _lib.EdgeConvBwdArgs),
-             ("gfs3d_pointwise_args", _lib.PointwiseArgs), ("gfs3d_pointwise_bwd_args", _lib.PointwiseBwdArgs)]
+             ("gfs3d_pointwise_args", _lib.PointwiseArgs), ("gfs3d_pointwise_bwd_args", _lib.PointwiseBwdArgs),
+             ("gfs3d_pack_args", _lib.PackArgs)]
     for cname, cls in pairs:
         assert _header_fields(header, cname) == [f[0] for f in cls._fields_], cname
-    src = '#include <stdio.h>\n#include "gfs3d.h"\nint main(void){printf("%zu %zu %zu %zu\\n",' + ",".join(
+    src = '#include <stdio.h>\n#include "gfs3d.h"\nint main(void){printf("' + "%zu " * len(pairs) + '\\n",' + ",".join(
         "sizeof(%s)" % c for c, _ in pairs) + ");return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
     assert sizes == [ctypes.sizeof(cls) for _, cls in pairs]
+
+
+def test_entry_points_reject_bad_arguments_before_touching_a_device():
+    """Argument validation of the round-2 entry points happens on the host: wrong shapes / NULL pointers come back as an
+    error code with a message (no GPU needed, nothing is launched), and the workspace queries return 0 for unsupported shapes."""
+    import ctypes
+    from gfs3d import _lib
+    L = _lib.lib()
+    arr = (ctypes.c_int * 2)(128, 64)
+    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 1, 256, 2, arr) > 0
+    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 1, 100, 2, arr) == 0          # segment width not a multiple of 64
+    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 5, 64, 2, arr) == 0           # too many segments
+    assert L.gfs3d_linear_workspace_bytes(2, 256, 256, 192) > 0
+    assert L.gfs3d_linear_workspace_bytes(2, 256, 100, 192) == 0 and L.gfs3d_linear_workspace_bytes(2, 256, 256, 320) == 0
+    a = _lib.PackArgs()
+    assert L.gfs3d_pack_rows_f32(None, None) != 0 and b"NULL args" in L.gfs3d_last_error()
+    a.B, a.N, a.n_src = 1, 64, 0
+    assert L.gfs3d_pack_rows_f32(ctypes.byref(a), None) != 0 and b"n_src" in L.gfs3d_last_error()
+    a.n_src, a.dst, a.dst_ld = 1, 1, 16
+    a.src[0], a.width[0] = 1, 64
+    assert L.gfs3d_unpack_rows_f32(ctypes.byref(a), None) != 0 and b"dst_ld" in L.gfs3d_last_error()
+    ptrs = (ctypes.c_void_p * 3)(None, None, None)
+    assert L.gfs3d_linear_forward_f32(None, 1, 64, 256, None, 192, ptrs, 0, None, 0, None) != 0
+    assert L.gfs3d_linear_forward_f32(1, 1, 64, 100, 1, 192, ptrs, 0, 1, 1 << 30, None) != 0 and b"K=100" in L.gfs3d_last_error()
+    assert L.gfs3d_attention_forward_mixed(1, 1, 1, 1, 64, 64, 0.125, 0.0, 0, None, 1, 1, 7, None) != 0 \
+        and b"compute" in L.gfs3d_last_error()
+    assert L.gfs3d_attention_forward_mixed(1, 1, 1, 1, 32, 64, 0.125, 0.0, 0, None, 1, 1, 0, None) != 0 \
+        and b"head dimension" in L.gfs3d_last_error()
 
 
 def test_dgcnn_state_dict_and_seeded_init_match_reference():
