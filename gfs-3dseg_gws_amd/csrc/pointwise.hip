@@ -401,7 +401,12 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
             if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
             const float v4[4] = {v[0], v[1], v[2], v[3]};
             uint2 pc[NP];
+#if defined(PW_ABL) && (PW_ABL & 1)       // ablation builds only: no operand split (wrong results, timing of the rest)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) pc[q] = make_uint2(__builtin_bit_cast(unsigned, v4[0]) ^ __builtin_bit_cast(unsigned, v4[1]), __builtin_bit_cast(unsigned, v4[2]));
+#else
             mm_pieces4<PREC>(v4, pc);
+#endif
             char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8;
 #pragma unroll
             for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];

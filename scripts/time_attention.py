@@ -1,6 +1,6 @@
 """SelfAttention (256 -> 64 head, N = 2048, B = 32): fused HIP kernel (K5) vs the torch formulation, fwd and fwd+bwd."""
 import sys, time, torch
-sys.path.insert(0, "gfs-3dseg_gws_amd")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "gfs-3dseg_gws_amd"))
 from gfs3d import ops
 dev = torch.device("cuda:0")
 B, N = 32, 2048

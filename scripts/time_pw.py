@@ -1,6 +1,7 @@
 """Time the point-wise stack (K4) at BASELINE config 2 size; run under rocprofv3 --kernel-trace --stats for per-kernel times."""
-import sys, time, torch
-sys.path.insert(0, "gfs-3dseg_gws_amd")
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gfs-3dseg_gws_amd"))
 from gfs3d import ops
 from model.dgcnn import conv1d
 dev = torch.device("cuda:0")
