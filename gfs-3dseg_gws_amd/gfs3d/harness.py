@@ -35,6 +35,9 @@ def post_processing_hard_coding(coding: torch.Tensor, energy: float) -> torch.Te
 
 def _words(model, x: torch.Tensor) -> torch.Tensor:
     """(B,N) int64 geometric-word id of every point."""
+    if hasattr(model, "_features"):                     # the word index straight from the assignment kernel (no one-hot tensor)
+        _, _, word = model._features(x, want_semantic=False, want_onehot=False)
+        return word.long()
     _, _, one_hot = model.getFeatures(x)
     return one_hot.argmax(dim=1)
 
