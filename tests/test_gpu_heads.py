@@ -299,3 +299,60 @@ def test_whole_model_train_step_bit_reproducible_in_deterministic_mode(dev):
         assert abs(float(other[0]) - float(runs[0][0])) <= 1e-6 * abs(float(runs[0][0]))
         for a_, b_ in zip(runs[0][1:], other[1:]):
             assert torch.equal(a_, b_)
+
+
+def test_base_learner_two_shards_synchronised_equal_whole_batch(dev):
+    """The head options of the K4 stack under synchronised BatchNorm (phased C ABI): a BaseLearner - conv bias, ReLU then no
+    activation, one 256-wide input segment, point-major result - run as two block shards whose fp64 column sums are added
+    between the phases reproduces the whole-batch run: outputs, running statistics (the bias enters the running mean
+    once), input gradients; shard parameter gradients add up."""
+    from gfs3d import ops
+    from model.dgcnn import BaseLearner
+    torch.manual_seed(31)
+    bl = BaseLearner(256, [128, 64]).to(dev).train()
+    _randomise_bn(bl)
+    for blk in bl.convs:
+        blk[0].bias.data.normal_(0, 0.5)
+    B, N = 4, 150
+    x = torch.randn(B, N, 256, device=dev)
+    cot = torch.randn(B, N, 64, device=dev)
+    whole = copy.deepcopy(bl)
+    xw = x.clone().requires_grad_(True)
+    yw = whole.forward_pm(xw)
+    yw.backward(cot)
+
+    mods = [copy.deepcopy(bl), copy.deepcopy(bl)]
+    slopes = [0.0, 1.0]
+    runs = []
+    for r, m in enumerate(mods):
+        layers = [(c.weight.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var) for c, bn in m.fused_parts()]
+        runs.append(ops.PointwiseRun([x[2 * r:2 * r + 2].contiguous()], layers, True, 1e-5, 0.1, 0.0, private_workspace=True,
+                                     biases=[c.bias.detach() for c, _ in m.fused_parts()], slopes=slopes, want_cf=False, want_pm=True))
+    row = 2 * 128
+    accs = [torch.zeros(2 * 2 * row, dtype=torch.float64, device=dev) for _ in runs]
+    count = float(B * N)
+
+    def exchange(l):
+        tot = accs[0][l * row:(l + 1) * row] + accs[1][l * row:(l + 1) * row]
+        for a_ in accs:
+            a_[l * row:(l + 1) * row] = tot
+    for ph in range(3):
+        for run, a_ in zip(runs, accs):
+            run.forward_phase(ph, a_, count)
+        if ph < 2:
+            exchange(ph)
+    assert maxerr(torch.cat([r_.y_pm for r_ in runs], 0), yw) < 1e-5
+    gs = [None, None]
+    for ph in range(3):
+        for i, (run, a_) in enumerate(zip(runs, accs)):
+            gs[i] = run.backward_phase(ph, a_, count, None, cot[2 * i:2 * i + 2] if ph == 0 else None)
+        if ph < 2:
+            exchange(1 - ph)
+    assert relerr(torch.cat([gs[0][0][0], gs[1][0][0]], 0), xw.grad) < TOL
+    parts = whole.fused_parts()
+    for l, (c, bn) in enumerate(parts):
+        assert relerr(gs[0][1][l] + gs[1][1][l], c.weight.grad.reshape(gs[0][1][l].shape)) < TOL
+        assert relerr(gs[0][2][l] + gs[1][2][l], bn.weight.grad) < TOL
+        assert relerr(gs[0][3][l] + gs[1][3][l], bn.bias.grad) < 1e-3 or float(bn.bias.grad.abs().max()) < 1e-4
+    for (c0, bn0), (cw, bnw) in zip(mods[0].fused_parts(), parts):
+        assert maxerr(bn0.running_mean, bnw.running_mean) < 1e-6 and maxerr(bn0.running_var, bnw.running_var) < 1e-6
