@@ -683,14 +683,12 @@ class PackRowsFunction(torch.autograd.Function):
         ddst = ddst.contiguous()
         outs = [torch.empty(sh, dtype=torch.float32, device=ddst.device) if need else None
                 for sh, need in zip(shapes, ctx.needs_input_grad[2:])]
-        live = [(o, cf) for o, cf in zip(outs, cf_flags)]
         # sources that need no gradient still occupy their columns: give them scratch so that offsets stay right
         tmp = [o if o is not None else torch.empty(sh, dtype=torch.float32, device=ddst.device) for o, sh in zip(outs, shapes)]
         a = _pack_args(B, N, tmp, cf_flags, ddst)
         with torch.cuda.device(ddst.device):
             rc = _lib.lib().gfs3d_unpack_rows_f32(ctypes.byref(a), _stream())
         _lib.check(rc, "gfs3d_unpack_rows_f32")
-        del live
         return (None, None) + tuple(outs)
 
 
