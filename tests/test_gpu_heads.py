@@ -356,3 +356,68 @@ def test_base_learner_two_shards_synchronised_equal_whole_batch(dev):
         assert relerr(gs[0][3][l] + gs[1][3][l], bn.bias.grad) < 1e-3 or float(bn.bias.grad.abs().max()) < 1e-4
     for (c0, bn0), (cw, bnw) in zip(mods[0].fused_parts(), parts):
         assert maxerr(bn0.running_mean, bnw.running_mean) < 1e-6 and maxerr(bn0.running_var, bnw.running_var) < 1e-6
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs[3] shapes)
+def test_attention_full_size_properties(dev):
+    """B = 32 x 2048, d = 64 (no oracle finishes this in seconds): size-independent properties of softmax attention.
+    (i) constant values come back unchanged (the weights of a query sum to 1); (ii) linearity in v; (iii) a joint permutation
+    of keys and values changes nothing; (iv) the output of query i only depends on q_i (changing other queries leaves it
+    bit-identical)."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(11)
+    B, N = 32, 2048
+    q, k, v1, v2 = (torch.randn(B, 64, N, generator=g).to(dev) for _ in range(4))
+    scale = 0.125
+    with torch.no_grad():
+        const = torch.linspace(-2, 2, 64, device=dev).view(1, 64, 1).expand(B, 64, N).contiguous()
+        y = ops.attention(q, k, const, scale)
+        assert maxerr(y, const) < 3e-5                      # |const| <= 2: 2048 fp32 probabilities per query, each summed with rounding
+        y1, y2 = ops.attention(q, k, v1, scale), ops.attention(q, k, v2, scale)
+        y12 = ops.attention(q, k, 0.5 * v1 - 2.0 * v2, scale)
+        assert relerr(y12, 0.5 * y1 - 2.0 * y2) < 1e-5
+        perm = torch.randperm(N, generator=g).to(dev)
+        yp = ops.attention(q, k[:, :, perm].contiguous(), v1[:, :, perm].contiguous(), scale)
+        assert relerr(yp, y1) < 1e-5
+        q2 = q.clone()
+        q2[:, :, 1::2] = torch.randn(B, 64, N // 2, generator=g).to(dev)
+        y1b = ops.attention(q2, k, v1, scale)
+        assert torch.equal(y1b[:, :, 0::2], y1[:, :, 0::2])
+
+
+def test_word_assign_full_size_properties(dev):
+    """B = 32 x 2048, C = 192, K_w = 200: soft assignments sum to 1, the one-hot tensor is the arg-max of the soft one and
+    agrees with the index output, and permuting the words permutes both."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(12)
+    feat = torch.randn(32, 192, 2048, generator=g).to(dev)
+    words = torch.randn(200, 192, generator=g).to(dev)
+    with torch.no_grad():
+        soft, onehot, assign = ops.WordAssignFunction.apply(feat, words, 10.0)
+        soft2, assign2 = ops.WordSoftAssignFunction.apply(feat, words, 10.0)
+        assert maxerr(soft.sum(1), torch.ones(32, 2048)) < 1e-5
+        assert bool((onehot.sum(1) == 1).all()) and torch.equal(onehot.argmax(1).int(), assign)
+        assert torch.equal(soft2, soft) and torch.equal(assign2, assign)
+        top = soft.max(1)[0]
+        assert bool((soft.gather(1, assign.long().unsqueeze(1)).squeeze(1) == top).all())
+        perm = torch.randperm(200, generator=g).to(dev)
+        softp, _, assignp = ops.WordAssignFunction.apply(feat, words[perm].contiguous(), 10.0)
+        assert relerr(softp, soft[:, perm]) < 1e-5
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(200, device=dev)
+        clear = (soft.topk(2, dim=1)[0][:, 0] - soft.topk(2, dim=1)[0][:, 1]) > 1e-4      # ties at rounding level may flip
+        assert bool((inv[assign.long()] == assignp.long())[clear].all())
+
+
+def test_pack_unpack_round_trip_full_size(dev):
+    """The fusion input of configs[3] at B = 32 x 2048: unpack(pack(x)) == x bit for bit, pad columns zero."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(13)
+    B, N = 32, 2048
+    srcs = [torch.randn(B, 200, N, generator=g).to(dev).requires_grad_(True), torch.randn(B, N, 64, generator=g).to(dev).requires_grad_(True),
+            torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True), torch.randn(B, N, 64, generator=g).to(dev).requires_grad_(True)]
+    packed = ops.pack_rows(srcs, [True, False, True, False], ld=448)
+    assert float(packed.detach()[:, :, 392:].abs().max()) == 0.0
+    packed.backward(packed.detach())                       # the adjoint applied to the packed matrix itself
+    for t in srcs:
+        assert torch.equal(t.grad, t.detach())
