@@ -487,6 +487,8 @@ constexpr int KS_CAP = 64;                     // candidate ids kept per query
 //   NKB = 4: 32 candidates per LDS stage (64 = two MFMA tiles per barrier was measured: 110 -> 153 us), rows of
 //            [hi 64 x bf16 | mid | 16 B pad] = 272 B (17 slots: conflict-free ds_read_b128)
 //   NKB = 1: 128 candidates per stage (four MFMA tiles per barrier), rows of [hi 16 x bf16 | mid | 16 B pad] = 80 B (5 slots)
+template <int V> struct ks_int { static constexpr int value = V; };
+struct ks_rt { int value; };
 constexpr int ks_tc(int nkb) { return 4 * (256 / (8 * nkb)); }
 constexpr int ks_tld(int nkb) { return 64 * nkb + 16; }
 
@@ -660,7 +662,11 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     float thr = -__builtin_inff(), thr2 = -__builtin_inff();
     int cnt = 0;
     float a0[KS_CPT], a1[KS_CPT], b0[KS_CPT], b1[KS_CPT], aq = 0.f, bq = 0.f;      // two stages in flight: s + 1 and s + 2
-    for (int sweep = 0; sweep < 2; ++sweep) {
+    // 64-channel form: the two sweeps are two INSTANTIATIONS of this body (sweep a compile-time constant) - as a run-time loop
+    // variable the compiler kept one copy and computed the cheap parts of both branches (bucket maxima AND candidate masks) in
+    // every stage: 67 -> 22 VALU in the scoring block of sweep 0
+    auto run_sweep = [&](auto sweep_c) {
+        const int sweep = sweep_c.value;                   // a constant for ks_int<V>, a run-time value for ks_rt
         fetch(0, a0, a1, aq);
         __syncthreads();                                   // (the previous sweep's last stage has been read by every wave)
         put(0, a0, a1, aq);
@@ -729,6 +735,12 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
             // pd = fl(tv - |xq|^2) >= thr  implies  tv >= thr + |xq|^2 - (roundings of the subtraction and of this sum)
             thr2 = (thr == -__builtin_inff()) ? thr : (thr + sqq) - 4.8e-7f * (fabsf(thr) + fabsf(sqq)) - 1e-37f;
         }
+    };
+    if constexpr (NKB == 4) {
+        run_sweep(ks_int<0>{});
+        run_sweep(ks_int<1>{});
+    } else {                                               // (four tiles per stage: two copies of the body do not fit the registers)
+        for (int sw = 0; sw < 2; ++sw) run_sweep(ks_rt{sw});
     }
     // ---- publish: the two halves of a query one after the other; overflow (or more than KS_CAP) -> exhaustive scan
     const int c0 = __shfl(cnt, j, 64), c1 = __shfl(cnt, j + 32, 64);
