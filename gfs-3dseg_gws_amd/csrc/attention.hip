@@ -132,7 +132,9 @@ __device__ __forceinline__ void at_regfrag(const float (&v)[16], int s, uint4 (&
 }
 
 // ------------------------------------------------------------------ forward
-template <bool HAS_MASK, int PREC>
+// DROP: 0 = no dropout (eval), 1 = counter-based hash, 2 = explicit keep mask - a template parameter: as a run-time flag the
+// compiler kept the hash arithmetic (~180 of 530 VALU per tile) in the loop of every mode
+template <int DROP, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, float *__restrict__ out, float *__restrict__ lse)
 {
     constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, floa
     const float *qb = g.q + (size_t)b * AT_D * N, *kb_ = g.k + (size_t)b * AT_D * N, *vb = g.v + (size_t)b * AT_D * N;
     const int qi = min(q0 + j, N - 1);
     const unsigned sb = at_seed(g.seed, b);
-    const bool drop = HAS_MASK || g.thresh != 0u;
+    constexpr bool drop = DROP != 0, HAS_MASK = DROP == 2;
     uint4 qp[4][NP];
     at_colfrags<PREC>(qb, N, qi, h, g.scale, qp);
     float m = -__builtin_inff(), l = 0.f;
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, floa
         m = m_new;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { O0[r] *= sc; O1[r] *= sc; }
-        if (drop) {
+        if constexpr (drop) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = min(j0 + at_drow(r, h), N - 1);
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(256) attn_bwd_D_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------ backward, query side: dQ
-template <bool HAS_MASK, int PREC>
+template <int DROP, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, float *__restrict__ dq)
 {
     constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
     const float *kb_ = g.k + boff, *vb = g.v + boff;
     const int qi = min(q0 + j, N - 1);
     const unsigned sb = at_seed(g.seed, b);
-    const bool drop = HAS_MASK || g.thresh != 0u;
+    constexpr bool drop = DROP != 0, HAS_MASK = DROP == 2;
     uint4 qp[4][NP], gp[4][NP];
     at_colfrags<PREC>(g.q + boff, N, qi, h, g.scale, qp);
     at_colfrags<PREC>(g.dout + boff, N, qi, h, 1.f, gp);
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
             const float pe = __expf(acc[r] - Lq);            // (a key past N is a clamped copy of the last one: finite)
             ds[r] = j0 + at_drow(r, h) < N ? pe : 0.f;
         }
-        if (drop) {
+        if constexpr (drop) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, min(j0 + at_drow(r, h), N - 1), N);
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
 }
 
 // ------------------------------------------------------------------ backward, key side: dK, dV
-template <bool HAS_MASK, int PREC>
+template <int DROP, int PREC>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, float *__restrict__ dk, float *__restrict__ dv)
 {
     constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
     const int ki = min(k0 + j, N - 1);
     const bool kvalid = k0 + j < N;
     const unsigned sb = at_seed(g.seed, b);
-    const bool drop = HAS_MASK || g.thresh != 0u;
+    constexpr bool drop = DROP != 0, HAS_MASK = DROP == 2;
     uint4 kp[4][NP], vp[4][NP];
     at_colfrags<PREC>(g.k + boff, N, ki, h, 1.f, kp);
     at_colfrags<PREC>(g.v + boff, N, ki, h, 1.f, vp);
@@ -379,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
             const float pe = __expf(acc[r] - Ls[cur][at_drow(r, h)]);     // (a query past N is a clamped copy of the last one: finite)
             pd[r] = ok ? pe : 0.f;
         }
-        if (drop) {
+        if constexpr (drop) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, min(p0 + at_drow(r, h), N - 1), ki, N);
@@ -461,8 +463,9 @@ template <int PREC>
 static int at_forward(const AttnArgs &a, bool has_mask, dim3 grid, float *out, float *lse, hipStream_t st)
 {
     const size_t lds = 4 * Mx<PREC>::NP * AT_PLANE;
-    if (has_mask) hipLaunchKernelGGL((attn_fwd_kernel<true, PREC>), grid, dim3(256), lds, st, a, out, lse);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, PREC>), grid, dim3(256), lds, st, a, out, lse);
+    if (has_mask) hipLaunchKernelGGL((attn_fwd_kernel<2, PREC>), grid, dim3(256), lds, st, a, out, lse);
+    else if (a.thresh != 0u) hipLaunchKernelGGL((attn_fwd_kernel<1, PREC>), grid, dim3(256), lds, st, a, out, lse);
+    else hipLaunchKernelGGL((attn_fwd_kernel<0, PREC>), grid, dim3(256), lds, st, a, out, lse);
     GFS3D_LAUNCH_CHECK("attn_fwd_kernel");
     return GFS3D_OK;
 }
@@ -472,11 +475,14 @@ static int at_backward(const AttnArgs &a, bool has_mask, dim3 grid, float *dq, f
 {
     const size_t lds = 4 * Mx<PREC>::NP * AT_PLANE;
     if (has_mask) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, PREC>), grid, dim3(256), lds, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<2, PREC>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+    } else if (a.thresh != 0u) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, PREC>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<false, PREC>), grid, dim3(256), lds, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<0, PREC>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<0, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
     }
     GFS3D_LAUNCH_CHECK("attn_bwd kernels");
     return GFS3D_OK;
