@@ -404,6 +404,10 @@ def main():
             traffic, src = hbm_traffic(KERNELS[dom], "r02")
             roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
+            if dom == 2:
+                roof["traffic_note"] = ("ec_main_bwd_kernel: ~184 MB read (P', Q', neighbour ids, winners, gradients) + ~357 MB of plain 256-B row "
+                                        "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once "
+                                        "(the fixed-order replacement of round 1's float-atomic scatter)")
         roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass). f32 mode: against "
                         "the fp32 (vector == fp32-MFMA) peak; the EdgeConv / point-wise GEMMs run on the bf16 matrix cores at fp32 accuracy "
                         "(exact 3-way bf16 split, 6 piece products per fp32 product); kNN stays on the bit-exact fp32 MFMA chain. Reduced "
