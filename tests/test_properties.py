@@ -155,12 +155,12 @@ def test_edgeconv_hip_is_invariant_to_neighbour_order_and_point_relabelling(dev,
     y2 = run(x, torch.gather(idx, 2, perm_k))
     # the max over the neighbours does not see their order; in training mode the batch statistics are sums over the
     # same multiset of edges in another order (fp64 accumulators): equal to rounding
-    assert float((y - y2).abs().max()) <= (0.0 if not training else 2e-6)
+    assert float((y - y2).abs().max()) <= (0.0 if not training else 1e-5)      # |y| ~ 1-4: a few fp32 ulps
     perm = torch.randperm(N, generator=g)
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(N)
     yp = run(x[:, :, perm].contiguous(), inv[idx[:, perm, :]])
-    assert float((yp - y[:, :, perm]).abs().max()) < 2e-6
+    assert float((yp - y[:, :, perm]).abs().max()) < 1e-5
 
 
 # ---------------------------------------------------------------------------
