@@ -1202,9 +1202,226 @@ kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Centroid sums as a SEGMENT SUM over the points grouped by label (workspace form of the entry point): a stable counting
+// sort of the point indices by label (per-chunk histograms -> prefix over the chunks -> in-order placement), then every
+// label's rows are summed in that fixed order, 256 at a time, and the partial rows are added in chunk order.  The points
+// are read ONCE as whole 4 C-byte rows; no float atomics, the sums are bit-reproducible.  (The one-hot GEMM above spends
+// K/32 row tiles of MFMAs on every point although it belongs to one centroid.)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KS_SORT_CHUNK = 1024;       // points per (one-wave) block of the histogram / placement kernels
+constexpr int KS_SEG = 256;               // rows per partial sum
+struct KmWs { size_t off_perm, off_bh, off_tot, off_off, off_cb, off_part, total; int nblk, nchmax; };
+static KmWs km_ws(long long M, int C, int K)
+{
+    KmWs w{};
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    w.nblk = (int)((M + KS_SORT_CHUNK - 1) / KS_SORT_CHUNK);
+    w.nchmax = (int)((M + KS_SEG - 1) / KS_SEG) + K;
+    w.off_perm = take(sizeof(int) * (size_t)M);
+    w.off_bh = take(sizeof(int) * (size_t)w.nblk * K);          // per-chunk histograms, then their exclusive prefix over the chunks
+    w.off_tot = take(sizeof(int) * (size_t)K);
+    w.off_off = take(sizeof(int) * (size_t)(K + 1));
+    w.off_cb = take(sizeof(int) * (size_t)(K + 1));
+    w.off_part = take(sizeof(float) * (size_t)w.nchmax * C);
+    w.total = o;
+    return w;
+}
+
+__global__ void __launch_bounds__(64)
+km_hist_kernel(const int32_t *__restrict__ label, long long M, int K, int *__restrict__ bh)
+{
+    extern __shared__ int km_h[];
+    for (int k = threadIdx.x; k < K; k += 64) km_h[k] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const long long m0 = (long long)blockIdx.x * KS_SORT_CHUNK;
+    for (int e = threadIdx.x; e < KS_SORT_CHUNK; e += 64)
+        if (m0 + e < M) atomicAdd(&km_h[label[m0 + e]], 1);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = threadIdx.x; k < K; k += 64) bh[(size_t)blockIdx.x * K + k] = km_h[k];
+}
+
+// block k: exclusive prefix of bh[.][k] over the chunks (in place) and the label's total
+__global__ void __launch_bounds__(256)
+km_scan_kernel(int *__restrict__ bh, int nblk, int K, int *__restrict__ total)
+{
+    __shared__ int part[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int per = (nblk + 255) / 256, b0 = t * per, b1 = min(nblk, b0 + per);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += bh[(size_t)b * K + k];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int q = 0; q < 256; ++q) { const int v = part[q]; part[q] = run; run += v; }
+        total[k] = run;
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int b = b0; b < b1; ++b) { const int v = bh[(size_t)b * K + k]; bh[(size_t)b * K + k] = run; run += v; }
+}
+
+// label offsets and the table of 256-row partial-sum chunks (one block)
+__global__ void __launch_bounds__(64)
+km_offsets_kernel(const int *__restrict__ total, int K, int *__restrict__ off, int *__restrict__ cb)
+{
+    if (threadIdx.x != 0) return;
+    int o = 0, c = 0;
+    for (int k = 0; k < K; ++k) {
+        off[k] = o; cb[k] = c;
+        o += total[k];
+        c += (total[k] + KS_SEG - 1) / KS_SEG;
+    }
+    off[K] = o; cb[K] = c;
+}
+
+// stable placement: one wave walks its chunk 64 points at a time.  A step sorts the 64 keys (label, lane) with a bitonic network
+// across the lanes; in sorted order the points of one label are consecutive and in lane order, so a point's place is its
+// label's running position + its distance from the label's first lane (a prefix-max scan), and the last lane of each run
+// advances the label's counter - no atomics, no per-label loop (the first form iterated over the distinct labels of a step:
+// ~55 of them for 200 clusters, 122 us at 2.1 M points).
+__global__ void __launch_bounds__(64)
+km_place_kernel(const int32_t *__restrict__ label, long long M, int K, const int *__restrict__ bh, const int *__restrict__ off,
+                int *__restrict__ perm)
+{
+    extern __shared__ int km_c[];                                   // running position per label
+    const int lane = threadIdx.x;
+    for (int k = lane; k < K; k += 64) km_c[k] = off[k] + bh[(size_t)blockIdx.x * K + k];
+    __builtin_amdgcn_wave_barrier();
+    const long long m0 = (long long)blockIdx.x * KS_SORT_CHUNK;
+    for (int e0 = 0; e0 < KS_SORT_CHUNK; e0 += 64) {
+        const long long m = m0 + e0 + lane;
+        unsigned key = m < M ? ((unsigned)label[m] << 6) | (unsigned)lane : 0xffffffffu;       // invalid points sort last
+#pragma unroll
+        for (int kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)key, jj, 64);
+                const bool up = (lane & kk) == 0, lower = (lane & jj) == 0;
+                key = (lower == up) ? min(key, other) : max(key, other);
+            }
+        const bool valid = key != 0xffffffffu;
+        const int lb = (int)(key >> 6), src = (int)(key & 63u);
+        const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+        const bool head = lane == 0 || (prev >> 6) != (key >> 6);
+        int start = head ? lane : 0;                                // first lane of this lane's run: prefix maximum of the heads
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(start, d, 64);
+            if (lane >= d) start = max(start, o);
+        }
+        const unsigned next = (unsigned)__shfl_down((int)key, 1, 64);
+        const bool tail = lane == 63 || (next >> 6) != (key >> 6);
+        const int base = valid ? km_c[lb] : 0;
+        __builtin_amdgcn_wave_barrier();
+        const int pos = base + (lane - start);
+        if (valid) {
+            perm[pos] = (int)(m0 + e0 + src);
+            if (tail) km_c[lb] = pos + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// partial sums: block c of the chunk table = up to KS_SEG consecutive rows of one label, summed in order
+__global__ void __launch_bounds__(256)
+km_segsum_kernel(const float *__restrict__ pts, int C, int K, const int *__restrict__ perm, const int *__restrict__ off,
+                 const int *__restrict__ cb, float *__restrict__ part)
+{
+    extern __shared__ float km_red[];                               // [4][C]
+    const int c = blockIdx.x;
+    if (c >= cb[K]) return;
+    int lo = 0, hi = K;                                             // the label whose chunk range holds c
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cb[mid] <= c) lo = mid; else hi = mid; }
+    const int k = lo;
+    const int p0 = off[k] + (c - cb[k]) * KS_SEG, p1 = min(off[k + 1], p0 + KS_SEG);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q0 = p0 + wv * (KS_SEG / 4), q1 = min(p1, q0 + KS_SEG / 4);
+    for (int ch0 = 0; ch0 < C; ch0 += 256) {                        // 4 channels per lane and pass
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int c0 = ch0 + lane, c1 = c0 + 64, c2 = c0 + 128, c3 = c0 + 192;
+        int q = q0;
+        for (; q + 4 <= q1; q += 4) {                               // four rows in flight, added in row order
+            const float *r0 = pts + (size_t)perm[q] * C, *r1 = pts + (size_t)perm[q + 1] * C;
+            const float *r2 = pts + (size_t)perm[q + 2] * C, *r3 = pts + (size_t)perm[q + 3] * C;
+            float v[4][4];
+            const float *rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u][0] = c0 < C ? rr[u][c0] : 0.f; v[u][1] = c1 < C ? rr[u][c1] : 0.f;
+                v[u][2] = c2 < C ? rr[u][c2] : 0.f; v[u][3] = c3 < C ? rr[u][c3] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; a2 += v[u][2]; a3 += v[u][3]; }
+        }
+        for (; q < q1; ++q) {
+            const float *r = pts + (size_t)perm[q] * C;
+            if (c0 < C) a0 += r[c0];
+            if (c1 < C) a1 += r[c1];
+            if (c2 < C) a2 += r[c2];
+            if (c3 < C) a3 += r[c3];
+        }
+        if (c0 < C) km_red[wv * C + c0] = a0;
+        if (c1 < C) km_red[wv * C + c1] = a1;
+        if (c2 < C) km_red[wv * C + c2] = a2;
+        if (c3 < C) km_red[wv * C + c3] = a3;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256)
+        part[(size_t)c * C + ch] = ((km_red[ch] + km_red[C + ch]) + km_red[2 * C + ch]) + km_red[3 * C + ch];
+}
+
+// sums[k] = its partial rows added in chunk order (an empty label: zeros)
+__global__ void __launch_bounds__(256)
+km_final_kernel(const float *__restrict__ part, int C, const int *__restrict__ cb, float *__restrict__ sums)
+{
+    // four row slots (waves) take the partial rows j0 + slot, + 4, ... with four loads in flight each; the slots are added in
+    // slot order - a fixed order, like everything above
+    extern __shared__ float km_fin[];                               // [4][C]
+    const int k = blockIdx.x, j0 = cb[k], j1 = cb[k + 1];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    for (int ch = lane; ch < C; ch += 64) {
+        float s = 0.f;
+        int j = j0 + slot;
+        for (; j + 12 < j1; j += 16) {
+            const float v0 = part[(size_t)j * C + ch], v1 = part[(size_t)(j + 4) * C + ch];
+            const float v2 = part[(size_t)(j + 8) * C + ch], v3 = part[(size_t)(j + 12) * C + ch];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; j < j1; j += 4) s += part[(size_t)j * C + ch];
+        km_fin[slot * C + ch] = s;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256)
+        sums[(size_t)k * C + ch] = ((km_fin[ch] + km_fin[C + ch]) + km_fin[2 * C + ch]) + km_fin[3 * C + ch];
+}
+
+static int launch_km_segsums(const float *pts, long long M, int C, int K, const int32_t *label, float *sums, char *ws, hipStream_t st)
+{
+    const KmWs w = km_ws(M, C, K);
+    int *perm = reinterpret_cast<int *>(ws + w.off_perm), *bh = reinterpret_cast<int *>(ws + w.off_bh);
+    int *tot = reinterpret_cast<int *>(ws + w.off_tot), *off = reinterpret_cast<int *>(ws + w.off_off), *cb = reinterpret_cast<int *>(ws + w.off_cb);
+    float *part = reinterpret_cast<float *>(ws + w.off_part);
+    hipLaunchKernelGGL(km_hist_kernel, dim3(w.nblk), dim3(64), sizeof(int) * K, st, label, M, K, bh);
+    GFS3D_LAUNCH_CHECK("km_hist_kernel");
+    hipLaunchKernelGGL(km_scan_kernel, dim3(K), dim3(256), 0, st, bh, w.nblk, K, tot);
+    GFS3D_LAUNCH_CHECK("km_scan_kernel");
+    hipLaunchKernelGGL(km_offsets_kernel, dim3(1), dim3(64), 0, st, tot, K, off, cb);
+    GFS3D_LAUNCH_CHECK("km_offsets_kernel");
+    hipLaunchKernelGGL(km_place_kernel, dim3(w.nblk), dim3(64), sizeof(int) * K, st, label, M, K, bh, off, perm);
+    GFS3D_LAUNCH_CHECK("km_place_kernel");
+    hipLaunchKernelGGL(km_segsum_kernel, dim3(w.nchmax), dim3(256), sizeof(float) * 4 * C, st, pts, C, K, perm, off, cb, part);
+    GFS3D_LAUNCH_CHECK("km_segsum_kernel");
+    hipLaunchKernelGGL(km_final_kernel, dim3(K), dim3(256), sizeof(float) * 4 * C, st, part, C, cb, sums);
+    GFS3D_LAUNCH_CHECK("km_final_kernel");
+    return GFS3D_OK;
+}
+
 template <int NT>
 static int launch_kmeans(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums,
-                         float *counts, double *inertia, hipStream_t st)
+                         float *counts, double *inertia, hipStream_t st, char *ws = nullptr)
 {
     ProfScope prof(5, st);
     bool x6 = false;
@@ -1225,6 +1442,7 @@ static int launch_kmeans(const float *pts, long long M, int C, const float *cent
                            pts, M, C, cent, K, label, counts, inertia);
         GFS3D_LAUNCH_CHECK("kmeans_assign_mfma_kernel");
     }
+    if (ws) return launch_km_segsums(pts, M, C, K, label, sums, ws, st);      // sorted segment sums: no atomics, fixed order
     hipLaunchKernelGGL(kmeans_sums_mfma_kernel, dim3((unsigned)((M + KM_CHUNK - 1) / KM_CHUNK), (C + 31) / 32), dim3(256), 0, st,
                        pts, M, C, K, label, sums);
     GFS3D_LAUNCH_CHECK("kmeans_sums_mfma_kernel");
@@ -1271,8 +1489,21 @@ extern "C" int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride,
                                        static_cast<hipStream_t>(stream), "gfs3d_proto_cosine_f32");
 }
 
+extern "C" size_t gfs3d_kmeans_workspace_bytes(long long M, int C, int K)
+{
+    if (M < 1 || M >= (1ll << 31) || C < 1 || C > 1024 || K < 1 || K > 256) return 0;
+    return gfs3d::km_ws(M, C, K).total;
+}
+
 extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                                        int32_t *label, float *sums, float *counts, double *inertia, void *stream)
+{
+    return gfs3d_kmeans_assign_ws_f32(pts, M, C, cent, K, label, sums, counts, inertia, nullptr, 0, stream);
+}
+
+extern "C" int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
+                                          int32_t *label, float *sums, float *counts, double *inertia,
+                                          void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(pts && cent && label && sums && counts, "gfs3d_kmeans_assign_f32: NULL pointer");
@@ -1280,10 +1511,19 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
     if (K <= 256 && (M + 127) / 128 < (1ll << 31)) {           // matrix-pipe path
         hipStream_t st = static_cast<hipStream_t>(stream);
         const int nt = (K + 31) / 32;
-        if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st);
-        if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st);
-        if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st);
-        return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st);
+        // with a workspace (and M < 2^31, C <= 1024) the centroid sums are sorted segment sums, else float-atomic tiles
+        char *ws = nullptr;
+        if (workspace && M < (1ll << 31) && C <= 1024) {
+            if (workspace_bytes < km_ws(M, C, K).total) {
+                set_error("gfs3d_kmeans_assign_ws_f32: workspace too small (%zu < %zu)", workspace_bytes, km_ws(M, C, K).total);
+                return GFS3D_ERR_WORKSPACE;
+            }
+            ws = static_cast<char *>(workspace);
+        }
+        if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
+        if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
+        if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
+        return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
     }
     const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
     GFS3D_ENSURE_LDS(kmeans_assign_kernel, lds, "gfs3d_kmeans_assign_f32");

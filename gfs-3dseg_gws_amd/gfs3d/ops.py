@@ -925,7 +925,10 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor):
     counts = torch.zeros(K, dtype=torch.float32, device=dev)
     inertia = torch.zeros(1, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().gfs3d_kmeans_assign_f32(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts),
-                                                _p(inertia), _stream())
-    _lib.check(rc, "gfs3d_kmeans_assign_f32")
+        L = _lib.lib()
+        nbytes = L.gfs3d_kmeans_workspace_bytes(M, C, K)       # > 0: centroid sums as sorted segment sums (fixed order, no atomics)
+        ws = _workspace(dev, nbytes) if nbytes else None
+        rc = L.gfs3d_kmeans_assign_ws_f32(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia),
+                                          _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _lib.check(rc, "gfs3d_kmeans_assign_ws_f32")
     return label, sums, counts, inertia

@@ -339,6 +339,13 @@ int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_bstride, in
                                    void *workspace, size_t workspace_bytes, void *stream);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
+/* The same with a workspace (gfs3d_kmeans_workspace_bytes; 0 = unsupported shape): the centroid sums are then SEGMENT SUMS over
+ * the points sorted by label (stable counting sort, fixed summation order: no float atomics, bit-reproducible; `sums` need
+ * not be zeroed) - the points are read once as whole rows instead of going through a one-hot GEMM. */
+size_t gfs3d_kmeans_workspace_bytes(long long M, int C, int K);
+int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
+                               int32_t *label, float *sums, float *counts, double *inertia,
+                               void *workspace, size_t workspace_bytes, void *stream);
 /* gfs3d_word_assign_f32 / gfs3d_proto_backward_feat_f32 with the matrix-core operand form chosen by the caller
  * (`compute` = GFS3D_COMPUTE_*; tensors stay fp32).  The reduced forms apply to the geometric-word shapes (more than 32
  * prototypes, C % 32 == 0); get_pred-sized calls (<= 32 prototypes) are HBM-bound on fp32 MFMAs and ignore it. */

@@ -421,3 +421,25 @@ def test_pack_unpack_round_trip_full_size(dev):
     packed.backward(packed.detach())                       # the adjoint applied to the packed matrix itself
     for t in srcs:
         assert torch.equal(t.grad, t.detach())
+
+
+@pytest.mark.parametrize("M,C,K", [(100003, 192, 200), (777, 64, 12), (5000, 33, 256), (70, 16, 3), (1, 8, 1), (3000, 192, 200)])
+def test_kmeans_centroid_sums_are_sorted_segment_sums(dev, M, C, K):
+    """get_basis.py:210 (Lloyd step): with the workspace form of the entry point the centroid sums come from a stable
+    counting sort of the points by label + fixed-order segment sums - equal to an fp64 index_add within fp32 rounding, member
+    counts exact, empty clusters (K close to M) zero, and two runs bit-identical (no float atomics)."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(M + K)
+    pts = torch.randn(M, C, generator=g).to(dev)
+    cent = torch.randn(K, C, generator=g).to(dev) * 0.5
+    lab, sums, cnt, inertia = ops.kmeans_assign(pts, cent)
+    ref = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, lab.long(), pts.double())
+    assert maxerr(sums, ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(cnt.long(), torch.bincount(lab.long(), minlength=K))
+    empty = cnt == 0
+    assert float(sums[empty].abs().max()) == 0.0 if bool(empty.any()) else True
+    d2 = ((pts.double()[:, None, :] - cent.double()[None]) ** 2).sum(-1) if M * K <= 2_000_000 else None
+    if d2 is not None:
+        assert abs(float(inertia) - float(d2.min(1)[0].sum())) <= 1e-4 * float(d2.min(1)[0].sum())
+    lab2, sums2, cnt2, _ = ops.kmeans_assign(pts, cent)
+    assert torch.equal(lab2, lab) and torch.equal(sums2, sums) and torch.equal(cnt2, cnt)
