@@ -245,7 +245,7 @@ def extras(dev, L, gdist):
         out["lloyd_step"] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3), "bound": "hbm",
                              "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
                              "algorithmic_TFLOPps": round(2.0 * M * 192 * 200 / ms / 1e9, 2),
-                             "note": "assignment + centroid sums: the points are read twice (two kernels)"}
+                             "note": "assignment (bf16x6 GEMM, matrix-bound: the larger part) + centroid sums as sorted segment sums; the points are read twice"}
         del pts
     q, k_, v = (torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
     cot = torch.randn(B, 64, N, generator=g).to(dev)
