@@ -87,6 +87,21 @@ __device__ __forceinline__ void at_put(unsigned char *img, int t, const float (&
 #pragma unroll
     for (int p = 0; p < Mx<PREC>::NP; ++p) *reinterpret_cast<uint4 *>(img + p * AT_PLANE + (t & 31) * AT_PROW + 16 * (t >> 5)) = pc[p];
 }
+// Backward of a HALF forward (compute = f16): the gradient GEMMs run on bf16 operands (gradients underflow in half), but S
+// must be recomputed from the operands the FORWARD used - exp(S_bf16 - lse_f16) is not a normalised row, and the rows of dS
+// would no longer sum to zero (a systematic gradient error).  The images of such a pass carry one more plane: the
+// f16 rounding of the same tile, read only by the S product.  SP = precision of the S operands (= PREC in every other mode).
+template <int PREC, int SP> struct AtImg {
+    static constexpr bool DUAL = SP != PREC;
+    static constexpr int NPI = Mx<PREC>::NP + (DUAL ? 1 : 0);     // planes per image
+    static constexpr int SOFF = DUAL ? Mx<PREC>::NP * AT_PLANE : 0;  // byte offset of the S operand's plane(s)
+};
+template <int PREC, int SP>
+__device__ __forceinline__ void at_put2(unsigned char *img, int t, const float (&r)[8], float s)
+{
+    at_put<PREC>(img, t, r, s);
+    if constexpr (AtImg<PREC, SP>::DUAL) at_put<SP>(img + AtImg<PREC, SP>::SOFF, t, r, s);
+}
 // rows = positions: lane (row j, half h), K-block kb -> channels 16 kb + 8 h + e
 template <int PREC>
 __device__ __forceinline__ void at_rowfrag(const unsigned char *img, int j, int h, int kb, uint4 (&f)[Mx<PREC>::NP])
@@ -240,10 +255,10 @@ __global__ void __launch_bounds__(256) attn_bwd_D_kernel(const float *__restrict
 }
 
 // ------------------------------------------------------------------ backward, query side: dQ
-template <int DROP, int PREC>
+template <int DROP, int PREC, int SP>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, float *__restrict__ dq)
 {
-    constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
+    constexpr int NP = Mx<PREC>::NP, NPS = Mx<SP>::NP, IMG = AtImg<PREC, SP>::NPI * AT_PLANE, SOFF = AtImg<PREC, SP>::SOFF;
     extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
     unsigned char *Kimg = at_smem, *Vimg = at_smem + 2 * IMG;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, j = lane & 31, h = lane >> 5;
@@ -253,8 +268,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
     const int qi = min(q0 + j, N - 1);
     const unsigned sb = at_seed(g.seed, b);
     constexpr bool drop = DROP != 0, HAS_MASK = DROP == 2;
-    uint4 qp[4][NP], gp[4][NP];
-    at_colfrags<PREC>(g.q + boff, N, qi, h, g.scale, qp);
+    uint4 qp[4][NPS], gp[4][NP];
+    at_colfrags<SP>(g.q + boff, N, qi, h, g.scale, qp);
     at_colfrags<PREC>(g.dout + boff, N, qi, h, 1.f, gp);
     const float Lq = g.lse[(size_t)b * N + qi], Dv = g.Dq[(size_t)b * N + qi];
     f32x16 G0, G1;
@@ -264,7 +279,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
     float rk[8], rv[8];
     at_load8(kb_, N, 0, t, rk);
     at_load8(vb, N, 0, t, rv);
-    at_put<PREC>(Kimg, t, rk, 1.f);
+    at_put2<PREC, SP>(Kimg, t, rk, 1.f);
     at_put<PREC>(Vimg, t, rv, 1.f);
     __syncthreads();
     const int nt = (N + 31) / 32;
@@ -277,10 +292,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            uint4 ak[NP], av[NP];
-            at_rowfrag<PREC>(Kc, j, h, kb, ak);
+            uint4 ak[NPS], av[NP];
+            at_rowfrag<SP>(Kc + SOFF, j, h, kb, ak);
             at_rowfrag<PREC>(Vc, j, h, kb, av);
-            mm_mac<PREC>(ak, qp[kb], acc);
+            mm_mac<SP>(ak, qp[kb], acc);
             mm_mac<PREC>(av, gp[kb], dp);
         }
         float ds[16];                                      // element-wise part, branch-free (one uniform branch for the dropout)
@@ -309,7 +324,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
             at_trfrag<PREC>(Kc, lane, 1, s, ak);
             mm_mac<PREC>(ak, dsp, G1);
         }
-        if (tt + 1 < nt) { at_put<PREC>(Kimg + (cur ^ 1) * IMG, t, rk, 1.f); at_put<PREC>(Vimg + (cur ^ 1) * IMG, t, rv, 1.f); }
+        if (tt + 1 < nt) { at_put2<PREC, SP>(Kimg + (cur ^ 1) * IMG, t, rk, 1.f); at_put<PREC>(Vimg + (cur ^ 1) * IMG, t, rv, 1.f); }
         __syncthreads();
     }
     if (q0 + j < N) {
@@ -323,10 +338,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
 }
 
 // ------------------------------------------------------------------ backward, key side: dK, dV
-template <int DROP, int PREC>
+template <int DROP, int PREC, int SP>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, float *__restrict__ dk, float *__restrict__ dv)
 {
-    constexpr int NP = Mx<PREC>::NP, IMG = NP * AT_PLANE;
+    constexpr int NP = Mx<PREC>::NP, NPS = Mx<SP>::NP, IMG = AtImg<PREC, SP>::NPI * AT_PLANE, SOFF = AtImg<PREC, SP>::SOFF;
     extern __shared__ __attribute__((aligned(16))) unsigned char at_smem[];
     unsigned char *Qimg = at_smem, *Gimg = at_smem + 2 * IMG;                  // queries (scaled) and dout, [2 buffers] each
     float (*Ls)[32] = reinterpret_cast<float (*)[32]>(at_smem + 4 * IMG);       // [2][32]
@@ -339,8 +354,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
     const bool kvalid = k0 + j < N;
     const unsigned sb = at_seed(g.seed, b);
     constexpr bool drop = DROP != 0, HAS_MASK = DROP == 2;
-    uint4 kp[4][NP], vp[4][NP];
-    at_colfrags<PREC>(g.k + boff, N, ki, h, 1.f, kp);
+    uint4 kp[4][NPS], vp[4][NP];
+    at_colfrags<SP>(g.k + boff, N, ki, h, 1.f, kp);
     at_colfrags<PREC>(g.v + boff, N, ki, h, 1.f, vp);
     f32x16 K0, K1, V0, V1;
 #pragma unroll
@@ -348,7 +363,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
 
     float rq[8], rg[8];
     auto put = [&](int buf, int p0) {
-        at_put<PREC>(Qimg + buf * IMG, t, rq, g.scale);
+        at_put2<PREC, SP>(Qimg + buf * IMG, t, rq, g.scale);
         at_put<PREC>(Gimg + buf * IMG, t, rg, 1.f);
         if (t < 32) { const int qq = min(p0 + t, N - 1); Ls[buf][t] = g.lse[(size_t)b * N + qq]; Ds[buf][t] = g.Dq[(size_t)b * N + qq]; }
     };
@@ -366,10 +381,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const AttnArgs g, 
         for (int r = 0; r < 16; ++r) { acc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            uint4 aq[NP], ag[NP];
-            at_rowfrag<PREC>(Qc, j, h, kb, aq);
+            uint4 aq[NPS], ag[NP];
+            at_rowfrag<SP>(Qc + SOFF, j, h, kb, aq);
             at_rowfrag<PREC>(Gc, j, h, kb, ag);
-            mm_mac<PREC>(aq, kp[kb], acc);
+            mm_mac<SP>(aq, kp[kb], acc);
             mm_mac<PREC>(ag, vp[kb], dp);
         }
         // element-wise part, branch-free (ONE uniform branch for the dropout decisions: as a per-element `if` it became 16
@@ -470,19 +485,19 @@ static int at_forward(const AttnArgs &a, bool has_mask, dim3 grid, float *out, f
     return GFS3D_OK;
 }
 
-template <int PREC>
+template <int PREC, int SP>
 static int at_backward(const AttnArgs &a, bool has_mask, dim3 grid, float *dq, float *dk, float *dv, hipStream_t st)
 {
-    const size_t lds = 4 * Mx<PREC>::NP * AT_PLANE;
+    const size_t lds = 4 * AtImg<PREC, SP>::NPI * AT_PLANE;
     if (has_mask) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<2, PREC>), grid, dim3(256), lds, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<2, PREC, SP>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, PREC, SP>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
     } else if (a.thresh != 0u) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, PREC>), grid, dim3(256), lds, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<1, PREC, SP>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, PREC, SP>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<0, PREC>), grid, dim3(256), lds, st, a, dq);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<0, PREC>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<0, PREC, SP>), grid, dim3(256), lds, st, a, dq);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<0, PREC, SP>), grid, dim3(256), lds + sizeof(float) * 4 * 32, st, a, dk, dv);
     }
     GFS3D_LAUNCH_CHECK("attn_bwd kernels");
     return GFS3D_OK;
@@ -529,9 +544,11 @@ extern "C" int gfs3d_attention_backward_mixed(const float *q, const float *k, co
     hipLaunchKernelGGL(attn_bwd_D_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, dout, out, N, workspace);
     GFS3D_LAUNCH_CHECK("attn_bwd_D_kernel");
     dim3 grid((N + 127) / 128, B);
-    // (gradients never run on half operands: prec_of)
-    if (prec_of(compute, true) == PREC_BF16) return at_backward<PREC_BF16>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
-    return at_backward<PREC_X6>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
+    // gradients never run on half operands (prec_of); the backward of a half forward recomputes S from HALF operands all the same,
+    // so that exp(S - lse) is the forward's normalised row (AtImg)
+    if (compute == GFS3D_COMPUTE_F16) return at_backward<PREC_BF16, PREC_F16>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
+    if (compute == GFS3D_COMPUTE_BF16) return at_backward<PREC_BF16, PREC_BF16>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
+    return at_backward<PREC_X6, PREC_X6>(a, keep_mask != nullptr, grid, dq, dk, dv, st);
 }
 
 extern "C" int gfs3d_attention_backward_f32(const float *q, const float *k, const float *v, const float *out, const float *lse,

@@ -234,7 +234,7 @@ rev_overflow_kernel(const float *__restrict__ Q, const int *__restrict__ ovf_cnt
 }
 
 // ---------------------------------------------------------------------------
-// The reverse graph in CSR form, one workgroup per point-cloud block (N k <= 65536 edges and the tables below within
+// The reverse graph in CSR form, one workgroup per point-cloud block (N k < 65536 edges and the tables below within
 // LDS): for every target m its in-edges in ASCENDING edge order (edge e = n k + j), so that everything summed over the
 // in-edges of a point - SQ here, G_P in the backward - has a FIXED order: bit-reproducible, and no float atomics.
 //   rowptr[b N + m]      first row of target m in the global CSR order (rows b N k .. (b+1) N k - 1 belong to block b);
@@ -264,13 +264,13 @@ csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__re
     const int32_t *ib = idx + (size_t)b * ne;
     for (int q = tid; q < (CSR_WAVES / 2) * N; q += CSR_THREADS) cw[q] = 0u;
     __syncthreads();
-    // A: edges tid, tid + 1024, ... (N k <= 65536 -> at most 64): all loads in flight at once
+    // A: edges tid, tid + 1024, ... (N k < 65536 -> at most 64): all loads in flight at once
     {
         int tg[64];
 #pragma unroll
         for (int q = 0; q < 64; ++q) {
             const int e = tid + q * CSR_THREADS;
-            tg[q] = e < ne ? ib[e] : -1;
+            tg[q] = e < ne ? min(max(ib[e], 0), N - 1) : -1;      // (ids outside [0, N) are a caller error: clamped, so that the LDS tables stay intact)
         }
 #pragma unroll
         for (int q = 0; q < 64; ++q)
@@ -325,7 +325,7 @@ csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__re
     for (int n0 = n_lo; n0 < n_hi; n0 += 8) {               // the neighbour lists of 8 sources in flight
         int tg[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) tg[u] = (lane < k && n0 + u < n_hi) ? ib[(size_t)(n0 + u) * k + lane] : -1;
+        for (int u = 0; u < 8; ++u) tg[u] = (lane < k && n0 + u < n_hi) ? min(max(ib[(size_t)(n0 + u) * k + lane], 0), N - 1) : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (tg[u] >= 0) {
@@ -1582,7 +1582,9 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_slot = take(sizeof(int) * BN * (size_t)REV_CAP);
     p.off_ovf = take(sizeof(int2) * BN * (size_t)k);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)(((C + 31) / 32) * 32) * p.g_pq);
-    p.csr_ok = (size_t)N * k <= 65536 && csr_lds_bytes(N, k) <= 160 * 1024 && (BN * k + 4096) < (size_t)(1u << 24);
+    // N k < 65536 (strictly): the packed u16 prefixes / cursors of csr_build_kernel hold up to the largest in-degree, which a
+    // caller's idx with repeated neighbours can push to N k (every edge of the cloud into one target)
+    p.csr_ok = (size_t)N * k < 65536 && csr_lds_bytes(N, k) <= 160 * 1024 && (BN * k + 4096) < (size_t)(1u << 24);
     p.off_csrsrc = take(p.csr_ok ? sizeof(int) * BN * k : 0);
     p.off_dyb = take(p.csr_ok ? sizeof(float) * EC * (BN * k + (size_t)p.g_bwd * BWD_WAVES) : 0);
     p.total = o;

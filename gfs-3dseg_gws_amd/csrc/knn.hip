@@ -477,9 +477,20 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 //      exhaustively in chunks of 32 with a running merged top-32.  Two queries per wave.
 // Bit-exactness does not depend on the screen being tight - only on E being a true bound; a loose E costs candidates.
 // ---------------------------------------------------------------------------
-// operands enter as hi + mid, two bf16 roundings to nearest: x = hi + mid + lo with |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|; the
-// three products hi hi + hi mid + mid hi miss x lo_y + y lo_x + mid mid: <= 3 2^-18 |x||y| per dot, twice that per distance
-constexpr float KNN_SCREEN_REL = 4.0e-5f;      // > 2 (3 2^-18) + fp32 accumulation of 3 x 64 and 64 terms (both chains: 2 (256 2^-24))
+// The bound E (re-derived in round 3: the round-2 text took bf16's unit roundoff as 2^-9; it is 2^-8 - 8 significand bits,
+// round to nearest).  Operands enter as hi + mid: hi = RNE_bf16(x), mid = RNE_bf16(x - hi) (x - hi is exact in fp32), so
+// x = hi + mid + lo with |mid| <= 2^-8 |x| (1 + 2^-8) and |lo| <= 2^-17 |x| (a residual of exactly half an ulp is a bf16 number).
+// Per channel the three products hi hi + hi mid + mid hi miss  mid_x mid_y + lo_x y + x lo_y - lo_x lo_y:
+//     <= (2^-16 + 2^-17 + 2^-17)(1 + 2^-7) |x||y| < 2^-15 (1 + 2^-6) |x||y|,
+// summed over the channels with Cauchy-Schwarz: <= 3.1e-5 |x_i||x_j| per dot product.  On top of that
+//   * the screen's own accumulation: 3 C <= 192 piece products (each exact in fp32) added in fp32 inside the matrix core, whose
+//     internal order and rounding mode are not documented - priced at one 2^-23 (twice round-to-nearest) per term:
+//     192 * 2^-23 * (1 + 2^-7) |x_i||x_j| < 2.4e-5 |x_i||x_j|;
+//   * the oracle's fma chain over C <= 64 channels: 64 * 2^-24 |x_i||x_j| < 0.4e-5 |x_i||x_j|.
+// Per dot 5.9e-5, per distance (2 dot) 1.18e-4 |x_i||x_j| <= 1.18e-4 sqrt(|x_i|^2 max_j |x_j|^2); the norms are the oracle's own
+// fp32 values (relative error 64 * 2^-24, covered by the margin to 1.25e-4).  A larger E only costs candidates: at the
+// norms of BatchNorm-ed features (|x|^2 ~ 64) 2 E = 0.03 against neighbour distances of ~10, a fraction of a candidate per query.
+constexpr float KNN_SCREEN_REL = 1.25e-4f;     // > 2 (2^-15 (1 + 2^-6) + 192 2^-23 + 64 2^-24) = 1.18e-4, see above
 constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
 constexpr int KS_QS = 32;                      // queue slots per lane (= per query half)
 constexpr int KS_CAP = 64;                     // candidate ids kept per query

@@ -904,10 +904,17 @@ class ProtoCosineFunction(torch.autograd.Function):
                 raise NotImplementedError("gfs3d.proto_cosine: the backward kernel handles up to 192 feature channels")
             dfeat = proto_backward_feat(feat, proto, s, dout)                    # fused HIP kernel
         if ctx.needs_input_grad[1]:                                              # (K, C) / (B, K, C): a skinny reduction over the points
-            if proto.shape[-2] <= 32 and feat.shape[1] <= 192:
+            if feat.shape[1] > 192:
+                raise NotImplementedError("gfs3d.proto_cosine: the prototype gradient handles up to 192 feature channels")
+            K = proto.shape[-2]
+            if K <= 32:
                 dproto = proto_backward_proto(feat, proto, s, dout)              # MFMA partials + fixed-order reduction
             else:
-                raise NotImplementedError("gfs3d.proto_cosine: the prototype gradient handles up to 32 prototypes of <= 192 channels")
+                # the gradient of 10 cos(f, p_k) w.r.t. p_k involves no other prototype: slices of <= 32 prototypes through the
+                # same kernel (the forward accepts up to 256 prototypes; ADVICE r2: this used to raise at backward time)
+                parts = [proto_backward_proto(feat, proto[..., k0:k0 + 32, :], s, dout[:, k0:k0 + 32])
+                         for k0 in range(0, K, 32)]
+                dproto = torch.cat(parts, dim=-2)
         return dfeat, dproto, None
 
 

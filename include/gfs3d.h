@@ -133,8 +133,8 @@ typedef struct gfs3d_edgeconv_args {
                                      the next layer's graph instead of a norm pass */
     int compute;                  /* GFS3D_COMPUTE_*: arithmetic of conv2 (heavy kernels) and of the point-major projection GEMM */
     int32_t *csr_rowptr;          /* optional, saved for backward: (B*N + 1) first CSR row of every target point's in-edges */
-    int32_t *csr_pos;             /* optional, saved for backward: (B, N, k) CSR row of every edge.  Both given (and N k <= 65536
-                                     edges per block): the training forward builds the reverse kNN graph in CSR form and the
+    int32_t *csr_pos;             /* optional, saved for backward: (B, N, k) CSR row of every edge.  Both given (and N k < 65536
+                                     edges per block; idx values outside [0, N) are a caller error - the graph builder clamps them): the training forward builds the reverse kNN graph in CSR form and the
                                      backward stores per-edge rows + sums CSR segments instead of float atomics - every sum over
                                      the in-edges of a point then has a fixed order.  NULL: slot table + float atomics */
 } gfs3d_edgeconv_args;

@@ -435,7 +435,8 @@ def test_word_assign_vs_oracle(dev, B, C, N, Kw):
 
 
 @pytest.mark.parametrize("B,C,N,K,per_sample", [(3, 128, 50, 13, False), (3, 128, 50, 14, True), (2, 128, 2048, 22, False),
-                                                (1, 64, 33, 32, True), (4, 128, 1100, 22, True), (2, 192, 700, 5, False)])
+                                                (1, 64, 33, 32, True), (4, 128, 1100, 22, True), (2, 192, 700, 5, False),
+                                                (2, 128, 300, 70, False), (2, 64, 130, 40, True)])     # K > 32: sliced prototype gradient
 def test_proto_cosine_vs_oracle_with_grads(dev, B, C, N, K, per_sample):
     from gfs3d import ops
     g = torch.Generator().manual_seed(K + N)

@@ -178,6 +178,31 @@ def test_attention_reduced_vs_fp64(dev, mode, B, N, p_drop):
         assert cosine(a_.grad, b_.grad) > KERNEL_COS[mode]
 
 
+def test_attention_half_forward_backward_recomputes_the_forwards_scores(dev):
+    """The backward of a HALF forward runs its gradient GEMMs on bf16 operands but must rebuild P = exp(S - lse) from the
+    operands the forward used (half), or the rows of dS stop summing to zero.  With peaked scores (|S| ~ 10) a
+    bf16 S differs from the half S by ~0.04: that showed as a gradient direction error an order above the half mode's own.
+    Property asserted: the q / k gradients of the f16 mode are as close to fp64 as those of a run whose forward AND backward
+    both use the fp32-accurate path are to within the half-operand tolerance - and markedly closer than bf16's."""
+    from gfs3d import ops
+    B, N = 2, 512
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B, 64, N, generator=g) * s for s in (3.0, 3.0, 1.0))
+    cot = torch.randn(B, 64, N, generator=g)
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    att = torch.softmax(torch.bmm(q64.transpose(1, 2), k64) / 8.0, dim=-1)
+    torch.bmm(att, v64.transpose(1, 2)).transpose(1, 2).backward(cot.double())
+    res = {}
+    for mode in ("f16", "bf16"):
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        with ops.compute(mode):
+            ops.attention(qd, kd, vd, 1.0 / 8.0, 0.0, 0, None).backward(cot.to(dev))
+        res[mode] = [1.0 - cosine(a_.grad, b_.grad) for a_, b_ in ((qd, q64), (kd, k64))]
+    # half forward + consistent S: direction error of dq / dk below 2e-4 (measured ~5e-5); a bf16 S under a half lse gave ~2e-3
+    assert max(res["f16"]) < 2e-4, res
+    assert max(res["f16"]) < 0.5 * max(res["bf16"]), res
+
+
 def _capl(g, dev, classes, base):
     from model.capl import mpti_net_Point_GeoAsWeight_v2
     a = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,

@@ -169,7 +169,7 @@ def test_edgeconv_hip_is_invariant_to_neighbour_order_and_point_relabelling(dev,
 # for every pair; this restates the screen's arithmetic in numpy (hi + mid round-to-nearest bf16 pieces, the three products
 # hi hi + hi mid + mid hi, fp32 accumulation) and measures the worst pair.  The constants are the kernel's.
 # ---------------------------------------------------------------------------
-KNN_SCREEN_REL, KNN_SCREEN_ABS = 4.0e-5, 4e-6
+KNN_SCREEN_REL, KNN_SCREEN_ABS = 1.25e-4, 4e-6
 _WORST = {}
 
 
@@ -187,21 +187,45 @@ def _knn_screen_constants_from_source():
     return rel, ab
 
 
-@settings(**CPU_SETTINGS)
-@given(seed=st.integers(0, 2 ** 31 - 1), C=st.sampled_from([16, 33, 64]), N=st.sampled_from([64, 160]),
-       kind=st.sampled_from(["randn", "ints", "dups", "offset", "relu", "scaled"]))
+def _screen_case(seed, C, N, kind):
+    """Inputs for the bound test.  Beside the random kinds, ADVERSARIAL ones for the two-piece split: values just
+    below a bf16 rounding tie (1 + 2^-8 - eps: hi = 1, mid = +2^-8 (1 - tiny), the largest possible mid . mid term, all of
+    one sign so nothing cancels), the same with random signs per element (mixed-sign mids), with the magnitudes spread over
+    binades, and constant channels (every point the same tie value: all products equal, the accumulation error has one sign)."""
+    g = torch.Generator().manual_seed(seed)
+    tie = 1.0 + 2.0 ** -8 - 2.0 ** -20
+    if kind == "relu":
+        return torch.relu(_points(seed, 1, C, N, "randn")) * 4.0 + 0.5
+    if kind == "scaled":
+        return _points(seed, 1, C, N, "randn") * 1e3
+    if kind == "tie":
+        return torch.full((1, C, N), tie)
+    if kind == "tie_signs":
+        return torch.full((1, C, N), tie) * (torch.randint(0, 2, (1, C, N), generator=g).float() * 2 - 1)
+    if kind == "tie_binades":
+        return torch.full((1, C, N), tie) * torch.exp2(torch.randint(-3, 4, (1, C, N), generator=g).float())
+    if kind == "tie_neg_mid":        # just ABOVE a tie: hi = 1 + 2^-7, mid = -2^-8 (1 - tiny)
+        return torch.full((1, C, N), 1.0 + 2.0 ** -8 + 2.0 ** -20) * (torch.randint(0, 2, (1, 1, N), generator=g).float() * 2 - 1)
+    if kind == "const_channels":     # half of the channels constant over the points at a tie value, the others random
+        x = torch.randn(1, C, N, generator=g)
+        x[:, ::2, :] = tie * 3.0
+        return x
+    return _points(seed, 1, C, N, kind)
+
+
+@settings(**dict(CPU_SETTINGS, max_examples=60))
+@given(seed=st.integers(0, 2 ** 31 - 1), C=st.sampled_from([9, 16, 33, 64]), N=st.sampled_from([64, 160]),
+       kind=st.sampled_from(["randn", "ints", "dups", "offset", "relu", "scaled", "tie", "tie_signs", "tie_binades", "tie_neg_mid",
+                             "const_channels"]))
 def test_knn_screen_error_bound_holds(seed, C, N, kind):
     assert _knn_screen_constants_from_source() == (KNN_SCREEN_REL, KNN_SCREEN_ABS)
-    if kind == "relu":
-        x = torch.relu(_points(seed, 1, C, N, "randn")) * 4.0 + 0.5
-    elif kind == "scaled":
-        x = _points(seed, 1, C, N, "randn") * 1e3
-    else:
-        x = _points(seed, 1, C, N, kind)
+    x = _screen_case(seed, C, N, kind)
     pd = _oracle_pd(x)[0].astype(np.float64)                     # [i][j]: query i, candidate j
     xb = x[0].numpy()
     hi = _bf16_rne(xb)
     mid = _bf16_rne((xb - hi).astype(np.float32))                # exact residual, rounded again
+    assert np.abs(mid).max() <= 2.0 ** -8 * (1 + 2.0 ** -8) * np.abs(xb).max()      # the unit roundoff the derivation uses
+    assert np.abs(xb - hi - mid).max() <= 2.0 ** -17 * np.abs(xb).max()
     acc = np.zeros((N, N), dtype=np.float32)
     for c0 in range(0, C, 16):                                   # one MFMA K-step = 16 channels; smallest products first
         for a, b in ((mid, hi), (hi, mid), (hi, hi)):
@@ -215,4 +239,26 @@ def test_knn_screen_error_bound_holds(seed, C, N, kind):
     E = KNN_SCREEN_REL * np.sqrt(sq.astype(np.float64) * sqmax) + KNN_SCREEN_ABS * (sq.astype(np.float64) + sqmax)
     worst = (np.abs(approx - pd) / np.maximum(E[:, None], 1e-300)).max()
     _WORST[kind] = max(_WORST.get(kind, 0.0), float(worst))
-    assert worst <= 0.75, worst                                  # a quarter of the bound is kept as margin for the MFMA's internal order
+    # This restatement rounds ONCE per 16-channel K-step and product kind; the derivation prices every one of the 3 C piece
+    # products at 2^-23 (the matrix core's internal order is not documented).  The dropped-term part of the bound alone is
+    # 2 * 2^-15 / 1.25e-4 = 0.49 of E and the tie cases come close to it: what this asserts is that nothing measured exceeds
+    # dropped terms + this restatement's own accumulation, i.e. that the remaining 0.4 of E is untouched margin.
+    assert worst <= 0.6, worst
+
+
+def test_knn_screen_bound_adversarial_value_is_near_the_dropped_term_limit():
+    """The ADVICE r2 counter-example: every channel at 1.0038909 (hi = 1, mid = +2^-8).  The dropped mid . mid terms ALONE are
+    0.74 of the round-2 bound (4.0e-5 |x||y|) - the accumulation roundings of both forms took it past 1 - and must sit inside the
+    re-derived one with the accumulation share (0.5 of it) to spare."""
+    C, N = 64, 64
+    v = np.float32(1.0038909)
+    xb = np.full((C, N), v, dtype=np.float32)
+    hi = _bf16_rne(xb)
+    mid = _bf16_rne((xb - hi).astype(np.float32))
+    assert float(hi[0, 0]) == 1.0 and abs(float(mid[0, 0]) - 2.0 ** -8) < 2.0 ** -15
+    exact = 2.0 * C * float(v) ** 2
+    approx = 2.0 * C * (float(hi[0, 0]) ** 2 + 2 * float(hi[0, 0]) * float(mid[0, 0]))
+    sq = C * float(v) ** 2
+    err = abs(approx - exact)
+    assert err > 0.7 * 4.0e-5 * sq               # 2 * 2^-16 / 1.0078 = 3.0e-5 per unit of |x||y|: no room left in the old constant
+    assert err < 0.5 * KNN_SCREEN_REL * sq       # the new one does, with the accumulation share to spare
