@@ -1,0 +1,915 @@
+// K6: the prototype head of the CAPL training step, fused  (reference model/capl.py:194-242 with generate_fake_proto
+// :364-411, get_pred :290-322, post_refine_proto_v2 :245-287 and the two CrossEntropyLoss calls of train.py:317).
+//
+//   ori      = unit(main_proto), rows of the fake-novel classes replaced by the masked mean of the unit point features of the
+//              support half of the batch                                                   (generate_fake_proto)
+//   L1       = 10 cos(F, [bg; ori])                               loss_1 = CE(L1, y)          (get_pred, 2-D prototypes)
+//   resp     = softmax over the POINTS of 10 cos(F, [bg; main])   pooled = resp F^T           (post_refine_proto_v2)
+//   w        = relu(cos(pooled, main))                            ref0   = w pooled + (1 - w) main
+//   refined  = ref0 + ori (base classes) | ori (the others)
+//   L2       = 10 cos(F, [bg; refined_b])                         loss_2 = CE(L2, y), pred = argmax L2   (3-D prototypes)
+//   loss     = (loss_1 + loss_2) / 2
+//
+// The torch form of this chain is ~200 small launches per step (1.2 of the 8.3 ms of BASELINE configs[3]); here it is
+// four passes over the (B, 128, N) feature tensor (two forward, two backward) and a handful of per-class kernels:
+//   hd_fwd1   per point: cosines against [bg; main], e = exp(L3 - 10); per workgroup the point contractions
+//             sum_n e[k][n] F[c][n] (soft pooling) and sum_n [y_n = fake_f] F[c][n] / |F_n| (fake-novel sums) as ONE fp32 MFMA
+//             product (rows = classes + fake classes, k = points)                             -> partial tiles
+//   hd_mid1   fake-novel sums over the support half                                           -> fsum  (all-reduced under DP)
+//   hd_mid2   per batch item: pooled, w, ref0, ori, refined -> unit prototype tables q1 (shared), q2 (per item)
+//   hd_fwd2   per point: L1, L2, both cross-entropies, arg-max                                 -> loss partials, pred
+//   hd_loss   fixed-order sum of the loss partials
+//   hd_bwd1   per point: softmax - one-hot of both heads; the prototype-gradient contractions sum_n g[k][n] Fhat[c][n]
+//   hd_bwdm1  per batch item: back through refined / ref0 / w / pooled                        -> dpooled, partial d main
+//   hd_bwdm2  per class: gradient of ori, of the fake-novel sums (dfsum, all-reduced under DP), of main through unit()
+//   hd_bwd2   per point: d F from all four paths (both heads, the soft pooling, the fake-novel means), written once;
+//             contraction sum_n dL3[k][n] Fhat[c][n]
+//   hd_bwdfin per class: gradient through the normalisation of [bg; main], final d main / d bg
+// Layout of the point passes: lane = ONE point, a wave = 64 points, a workgroup = 256 points of one batch item; the class
+// tables live in LDS and are read as 16-byte broadcasts (every lane the same address); the few products whose contraction
+// index is the POINT (a cross-lane sum) go through v_mfma_f32_32x32x2_f32 with both operands transposed through small
+// per-wave LDS tiles.  Everything is an exact fp32 fma chain: no operand splitting needed at <= 24 classes.
+// No atomics anywhere: every cross-workgroup sum is a partial tile added in a fixed order (bit-reproducible).
+#include "common.h"
+
+namespace gfs3d {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD_C = 128;            // feature channels (main_dim of capl.py:46)
+constexpr int HD_PTS = 256;          // points per workgroup (4 waves, lane = point)
+constexpr int HD_LD = 65;            // row stride of the per-wave LDS tiles (floats): [row][point], conflict-free both ways
+constexpr int HD_FLD = HD_C + 1;     // row stride of the fsum / dfsum tables: [fake class][128 sums | count]
+constexpr float HD_EPS = 1e-12f;
+constexpr float HD_SCALE = 10.0f;    // get_pred's `pred * 10`
+constexpr float HD_SHIFT = 10.0f;    // exp(L - 10): the logits are 10 cos in [-10, 10], so no running maximum is needed
+
+struct HeadFake { int n, half; int cls[GFS3D_HEAD_MAX_FAKE]; };       // fake-novel labels; support half = batch items >= half
+
+__device__ __forceinline__ int hd_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ f32x4 hd_ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ float hd_wsum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int hd_fake_index(const HeadFake &fk, long long y)
+{
+    int r = -1;
+    for (int i = 0; i < fk.n; ++i) r = (y == (long long)fk.cls[i]) ? i : r;
+    return r;
+}
+
+// rows [0, rows) of a (rows, 128) matrix into an LDS table of KT rows (the rest zero); 256 threads, ends with a barrier
+template <int KT>
+__device__ __forceinline__ void hd_load_table(float *dst, const float *src, int rows, int tid)
+{
+    for (int e = tid; e < KT * (HD_C / 4); e += 256) {
+        const int row = e >> 5, c4 = e & 31;
+        const f32x4 v = row < rows ? hd_ldg4(src + (size_t)row * HD_C + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(dst + row * HD_C + 4 * c4) = v;
+    }
+    __syncthreads();
+}
+// [bg; main] (K1 = classes + 1 rows), every row divided by max(|row|, eps) (F.normalize); 256 threads, ends with a barrier
+template <int KT>
+__device__ __forceinline__ void hd_load_bgmain_unit(float *dst, const float *bg, const float *main_proto, int K1, int tid)
+{
+    for (int e = tid; e < KT * (HD_C / 4); e += 256) {
+        const int row = e >> 5, c4 = e & 31;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row == 0) v = hd_ldg4(bg + 4 * c4);
+        else if (row < K1) v = hd_ldg4(main_proto + (size_t)(row - 1) * HD_C + 4 * c4);
+        *reinterpret_cast<f32x4 *>(dst + row * HD_C + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    for (int row = w; row < K1; row += 4) {
+        const float a = dst[row * HD_C + lane], b = dst[row * HD_C + 64 + lane];
+        const float inv = 1.0f / fmaxf(sqrtf(hd_wsum(fmaf(a, a, b * b))), HD_EPS);
+        dst[row * HD_C + lane] = a * inv;
+        dst[row * HD_C + 64 + lane] = b * inv;
+    }
+    __syncthreads();
+}
+
+// lane = point: |f|^2 and the dot products of the point's 128 channels with NT tables of KT rows in LDS.  The column is
+// streamed four channels at a time, the next group requested before the current one is used (the ~KT NT 16-byte broadcast
+// reads and 4 KT NT fma of a group cover an L2 round trip).
+template <int KT, int NT>
+__device__ __forceinline__ void hd_dots(const float *col, size_t N, const float *const (&tab)[NT], float (&d)[NT][KT], float &sq)
+{
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) d[t][k] = 0.f;
+    sq = 0.f;
+    float a0 = col[0], a1 = col[N], a2 = col[2 * N], a3 = col[3 * N];
+#pragma unroll 1
+    for (int c4 = 0; c4 < HD_C / 4; ++c4) {
+        const float v0 = a0, v1 = a1, v2 = a2, v3 = a3;
+        if (c4 + 1 < HD_C / 4) {
+            const float *nx = col + (size_t)(4 * c4 + 4) * N;
+            a0 = nx[0]; a1 = nx[N]; a2 = nx[2 * N]; a3 = nx[3 * N];
+        }
+        sq = fmaf(v3, v3, fmaf(v2, v2, fmaf(v1, v1, fmaf(v0, v0, sq))));
+        // (a fence every eight rows: left alone the scheduler issues all KT NT table reads of a group first - 4 registers each)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(tab[t] + k * HD_C + 4 * c4);
+                d[t][k] = fmaf(v3, q[3], fmaf(v2, q[2], fmaf(v1, q[1], fmaf(v0, q[0], d[t][k]))));
+                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+// log-sum-exp and probabilities of KT logits (rows >= K1 excluded), in place: L -> p
+template <int KT>
+__device__ __forceinline__ float hd_softmax(float (&L)[KT], int K1)
+{
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < KT; ++k) mx = k < K1 ? fmaxf(mx, L[k]) : mx;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { L[k] = k < K1 ? expf(L[k] - mx) : 0.f; s += L[k]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) L[k] *= inv;
+    return mx + logf(s);
+}
+
+// One 32-channel tile of the point contraction  D[row][c] += sum over the wave's 64 points of A[row][n] F[c][n]:
+// the lane (= point) re-reads its 32 channel values (L2: the dots pass has just streamed them), the wave transposes them
+// through its LDS tile and issues 32 MFMA steps of two points each per row tile.
+template <int RT>
+__device__ __forceinline__ void hd_contract_tile(const float *col, size_t N, int ct, bool valid, const float *at, float *bt, int lane,
+                                                 f32x16 (&acc)[RT])
+{
+    const int j = lane & 31, h = lane >> 5;
+    float v[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) v[r] = col[(size_t)(32 * ct + r) * N];
+    __syncthreads();                                     // (the previous tile's reads are done)
+#pragma unroll
+    for (int r = 0; r < 32; ++r) bt[r * HD_LD + lane] = valid ? v[r] : 0.f;
+    __syncthreads();
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const float bv = bt[j * HD_LD + 2 * s + h];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[(rt * 32 + j) * HD_LD + 2 * s + h], bv, acc[rt], 0, 0, 0);
+    }
+}
+
+// the four waves' result tiles of channel tile ct added in wave order and stored: part[(rt 32 + row)][32 ct + c]
+template <int RT>
+__device__ __forceinline__ void hd_reduce_store(const f32x16 (&acc)[RT], float *red /* [4][32][33] */, int ct, int tid, float *part)
+{
+    const int lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(w * 32 + hd_acc_row(r, h)) * 33 + j] = acc[rt][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, row = e >> 5, c = e & 31;
+            const float s = ((red[row * 33 + c] + red[(32 + row) * 33 + c]) + red[(64 + row) * 33 + c]) + red[(96 + row) * 33 + c];
+            part[(size_t)(rt * 32 + row) * HD_C + 32 * ct + c] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pass 1
+// part1[(b nchunk + chunk)][32][128]: rows k < K1: sum_n e[k][n] F[c][n]; rows K1 + f: sum_n [support, y_n = fake f] F[c][n] / (|F_n| + eps)
+// sums1[(b nchunk + chunk)][32]:      rows k < K1: sum_n e[k][n];        rows K1 + f: the number of such points
+template <int KT>
+__global__ void __launch_bounds__(256, 1)
+hd_fwd1_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, const float *__restrict__ main_proto,
+               const float *__restrict__ bg, int K1, const HeadFake fk, float *__restrict__ part1, float *__restrict__ sums1)
+{
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q3 = hd_smem;                                 // [KT][128]
+    float *atile = q3 + KT * HD_C;                       // [4][32][65]
+    float *btile = atile + 4 * 32 * HD_LD;               // [4][32][65]   (later: the reduction buffer)
+    float *wsums = btile + 4 * 32 * HD_LD;               // [4][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n = chunk * HD_PTS + w * 64 + lane;
+    const bool valid = n < N;
+    const float *col = feat + (size_t)b * bs + min(n, N - 1);
+    hd_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
+    float d[1][KT], sq;
+    const float *const tabs[1] = {q3};
+    hd_dots<KT, 1>(col, (size_t)N, tabs, d, sq);
+    const float nrm = sqrtf(sq);
+    const float rn = 1.0f / fmaxf(nrm, HD_EPS);
+    float *at = atile + w * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) at[r * HD_LD + lane] = 0.f;
+    if (lane < 32) wsums[w * 32 + lane] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const float e = (valid && k < K1) ? __expf(HD_SCALE * d[0][k] * rn - HD_SHIFT) : 0.f;
+        if (k < K1) at[k * HD_LD + lane] = e;
+        const float se = hd_wsum(e);
+        if (lane == 0 && k < K1) wsums[w * 32 + k] = se;
+    }
+    if (fk.n > 0 && b >= fk.half) {                      // (workgroup-uniform)
+        const long long y = label[(size_t)b * N + min(n, N - 1)];
+        const int fi = valid ? hd_fake_index(fk, y) : -1;
+        const float rn2 = 1.0f / (nrm + HD_EPS);         // generate_fake_proto divides by (|f| + 1e-12)
+        for (int f = 0; f < fk.n; ++f) {
+            at[(K1 + f) * HD_LD + lane] = fi == f ? rn2 : 0.f;
+            const float cnt = hd_wsum(fi == f ? 1.f : 0.f);
+            if (lane == 0) wsums[w * 32 + K1 + f] = cnt;
+        }
+    }
+    f32x16 acc[4][1];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][0][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) hd_contract_tile<1>(col, (size_t)N, ct, valid, at, bt, lane, acc[ct]);
+    float *part = part1 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) hd_reduce_store<1>(acc[ct], btile, ct, tid, part);
+    if (tid < 32) sums1[(size_t)(b * nchunk + chunk) * 32 + tid] = ((wsums[tid] + wsums[32 + tid]) + wsums[64 + tid]) + wsums[96 + tid];
+}
+
+// Fixed-order sum of `count` partial rows, `stride` floats apart, by a block of 1024 threads: thread (g, c) adds the rows
+// p = g, g + 8, ... of channel c (independent loads, eight in flight), the eight group sums are then added in group order.
+// Returns the total in the threads of group 0 (c = tid & 127); ends with a barrier.
+__device__ __forceinline__ float hd_sum_rows(const float *base, size_t stride, int count, float (*sh)[HD_C], int tid)
+{
+    const int c = tid & 127, g = tid >> 7;
+    float s = 0.f;
+#pragma unroll 4
+    for (int p = g; p < count; p += 8) s += base[(size_t)p * stride + c];
+    __syncthreads();                                     // (sh may still be read from a previous call)
+    sh[g][c] = s;
+    __syncthreads();
+    float t = 0.f;
+    if (g == 0)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q][c];
+    return t;
+}
+
+// fsum[f][c] = sum over the support half's partial tiles (fixed order); fsum[f][128] = the point count.  grid = n_fake
+__global__ void __launch_bounds__(1024)
+hd_mid1_kernel(const float *__restrict__ part1, const float *__restrict__ sums1, int B, int nchunk, int K1, int half, float *__restrict__ fsum)
+{
+    __shared__ float sh[8][HD_C];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int count = (B - half) * nchunk;
+    const float s = hd_sum_rows(part1 + ((size_t)half * nchunk * 32 + K1 + f) * HD_C, (size_t)32 * HD_C, count, sh, tid);
+    if (tid < HD_C) fsum[f * HD_FLD + tid] = s;
+    if (tid == 0) {
+        float cnt = 0.f;
+        for (int p = half * nchunk; p < B * nchunk; ++p) cnt += sums1[(size_t)p * 32 + K1 + f];
+        fsum[f * HD_FLD + HD_C] = cnt;
+    }
+}
+
+// per-item state of the refinement kept for the backward: hs[(b KT + k)][8] = {s, w, cos, |pooled|, |refined|, -, -, -}
+constexpr int HD_HS = 8;
+// grid = (B, ceil(K1 / 4)), 4 waves = 4 rows k; a lane owns channels lane and lane + 64
+template <int KT>
+__global__ void __launch_bounds__(256)
+hd_mid2_kernel(const float *__restrict__ part1, const float *__restrict__ sums1, int nchunk, const float *__restrict__ main_proto,
+               const float *__restrict__ bg, int K1, int base_num, const HeadFake fk, const float *__restrict__ fsum,
+               float *__restrict__ q1, float *__restrict__ q2, float *__restrict__ ori_s, float *__restrict__ onrm,
+               float *__restrict__ pooled_s, float *__restrict__ hs)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    {
+        const int k = blockIdx.y * 4 + w;                // one wave per row
+        if (k >= K1) return;
+        float *q2r = q2 + ((size_t)b * KT + k) * HD_C;
+        if (k == 0) {
+            const float v0 = bg[lane], v1 = bg[64 + lane];
+            const float inv = 1.0f / fmaxf(sqrtf(hd_wsum(fmaf(v0, v0, v1 * v1))), HD_EPS);
+            q2r[lane] = v0 * inv; q2r[64 + lane] = v1 * inv;
+            if (b == 0) { q1[lane] = v0 * inv; q1[64 + lane] = v1 * inv; }
+            return;
+        }
+        const int j = k - 1;
+        const float P0 = main_proto[(size_t)j * HD_C + lane], P1 = main_proto[(size_t)j * HD_C + 64 + lane];
+        float u0 = 0.f, u1 = 0.f, s = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const size_t p = (size_t)b * nchunk + ch;
+            u0 += part1[(p * 32 + k) * HD_C + lane];
+            u1 += part1[(p * 32 + k) * HD_C + 64 + lane];
+            s += sums1[p * 32 + k];
+        }
+        const float is = 1.0f / s;
+        const float p0 = u0 * is, p1 = u1 * is;                          // pooled = softmax-over-points . F^T
+        const float Pr = sqrtf(hd_wsum(fmaf(P0, P0, P1 * P1)));
+        const float pn = fmaxf(sqrtf(hd_wsum(fmaf(p0, p0, p1 * p1))), HD_EPS), Pn = fmaxf(Pr, HD_EPS);
+        const float cosw = hd_wsum(fmaf(p0 / pn, P0 / Pn, (p1 / pn) * (P1 / Pn)));
+        const float wv = cosw > 0.f ? cosw : 0.f;
+        const float r0 = fmaf(wv, p0, (1.0f - wv) * P0), r1 = fmaf(wv, p1, (1.0f - wv) * P1);
+        // ori row: unit(main) or, for a fake-novel class, the masked mean of the unit features
+        const int fi = hd_fake_index(fk, (long long)(j + 1));
+        float o0, o1;
+        if (fi >= 0) {
+            const float den = fsum[fi * HD_FLD + HD_C] + HD_EPS;
+            o0 = fsum[fi * HD_FLD + lane] / den; o1 = fsum[fi * HD_FLD + 64 + lane] / den;
+        } else {
+            o0 = P0 / (Pr + HD_EPS); o1 = P1 / (Pr + HD_EPS);
+        }
+        const float f0 = j < base_num ? r0 + o0 : o0, f1 = j < base_num ? r1 + o1 : o1;
+        const float fn = fmaxf(sqrtf(hd_wsum(fmaf(f0, f0, f1 * f1))), HD_EPS);
+        q2r[lane] = f0 / fn; q2r[64 + lane] = f1 / fn;
+        float *ps = pooled_s + ((size_t)b * KT + k) * HD_C;
+        ps[lane] = p0; ps[64 + lane] = p1;
+        if (lane == 0) {
+            float *hr = hs + ((size_t)b * KT + k) * HD_HS;
+            hr[0] = s; hr[1] = wv; hr[2] = cosw; hr[3] = pn; hr[4] = fn;
+        }
+        if (b == 0) {
+            const float on = fmaxf(sqrtf(hd_wsum(fmaf(o0, o0, o1 * o1))), HD_EPS);
+            q1[(size_t)k * HD_C + lane] = o0 / on; q1[(size_t)k * HD_C + 64 + lane] = o1 / on;
+            ori_s[(size_t)j * HD_C + lane] = o0; ori_s[(size_t)j * HD_C + 64 + lane] = o1;
+            if (lane == 0) onrm[j] = on;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pass 2
+// loss partials part2[(b nchunk + chunk)][4] = {sum nll_1, sum nll_2, counted points, -}; pred (B, N) int64
+template <int KT>
+__global__ void __launch_bounds__(256, 1)
+hd_fwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+               const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, float *__restrict__ part2, long long *__restrict__ pred)
+{
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_C;
+    float *wred = q2 + KT * HD_C;                        // [4][4]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n = chunk * HD_PTS + w * 64 + lane;
+    const bool valid = n < N;
+    const float *col = feat + (size_t)b * bs + min(n, N - 1);
+    hd_load_table<KT>(q1, q1g, K1, tid);
+    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    float d[2][KT], sq;
+    const float *const tabs[2] = {q1, q2};
+    hd_dots<KT, 2>(col, (size_t)N, tabs, d, sq);
+    const float rn = HD_SCALE / fmaxf(sqrtf(sq), HD_EPS);
+    const long long y = label[(size_t)b * N + min(n, N - 1)];
+    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+    float pick1 = 0.f, pick2 = 0.f, best = -__builtin_inff();
+    int bk = 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        d[0][k] *= rn; d[1][k] *= rn;
+        pick1 = (long long)k == y ? d[0][k] : pick1;
+        pick2 = (long long)k == y ? d[1][k] : pick2;
+        if (k < K1 && d[1][k] > best) { best = d[1][k]; bk = k; }
+    }
+    const float lse1 = hd_softmax<KT>(d[0], K1), lse2 = hd_softmax<KT>(d[1], K1);
+    if (valid) pred[(size_t)b * N + n] = (long long)bk;
+    const float s1 = hd_wsum(ok ? lse1 - pick1 : 0.f), s2 = hd_wsum(ok ? lse2 - pick2 : 0.f), sc = hd_wsum(ok ? 1.f : 0.f);
+    if (lane == 0) { wred[w * 4 + 0] = s1; wred[w * 4 + 1] = s2; wred[w * 4 + 2] = sc; }
+    __syncthreads();
+    if (tid < 3) part2[(size_t)(b * nchunk + chunk) * 4 + tid] = ((wred[tid] + wred[4 + tid]) + wred[8 + tid]) + wred[12 + tid];
+}
+
+// loss[0] = (mean nll_1 + mean nll_2) / 2 over the counted points, loss[1] = their number   (one wave)
+__global__ void __launch_bounds__(64)
+hd_loss_kernel(const float *__restrict__ part2, int nparts, float *__restrict__ loss)
+{
+    double s1 = 0.0, s2 = 0.0, sc = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) { s1 += part2[(size_t)p * 4]; s2 += part2[(size_t)p * 4 + 1]; sc += part2[(size_t)p * 4 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); sc += __shfl_xor(sc, o, 64); }
+    if (threadIdx.x == 0) { loss[0] = (float)(0.5 * (s1 + s2) / sc); loss[1] = (float)sc; }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, pass 1
+// g_t[k][n] = d loss / d (cos_t[k][n]) = 10 . 0.5 . dloss / count . (softmax_t - onehot);  part3 rows: head 1 at k, head 2 at
+// R2 + k (R2 = 16 for KT = 16, else 32): sum_n g_t[k][n] Fhat[c][n]
+template <int KT>
+__global__ void __launch_bounds__(256, 1)
+hd_bwd1_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+               const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, const float *__restrict__ loss,
+               const float *__restrict__ dloss, float *__restrict__ part3)
+{
+    constexpr int RT = 2 * KT <= 32 ? 1 : 2, R2 = 2 * KT <= 32 ? KT : 32;
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_C;
+    float *atile = q2 + KT * HD_C;                       // [4][RT 32][65]
+    float *btile = atile + 4 * RT * 32 * HD_LD;          // [4][32][65]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n = chunk * HD_PTS + w * 64 + lane;
+    const bool valid = n < N;
+    const float *col = feat + (size_t)b * bs + min(n, N - 1);
+    hd_load_table<KT>(q1, q1g, K1, tid);
+    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    float d[2][KT], sq;
+    const float *const tabs[2] = {q1, q2};
+    hd_dots<KT, 2>(col, (size_t)N, tabs, d, sq);
+    const float rinv = 1.0f / fmaxf(sqrtf(sq), HD_EPS);
+    const long long y = label[(size_t)b * N + min(n, N - 1)];
+    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+    const float coef = ok ? HD_SCALE * 0.5f * dloss[0] / loss[1] : 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { d[0][k] *= HD_SCALE * rinv; d[1][k] *= HD_SCALE * rinv; }
+    hd_softmax<KT>(d[0], K1);
+    hd_softmax<KT>(d[1], K1);
+    float *at = atile + w * RT * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
+#pragma unroll
+    for (int r = 0; r < RT * 32; ++r) at[r * HD_LD + lane] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const float oh = (long long)k == y ? 1.f : 0.f;
+        at[k * HD_LD + lane] = coef * (d[0][k] - oh) * rinv;            // (Fhat = F / |F|: the 1 / |F| rides in the A operand)
+        at[(R2 + k) * HD_LD + lane] = coef * (d[1][k] - oh) * rinv;
+    }
+    f32x16 acc[4][RT];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][rt][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) hd_contract_tile<RT>(col, (size_t)N, ct, valid, at, bt, lane, acc[ct]);
+    float *part = part3 + (size_t)(b * nchunk + chunk) * 64 * HD_C;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) hd_reduce_store<RT>(acc[ct], btile, ct, tid, part);
+}
+
+// grid = (B, ceil(K1 / 4)); wave per row k.  Back through q2 = unit([bg; refined_b]) and the refinement, per batch item:
+//   dbg_part[b], dori_part[b][j], dP_part[b][j], dpool[b][k] (the gradient of pooled, row 0 zero), t3[b][k] = <dpool, pooled>
+template <int KT>
+__global__ void __launch_bounds__(256)
+hd_bwdm1_kernel(const float *__restrict__ part3, int nchunk, const float *__restrict__ main_proto, const float *__restrict__ bg, int K1,
+                int base_num, const float *__restrict__ q2, const float *__restrict__ pooled_s, const float *__restrict__ hs,
+                float *__restrict__ dbg_part, float *__restrict__ dori_part, float *__restrict__ dP_part, float *__restrict__ dpool,
+                float *__restrict__ t3)
+{
+    constexpr int R2 = 2 * KT <= 32 ? KT : 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    {
+        const int k = blockIdx.y * 4 + w;                // one wave per row
+        if (k >= K1) return;
+        float g0 = 0.f, g1 = 0.f;                        // d loss / d q2[b][k]
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float *pr = part3 + (((size_t)b * nchunk + ch) * 64 + R2 + k) * HD_C;
+            g0 += pr[lane]; g1 += pr[64 + lane];
+        }
+        float *dpr = dpool + ((size_t)b * KT + k) * HD_C;
+        if (k == 0) {
+            const float v0 = bg[lane], v1 = bg[64 + lane];
+            const float nr = fmaxf(sqrtf(hd_wsum(fmaf(v0, v0, v1 * v1))), HD_EPS);
+            const float q0 = v0 / nr, q1v = v1 / nr;
+            const float dt = hd_wsum(fmaf(q0, g0, q1v * g1));
+            dbg_part[(size_t)b * HD_C + lane] = (g0 - q0 * dt) / nr;
+            dbg_part[(size_t)b * HD_C + 64 + lane] = (g1 - q1v * dt) / nr;
+            dpr[lane] = 0.f; dpr[64 + lane] = 0.f;
+            if (lane == 0) t3[(size_t)b * KT] = 0.f;
+            return;
+        }
+        const int j = k - 1;
+        const float *hr = hs + ((size_t)b * KT + k) * HD_HS;
+        const float wv = hr[1], cosw = hr[2], pn = hr[3], fn = hr[4];
+        const float *qr = q2 + ((size_t)b * KT + k) * HD_C;
+        const float q0 = qr[lane], q1v = qr[64 + lane];
+        const float dt = hd_wsum(fmaf(q0, g0, q1v * g1));
+        const float dR0 = (g0 - q0 * dt) / fn, dR1 = (g1 - q1v * dt) / fn;            // gradient of refined[b][j]
+        dori_part[((size_t)b * 32 + j) * HD_C + lane] = dR0;
+        dori_part[((size_t)b * 32 + j) * HD_C + 64 + lane] = dR1;
+        const float r0 = j < base_num ? dR0 : 0.f, r1 = j < base_num ? dR1 : 0.f;     // gradient of ref0[b][j]
+        const float P0 = main_proto[(size_t)j * HD_C + lane], P1 = main_proto[(size_t)j * HD_C + 64 + lane];
+        const float p0 = pooled_s[((size_t)b * KT + k) * HD_C + lane], p1 = pooled_s[((size_t)b * KT + k) * HD_C + 64 + lane];
+        const float Pn = fmaxf(sqrtf(hd_wsum(fmaf(P0, P0, P1 * P1))), HD_EPS);
+        const float dw = hd_wsum(fmaf(r0, p0 - P0, r1 * (p1 - P1)));
+        const float dc = cosw > 0.f ? dw : 0.f;
+        const float ph0 = p0 / pn, ph1 = p1 / pn, Ph0 = P0 / Pn, Ph1 = P1 / Pn;
+        const float a = hd_wsum(fmaf(ph0, Ph0, ph1 * Ph1));                            // <phat, Phat>
+        // d pooled = w dref0 + dc (Phat - phat <phat, Phat>) / |pooled|;  d main += (1 - w) dref0 + dc (phat - Phat <Phat, phat>) / |main|
+        const float dp0 = fmaf(wv, r0, dc * (Ph0 - ph0 * a) / pn), dp1 = fmaf(wv, r1, dc * (Ph1 - ph1 * a) / pn);
+        dP_part[((size_t)b * 32 + j) * HD_C + lane] = fmaf(1.0f - wv, r0, dc * (ph0 - Ph0 * a) / Pn);
+        dP_part[((size_t)b * 32 + j) * HD_C + 64 + lane] = fmaf(1.0f - wv, r1, dc * (ph1 - Ph1 * a) / Pn);
+        dpr[lane] = dp0; dpr[64 + lane] = dp1;
+        const float tt = hd_wsum(fmaf(dp0, p0, dp1 * p1));
+        if (lane == 0) t3[(size_t)b * KT + k] = tt;
+    }
+}
+
+// grid = K1 (row k of the shared table q1 = unit([bg; ori])), 1024 threads: the sum of ALL partial tiles in a fixed order, then
+//   k = 0: dbg_a = the bg gradient through q1 + sum_b dbg_part;   k >= 1: d ori[j] -> dfsum (fake class) or d main through unit()
+__global__ void __launch_bounds__(1024)
+hd_bwdm2_kernel(const float *__restrict__ part3, int B, int nchunk, const float *__restrict__ main_proto, const float *__restrict__ bg,
+                const HeadFake fk, const float *__restrict__ fsum, const float *__restrict__ ori_s, const float *__restrict__ onrm,
+                const float *__restrict__ dbg_part, const float *__restrict__ dori_part, const float *__restrict__ dP_part,
+                float *__restrict__ dbg_a, float *__restrict__ dmain_a, float *__restrict__ dfsum)
+{
+    __shared__ float shr[8][HD_C];
+    __shared__ float sh[3][HD_C];
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const float s = hd_sum_rows(part3 + (size_t)k * HD_C, (size_t)64 * HD_C, B * nchunk, shr, tid);
+    const float so = k == 0 ? hd_sum_rows(dbg_part, (size_t)HD_C, B, shr, tid)
+                            : hd_sum_rows(dori_part + (size_t)(k - 1) * HD_C, (size_t)32 * HD_C, B, shr, tid);
+    const float sp = k == 0 ? 0.f : hd_sum_rows(dP_part + (size_t)(k - 1) * HD_C, (size_t)32 * HD_C, B, shr, tid);
+    if (tid < HD_C) { sh[0][tid] = s; sh[1][tid] = so; sh[2][tid] = sp; }
+    __syncthreads();
+    if (tid >= 64) return;                               // wave 0 finishes the row: channels lane and lane + 64
+    const int lane = tid;
+    const float g0 = sh[0][lane], g1 = sh[0][64 + lane], o0 = sh[1][lane], o1 = sh[1][64 + lane];
+    if (k == 0) {
+        const float v0 = bg[lane], v1 = bg[64 + lane];
+        const float nr = fmaxf(sqrtf(hd_wsum(fmaf(v0, v0, v1 * v1))), HD_EPS);
+        const float q0 = v0 / nr, q1v = v1 / nr;
+        const float dt = hd_wsum(fmaf(q0, g0, q1v * g1));
+        dbg_a[lane] = (g0 - q0 * dt) / nr + o0;
+        dbg_a[64 + lane] = (g1 - q1v * dt) / nr + o1;
+        return;
+    }
+    const int j = k - 1;
+    const float on = onrm[j];
+    const float q0 = ori_s[(size_t)j * HD_C + lane] / on, q1v = ori_s[(size_t)j * HD_C + 64 + lane] / on;
+    const float dt = hd_wsum(fmaf(q0, g0, q1v * g1));
+    const float dO0 = (g0 - q0 * dt) / on + o0, dO1 = (g1 - q1v * dt) / on + o1;          // gradient of ori[j]
+    const int fi = hd_fake_index(fk, (long long)(j + 1));
+    float m0 = sh[2][lane], m1 = sh[2][64 + lane];
+    if (fi >= 0) {                                       // ori[j] = fsum[fi] / (count + eps)
+        const float den = fsum[fi * HD_FLD + HD_C] + HD_EPS;
+        dfsum[fi * HD_FLD + lane] = dO0 / den;
+        dfsum[fi * HD_FLD + 64 + lane] = dO1 / den;
+        if (lane == 0) dfsum[fi * HD_FLD + HD_C] = 0.f;
+    } else {                                             // ori[j] = P / (|P| + eps)
+        const float P0 = main_proto[(size_t)j * HD_C + lane], P1 = main_proto[(size_t)j * HD_C + 64 + lane];
+        const float r = sqrtf(hd_wsum(fmaf(P0, P0, P1 * P1))), re = r + HD_EPS;
+        const float pd = hd_wsum(fmaf(P0, dO0, P1 * dO1)) / (fmaxf(r, 1e-30f) * re * re);
+        m0 += dO0 / re - P0 * pd;
+        m1 += dO1 / re - P1 * pd;
+    }
+    dmain_a[(size_t)j * HD_C + lane] = m0;
+    dmain_a[(size_t)j * HD_C + 64 + lane] = m1;
+}
+
+// ------------------------------------------------------------------------------------------------ backward, pass 2
+// d F from all four paths, written once; part4 rows k: sum_n gl3[k][n] Fhat[c][n]  (gl3 = the gradient of cos(F, [bg; main]))
+template <int KT>
+__global__ void __launch_bounds__(256, 1)
+hd_bwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+               const float *__restrict__ q1g, const float *__restrict__ q2g, const float *__restrict__ main_proto, const float *__restrict__ bg,
+               int K1, const HeadFake fk, const float *__restrict__ loss, const float *__restrict__ dloss, const float *__restrict__ hs,
+               const float *__restrict__ dpoolg, const float *__restrict__ t3g, const float *__restrict__ dfsum,
+               float *__restrict__ dfeat, float *__restrict__ part4)
+{
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_C, *q3 = q2 + KT * HD_C, *dpl = q3 + KT * HD_C;     // four [KT][128] tables
+    float *atile = dpl + KT * HD_C;                      // [4][32][65]
+    float *btile = atile + 4 * 32 * HD_LD;               // [4][32][65]
+    float *dfs = btile + 4 * 32 * HD_LD;                 // [MAX_FAKE][129]
+    float *sk = dfs + GFS3D_HEAD_MAX_FAKE * HD_FLD;      // [KT] 1 / s[b][k]
+    float *tk = sk + KT;                                 // [KT] t3[b][k]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n = chunk * HD_PTS + w * 64 + lane;
+    const bool valid = n < N;
+    const float *col = feat + (size_t)b * bs + min(n, N - 1);
+    const bool support = fk.n > 0 && b >= fk.half;       // (workgroup-uniform)
+    if (tid < KT) {
+        sk[tid] = (tid >= 1 && tid < K1) ? 1.0f / hs[((size_t)b * KT + tid) * HD_HS] : 0.f;
+        tk[tid] = tid < K1 ? t3g[(size_t)b * KT + tid] : 0.f;
+    }
+    for (int e = tid; e < max(fk.n, 1) * HD_FLD; e += 256) dfs[e] = support ? dfsum[e] : 0.f;
+    hd_load_table<KT>(q1, q1g, K1, tid);
+    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    hd_load_table<KT>(dpl, dpoolg + (size_t)b * KT * HD_C, K1, tid);
+    hd_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
+    float d[4][KT], sq;
+    const float *const tabs[4] = {q1, q2, q3, dpl};
+    hd_dots<KT, 4>(col, (size_t)N, tabs, d, sq);
+    const float nrm = sqrtf(sq);
+    const float rinv = 1.0f / fmaxf(nrm, HD_EPS);
+    const long long y = label[(size_t)b * N + min(n, N - 1)];
+    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+    const float coef = ok ? HD_SCALE * 0.5f * dloss[0] / loss[1] : 0.f;
+    // coefficient rows: d[0], d[1] <- g1, g2 (gradients of the cosines of the two heads); d[2] <- gl3; d[3] <- resp
+    float tsum = 0.f;                                    // <Fhat, dFhat> = sum over the three cosine paths of g[k] cos[k]
+    {
+        float c1[KT], c2[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { c1[k] = d[0][k] * rinv; c2[k] = d[1][k] * rinv; d[0][k] = c1[k] * HD_SCALE; d[1][k] = c2[k] * HD_SCALE; }
+        hd_softmax<KT>(d[0], K1);
+        hd_softmax<KT>(d[1], K1);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float oh = (long long)k == y ? 1.f : 0.f;
+            d[0][k] = coef * (d[0][k] - oh);
+            d[1][k] = coef * (d[1][k] - oh);
+            tsum = fmaf(d[0][k], c1[k], fmaf(d[1][k], c2[k], tsum));
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const float c3 = d[2][k] * rinv;
+            const float resp = (valid && k >= 1 && k < K1) ? __expf(HD_SCALE * c3 - HD_SHIFT) * sk[k] : 0.f;     // softmax over the points
+            const float gl = HD_SCALE * resp * (d[3][k] - tk[k]);        // d[3][k] = <dpool[k], F_n> (raw features)
+            d[2][k] = gl;
+            d[3][k] = resp;
+            tsum = fmaf(gl, c3, tsum);
+        }
+    }
+    // the fake-novel mean path: this point contributes F / (|F| + eps) to fsum[fi]
+    const int fi = (support && valid) ? hd_fake_index(fk, y) : -1;
+    float fa1 = 0.f, fa2 = 0.f;
+    if (support) {                                       // (uniform)
+        const float *dr = dfs + max(fi, 0) * HD_FLD;
+        float tf = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < HD_C; ++c) tf = fmaf(col[(size_t)c * N], dr[c], tf);
+        const float re = nrm + HD_EPS;
+        fa1 = fi >= 0 ? 1.0f / re : 0.f;
+        fa2 = fi >= 0 ? tf / (fmaxf(nrm, 1e-30f) * re * re) : 0.f;
+    }
+    float *at = atile + w * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) at[r * HD_LD + lane] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) at[k * HD_LD + lane] = d[2][k] * rinv;
+    const float tn = tsum * rinv;                        // dF = (dFhat - Fhat <Fhat, dFhat>) / |F|, Fhat = F / |F|
+    const float *drow = dfs + max(fi, 0) * HD_FLD;
+    const int j = lane & 31, h = lane >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rs_df = __builtin_amdgcn_make_buffer_rsrc(dfeat + (size_t)b * HD_C * N, 0, HD_C * N * 4, 0x00020000);
+    const int voff = valid ? n * 4 : 0x7fffffff;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        __syncthreads();
+#pragma unroll 1
+        for (int g4 = 0; g4 < 8; ++g4) {
+            const int c0 = 32 * ct + 4 * g4;
+            float v[4], o[4], dd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = col[(size_t)(c0 + e) * N]; o[e] = 0.f; dd[e] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(q1 + k * HD_C + c0), a2 = *reinterpret_cast<const f32x4 *>(q2 + k * HD_C + c0);
+                const f32x4 a3 = *reinterpret_cast<const f32x4 *>(q3 + k * HD_C + c0), a4 = *reinterpret_cast<const f32x4 *>(dpl + k * HD_C + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = fmaf(d[2][k], a3[e], fmaf(d[1][k], a2[e], fmaf(d[0][k], a1[e], o[e])));
+                    dd[e] = fmaf(d[3][k], a4[e], dd[e]);
+                }
+                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // (branch-free, stores included - a lane past N stores through an offset the buffer's range check drops: with a
+            // branch in here the compiler sank the fma chains into the guarded block, left the 4 KT table reads of the group
+            // in front of it and kept all their results alive - 512 registers and spills)
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                r[e] = fmaf(rinv, o[e] - v[e] * tn, dd[e]) + (fa1 * drow[c0 + e] - fa2 * v[e]);     // (fa1 = fa2 = 0 off the fake path)
+                bt[(4 * g4 + e) * HD_LD + lane] = valid ? v[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r[e]), rs_df, voff, (c0 + e) * N * 4, 0);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[j * HD_LD + 2 * s + h], bt[j * HD_LD + 2 * s + h], acc[ct], 0, 0, 0);
+    }
+    float *part = part4 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        f32x16 one[1] = {acc[ct]};
+        hd_reduce_store<1>(one, btile, ct, tid, part);
+    }
+}
+
+// grid = K1: d unit([bg; main])[k] summed over all partial tiles, back through the normalisation, added to the other paths
+__global__ void __launch_bounds__(1024)
+hd_bwdfin_kernel(const float *__restrict__ part4, int nparts, const float *__restrict__ main_proto, const float *__restrict__ bg,
+                 const float *__restrict__ dbg_a, const float *__restrict__ dmain_a, float *__restrict__ dbg, float *__restrict__ dmain)
+{
+    __shared__ float shr[8][HD_C];
+    __shared__ float sh[HD_C];
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const float s = hd_sum_rows(part4 + (size_t)k * HD_C, (size_t)32 * HD_C, nparts, shr, tid);
+    if (tid < HD_C) sh[tid] = s;
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
+    const float *src = k == 0 ? bg : main_proto + (size_t)(k - 1) * HD_C;
+    const float v0 = src[lane], v1 = src[64 + lane], g0 = sh[lane], g1 = sh[64 + lane];
+    const float nr = fmaxf(sqrtf(hd_wsum(fmaf(v0, v0, v1 * v1))), HD_EPS);
+    const float q0 = v0 / nr, q1v = v1 / nr;
+    const float dt = hd_wsum(fmaf(q0, g0, q1v * g1));
+    const float r0 = (g0 - q0 * dt) / nr, r1 = (g1 - q1v * dt) / nr;
+    if (k == 0) { dbg[lane] = dbg_a[lane] + r0; dbg[64 + lane] = dbg_a[64 + lane] + r1; }
+    else {
+        dmain[(size_t)(k - 1) * HD_C + lane] = dmain_a[(size_t)(k - 1) * HD_C + lane] + r0;
+        dmain[(size_t)(k - 1) * HD_C + 64 + lane] = dmain_a[(size_t)(k - 1) * HD_C + 64 + lane] + r1;
+    }
+}
+
+// bit c of mask[0] set <=> some label equals c (0 <= c < 64); integer atomics: order-independent
+__global__ void __launch_bounds__(256)
+hd_presence_kernel(const long long *__restrict__ label, long long n, unsigned long long *__restrict__ mask)
+{
+    unsigned long long m = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long y = label[i];
+        if (y >= 0 && y < 64) m |= 1ull << y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(mask, m);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct HeadPlan {
+    int KT, nchunk;
+    size_t off_part, off_sums1, off_part2, off_q1, off_q2, off_ori, off_onrm, off_pooled, off_hs, off_dpool, off_t3, off_dbgp, off_dorip,
+        off_dPp, off_dbga, off_dmaina, total;
+};
+HeadPlan hd_plan(int B, int N, int classes)
+{
+    HeadPlan p{};
+    const int K1 = classes + 1;
+    p.KT = K1 <= 16 ? 16 : 24;
+    p.nchunk = (N + HD_PTS - 1) / HD_PTS;
+    size_t o = 0;
+    auto take = [&](size_t floats) { const size_t at = o; o += align_up(floats * sizeof(float), 256); return at; };
+    p.off_part = take((size_t)B * p.nchunk * 64 * HD_C);           // part1 (32 rows) / part3 (64 rows) / part4 (32 rows), one after the other
+    p.off_sums1 = take((size_t)B * p.nchunk * 32);
+    p.off_part2 = take((size_t)B * p.nchunk * 4);
+    p.off_q1 = take((size_t)p.KT * HD_C);
+    p.off_q2 = take((size_t)B * p.KT * HD_C);
+    p.off_ori = take((size_t)32 * HD_C);
+    p.off_onrm = take(32);
+    p.off_pooled = take((size_t)B * p.KT * HD_C);
+    p.off_hs = take((size_t)B * p.KT * HD_HS);
+    p.off_dpool = take((size_t)B * p.KT * HD_C);
+    p.off_t3 = take((size_t)B * p.KT);
+    p.off_dbgp = take((size_t)B * HD_C);
+    p.off_dorip = take((size_t)B * 32 * HD_C);
+    p.off_dPp = take((size_t)B * 32 * HD_C);
+    p.off_dbga = take(HD_C);
+    p.off_dmaina = take((size_t)32 * HD_C);
+    p.total = o;
+    return p;
+}
+
+int hd_check(const gfs3d_capl_head_args *a, const char *who, HeadFake &fk)
+{
+    GFS3D_REQUIRE(a != nullptr, "%s: args is NULL", who);
+    GFS3D_REQUIRE(a->B >= 1 && a->B <= 65535 && a->N >= 1 && a->N < (1 << 22), "%s: bad shape B=%d N=%d", who, a->B, a->N);
+    GFS3D_REQUIRE(a->C == HD_C, "%s: %d feature channels unsupported (the prototype head is built for main_dim = %d)", who, a->C, HD_C);
+    GFS3D_REQUIRE(a->classes >= 1 && a->classes + 1 <= 24, "%s: %d classes unsupported (at most 23 + background)", who, a->classes);
+    GFS3D_REQUIRE(a->base_num >= 0 && a->base_num <= a->classes, "%s: base_num %d outside [0, classes]", who, a->base_num);
+    GFS3D_REQUIRE(a->n_fake >= 0 && a->n_fake <= GFS3D_HEAD_MAX_FAKE && a->classes + 1 + a->n_fake <= 32,
+                  "%s: %d fake-novel classes unsupported (at most %d, and classes + 1 + fakes <= 32)", who, a->n_fake, GFS3D_HEAD_MAX_FAKE);
+    GFS3D_REQUIRE(a->half >= 0 && a->half <= a->B, "%s: support half %d outside [0, B]", who, a->half);
+    GFS3D_REQUIRE(a->feat_bstride >= (long long)a->C * a->N, "%s: feat_bstride smaller than C * N", who);
+    GFS3D_REQUIRE(a->feat && a->label && a->main_proto && a->bg_proto && a->fsum && a->workspace && a->loss, "%s: NULL buffer", who);
+    GFS3D_REQUIRE(a->workspace_bytes >= gfs3d_capl_head_workspace_bytes(a->B, a->N, a->classes), "%s: workspace too small", who);
+    fk.n = a->n_fake; fk.half = a->half;
+    for (int i = 0; i < GFS3D_HEAD_MAX_FAKE; ++i) fk.cls[i] = i < a->n_fake ? a->fake[i] : -1;
+    for (int i = 0; i < a->n_fake; ++i)
+        GFS3D_REQUIRE(a->fake[i] >= 1 && a->fake[i] <= a->classes, "%s: fake-novel label %d outside [1, classes]", who, a->fake[i]);
+    return GFS3D_OK;
+}
+
+template <int KT>
+int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
+{
+    const HeadPlan p = hd_plan(a->B, a->N, a->classes);
+    char *ws = static_cast<char *>(a->workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int K1 = a->classes + 1;
+    const dim3 grid(p.nchunk, a->B);
+    const long long *label = reinterpret_cast<const long long *>(a->label);
+    if (phase == 0) {
+        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
+        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, a->main_proto, a->bg_proto, K1,
+                           fk, F(p.off_part), F(p.off_sums1));
+        GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
+        if (fk.n > 0) {
+            hipLaunchKernelGGL(hd_mid1_kernel, dim3(fk.n), dim3(1024), 0, st, F(p.off_part), F(p.off_sums1), a->B, p.nchunk, K1, fk.half, a->fsum);
+            GFS3D_LAUNCH_CHECK("hd_mid1_kernel");
+        }
+        return GFS3D_OK;
+    }
+    GFS3D_REQUIRE(a->pred != nullptr, "%s: NULL pred", who);
+    hipLaunchKernelGGL((hd_mid2_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk, a->main_proto, a->bg_proto, K1,
+                       a->base_num, fk, a->fsum, F(p.off_q1), F(p.off_q2), F(p.off_ori), F(p.off_onrm), F(p.off_pooled), F(p.off_hs));
+    GFS3D_LAUNCH_CHECK("hd_mid2_kernel");
+    const size_t lds = sizeof(float) * (2 * KT * HD_C + 16);
+    GFS3D_ENSURE_LDS((hd_fwd2_kernel<KT>), lds, who);
+    hipLaunchKernelGGL((hd_fwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
+                       F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+    GFS3D_LAUNCH_CHECK("hd_fwd2_kernel");
+    hipLaunchKernelGGL(hd_loss_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * p.nchunk, a->loss);
+    GFS3D_LAUNCH_CHECK("hd_loss_kernel");
+    return GFS3D_OK;
+}
+
+template <int KT>
+int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
+{
+    constexpr int RT = 2 * KT <= 32 ? 1 : 2;
+    const HeadPlan p = hd_plan(a->B, a->N, a->classes);
+    char *ws = static_cast<char *>(a->workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int K1 = a->classes + 1;
+    const dim3 grid(p.nchunk, a->B);
+    const long long *label = reinterpret_cast<const long long *>(a->label);
+    GFS3D_REQUIRE(a->dloss && a->dfsum && a->dfeat && a->dmain && a->dbg, "%s: NULL gradient buffer", who);
+    if (phase == 0) {
+        const size_t lds = sizeof(float) * (2 * KT * HD_C + 4 * (RT + 1) * 32 * HD_LD);
+        GFS3D_ENSURE_LDS((hd_bwd1_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_bwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index,
+                           F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+        GFS3D_LAUNCH_CHECK("hd_bwd1_kernel");
+        hipLaunchKernelGGL((hd_bwdm1_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), p.nchunk, a->main_proto, a->bg_proto, K1, a->base_num,
+                           F(p.off_q2), F(p.off_pooled), F(p.off_hs), F(p.off_dbgp), F(p.off_dorip), F(p.off_dPp), F(p.off_dpool), F(p.off_t3));
+        GFS3D_LAUNCH_CHECK("hd_bwdm1_kernel");
+        hipLaunchKernelGGL(hd_bwdm2_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B, p.nchunk, a->main_proto, a->bg_proto, fk, a->fsum,
+                           F(p.off_ori), F(p.off_onrm), F(p.off_dbgp), F(p.off_dorip), F(p.off_dPp), F(p.off_dbga), F(p.off_dmaina), a->dfsum);
+        GFS3D_LAUNCH_CHECK("hd_bwdm2_kernel");
+        return GFS3D_OK;
+    }
+    const size_t lds = sizeof(float) * (4 * KT * HD_C + 8 * 32 * HD_LD + GFS3D_HEAD_MAX_FAKE * HD_FLD + 2 * KT);
+    GFS3D_ENSURE_LDS((hd_bwd2_kernel<KT>), lds, who);
+    hipLaunchKernelGGL((hd_bwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
+                       F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs), F(p.off_dpool), F(p.off_t3), a->dfsum,
+                       a->dfeat, F(p.off_part));
+    GFS3D_LAUNCH_CHECK("hd_bwd2_kernel");
+    hipLaunchKernelGGL(hd_bwdfin_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B * p.nchunk, a->main_proto, a->bg_proto, F(p.off_dbga),
+                       F(p.off_dmaina), a->dbg, a->dmain);
+    GFS3D_LAUNCH_CHECK("hd_bwdfin_kernel");
+    return GFS3D_OK;
+}
+
+}  // namespace
+}  // namespace gfs3d
+
+using namespace gfs3d;
+
+extern "C" size_t gfs3d_capl_head_workspace_bytes(int B, int N, int classes)
+{
+    if (B < 1 || N < 1 || classes < 1 || classes + 1 > 24) return 0;
+    return hd_plan(B, N, classes).total;
+}
+
+extern "C" int gfs3d_capl_head_forward_phase(const gfs3d_capl_head_args *a, int phase)
+{
+    const char *who = "gfs3d_capl_head_forward_phase";
+    HeadFake fk;
+    if (int rc = hd_check(a, who, fk)) return rc;
+    GFS3D_REQUIRE(phase == 0 || phase == 1, "%s: phase %d outside [0, 1]", who, phase);
+    ProfScope prof(3, static_cast<hipStream_t>(a->stream));
+    return a->classes + 1 <= 16 ? hd_forward<16>(a, phase, fk, who) : hd_forward<24>(a, phase, fk, who);
+}
+
+extern "C" int gfs3d_capl_head_backward_phase(const gfs3d_capl_head_args *a, int phase)
+{
+    const char *who = "gfs3d_capl_head_backward_phase";
+    HeadFake fk;
+    if (int rc = hd_check(a, who, fk)) return rc;
+    GFS3D_REQUIRE(phase == 0 || phase == 1, "%s: phase %d outside [0, 1]", who, phase);
+    ProfScope prof(3, static_cast<hipStream_t>(a->stream));
+    return a->classes + 1 <= 16 ? hd_backward<16>(a, phase, fk, who) : hd_backward<24>(a, phase, fk, who);
+}
+
+extern "C" int gfs3d_label_presence(const int64_t *label, long long n, uint64_t *mask, void *stream)
+{
+    const char *who = "gfs3d_label_presence";
+    GFS3D_REQUIRE(label && mask && n >= 1, "%s: bad argument", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(mask, 0, sizeof(uint64_t), st) != hipSuccess) {
+        set_error("%s: hipMemsetAsync failed", who);
+        return GFS3D_ERR_HIP;
+    }
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    hipLaunchKernelGGL(hd_presence_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(256), 0, st,
+                       reinterpret_cast<const long long *>(label), n, reinterpret_cast<unsigned long long *>(mask));
+    GFS3D_LAUNCH_CHECK("hd_presence_kernel");
+    return GFS3D_OK;
+}

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
-_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip")
 _lib = None
 
 
@@ -100,6 +100,25 @@ class PackArgs(Structure):
     ]
 
 
+HEAD_MAX_FAKE = 16
+
+
+class CaplHeadArgs(Structure):
+    _fields_ = [
+        ("B", c_int), ("C", c_int), ("N", c_int),
+        ("feat", c_void_p), ("feat_bstride", c_longlong),
+        ("label", c_void_p), ("ignore_index", c_longlong),
+        ("main_proto", c_void_p), ("classes", c_int),
+        ("bg_proto", c_void_p), ("base_num", c_int),
+        ("n_fake", c_int), ("fake", c_int * HEAD_MAX_FAKE), ("half", c_int),
+        ("fsum", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("loss", c_void_p), ("pred", c_void_p),
+        ("dloss", c_void_p), ("dfsum", c_void_p), ("dfeat", c_void_p), ("dmain", c_void_p), ("dbg", c_void_p),
+        ("stream", c_void_p),
+    ]
+
+
 # every symbol include/gfs3d.h declares: (restype, argtypes)
 SYMBOLS = {
     "gfs3d_version": (c_int, []),
@@ -153,6 +172,10 @@ SYMBOLS = {
     "gfs3d_proto_backward_proto_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfs3d_proto_backward_proto_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),
+    "gfs3d_label_presence": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p]),
+    "gfs3d_capl_head_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gfs3d_capl_head_forward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
+    "gfs3d_capl_head_backward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
     "gfs3d_word_assign_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gfs3d_proto_backward_feat_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,

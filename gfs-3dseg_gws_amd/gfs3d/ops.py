@@ -918,6 +918,114 @@ class ProtoCosineFunction(torch.autograd.Function):
         return dfeat, dproto, None
 
 
+# --------------------------------------------------------------------------
+# K6: the fused prototype head of the CAPL training step (csrc/head.hip)
+# --------------------------------------------------------------------------
+HEAD_MAX_FAKE = _lib.HEAD_MAX_FAKE
+HEAD_C = 128
+
+
+def capl_head_supported(feat: torch.Tensor, classes: int, n_fake: int) -> bool:
+    """Shapes gfs3d_capl_head_* is built for: main_dim 128, at most 23 classes + background, fake-novel classes that fit
+    the 32-row tile beside them."""
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 3 and feat.shape[1] == HEAD_C and 1 <= classes <= 23
+            and n_fake <= HEAD_MAX_FAKE and classes + 1 + n_fake <= 32 and feat.shape[2] < (1 << 22))
+
+
+def _dp_world() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class CaplTrainHeadFunction(torch.autograd.Function):
+    """(point_feat (B,128,N), main_proto (cls,128), bg_proto (1,128), y (B,N) int64) -> (pred (B,N) int64, loss) of the
+    reference's training forward (capl.py:194-242 with CrossEntropyLoss(ignore_index) as the criterion), one fused HIP
+    pipeline forward and backward.  Under block-sharded data parallelism the fake-novel feature sums (forward) and their
+    gradients (backward) are all-reduced between the two phases of each pass, as the differentiable all-reduce of the
+    unfused form did."""
+
+    @staticmethod
+    def forward(ctx, feat, main_proto, bg_proto, y, fake, base_num, ignore_index):
+        _need_gpu(feat, "point_feat")
+        _need_gpu(main_proto, "main_proto")
+        _need_gpu(bg_proto, "bg_proto")
+        if y.dtype != torch.int64 or not y.is_cuda:
+            raise RuntimeError("gfs3d.capl_train_head: labels must be an int64 HIP tensor")
+        feat, main_proto, bg_proto, y = feat.contiguous(), main_proto.contiguous(), bg_proto.contiguous(), y.contiguous()
+        B, C, N = feat.shape
+        classes = main_proto.shape[0]
+        fake = [int(c) for c in fake]
+        if not capl_head_supported(feat, classes, len(fake)):
+            raise NotImplementedError("gfs3d.capl_train_head: unsupported shape (main_dim 128, <= 23 classes)")
+        dev = feat.device
+        a = _lib.CaplHeadArgs()
+        a.B, a.C, a.N = B, C, N
+        a.feat, a.feat_bstride = feat.data_ptr(), C * N
+        a.label, a.ignore_index = y.data_ptr(), int(ignore_index)
+        a.main_proto, a.classes = main_proto.data_ptr(), classes
+        a.bg_proto, a.base_num = bg_proto.data_ptr(), int(base_num)
+        a.n_fake = len(fake)
+        for i, c in enumerate(fake):
+            a.fake[i] = c
+        a.half = B // 2
+        fsum = torch.zeros((HEAD_MAX_FAKE, C + 1), dtype=torch.float32, device=dev)
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        pred = torch.empty((B, N), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            L = _lib.lib()
+            ws = torch.empty(L.gfs3d_capl_head_workspace_bytes(B, N, classes), dtype=torch.uint8, device=dev)   # lives until backward
+            a.fsum, a.workspace, a.workspace_bytes = fsum.data_ptr(), ws.data_ptr(), ws.numel()
+            a.loss, a.pred = loss.data_ptr(), pred.data_ptr()
+            a.stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0), "gfs3d_capl_head_forward_phase(0)")
+            if fake and _dp_world() > 1:
+                torch.distributed.all_reduce(fsum)
+            _lib.check(L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 1), "gfs3d_capl_head_forward_phase(1)")
+        ctx.args = a
+        ctx.keep = (feat, main_proto, bg_proto, y, fsum, loss, ws)       # the pointers in `a` stay valid as long as these do
+        ctx.has_fake = bool(fake)
+        ctx.mark_non_differentiable(pred)
+        return pred, loss[0]
+
+    @staticmethod
+    def backward(ctx, _dpred, dloss):
+        a = ctx.args
+        feat, main_proto, bg_proto = ctx.keep[0], ctx.keep[1], ctx.keep[2]
+        dev = feat.device
+        dloss = dloss.to(device=dev, dtype=torch.float32).contiguous()
+        dfeat = torch.empty_like(feat)
+        dmain = torch.empty_like(main_proto)
+        dbg = torch.empty_like(bg_proto)
+        dfsum = torch.zeros((HEAD_MAX_FAKE, feat.shape[1] + 1), dtype=torch.float32, device=dev)
+        a.dloss, a.dfsum = dloss.data_ptr(), dfsum.data_ptr()
+        a.dfeat, a.dmain, a.dbg = dfeat.data_ptr(), dmain.data_ptr(), dbg.data_ptr()
+        with torch.cuda.device(dev):
+            L = _lib.lib()
+            a.stream = torch.cuda.current_stream().cuda_stream
+            _lib.check(L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 0), "gfs3d_capl_head_backward_phase(0)")
+            if ctx.has_fake and _dp_world() > 1:
+                torch.distributed.all_reduce(dfsum)
+            _lib.check(L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 1), "gfs3d_capl_head_backward_phase(1)")
+        return dfeat, dmain, dbg, None, None, None, None
+
+
+def label_presence(y: torch.Tensor):
+    """Sorted list of the distinct labels in [0, 64) of an int64 HIP tensor: one small kernel (integer OR) and an 8-byte
+    read-back instead of torch.unique's device sort (generate_fake_proto's `unique(y)`, capl.py:378-386)."""
+    if not (y.is_cuda and y.dtype == torch.int64):
+        raise RuntimeError("gfs3d.label_presence: labels must be an int64 HIP tensor")
+    y = y.contiguous()
+    mask = torch.empty(1, dtype=torch.int64, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.lib().gfs3d_label_presence(_p(y), y.numel(), _p(mask), _stream()), "gfs3d_label_presence")
+    m = int(mask.item()) & 0xFFFFFFFFFFFFFFFF
+    return [c for c in range(64) if (m >> c) & 1]
+
+
+def capl_train_head(feat, main_proto, bg_proto, y, fake, base_num, ignore_index=-100):
+    return CaplTrainHeadFunction.apply(feat, main_proto, bg_proto, y, fake, base_num, ignore_index)
+
+
 def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor):
     """One Lloyd assignment step on device: labels, per-centroid sums/counts and
     inertia (get_basis.py:210 runs sklearn KMeans on the CPU)."""

@@ -198,6 +198,16 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             weight, gp_acc, gp_novel_acc = self.get_gp_weight(coding, word, gt_label=y, th=self.args.eval_weight)
             return logits * weight, gp_acc, gp_novel_acc
 
+        return self.train_head(point_feat, y, fake_novel)
+
+    def train_head(self, point_feat, y, fake_novel):
+        """capl.py:194-242 after getFeatures: (pred (B,N), loss).  One fused HIP pipeline, forward and backward
+        (csrc/head.hip: fake prototypes, refinement, both cosine heads, both cross-entropies, arg-max) when the criterion is the
+        reference's CrossEntropyLoss; the tensor-library form below otherwise (and as the fused form's reference in the tests)."""
+        nb = self.base_num
+        half = point_feat.size(0) // 2
+        if self._head_fusable(point_feat, y, fake_novel):
+            return ops.capl_train_head(point_feat, self.main_proto, self.bg_proto, y, fake_novel, nb, self.criterion.ignore_index)
         ori_proto, _ = self.generate_fake_proto(x=point_feat[half:], y=y[half:], main_proto=self.main_proto.clone(),
                                                 fake_novel=fake_novel)
         loss_1 = self.criterion(self.get_pred(point_feat, ori_proto, use_bg_proto=True), y)
@@ -208,6 +218,17 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         logits_2 = self.get_pred(point_feat, refined, use_bg_proto=True)
         loss_2 = self.criterion(logits_2, y)
         return logits_2.max(1)[1], 0.5 * loss_2 + 0.5 * loss_1
+
+    fuse_head = True          # False: the unfused (tensor-library) form of the training head, kept as the reference of the fused one
+
+    def _head_fusable(self, point_feat, y, fake_novel):
+        """The fused training head reproduces `criterion` only when it is the reference's plain CrossEntropyLoss
+        (train.py:317: mean reduction, no class weights, no label smoothing, any ignore_index)."""
+        crit = self.criterion
+        return (self.fuse_head and type(crit) is nn.CrossEntropyLoss and crit.weight is None and crit.reduction == 'mean'
+                and getattr(crit, 'label_smoothing', 0.0) == 0.0 and y is not None and y.dtype == torch.int64 and y.is_cuda
+                and ops.capl_head_supported(point_feat, self.main_proto.shape[0], len(fake_novel))
+                and self.main_proto.shape[1] == point_feat.shape[1])
 
     # ------------------------------------------------------------------ prototypes
     def generate_fake_proto(self, x, y, main_proto, fake_novel=None, post_processing=False):
@@ -251,6 +272,9 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             seen[y.unique().long().clamp_max(n_cls)] = 1
             torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
             present = [int(v) for v in torch.nonzero(seen).flatten().tolist() if int(v) != 0]
+        elif y.is_cuda and y.dtype == torch.int64 and n_cls < 64:
+            # ascending like unique(); labels beyond the classes (an ignore label: the reference's sample would index out of range) are skipped
+            present = [v for v in ops.label_presence(y) if v != 0 and v <= n_cls]
         else:
             present = [int(v) for v in y.unique().tolist() if int(v) != 0]
         return random.sample(present, len(present) // 2)

@@ -337,6 +337,51 @@ size_t gfs3d_proto_backward_proto_workspace_bytes(int B, int C, int N);
 int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_bstride, int B, int C, int N,
                                    const float *proto, int P, int K, float scale, const float *dout, float *dproto,
                                    void *workspace, size_t workspace_bytes, void *stream);
+/* The prototype head of the CAPL TRAINING step, fused (reference model/capl.py:194-242: generate_fake_proto :364-411, three
+ * get_pred calls :290-322, post_refine_proto_v2 :245-287, the two CrossEntropyLoss(ignore_index) calls of train.py:317 and
+ * `x_pre_2.max(1)[1]`), forward and backward.  Replaces ~200 small tensor-library launches per step by four passes over the
+ * feature tensor and a handful of per-class kernels (csrc/head.hip); bit-reproducible (no atomics).
+ *   forward phase 0:  feat, label, main_proto, bg_proto, fake[] -> fsum (the fake-novel classes' masked feature sums | point
+ *                     counts over the support half: items b >= half).  Under block-sharded data parallelism the caller
+ *                     all-reduces (SUM) fsum between the phases (capl.py:378-408 averages over the whole support half).
+ *   forward phase 1:  -> loss[0] (= 0.5 loss_1 + 0.5 loss_2), loss[1] (number of counted points), pred (B, N) int64
+ *   backward phase 0: dloss -> dfsum (gradient of fsum: all-reduce SUM under data parallelism)
+ *   backward phase 1: -> dfeat (B, C, N), dmain (classes, C), dbg (1, C)
+ * C must be 128 (main_dim, capl.py:46), classes <= 23, n_fake <= GFS3D_HEAD_MAX_FAKE.  The workspace carries the state
+ * from the forward to the backward and must not be reused in between.  Labels outside [0, classes] other than
+ * ignore_index are not counted (the reference would raise). */
+#define GFS3D_HEAD_MAX_FAKE 16
+typedef struct gfs3d_capl_head_args {
+    int B, C, N;
+    const float *feat;            /* (B, C, N) point_feat, rows dense */
+    long long feat_bstride;       /* floats between batch items */
+    const int64_t *label;         /* (B, N): 0 = background, 1 .. classes */
+    long long ignore_index;
+    const float *main_proto;      /* (classes, C) */
+    int classes;
+    const float *bg_proto;        /* (1, C) */
+    int base_num;                 /* classes [0, base_num) keep the refined prototype (capl.py:229-230) */
+    int n_fake;
+    int fake[GFS3D_HEAD_MAX_FAKE];/* HOST values: labels (1-based) of the fake-novel classes drawn for this step */
+    int half;                     /* first batch item of the support half (B / 2) */
+    float *fsum;                  /* (GFS3D_HEAD_MAX_FAKE, C + 1) */
+    void *workspace;
+    size_t workspace_bytes;       /* >= gfs3d_capl_head_workspace_bytes() */
+    float *loss;                  /* 2 floats */
+    int64_t *pred;                /* (B, N) */
+    const float *dloss;           /* backward: device scalar, gradient of loss[0] */
+    float *dfsum;                 /* (GFS3D_HEAD_MAX_FAKE, C + 1) */
+    float *dfeat;
+    float *dmain;
+    float *dbg;
+    void *stream;
+} gfs3d_capl_head_args;
+/* mask[0] = OR over the n labels y in [0, 64) of (1 << y): the set of classes present in a label tensor (the `unique(y)` of
+ * generate_fake_proto, capl.py:378-386, without a device sort); labels outside [0, 64) are skipped. */
+int gfs3d_label_presence(const int64_t *label, long long n, uint64_t *mask, void *stream);
+size_t gfs3d_capl_head_workspace_bytes(int B, int N, int classes);      /* 0: unsupported shape */
+int gfs3d_capl_head_forward_phase(const gfs3d_capl_head_args *args, int phase);
+int gfs3d_capl_head_backward_phase(const gfs3d_capl_head_args *args, int phase);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
 /* The same with a workspace (gfs3d_kmeans_workspace_bytes; 0 = unsupported shape): the centroid sums are then SEGMENT SUMS over

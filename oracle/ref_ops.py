@@ -221,7 +221,7 @@ def post_refine_proto_v2(proto: Tensor, x: Tensor, point_feat: Tensor,
     if bg_proto is not None:
         pp = pp[:, 1:, :]
     w = (F.normalize(pp, 2, -1) * F.normalize(proto, 2, -1).unsqueeze(0)).sum(-1, keepdim=True)
-    w = w * (w > 0).float()
+    w = w * (w > 0).to(w.dtype)
     return w * pp + (1 - w) * proto.unsqueeze(0)
 
 
@@ -274,9 +274,9 @@ def generate_fake_proto(x: Tensor, y: Tensor, main_proto: Tensor, fake_novel: Op
     proto = main_proto / (torch.norm(main_proto, 2, 1, True) + 1e-12)
     xn = x / (torch.norm(x, 2, 1, True) + 1e-12)
     for fn in fake_novel:
-        m = (ty == fn).float()
+        m = (ty == fn).to(xn.dtype)
         mean = (xn * m).sum(0).sum(-1) / (m.sum(0).sum(-1) + 1e-12)
-        sel = torch.zeros(proto.size(0), 1)
+        sel = torch.zeros(proto.size(0), 1, dtype=proto.dtype)
         sel[int(fn) - 1] = 1
         proto = proto * (1 - sel) + mean.unsqueeze(0) * sel
     return proto, fake_novel
@@ -303,15 +303,24 @@ def capl_forward_train(p: Params, gp: Tensor, x: Tensor, y: Tensor, base_num: in
     """capl.py:194-242: two CE losses on cosine logits with fake-novel prototypes."""
     pf, _, _ = get_features(p, gp, x, k=k, training=True, new_stats=new_stats, dropout_mask=dropout_mask, knn_fn=knn_fn,
                             encoder_out=encoder_out)
+    logits2, loss, fake_novel = capl_train_head(pf, y, p["main_proto"], p["bg_proto"], base_num, fake_novel)
+    return logits2.max(1)[1], loss, fake_novel
+
+
+def capl_train_head(pf: Tensor, y: Tensor, main_proto: Tensor, bg_proto: Tensor, base_num: int,
+                    fake_novel: Optional[Sequence] = None, ignore_index: int = -100):
+    """capl.py:194-242 after getFeatures: fake-novel prototypes, first cosine head + CE, prototype refinement, second cosine
+    head + CE (criterion = CrossEntropyLoss(ignore_index), train.py:317).  Returns (logits_2, loss, fake_novel).  Works in
+    float32 and float64 (the GPU parity test of the fused head evaluates it in float64)."""
     half = pf.size(0) // 2
-    ori, fake_novel = generate_fake_proto(pf[half:], y[half:], p["main_proto"].clone(), fake_novel)
-    l1 = F.cross_entropy(get_pred(pf, ori, p["bg_proto"]), y)
-    rp = post_refine_proto_v2(p["main_proto"].clone(), pf, pf, p["bg_proto"]).clone()
+    ori, fake_novel = generate_fake_proto(pf[half:], y[half:], main_proto.clone(), fake_novel)
+    l1 = F.cross_entropy(get_pred(pf, ori, bg_proto), y, ignore_index=ignore_index)
+    rp = post_refine_proto_v2(main_proto.clone(), pf, pf, bg_proto).clone()
     rp[:, :base_num] = rp[:, :base_num] + ori[:base_num].unsqueeze(0)
     rp[:, base_num:] = rp[:, base_num:] * 0 + ori[base_num:].unsqueeze(0)
-    logits2 = get_pred(pf, rp, p["bg_proto"])
-    l2 = F.cross_entropy(logits2, y)
-    return logits2.max(1)[1], 0.5 * l2 + 0.5 * l1, fake_novel
+    logits2 = get_pred(pf, rp, bg_proto)
+    l2 = F.cross_entropy(logits2, y, ignore_index=ignore_index)
+    return logits2, 0.5 * l2 + 0.5 * l1, fake_novel
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,143 @@
+"""GPU parity of the fused prototype head of the CAPL training step (csrc/head.hip, gfs3d_capl_head_*: reference
+model/capl.py:194-242 - generate_fake_proto :364-411, three get_pred calls :290-322, post_refine_proto_v2 :245-287, the two
+CrossEntropyLoss(ignore_index=255) of train.py:317, `x_pre_2.max(1)[1]`) - through the C ABI, against
+
+  * the oracle's restatement of that chain (oracle/ref_ops.py, torch on the CPU) evaluated in float64: loss within 1e-5
+    relative, every gradient within 1e-4 of the tensor's largest magnitude, arg-max labels equal wherever the top-two
+    logit gap is clear;
+  * the reference's own training forward (tests/golden/capl.npz) through `capl.forward`, in test_gpu_parity.py (unchanged:
+    the model takes the fused head whenever its criterion is the reference's).
+"""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from gfs3d import _lib
+    _lib.lib()          # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def relmax(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def head_reference(feat, main, bg, y, fake, base_num, ignore_index):
+    """The oracle's restatement of the training head (oracle/ref_ops.py::capl_train_head - the function the golden-pinned
+    capl_forward_train is built from), here evaluated in float64.  Returns (logits_2, loss)."""
+    from oracle import ref_ops as R
+    logits_2, loss, _ = R.capl_train_head(feat, y, main, bg, base_num, fake_novel=list(fake), ignore_index=ignore_index)
+    return logits_2, loss
+
+
+CASES = [
+    # B, N, classes, base_num, labels in [0, hi], fake-novel labels, ignore fraction
+    (4, 300, 13, 7, 7, [2, 5, 7], 0.05),          # S3DIS shapes (13 + 1 rows -> the 16-row tables), ragged N, ignored points
+    (2, 2048, 13, 7, 7, [1, 4], 0.0),             # full-size blocks
+    (3, 100, 13, 7, 7, [], 0.0),                  # no fake-novel class drawn (fewer than two classes present), odd B
+    (4, 257, 21, 15, 15, [3, 8, 9, 11, 14, 15], 0.1),      # ScanNet shapes (21 + 1 rows -> the 24-row tables, two row tiles in the backward)
+    (2, 64, 5, 5, 5, [5], 0.0),                   # every class a base class
+    (1, 130, 13, 7, 7, [3], 0.0),                 # B = 1: the support half is the whole batch (capl.py:198: fake_num = 0)
+]
+
+
+@pytest.mark.parametrize("B,N,classes,base_num,hi,fake,ignore_frac", CASES)
+def test_fused_train_head_matches_the_reference_chain_in_float64(dev, B, N, classes, base_num, hi, fake, ignore_frac):
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(1000 * B + N + classes)
+    feat = torch.randn(B, 128, N, generator=g) * torch.rand(B, 1, N, generator=g).mul(3).add(0.2)      # norms spread over a decade
+    main = torch.randn(classes, 128, generator=g)
+    bg = torch.randn(1, 128, generator=g)
+    y = torch.randint(0, hi + 1, (B, N), generator=g)
+    if ignore_frac > 0:
+        y[torch.rand(B, N, generator=g) < ignore_frac] = 255
+    # pull the features towards their class prototype so that the heads are not at chance (peaked softmax, w > 0 rows)
+    proto_all = torch.cat([bg, main], 0)
+    feat = feat + 0.2 * proto_all[y.clamp_max(classes)].permute(0, 2, 1) * (feat.norm(dim=1, keepdim=True) / 11.3)
+    f64, m64, b64 = (t.double().requires_grad_(True) for t in (feat, main, bg))
+    logits_ref, loss_ref = head_reference(f64, m64, b64, y, fake, base_num, 255)
+    loss_ref.backward()
+    fd, md, bd = (t.to(dev).requires_grad_(True) for t in (feat, main, bg))
+    pred, loss = ops.capl_train_head(fd, md, bd, y.to(dev), fake, base_num, 255)
+    (loss * 1.0).backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
+    top2 = logits_ref.detach().topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert bool((pred.cpu() == logits_ref.argmax(1))[clear].all())
+    assert float(clear.float().mean()) > 0.99
+    assert relmax(fd.grad, f64.grad) < 1e-4
+    assert relmax(md.grad, m64.grad) < 1e-4
+    assert relmax(bd.grad, b64.grad) < 1e-4
+
+
+def test_fused_train_head_is_bit_reproducible_and_scales_with_the_incoming_gradient(dev):
+    from gfs3d import ops
+    B, N, classes = 4, 513, 13
+    g = torch.Generator().manual_seed(5)
+    feat, main, bg = torch.randn(B, 128, N, generator=g), torch.randn(classes, 128, generator=g), torch.randn(1, 128, generator=g)
+    y = torch.randint(0, 8, (B, N), generator=g).to(dev)
+
+    def run(scale):
+        fd, md, bd = (t.to(dev).requires_grad_(True) for t in (feat, main, bg))
+        pred, loss = ops.capl_train_head(fd, md, bd, y, [2, 6], 7, 255)
+        (loss * scale).backward()
+        return pred, loss.detach(), fd.grad, md.grad, bd.grad
+    a, b, c = run(1.0), run(1.0), run(-3.0)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)                       # no atomics: two runs agree bit for bit
+    for u, v in zip(a[2:], c[2:]):
+        assert relmax(v, -3.0 * u) < 1e-6
+
+
+def test_model_takes_the_fused_head_and_matches_its_unfused_form(dev):
+    """mpti_net_Point_GeoAsWeight_v2.train_head: the fused pipeline against the model's own tensor-library form on the same
+    features (the form the golden tests pinned in rounds 1-2), gradients through to the features and the prototypes."""
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    args = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                                 base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(3)
+    m = mpti_net_Point_GeoAsWeight_v2(classes=13, criterion=torch.nn.CrossEntropyLoss(ignore_index=255), args=args, base_num=7,
+                                      gp=torch.randn(200, 192), energy=0.9).to(dev)
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(4, 128, 700, generator=g).to(dev)
+    y = torch.randint(0, 8, (4, 700), generator=g).to(dev)
+    out = {}
+    for fused in (True, False):
+        m.fuse_head = fused
+        m.zero_grad()
+        f = feat.clone().requires_grad_(True)
+        pred, loss = m.train_head(f, y, [1, 3, 6])
+        loss.backward()
+        out[fused] = (pred, loss.detach(), f.grad, m.main_proto.grad.clone(), m.bg_proto.grad.clone())
+    assert float((out[True][0] == out[False][0]).float().mean()) > 0.999
+    assert abs(float(out[True][1]) - float(out[False][1])) < 1e-5 * abs(float(out[False][1]))
+    for u, v in zip(out[True][2:], out[False][2:]):
+        assert relmax(u, v) < 1e-4
+    # a criterion the fused head does not reproduce keeps the unfused path
+    m.fuse_head = True
+    m.criterion = torch.nn.CrossEntropyLoss(ignore_index=255, label_smoothing=0.1)
+    assert not m._head_fusable(feat, y, [1])
+
+
+def test_label_presence_equals_unique(dev):
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(2)
+    for n, hi in ((1, 3), (1000, 8), (70000, 22), (5, 64)):
+        y = torch.randint(0, hi, (n,), generator=g)
+        y[::7] = 255                                  # an ignore label: outside [0, 64), skipped
+        assert ops.label_presence(y.to(dev)) == [int(v) for v in y.unique().tolist() if v < 64]
+
+
+def test_capl_head_rejects_unsupported_shapes(dev):
+    from gfs3d import ops
+    feat = torch.randn(2, 64, 100, device=dev)
+    with pytest.raises(NotImplementedError):
+        ops.capl_train_head(feat, torch.randn(13, 64, device=dev), torch.randn(1, 64, device=dev),
+                            torch.zeros(2, 100, dtype=torch.int64, device=dev), [1], 7, 255)
