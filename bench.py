@@ -236,6 +236,23 @@ def extras(dev, L, gdist):
         byts = 4.0 * B * N * (128 + 14)
         out["get_pred"] = {"shape": "B=32x2048, C=128, K=13+1", "ms": round(ms, 4), "bound": "hbm",
                            "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
+        # the fused prototype head of the training step (capl.py:194-242), forward + backward, S3DIS shapes
+    f3 = (torch.randn(B, 128, N, generator=g).to(dev)).requires_grad_(True)
+    mp = torch.randn(13, 128, generator=g).to(dev).requires_grad_(True)
+    bgp = torch.randn(1, 128, generator=g).to(dev).requires_grad_(True)
+    yh = torch.randint(0, 8, (B, N), generator=g).to(dev)
+
+    def head():
+        f3.grad = mp.grad = bgp.grad = None
+        ops.capl_train_head(f3, mp, bgp, yh, [2, 4, 7], 7, 255)[1].backward()
+    ms = timed_ms(head, 20)
+    byts = 4.0 * B * N * 128 * 3                                     # features read by the forward and by the backward, gradient written
+    out["capl_train_head"] = {"shape": "B=32x2048, C=128, 13+1 classes, 3 fake-novel classes; forward + backward", "ms": round(ms, 4),
+                              "bound": "hbm", "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                              "note": "generate_fake_proto + 3 x get_pred + post_refine_proto_v2 + 2 x CrossEntropyLoss + arg-max as 11 "
+                                      "launches (csrc/head.hip); the tensor-library form it replaces took ~1.45 ms in ~200 launches"}
+    del f3, mp, bgp, yh
+    with torch.no_grad():
         # configs[2]: one Lloyd step over the full S3DIS base split (7 classes x 300 000 points, 192-d, 200 centroids)
         M = 7 * 300000
         pts = torch.randn(M, 192, generator=g).to(dev)

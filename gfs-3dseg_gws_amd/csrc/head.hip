@@ -74,14 +74,16 @@ __device__ __forceinline__ void hd_load_table(float *dst, const float *src, int 
     }
     __syncthreads();
 }
-// [bg; main] (K1 = classes + 1 rows), every row divided by max(|row|, eps) (F.normalize); 256 threads, ends with a barrier
+// [bg; main] (K1 = classes + 1 rows; bg == NULL: main alone, K1 = classes), every row divided by max(|row|, eps)
+// (F.normalize); 256 threads, ends with a barrier
 template <int KT>
 __device__ __forceinline__ void hd_load_bgmain_unit(float *dst, const float *bg, const float *main_proto, int K1, int tid)
 {
     for (int e = tid; e < KT * (HD_C / 4); e += 256) {
         const int row = e >> 5, c4 = e & 31;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row == 0) v = hd_ldg4(bg + 4 * c4);
+        if (bg == nullptr) { if (row < K1) v = hd_ldg4(main_proto + (size_t)row * HD_C + 4 * c4); }      // (the testing path: no bg row)
+        else if (row == 0) v = hd_ldg4(bg + 4 * c4);
         else if (row < K1) v = hd_ldg4(main_proto + (size_t)(row - 1) * HD_C + 4 * c4);
         *reinterpret_cast<f32x4 *>(dst + row * HD_C + 4 * c4) = v;
     }
@@ -273,10 +275,17 @@ hd_mid1_kernel(const float *__restrict__ part1, const float *__restrict__ sums1,
     const int count = (B - half) * nchunk;
     const float s = hd_sum_rows(part1 + ((size_t)half * nchunk * 32 + K1 + f) * HD_C, (size_t)32 * HD_C, count, sh, tid);
     if (tid < HD_C) fsum[f * HD_FLD + tid] = s;
+    // the point count: the partial counts are small integers in fp32, any summation order gives the same (exact) result
+    float cnt = 0.f;
+    for (int p = tid; p < count; p += 1024) cnt += sums1[((size_t)half * nchunk + p) * 32 + K1 + f];
+    cnt = hd_wsum(cnt);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[0][tid >> 6] = cnt;
+    __syncthreads();
     if (tid == 0) {
-        float cnt = 0.f;
-        for (int p = half * nchunk; p < B * nchunk; ++p) cnt += sums1[(size_t)p * 32 + K1 + f];
-        fsum[f * HD_FLD + HD_C] = cnt;
+        float t = 0.f;
+        for (int q = 0; q < 16; ++q) t += sh[0][q];
+        fsum[f * HD_FLD + HD_C] = t;
     }
 }
 
@@ -725,6 +734,95 @@ hd_bwdfin_kernel(const float *__restrict__ part4, int nparts, const float *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the testing path
+// capl.forward(eval_model=True) after getFeatures (capl.py:170-192): post_refine_proto_v2 WITHOUT the bg row, the refined
+// prototypes of the base classes + gened_proto, get_pred against them, the geometric-word re-weighting (get_gp_weight
+// :92-142 as a table look-up by word index) and its two accuracy figures.  hd_fwd1 (bg = NULL, no fake classes) does the
+// soft pooling; grid = (B, ceil(classes / 4)), one wave per class:
+template <int KT>
+__global__ void __launch_bounds__(256)
+hd_mid2_eval_kernel(const float *__restrict__ part1, const float *__restrict__ sums1, int nchunk, const float *__restrict__ main_proto,
+                    const float *__restrict__ gened, int K1, int base_num, float *__restrict__ q2)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+    const int k = blockIdx.y * 4 + w;
+    if (k >= K1) return;
+    const float P0 = main_proto[(size_t)k * HD_C + lane], P1 = main_proto[(size_t)k * HD_C + 64 + lane];
+    float u0 = 0.f, u1 = 0.f, s = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const size_t p = (size_t)b * nchunk + ch;
+        u0 += part1[(p * 32 + k) * HD_C + lane];
+        u1 += part1[(p * 32 + k) * HD_C + 64 + lane];
+        s += sums1[p * 32 + k];
+    }
+    const float is = 1.0f / s;
+    const float p0 = u0 * is, p1 = u1 * is;
+    const float pn = fmaxf(sqrtf(hd_wsum(fmaf(p0, p0, p1 * p1))), HD_EPS), Pn = fmaxf(sqrtf(hd_wsum(fmaf(P0, P0, P1 * P1))), HD_EPS);
+    const float cosw = hd_wsum(fmaf(p0 / pn, P0 / Pn, (p1 / pn) * (P1 / Pn)));
+    const float wv = cosw > 0.f ? cosw : 0.f;
+    const float g0 = gened[(size_t)k * HD_C + lane], g1 = gened[(size_t)k * HD_C + 64 + lane];
+    const float f0 = k < base_num ? fmaf(wv, p0, (1.0f - wv) * P0) + g0 : g0, f1 = k < base_num ? fmaf(wv, p1, (1.0f - wv) * P1) + g1 : g1;
+    const float fn = fmaxf(sqrtf(hd_wsum(fmaf(f0, f0, f1 * f1))), HD_EPS);
+    float *q2r = q2 + ((size_t)b * KT + k) * HD_C;
+    q2r[lane] = f0 / fn; q2r[64 + lane] = f1 / fn;
+}
+
+// out[b][k][n] = 10 cos(F_n, refined[b][k]) * (coding[k][word_n] == 1 ? th : 1); part2 = {sum hit, sum hit over novel points,
+// novel points, -} with hit = coding[y_n][word_n]
+template <int KT>
+__global__ void __launch_bounds__(256, 1)
+hd_fwd2_eval_kernel(const float *__restrict__ feat, long long bs, int N, const float *__restrict__ q2g, int K1, const int *__restrict__ word,
+                    const float *__restrict__ coding, int Kw, float th, const long long *__restrict__ label, int base_num,
+                    float *__restrict__ out, float *__restrict__ part2)
+{
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q2 = hd_smem;                                 // [KT][128]
+    float *wred = q2 + KT * HD_C;                        // [4][4]
+    float *cod = wred + 16;                              // [K1][Kw]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n = chunk * HD_PTS + w * 64 + lane;
+    const bool valid = n < N;
+    const float *col = feat + (size_t)b * bs + min(n, N - 1);
+    for (int e = tid; e < K1 * Kw; e += 256) cod[e] = coding[e];
+    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    float d[1][KT], sq;
+    const float *const tabs[1] = {q2};
+    hd_dots<KT, 1>(col, (size_t)N, tabs, d, sq);
+    const float rn = HD_SCALE / fmaxf(sqrtf(sq), HD_EPS);
+    const int wd = min(max(word[(size_t)b * N + min(n, N - 1)], 0), Kw - 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)b * K1 * N, 0, K1 * N * 4, 0x00020000);
+    const int voff = valid ? n * 4 : 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+        if (k < K1) {
+            const float wt = cod[k * Kw + wd] == 1.0f ? th : 1.0f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d[0][k] * rn * wt), rs, voff, k * N * 4, 0);
+        }
+    float hit = 0.f, nov = 0.f;
+    if (label != nullptr) {
+        const long long y = label[(size_t)b * N + min(n, N - 1)];
+        const bool ok = valid && y >= 0 && y < (long long)K1;
+        hit = ok ? cod[(int)(ok ? y : 0) * Kw + wd] : 0.f;
+        nov = (ok && y > (long long)(base_num - 1)) ? 1.f : 0.f;
+    }
+    const float s0 = hd_wsum(hit), s1 = hd_wsum(nov > 0.f ? hit : 0.f), s2 = hd_wsum(nov);
+    if (lane == 0) { wred[w * 4 + 0] = s0; wred[w * 4 + 1] = s1; wred[w * 4 + 2] = s2; }
+    __syncthreads();
+    if (tid < 3) part2[(size_t)(b * nchunk + chunk) * 4 + tid] = ((wred[tid] + wred[4 + tid]) + wred[8 + tid]) + wred[12 + tid];
+}
+
+// stats[0] = mean hit over all points, stats[1] = mean hit over the novel-class points (0 if there are none)
+__global__ void __launch_bounds__(64)
+hd_evalstat_kernel(const float *__restrict__ part2, int nparts, double npoints, float *__restrict__ stats)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) { s0 += part2[(size_t)p * 4]; s1 += part2[(size_t)p * 4 + 1]; s2 += part2[(size_t)p * 4 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (threadIdx.x == 0) { stats[0] = (float)(s0 / npoints); stats[1] = s2 > 0.0 ? (float)(s1 / s2) : 0.f; }
+}
+
 // bit c of mask[0] set <=> some label equals c (0 <= c < 64); integer atomics: order-independent
 __global__ void __launch_bounds__(256)
 hd_presence_kernel(const long long *__restrict__ label, long long n, unsigned long long *__restrict__ mask)
@@ -907,9 +1005,58 @@ extern "C" int gfs3d_label_presence(const int64_t *label, long long n, uint64_t 
         set_error("%s: hipMemsetAsync failed", who);
         return GFS3D_ERR_HIP;
     }
-    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16));
+    const int blocks = (int)((n + 256 * 2 - 1) / (256 * 2));
     hipLaunchKernelGGL(hd_presence_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(256), 0, st,
                        reinterpret_cast<const long long *>(label), n, reinterpret_cast<unsigned long long *>(mask));
     GFS3D_LAUNCH_CHECK("hd_presence_kernel");
     return GFS3D_OK;
+}
+
+template <int KT>
+static int hd_eval(const gfs3d_capl_eval_args *a, const char *who)
+{
+    const HeadPlan p = hd_plan(a->B, a->N, a->classes);
+    char *ws = static_cast<char *>(a->workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
+    hipStream_t st = static_cast<hipStream_t>(a->stream);
+    const int K1 = a->classes;                           // no bg row on the testing path
+    const dim3 grid(p.nchunk, a->B);
+    HeadFake fk{};
+    fk.n = 0; fk.half = a->B;
+    {
+        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
+        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, (const long long *)nullptr,
+                           a->main_proto, (const float *)nullptr, K1, fk, F(p.off_part), F(p.off_sums1));
+        GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
+    }
+    hipLaunchKernelGGL((hd_mid2_eval_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk,
+                       a->main_proto, a->gened_proto, K1, a->base_num, F(p.off_q2));
+    GFS3D_LAUNCH_CHECK("hd_mid2_eval_kernel");
+    const size_t lds = sizeof(float) * (KT * HD_C + 16 + (size_t)K1 * a->Kw);
+    GFS3D_ENSURE_LDS((hd_fwd2_eval_kernel<KT>), lds, who);
+    hipLaunchKernelGGL((hd_fwd2_eval_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, F(p.off_q2), K1, a->word, a->coding,
+                       a->Kw, a->th, reinterpret_cast<const long long *>(a->label), a->base_num, a->logits, F(p.off_part2));
+    GFS3D_LAUNCH_CHECK("hd_fwd2_eval_kernel");
+    hipLaunchKernelGGL(hd_evalstat_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * p.nchunk, (double)a->B * a->N, a->stats);
+    GFS3D_LAUNCH_CHECK("hd_evalstat_kernel");
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_capl_head_eval(const gfs3d_capl_eval_args *a)
+{
+    const char *who = "gfs3d_capl_head_eval";
+    GFS3D_REQUIRE(a != nullptr, "%s: args is NULL", who);
+    GFS3D_REQUIRE(a->B >= 1 && a->B <= 65535 && a->N >= 1 && a->N < (1 << 22), "%s: bad shape B=%d N=%d", who, a->B, a->N);
+    GFS3D_REQUIRE(a->C == HD_C, "%s: %d feature channels unsupported (the prototype head is built for main_dim = %d)", who, a->C, HD_C);
+    GFS3D_REQUIRE(a->classes >= 1 && a->classes <= 23, "%s: %d classes unsupported (at most 23)", who, a->classes);
+    GFS3D_REQUIRE(a->base_num >= 0 && a->base_num <= a->classes, "%s: base_num %d outside [0, classes]", who, a->base_num);
+    GFS3D_REQUIRE(a->Kw >= 1 && (size_t)a->classes * a->Kw <= 16384, "%s: coding of %d x %d words does not fit the kernel's table", who,
+                  a->classes, a->Kw);
+    GFS3D_REQUIRE(a->feat_bstride >= (long long)a->C * a->N, "%s: feat_bstride smaller than C * N", who);
+    GFS3D_REQUIRE(a->feat && a->main_proto && a->gened_proto && a->word && a->coding && a->logits && a->stats && a->workspace,
+                  "%s: NULL buffer", who);
+    GFS3D_REQUIRE(a->workspace_bytes >= gfs3d_capl_head_workspace_bytes(a->B, a->N, a->classes), "%s: workspace too small", who);
+    ProfScope prof(3, static_cast<hipStream_t>(a->stream));
+    return a->classes <= 16 ? hd_eval<16>(a, who) : hd_eval<24>(a, who);
 }

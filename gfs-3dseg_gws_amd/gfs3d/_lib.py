@@ -119,6 +119,18 @@ class CaplHeadArgs(Structure):
     ]
 
 
+class CaplEvalArgs(Structure):
+    _fields_ = [
+        ("B", c_int), ("C", c_int), ("N", c_int),
+        ("feat", c_void_p), ("feat_bstride", c_longlong),
+        ("main_proto", c_void_p), ("classes", c_int), ("base_num", c_int),
+        ("gened_proto", c_void_p), ("word", c_void_p), ("coding", c_void_p), ("Kw", c_int), ("th", c_float),
+        ("label", c_void_p), ("logits", c_void_p), ("stats", c_void_p),
+        ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("stream", c_void_p),
+    ]
+
+
 # every symbol include/gfs3d.h declares: (restype, argtypes)
 SYMBOLS = {
     "gfs3d_version": (c_int, []),
@@ -174,6 +186,7 @@ SYMBOLS = {
                                                c_void_p, c_size_t, c_void_p]),
     "gfs3d_label_presence": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p]),
     "gfs3d_capl_head_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gfs3d_capl_head_eval": (c_int, [POINTER(CaplEvalArgs)]),
     "gfs3d_capl_head_forward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
     "gfs3d_capl_head_backward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
     "gfs3d_word_assign_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,

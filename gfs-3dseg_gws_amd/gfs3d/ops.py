@@ -1009,6 +1009,46 @@ class CaplTrainHeadFunction(torch.autograd.Function):
         return dfeat, dmain, dbg, None, None, None, None
 
 
+def capl_eval_head(feat, main_proto, gened_proto, word, coding, th, base_num, y=None):
+    """capl.forward(eval_model=True) after getFeatures (capl.py:170-192) as one fused HIP pipeline: (point_feat (B,128,N),
+    main_proto, gened_proto (cls,128), word (B,N) int32, coding (cls,Kw), th) -> (logits * geometric-word weight (B,cls,N),
+    gp_acc, gp_novel_acc).  y (B,N) int64 or None (both accuracies 0., as in get_gp_weight)."""
+    _need_gpu(feat, "point_feat")
+    _need_gpu(main_proto, "main_proto")
+    _need_gpu(gened_proto, "gened_proto")
+    _need_gpu(coding, "coding")
+    if word.dtype != torch.int32 or not word.is_cuda:
+        raise RuntimeError("gfs3d.capl_eval_head: the word index must be an int32 HIP tensor")
+    feat, main_proto, gened_proto, coding, word = (t.contiguous() for t in (feat, main_proto, gened_proto, coding, word))
+    B, C, N = feat.shape
+    classes, Kw = coding.shape
+    if not (capl_head_supported(feat, classes, 0) and tuple(main_proto.shape) == (classes, C) and tuple(gened_proto.shape) == (classes, C)
+            and classes * Kw <= 16384 and tuple(word.shape) == (B, N)):
+        raise NotImplementedError("gfs3d.capl_eval_head: unsupported shape")
+    dev = feat.device
+    a = _lib.CaplEvalArgs()
+    a.B, a.C, a.N = B, C, N
+    a.feat, a.feat_bstride = feat.data_ptr(), C * N
+    a.main_proto, a.classes, a.base_num = main_proto.data_ptr(), classes, int(base_num)
+    a.gened_proto, a.word, a.coding, a.Kw, a.th = gened_proto.data_ptr(), word.data_ptr(), coding.data_ptr(), Kw, float(th)
+    if y is not None:
+        if y.dtype != torch.int64 or not y.is_cuda:
+            raise RuntimeError("gfs3d.capl_eval_head: labels must be an int64 HIP tensor")
+        y = y.contiguous()
+        a.label = y.data_ptr()
+    logits = torch.empty((B, classes, N), dtype=torch.float32, device=dev)
+    stats = torch.empty(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L = _lib.lib()
+        ws = _workspace(dev, L.gfs3d_capl_head_workspace_bytes(B, N, classes))
+        a.logits, a.stats, a.workspace, a.workspace_bytes = logits.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel()
+        a.stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.gfs3d_capl_head_eval(ctypes.byref(a)), "gfs3d_capl_head_eval")
+    if y is None:
+        return logits, 0., 0.
+    return logits, stats[0], stats[1]
+
+
 def label_presence(y: torch.Tensor):
     """Sorted list of the distinct labels in [0, 64) of an int64 HIP tensor: one small kernel (integer OR) and an 8-byte
     read-back instead of torch.unique's device sort (generate_fake_proto's `unique(y)`, capl.py:378-386)."""

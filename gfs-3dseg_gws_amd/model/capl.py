@@ -190,11 +190,17 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         if eval_model:
             if gened_proto.dim() == 3:
                 gened_proto = gened_proto[0]
+            coding = torch.cat([base_class_coding, novel_class_coding], dim=0)
+            if (self.fuse_head and not torch.is_grad_enabled() and word.dtype == torch.int32 and coding.shape[0] == self.main_proto.shape[0]
+                    and ops.capl_head_supported(point_feat, coding.shape[0], 0) and coding.numel() <= 16384
+                    and (y is None or (y.is_cuda and y.dtype == torch.int64))):
+                # the whole testing head (refinement, get_pred, geometric-word re-weighting, accuracy figures): csrc/head.hip
+                return ops.capl_eval_head(point_feat, self.main_proto.detach(), gened_proto.to(point_feat.dtype), word, coding.to(point_feat.dtype),
+                                          self.args.eval_weight, nb, y)
             refined = self.post_refine_proto_v2(proto=self.main_proto, x=point_feat, point_feat=point_feat)
             refined = torch.cat([refined[:, :nb] + gened_proto[:nb].unsqueeze(0),
                                  refined[:, nb:] * 0 + gened_proto[nb:].unsqueeze(0)], dim=1)
             logits = self.get_pred(point_feat, refined)
-            coding = torch.cat([base_class_coding, novel_class_coding], dim=0)
             weight, gp_acc, gp_novel_acc = self.get_gp_weight(coding, word, gt_label=y, th=self.args.eval_weight)
             return logits * weight, gp_acc, gp_novel_acc
 

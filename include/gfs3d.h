@@ -382,6 +382,31 @@ int gfs3d_label_presence(const int64_t *label, long long n, uint64_t *mask, void
 size_t gfs3d_capl_head_workspace_bytes(int B, int N, int classes);      /* 0: unsupported shape */
 int gfs3d_capl_head_forward_phase(const gfs3d_capl_head_args *args, int phase);
 int gfs3d_capl_head_backward_phase(const gfs3d_capl_head_args *args, int phase);
+/* The same head on the TESTING path (capl.forward(eval_model=True), capl.py:170-192, after getFeatures): prototype refinement
+ * without the background row, refined base prototypes + gened_proto, get_pred against them, the geometric-word
+ * re-weighting of get_gp_weight (capl.py:92-142: weight = th where coding[class][word of the point] == 1) and its two
+ * accuracy figures.  logits (B, classes, N); stats[0] = mean coding[y][word] over all points, stats[1] = over the points of
+ * novel classes (y >= base_num; 0 if none); label may be NULL (both figures 0).  classes <= 23, classes * Kw <= 16384. */
+typedef struct gfs3d_capl_eval_args {
+    int B, C, N;
+    const float *feat;            /* (B, C, N) point_feat */
+    long long feat_bstride;
+    const float *main_proto;      /* (classes, C) */
+    int classes;
+    int base_num;
+    const float *gened_proto;     /* (classes, C) */
+    const int32_t *word;          /* (B, N) geometric-word index of every point */
+    const float *coding;          /* (classes, Kw) multi-hot word coding of the classes */
+    int Kw;
+    float th;                     /* args.eval_weight */
+    const int64_t *label;         /* (B, N) or NULL */
+    float *logits;                /* out (B, classes, N) */
+    float *stats;                 /* out: 2 floats */
+    void *workspace;
+    size_t workspace_bytes;       /* >= gfs3d_capl_head_workspace_bytes(B, N, classes) */
+    void *stream;
+} gfs3d_capl_eval_args;
+int gfs3d_capl_head_eval(const gfs3d_capl_eval_args *args);
 int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *cent, int K,
                             int32_t *label, float *sums, float *counts, double *inertia, void *stream);
 /* The same with a workspace (gfs3d_kmeans_workspace_bytes; 0 = unsupported shape): the centroid sums are then SEGMENT SUMS over

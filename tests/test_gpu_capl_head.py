@@ -126,6 +126,33 @@ def test_model_takes_the_fused_head_and_matches_its_unfused_form(dev):
     assert not m._head_fusable(feat, y, [1])
 
 
+@pytest.mark.parametrize("B,N,classes,base_num,Kw,with_labels", [(3, 300, 13, 7, 200, True), (2, 2048, 13, 7, 200, True),
+                                                                 (2, 130, 21, 15, 180, True), (1, 64, 13, 7, 150, False)])
+def test_fused_eval_head_matches_the_reference_chain_in_float64(dev, B, N, classes, base_num, Kw, with_labels):
+    """capl.forward(eval_model=True) after getFeatures (capl.py:170-192): refinement without the bg row, gened_proto, get_pred,
+    get_gp_weight - the oracle's pieces in float64 against gfs3d_capl_head_eval."""
+    from gfs3d import ops
+    from oracle import ref_ops as R
+    g = torch.Generator().manual_seed(B * 31 + N)
+    feat = torch.randn(B, 128, N, generator=g) * torch.rand(B, 1, N, generator=g).mul(3).add(0.2)
+    main = torch.randn(classes, 128, generator=g)
+    gened = torch.nn.functional.normalize(torch.randn(classes, 128, generator=g), dim=1)
+    word = torch.randint(0, Kw, (B, N), generator=g, dtype=torch.int32)
+    coding = (torch.rand(classes, Kw, generator=g) > 0.6).float()
+    y = torch.randint(0, classes, (B, N), generator=g)
+    f64, m64, g64 = feat.double(), main.double(), gened.double()
+    rp = R.post_refine_proto_v2(m64, f64, f64)
+    rp[:, :base_num] = rp[:, :base_num] + g64[:base_num].unsqueeze(0)
+    rp[:, base_num:] = rp[:, base_num:] * 0 + g64[base_num:].unsqueeze(0)
+    onehot = torch.nn.functional.one_hot(word.long(), Kw).permute(0, 2, 1).double()
+    wref, acc_ref, nacc_ref = R.get_gp_weight(coding.double(), onehot, base_num, 1.2, gt_label=y if with_labels else None)
+    ref = R.get_pred(f64, rp) * wref
+    out, acc, nacc = ops.capl_eval_head(feat.to(dev), main.to(dev), gened.to(dev), word.to(dev), coding.to(dev), 1.2, base_num,
+                                        y.to(dev) if with_labels else None)
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-4           # logits: 1e-4 absolute (values within [-12, 12])
+    assert abs(float(acc) - float(acc_ref)) < 1e-6 and abs(float(nacc) - float(nacc_ref)) < 1e-6
+
+
 def test_label_presence_equals_unique(dev):
     from gfs3d import ops
     g = torch.Generator().manual_seed(2)

@@ -53,7 +53,8 @@ def test_args_structs_match_header_field_order_and_size():
     header = open(os.path.join(ROOT, "include", "gfs3d.h")).read()
     pairs = [("gfs3d_edgeconv_args", _lib.EdgeConvArgs), ("gfs3d_edgeconv_bwd_args", _lib.EdgeConvBwdArgs),
              ("gfs3d_pointwise_args", _lib.PointwiseArgs), ("gfs3d_pointwise_bwd_args", _lib.PointwiseBwdArgs),
-             ("gfs3d_pack_args", _lib.PackArgs), ("gfs3d_capl_head_args", _lib.CaplHeadArgs)]
+             ("gfs3d_pack_args", _lib.PackArgs), ("gfs3d_capl_head_args", _lib.CaplHeadArgs),
+             ("gfs3d_capl_eval_args", _lib.CaplEvalArgs)]
     for cname, cls in pairs:
         assert _header_fields(header, cname) == [f[0] for f in cls._fields_], cname
     src = '#include <stdio.h>\n#include "gfs3d.h"\nint main(void){printf("' + "%zu " * len(pairs) + '\\n",' + ",".join(
