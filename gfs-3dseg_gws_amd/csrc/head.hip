@@ -99,8 +99,10 @@ __device__ __forceinline__ void hd_load_bgmain_unit(float *dst, const float *bg,
 }
 
 // lane = point: |f|^2 and the dot products of the point's 128 channels with NT tables of KT rows in LDS.  The column is
-// streamed four channels at a time, the next group requested before the current one is used (the ~KT NT 16-byte broadcast
-// reads and 4 KT NT fma of a group cover an L2 round trip).
+// streamed SIXTEEN channels at a time, the next sixteen requested before the current ones are used: 16 loads in flight per
+// lane cover an HBM round trip with the ~4 KT NT 16-byte broadcast reads and 16 KT NT fma of a group (with four channels in
+// flight the pass ran at the memory latency: 32 round trips per wave, 35 us for the two-table forward pass).
+constexpr int HD_G = 16;
 template <int KT, int NT>
 __device__ __forceinline__ void hd_dots(const float *col, size_t N, const float *const (&tab)[NT], float (&d)[NT][KT], float &sq)
 {
@@ -109,24 +111,49 @@ __device__ __forceinline__ void hd_dots(const float *col, size_t N, const float 
 #pragma unroll
         for (int k = 0; k < KT; ++k) d[t][k] = 0.f;
     sq = 0.f;
-    float a0 = col[0], a1 = col[N], a2 = col[2 * N], a3 = col[3 * N];
+    float a[HD_G];
+#pragma unroll
+    for (int e = 0; e < HD_G; ++e) a[e] = col[(size_t)e * N];
 #pragma unroll 1
-    for (int c4 = 0; c4 < HD_C / 4; ++c4) {
-        const float v0 = a0, v1 = a1, v2 = a2, v3 = a3;
-        if (c4 + 1 < HD_C / 4) {
-            const float *nx = col + (size_t)(4 * c4 + 4) * N;
-            a0 = nx[0]; a1 = nx[N]; a2 = nx[2 * N]; a3 = nx[3 * N];
+    for (int cg = 0; cg < HD_C / HD_G; ++cg) {
+        float v[HD_G];
+#pragma unroll
+        for (int e = 0; e < HD_G; ++e) v[e] = a[e];
+        if (cg + 1 < HD_C / HD_G) {
+            const float *nx = col + (size_t)(HD_G * cg + HD_G) * N;
+#pragma unroll
+            for (int e = 0; e < HD_G; ++e) a[e] = nx[(size_t)e * N];
         }
-        sq = fmaf(v3, v3, fmaf(v2, v2, fmaf(v1, v1, fmaf(v0, v0, sq))));
-        // (a fence every eight rows: left alone the scheduler issues all KT NT table reads of a group first - 4 registers each)
+        // The 16 channels x NT tables x KT rows of a group as a flat sequence of units of eight rows x four channels, software
+        // pipelined by hand: the eight 16-byte table reads of unit u + 1 are issued, then the 32 fma of unit u, then an empty
+        // asm statement that names the eight accumulators (and clobbers memory) pins that order.  Left to itself the compiler
+        // places every table read of the group in front of the first fma (hundreds of registers); sched_barrier does not
+        // help - instruction selection has already put the chain-free fma behind the last read when it sees the fences.
+        constexpr int KG = 8, GPT = KT / KG, NU = (HD_G / 4) * NT * GPT;
+        f32x4 qb[2][KG];
+        auto rd = [&](int u, f32x4 (&q)[KG]) {
+            const int q4 = u / (NT * GPT), t = (u / GPT) % NT, kg = u % GPT;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int r = 0; r < KG; ++r) q[r] = *reinterpret_cast<const f32x4 *>(tab[t] + (kg * KG + r) * HD_C + HD_G * cg + 4 * q4);
+        };
+        rd(0, qb[0]);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const f32x4 q = *reinterpret_cast<const f32x4 *>(tab[t] + k * HD_C + 4 * c4);
-                d[t][k] = fmaf(v3, q[3], fmaf(v2, q[2], fmaf(v1, q[1], fmaf(v0, q[0], d[t][k]))));
-                if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < NU; ++u) {
+            const int q4 = u / (NT * GPT), t = (u / GPT) % NT, kg = u % GPT;
+            if (u + 1 < NU) rd(u + 1, qb[(u + 1) & 1]);
+            const float v0 = v[4 * q4], v1 = v[4 * q4 + 1], v2 = v[4 * q4 + 2], v3 = v[4 * q4 + 3];
+            if (t == 0 && kg == 0) sq = fmaf(v3, v3, fmaf(v2, v2, fmaf(v1, v1, fmaf(v0, v0, sq))));
+            float(&dk)[KT] = d[t];
+#pragma unroll
+            for (int r = 0; r < KG; ++r) {
+                const f32x4 q = qb[u & 1][r];
+                dk[kg * KG + r] = fmaf(v3, q[3], fmaf(v2, q[2], fmaf(v1, q[1], fmaf(v0, q[0], dk[kg * KG + r]))));
             }
+            asm volatile("" : "+v"(dk[kg * KG]), "+v"(dk[kg * KG + 1]), "+v"(dk[kg * KG + 2]), "+v"(dk[kg * KG + 3]), "+v"(dk[kg * KG + 4]),
+                         "+v"(dk[kg * KG + 5]), "+v"(dk[kg * KG + 6]), "+v"(dk[kg * KG + 7])
+                         :
+                         : "memory");
+        }
     }
 }
 
@@ -641,8 +668,14 @@ hd_bwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long l
     if (support) {                                       // (uniform)
         const float *dr = dfs + max(fi, 0) * HD_FLD;
         float tf = 0.f;
-#pragma unroll 4
-        for (int c = 0; c < HD_C; ++c) tf = fmaf(col[(size_t)c * N], dr[c], tf);
+#pragma unroll 1
+        for (int c0 = 0; c0 < HD_C; c0 += HD_G) {       // sixteen (L2-resident) channel values in flight
+            float v[HD_G];
+#pragma unroll
+            for (int e = 0; e < HD_G; ++e) v[e] = col[(size_t)(c0 + e) * N];
+#pragma unroll
+            for (int e = 0; e < HD_G; ++e) tf = fmaf(v[e], dr[c0 + e], tf);
+        }
         const float re = nrm + HD_EPS;
         fa1 = fi >= 0 ? 1.0f / re : 0.f;
         fa2 = fi >= 0 ? tf / (fmaxf(nrm, 1e-30f) * re * re) : 0.f;
@@ -665,12 +698,19 @@ hd_bwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long l
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         __syncthreads();
+        float nv[4];                                     // the next group's channel values, requested one group ahead (L2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nv[e] = col[(size_t)(32 * ct + e) * N];
 #pragma unroll 1
         for (int g4 = 0; g4 < 8; ++g4) {
             const int c0 = 32 * ct + 4 * g4;
             float v[4], o[4], dd[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = col[(size_t)(c0 + e) * N]; o[e] = 0.f; dd[e] = 0.f; }
+            for (int e = 0; e < 4; ++e) { v[e] = nv[e]; o[e] = 0.f; dd[e] = 0.f; }
+            if (g4 + 1 < 8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nv[e] = col[(size_t)(c0 + 4 + e) * N];
+            }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const f32x4 a1 = *reinterpret_cast<const f32x4 *>(q1 + k * HD_C + c0), a2 = *reinterpret_cast<const f32x4 *>(q2 + k * HD_C + c0);

@@ -52,7 +52,7 @@ class DGCNNSeg(nn.Module):
     def forward(self, pc, return_feat=False):
         n = pc.shape[2]
         from model.dgcnn import segmenter_fusable, segmenter_forward_pm
-        if pc.is_cuda and segmenter_fusable(self.segmenter) and self.encoder.conv.fused_parts() is not None:
+        if pc.is_cuda and segmenter_fusable(self.segmenter) and self.encoder.fully_fused():
             # point-major throughout: the global max is taken over the points of the (B, N, C) level-2 feature and enters
             # the packed classifier input as a broadcast channel-first source
             feats, feats_pm, level2_pm = self.encoder(pc, point_major=True)

@@ -84,7 +84,7 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
                 and self.att_learner.in_channel % 64 == 0 and len(f) == 3 and isinstance(f[0], nn.Conv1d)
                 and type(f[1]) in (nn.BatchNorm1d, nn.SyncBatchNorm) and isinstance(f[2], nn.LeakyReLU)
                 and f[0].out_channels % 64 == 0 and f[0].in_channels <= 1024 and self.encoder.n_edgeconv <= ops.PW_MAX_SEGS
-                and self.encoder.conv.fused_parts() is not None)
+                and self.encoder.fully_fused())
 
     def _features(self, x, want_semantic, want_onehot=True):
         """capl.py:324-362.  Returns (point_feat, semantic or None, one-hot words - or, want_onehot=False, the (B,N) int32 word

@@ -73,8 +73,15 @@ class conv2d(nn.Module):
         if not ok:
             raise NotImplementedError(
                 "gfs3d: the HIP EdgeConv kernel implements edgeconv widths [64, 64] with BatchNorm + LeakyReLU "
-                f"(got layer_dims={self.layer_dims}); there is no unfused fallback")
+                f"(got layer_dims={self.layer_dims}); DGCNN.forward runs other shapes through the general path")
         return m[0], m[1], m[3], m[4]
+
+    def is_fused_shape(self):
+        try:
+            self.fused_parts()
+            return True
+        except NotImplementedError:
+            return False
 
 
 class conv1d(nn.Module):
@@ -125,12 +132,32 @@ class DGCNN(nn.Module):
         self.conv = conv1d(sum(w[-1] for w in edgeconv_widths), mlp_widths)
         self.bn_sync = None      # gfs3d.ops.BNSync: whole-batch BatchNorm statistics under block-sharded DP
 
+    def fully_fused(self):
+        """Every block has the fused EdgeConv shape and the point-wise stack the K4 form: forward(point_major=True) is available
+        (training mode, or inference without gradients)."""
+        parts = self.conv.fused_parts() if self.n_edgeconv <= ops.PW_MAX_SEGS else None
+        return (all(b.is_fused_shape() for b in self.edge_convs) and self.k <= ops.MAX_K and parts is not None
+                and parts[0][0].in_channels == ops.PW_SEG_WIDTH * self.n_edgeconv
+                and (self.training or not torch.is_grad_enabled()))
+
     def edgeconv_features(self, x, with_point_major=False):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
         with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
         feats, feats_pm, bns = [], [], []
         x_pm = x_sq = None
         for block in self.edge_convs:
+            # Shapes outside the fused kernel (reference conv2d accepts any layer_dims, dgcnn.py:45-58; k > 32; a backward pass in
+            # eval mode): the graph still comes from the HIP kNN kernel (bit-exact contract), the block itself runs as the
+            # reference wrote it - gather, cat, the nn.Sequential, max over k - as tensor-library ops on the device.
+            if (not block.is_fused_shape() or self.k > ops.MAX_K or x.shape[1] > 128
+                    or (not self.training and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in block.parameters())))):
+                if self.bn_sync is not None and self.training:
+                    raise NotImplementedError("gfs3d: synchronised BatchNorm is implemented for the fused EdgeConv shape ([64, 64], k <= 32) only")
+                x = block(get_edge_feature(x, self.k, ops.knn_topk(x.detach(), self.k))).max(dim=-1)[0]
+                x_pm = x_sq = None
+                feats.append(x)
+                feats_pm.append(None)
+                continue
             c1, bn1, c2, bn2 = block.fused_parts()
             idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True, sqnorm=x_sq,
                                  x_pm=x_pm.detach() if (x_pm is not None and x.shape[1] == 64) else None)
@@ -150,7 +177,8 @@ class DGCNN(nn.Module):
         point-major (B,N,C) tensor) - no channel-first copy of the level-2 feature is written."""
         feats, feats_pm = self.edgeconv_features(x, with_point_major=True)
         parts = self.conv.fused_parts() if len(feats) <= ops.PW_MAX_SEGS else None
-        fused = parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats)
+        fused = (parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats) and all(t is not None for t in feats_pm)
+                 and (self.training or not (torch.is_grad_enabled() and any(t.requires_grad for t in feats))))
         if point_major:
             if not fused:
                 raise NotImplementedError("DGCNN(point_major=True): the point-wise stack is not in the HIP-fusable form")
@@ -229,7 +257,7 @@ class DGCNNSeg_att(nn.Module):
 
     def forward(self, pc, return_feat=False):
         if pc.is_cuda and segmenter_fusable(self.segmenter) and self.base_learner.fused_parts() is not None \
-                and self.att_learner.out_channel == 64 and self.encoder.conv.fused_parts() is not None:
+                and self.att_learner.out_channel == 64 and self.encoder.fully_fused():
             # everything after the EdgeConv blocks on the HIP point-wise kernels, point-major throughout
             feats, feats_pm, level2_pm = self.encoder(pc, point_major=True)
             att = self.att_learner.forward_pm(level2_pm)

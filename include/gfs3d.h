@@ -50,7 +50,9 @@ extern "C" {
                                     The heavy kernels are built around it: one point's 64 channels are one 256-B row (one
                                     coalesced load / store per wave), conv2 is exactly two 32x32 MFMA tiles per lane half, and the
                                     max over k, the BatchNorm sums and G_Q are in-lane reductions over the accumulator registers
-                                    of that tile shape.  Other widths return GFS3D_ERR_INVALID (Python: NotImplementedError). */
+                                    of that tile shape.  Other widths return GFS3D_ERR_INVALID; the Python mirror (model/dgcnn.py: DGCNN.edgeconv_features)
+                                    runs them - and k > 32, and a backward pass in eval mode - through its general path: the
+                                    graph from gfs3d_knn_topk_*, the block itself as device tensor ops. */
 #define GFS3D_MAX_K 32           /* neighbours per point supported by the EdgeConv kernels */
 
 int gfs3d_version(void);

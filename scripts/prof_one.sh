@@ -12,6 +12,6 @@ fi
 python3 "$root/scripts/prof_summary.py" $d/r_results.db | (head -${TOPN:-12} || true) | python3 -c "
 import sys,re
 for l in sys.stdin:
-    m=re.search(r'calls=.*', l); name=re.sub(r'\\(.*','',l.split('calls=')[0]).strip()
+    m=re.search(r'calls=.*', l); name=re.sub(r'\\(.*','',l.split('calls=')[0].replace('(anonymous namespace)::','').replace('void ','')).strip()
     print(name[:60].ljust(62), m.group(0) if m else '')"
 rm -rf $d $log

@@ -1434,3 +1434,26 @@ def test_edgeconv_norm_handoff_is_bit_exact(dev):
         for c in range(64):
             ref = (ref + (yc[:, c, :] * yc[:, c, :]).astype(np.float32)).astype(np.float32)
         assert np.array_equal(y_sq[:B * N].cpu().numpy().reshape(B, N), ref)
+
+
+@pytest.mark.parametrize("widths,k,training", [([[32, 48], [64, 64]], 10, False), ([[64, 64, 32]], 8, True), ([[64, 64], [64, 64]], 40, False)])
+def test_dgcnn_general_shapes_run_through_the_hip_graph_and_match_the_oracle(dev, widths, k, training):
+    """reference conv2d accepts any layer_dims (dgcnn.py:45-58) and any k: shapes outside the fused EdgeConv kernel ([64, 64],
+    k <= 32) take the general path - HIP kNN graph + the block as device tensor ops - instead of raising; outputs and input
+    gradient against the oracle's restatement with the same weights."""
+    from model.dgcnn import DGCNN
+    torch.manual_seed(4)
+    net = DGCNN(widths, [64, 64], 9, k=k, return_edgeconvs=True)
+    sd = {kk: v.clone() for kk, v in net.state_dict().items()}
+    x = R.synthetic_blocks(2, 200, seed=3)
+    xr = x.clone().requires_grad_(True)
+    fr, outr = R.dgcnn_forward(sd, xr, k=k, n_edgeconv=len(widths), n_conv_per_block=len(widths[0]), training=training, new_stats={},
+                               knn_fn=lambda t, kk: torch.from_numpy(c_oracle.knn(t.detach().numpy(), kk)))
+    net = net.to(dev).train(training)
+    xd = x.to(dev).requires_grad_(True)
+    fd, outd = net(xd)
+    for a, b in zip(fd + [outd], fr + [outr]):
+        assert maxerr(a, b) < 2e-4
+    (outd.sum() + fd[0].sum()).backward()
+    (outr.sum() + fr[0].sum()).backward()
+    assert relerr(xd.grad, xr.grad) < 1e-3
