@@ -87,7 +87,7 @@ def hbm_traffic(kernel, tag):
     scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
     import glob
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_hbm_traffic.json")))
-    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r01_e"]:
+    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r02_e", "r01_e"]:
         try:
             with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
                 d = json.load(f)
@@ -418,7 +418,7 @@ def main():
             avg_ms = ms / n
             achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
             peak = PEAK_16BIT_TFLOPS if (reduced and dom in (1, 2)) else PEAK_FP32_TFLOPS
-            traffic, src = hbm_traffic(KERNELS[dom], "r02")
+            traffic, src = hbm_traffic(KERNELS[dom], "r03")
             roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
             if dom == 2:

@@ -825,7 +825,8 @@ int launch_rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 template <int PRO, int EPI, bool OUT_CF>
 int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 {
-    if (rg.Nc % 128 == 0) return launch_rowgemm<128, PRO, EPI, OUT_CF>(rg, st, who);
+    static const int force_bn = getenv("GFS3D_PW_BN") ? atoi(getenv("GFS3D_PW_BN")) : 0;      // experiments: GFS3D_PW_BN=64
+    if (rg.Nc % 128 == 0 && force_bn != 64) return launch_rowgemm<128, PRO, EPI, OUT_CF>(rg, st, who);
     return launch_rowgemm<64, PRO, EPI, OUT_CF>(rg, st, who);
 }
 

@@ -594,6 +594,7 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
         if (half == 0 && w < NT * 32) ginv[w] = (w < K) ? 1.0f / fmaxf(sqrtf(gsq), NORM_EPS) : 0.f;
     }
     float dot = 0.f;
+#if !(defined(PBX_ABL) && (PBX_ABL & 1))      // ablation builds only (wrong results, timing of the rest)
     if (MODE == MODE_SOFTMAX) {
 #pragma unroll 4
         for (int t = 0; t < NT; ++t)
@@ -604,6 +605,7 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
             }
         dot += __shfl_xor(dot, 32, 64);
     }
+#endif
     __syncthreads();
 
     // staging of tile t: units of (word, 4 channels); unit q = tid + 512 u covers word q / (C/4), channels 4 (q % (C/4))
@@ -621,8 +623,12 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
         for (int r = 0; r < 16; ++r) {
             const int w = t * 32 + acc_row(r, h);
             const bool ok = w < K;
+#if defined(PBX_ABL) && (PBX_ABL & 4)
+            uv[r] = 0.25f * (float)r; sv[r] = 0.5f;
+#else
             uv[r] = ok ? ub[(size_t)w * N] : 0.f;
             sv[r] = (MODE == MODE_SOFTMAX && ok) ? sb[(size_t)w * N] : 0.f;
+#endif
         }
     };
     auto stage = [&](unsigned char *dst_img) {
@@ -691,7 +697,11 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+#if defined(PBX_ABL) && (PBX_ABL & 2)
+            const float fv = 1.0f + 0.01f * r;
+#else
             const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, (ct * 32 + acc_row(r, 0)) * N * 4, 0));
+#endif
             fsq = fmaf(fv, fv, fsq);
             fd = fmaf(fv, G[ct][r], fd);
         }
@@ -706,7 +716,14 @@ proto_bwd_x6_kernel(const float *__restrict__ feat, long long feat_bstride, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int so = (ct * 32 + acc_row(r, 0)) * N * 4;
+#if defined(PBX_ABL) && (PBX_ABL & 2)
+            const float fv = 1.0f + 0.01f * r;
+#else
             const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, so, 0));
+#endif
+#if defined(PBX_ABL) && (PBX_ABL & 8)
+            if (G[ct][r] == 12345.678f)
+#endif
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ct][r] - fv * coef) * finv), rs_o, ovoff, so, 0);
         }
 }
