@@ -257,12 +257,15 @@ def extras(dev, L, gdist):
         M = 7 * 300000
         pts = torch.randn(M, 192, generator=g).to(dev)
         cent = pts[torch.randperm(M, generator=g)[:200].to(dev)].contiguous()
-        ms = timed_ms(lambda: ops.kmeans_assign(pts, cent), 5, warm=2)
         byts = 4.0 * M * (192 + 1)                                   # every point read once, its label written
-        out["lloyd_step"] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3), "bound": "hbm",
-                             "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
-                             "algorithmic_TFLOPps": round(2.0 * M * 192 * 200 / ms / 1e9, 2),
-                             "note": "assignment (bf16x6 GEMM, matrix-bound: the larger part) + centroid sums as sorted segment sums; the points are read twice"}
+        for key, fast, note in (("lloyd_step", True, "the step of the Lloyd loop (get_basis.device_kmeans): SCREENED assignment (hi + mid bf16 operands, three "
+                                 "products, error bound; undecided points re-scored at fp32 accuracy from a list: same labels / sums / counts as the exact "
+                                 "form) + centroid sums as sorted segment sums; the points are read twice"),
+                                ("lloyd_step_exact", False, "every point scored at fp32 accuracy (bf16x6 GEMM): the final assignment, whose inertia is reported")):
+            ms = timed_ms(lambda: ops.kmeans_assign(pts, cent, fast=fast), 5, warm=2)
+            out[key] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3), "bound": "hbm",
+                        "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                        "algorithmic_TFLOPps": round(2.0 * M * 192 * 200 / ms / 1e9, 2), "note": note}
         del pts
     q, k_, v = (torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
     cot = torch.randn(B, 64, N, generator=g).to(dev)

@@ -82,26 +82,35 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 //   PREC_BF16 ONE bf16 product per fp32 product: operands rounded to nearest-even bf16 (8 significand bits), fp32 accumulate
 //   PREC_F16  the same with IEEE half operands (11 significand bits; forward passes only - gradients underflow in half)
 // All three use the same LDS row images ([piece 0 | piece 1 | piece 2 | pad]); the reduced forms fill and read piece 0 only.
-enum { PREC_X6 = GFS3D_COMPUTE_F32, PREC_BF16 = GFS3D_COMPUTE_BF16, PREC_F16 = GFS3D_COMPUTE_F16 };
+//   PREC_X3   (internal: screens with an error bound, never a result) operands as hi + mid round-to-nearest bf16 pairs, the three
+//             products hi hi + hi mid + mid hi: ~2^-15 |x||y| per product dropped (the screened kNN's form, knn.hip)
+enum { PREC_X6 = GFS3D_COMPUTE_F32, PREC_BF16 = GFS3D_COMPUTE_BF16, PREC_F16 = GFS3D_COMPUTE_F16, PREC_X3 = 3 };
 typedef float mm_f32x16 __attribute__((ext_vector_type(16)));
 typedef float mm_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 mm_bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 mm_f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int PREC> struct Mx {
-    static constexpr int NP = PREC == PREC_X6 ? 3 : 1;        // operand pieces
-    static constexpr int NTERM = PREC == PREC_X6 ? 6 : 1;     // piece products per fp32 product
+    static constexpr int NP = PREC == PREC_X6 ? 3 : (PREC == PREC_X3 ? 2 : 1);        // operand pieces
+    static constexpr int NTERM = PREC == PREC_X6 ? 6 : (PREC == PREC_X3 ? 3 : 1);     // piece products per fp32 product
 };
 // two fp32 values -> one dword of two 16-bit operands (a in the low half), rounded to nearest-even
 template <int PREC> __device__ __forceinline__ unsigned mm_pack2(float a, float b)
 {
-    static_assert(PREC == PREC_BF16 || PREC == PREC_F16, "mm_pack2: reduced forms only");
+    static_assert(PREC == PREC_BF16 || PREC == PREC_F16 || PREC == PREC_X3, "mm_pack2: reduced forms only");
     const mm_f32x2 v = {a, b};
-    if (PREC == PREC_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mm_bf16x2));
+    if (PREC == PREC_BF16 || PREC == PREC_X3) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mm_bf16x2));
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, mm_f16x2));
 }
 // one fp32 value -> its 16-bit operand (the weight / prototype images are written one element at a time)
 template <int PREC> __device__ __forceinline__ unsigned short mm_cvt1(float a) { return (unsigned short)(mm_pack2<PREC>(a, 0.f) & 0xffffu); }
+// two fp32 values -> their hi and mid bf16 pieces (both roundings to nearest-even; a - hi is exact), each pair in one dword
+__device__ __forceinline__ void mm_split2_rne(float a, float b, unsigned &hi, unsigned &mid)
+{
+    hi = mm_pack2<PREC_BF16>(a, b);
+    const float ra = a - __builtin_bit_cast(float, hi << 16), rb = b - __builtin_bit_cast(float, hi & 0xffff0000u);
+    mid = mm_pack2<PREC_BF16>(ra, rb);
+}
 // eight consecutive K values of one operand row -> NP dwordx4 pieces ([0] hi, [1] mid, [2] lo for PREC_X6)
 template <int PREC> __device__ __forceinline__ void mm_pieces8(const float *v8, uint4 (&out)[Mx<PREC>::NP])
 {
@@ -112,6 +121,12 @@ template <int PREC> __device__ __forceinline__ void mm_pieces8(const float *v8, 
         out[0] = make_uint4(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]), pack_hi16(ph[4], ph[5]), pack_hi16(ph[6], ph[7]));
         out[1] = make_uint4(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]), pack_hi16(pm[4], pm[5]), pack_hi16(pm[6], pm[7]));
         out[2] = make_uint4(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]), pack_hi16(pl[4], pl[5]), pack_hi16(pl[6], pl[7]));
+    } else if constexpr (PREC == PREC_X3) {
+        unsigned hi[4], mid[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mm_split2_rne(v8[2 * e], v8[2 * e + 1], hi[e], mid[e]);
+        out[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        out[1] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
     } else {
         out[0] = make_uint4(mm_pack2<PREC>(v8[0], v8[1]), mm_pack2<PREC>(v8[2], v8[3]), mm_pack2<PREC>(v8[4], v8[5]), mm_pack2<PREC>(v8[6], v8[7]));
     }
@@ -126,6 +141,12 @@ template <int PREC> __device__ __forceinline__ void mm_pieces4(const float *v4, 
         out[0] = make_uint2(pack_hi16(ph[0], ph[1]), pack_hi16(ph[2], ph[3]));
         out[1] = make_uint2(pack_hi16(pm[0], pm[1]), pack_hi16(pm[2], pm[3]));
         out[2] = make_uint2(pack_hi16(pl[0], pl[1]), pack_hi16(pl[2], pl[3]));
+    } else if constexpr (PREC == PREC_X3) {
+        unsigned hi[2], mid[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) mm_split2_rne(v4[2 * e], v4[2 * e + 1], hi[e], mid[e]);
+        out[0] = make_uint2(hi[0], hi[1]);
+        out[1] = make_uint2(mid[0], mid[1]);
     } else {
         out[0] = make_uint2(mm_pack2<PREC>(v4[0], v4[1]), mm_pack2<PREC>(v4[2], v4[3]));
     }
@@ -157,6 +178,10 @@ template <int PREC> __device__ __forceinline__ void mm_mac(const uint4 (&a)[Mx<P
         constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
         for (int term = 0; term < 6; ++term) acc = mm_mfma<PREC>(a[PA[term]], b[PB[term]], acc);
+    } else if constexpr (PREC == PREC_X3) {
+        acc = mm_mfma<PREC>(a[1], b[0], acc);
+        acc = mm_mfma<PREC>(a[0], b[1], acc);
+        acc = mm_mfma<PREC>(a[0], b[0], acc);
     } else {
         acc = mm_mfma<PREC>(a[0], b[0], acc);
     }

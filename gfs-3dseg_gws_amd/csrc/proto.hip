@@ -213,10 +213,12 @@ constexpr int PX_THREADS = 512;
 //                     valid: the wave reads its 32 x 32 chunk as 128-B row pieces (8 lanes per row) and turns it
 //                     through a wave-private LDS tile `wtile` [32][XS_LD] so that lane (j, h) gets point j's channels
 constexpr int XS_LD = 36;            // floats per row of that tile (144 B: 16-B aligned, 9 slots = odd)
+//                     (`ridx` != NULL: row r of the wave is point ridx[r] of the matrix at `pt` - the exact pass over a list)
 template <int NT, bool ROWMAJOR, int PREC = PREC_X6>
 __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t cstride, int nrows, float *wtile,
                                           const float *__restrict__ pb, int C, int K,
-                                          unsigned char *img, float *gsq_out, f32x16 (&acc)[NT], float &fsq)
+                                          unsigned char *img, float *gsq_out, f32x16 (&acc)[NT], float &fsq,
+                                          const int *__restrict__ ridx = nullptr)
 {
     constexpr int NROW = NT * 32;
     constexpr int NU = NROW * 8 / PX_THREADS;            // float4 units of a prototype chunk per thread (NT / 2)
@@ -246,7 +248,8 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
 #pragma unroll
             for (int i = 0; i < 4; ++i) {              // rows (lane >> 3) + 8 i, 16 B at column 4 (lane & 7)
                 const int row = min((lane >> 3) + 8 * i, nrows - 1);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(pt + (size_t)row * cstride + c0 + 4 * (lane & 7));
+                const size_t prow = ridx ? (size_t)ridx[row] : (size_t)row;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(pt + prow * cstride + c0 + 4 * (lane & 7));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) fr[4 * i + e] = v[e];
             }
@@ -1091,43 +1094,78 @@ kmeans_assign_mfma_kernel(const float *__restrict__ pts, long long M, int C, con
 }
 
 // The assignment step on the bf16x6 main loop of proto_x6_kernel (C % 32 == 0): 8 waves = 256 points per workgroup.
-template <int NT>
+//   PREC_X6, LIST = false   every point scored at fp32 accuracy (the form gfs3d_kmeans_assign_* ships)
+//   PREC_X3, LIST = false   SCREEN (gfs3d_kmeans_assign_fast_f32): hi + mid bf16 operands, three products - half the matrix work
+//                           and split arithmetic - with the error bound E of the screened kNN (knn.hip); a point whose two
+//                           best scores are more than 2 E apart has its exact arg-min decided, the others go to `flist`
+//   PREC_X6, LIST = true    the exact pass over `flist` (grid sized for M, blocks past the list's end leave at once)
+// so the labels - and with them the sums and counts - are those of the fp32-accurate form; only the inertia of the
+// screened points is the approximate score (within E of the exact one).
+struct KmFast { int *flist; int *fcount; float erel, eabs; };
+template <int NT, int PREC, bool LIST>
 __global__ void __launch_bounds__(PX_THREADS)
 kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ cent, int K,
-                        int32_t *__restrict__ label, float *__restrict__ counts, double *__restrict__ inertia)
+                        int32_t *__restrict__ label, float *__restrict__ counts, double *__restrict__ inertia, const KmFast fa)
 {
     constexpr int NROW = NT * 32;
+    constexpr bool SCREEN = PREC == PREC_X3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *img = reinterpret_cast<unsigned char *>(smem);
     float *cn = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);           // [NROW] |c_k|^2
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * 256 + wv * 32, m = m0 + j;
+    long long total = M;
+    if (LIST) total = (long long)*fa.fcount;
+    // (the exact pass runs a FIXED grid of a few hundred blocks that stride over the list: a grid sized for M would launch
+    // thousands of blocks that leave at once - 54 us for an empty list)
+    auto tile = [&](const long long blk) {
+    const long long m0 = blk * 256 + wv * 32;
     float *wtile = cn + NROW + wv * 32 * XS_LD;                               // wave-private [32][XS_LD]
     int *hist = reinterpret_cast<int *>(cn + NROW + 8 * 32 * XS_LD);          // [NROW] members of this workgroup per centroid
     if (tid < NROW) hist[tid] = 0;                                            // (ordered by the barriers of the main loop)
     f32x16 acc[NT];
     float psq;
-    const long long mb = m0 < M ? m0 : M - 1;                                  // (a wave past M recomputes the last point, stores nothing)
-    x6_scores<NT, true>(pts + (size_t)mb * C, (size_t)C, (int)min((long long)32, M - mb), wtile, cent, C, K, img, cn, acc, psq);
+    const long long mb = m0 < total ? m0 : total - 1;                          // (a wave past the end recomputes the last point, stores nothing)
+    const int nrows = (int)min((long long)32, total - mb);
+    if (LIST) x6_scores<NT, true, PREC>(pts, (size_t)C, nrows, wtile, cent, C, K, img, cn, acc, psq, fa.flist + mb);
+    else      x6_scores<NT, true, PREC>(pts + (size_t)mb * C, (size_t)C, nrows, wtile, cent, C, K, img, cn, acc, psq);
     psq += __shfl_xor(psq, 32, 64);
-    float best = __builtin_inff();
+    const bool live = h == 0 && m0 + j < total;
+    const long long m = LIST ? (long long)fa.flist[min(m0 + j, total - 1)] : m0 + j;
+    float best = __builtin_inff(), second = __builtin_inff();
     int bk = 0x7fffffff;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int w = t * 32 + acc_row(r, h);               // increasing within a lane: '<' keeps the lowest index of a tie
-            const float d = cn[w] - 2.f * acc[t][r];            // + |p|^2, constant per point
-            if (w < K && d < best) { best = d; bk = w; }
+            if constexpr (SCREEN) {
+                const float d = (w < K) ? cn[w] - 2.f * acc[t][r] : __builtin_inff();      // + |p|^2, constant per point
+                second = fminf(second, fmaxf(d, best));
+                if (d < best) { best = d; bk = w; }
+            } else {
+                const float d = cn[w] - 2.f * acc[t][r];
+                if (w < K && d < best) { best = d; bk = w; }
+            }
         }
     {
         const float ob = __shfl_xor(best, 32, 64);
         const int ok = __shfl_xor(bk, 32, 64);
+        if (SCREEN) second = fminf(fminf(second, __shfl_xor(second, 32, 64)), fmaxf(best, ob));
         if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
     }
+    bool decided = true;
+    if (SCREEN) {
+        float cmx = 0.f;                                  // max_k |c_k|^2
+        for (int w = lane; w < NROW; w += 64) cmx = fmaxf(cmx, w < K ? cn[w] : 0.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o, 64));
+        const float E = fa.erel * sqrtf(psq * cmx) + fa.eabs * (psq + cmx);
+        decided = second - best > 2.0f * E;               // (K == 1: second = +inf)
+        if (live && !decided) fa.flist[atomicAdd(fa.fcount, 1)] = (int)m;      // (order of the list: irrelevant, integer atomics)
+    }
     double contrib = 0.0;
-    if (h == 0 && m < M) {
+    if (live && decided) {
         label[m] = bk;
         atomicAdd(&hist[bk], 1);
         contrib = (double)fmaxf(best + psq, 0.f);
@@ -1149,6 +1187,13 @@ kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const
             atomicAdd(inertia, tot);
         }
     }
+    };   // tile
+    if constexpr (!LIST) tile((long long)blockIdx.x);
+    else
+        for (long long blk = blockIdx.x; blk * 256 < total; blk += gridDim.x) {
+            if (blk != (long long)blockIdx.x) __syncthreads();                  // (the previous tile's LDS reads are done)
+            tile(blk);
+        }
 }
 
 constexpr int KM_CHUNK = 2048;     // points per workgroup of the sums kernel
@@ -1228,7 +1273,7 @@ kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KS_SORT_CHUNK = 1024;       // points per (one-wave) block of the histogram / placement kernels
 constexpr int KS_SEG = 256;               // rows per partial sum
-struct KmWs { size_t off_perm, off_bh, off_tot, off_off, off_cb, off_part, total; int nblk, nchmax; };
+struct KmWs { size_t off_flist, off_fcnt, off_perm, off_bh, off_tot, off_off, off_cb, off_part, total; int nblk, nchmax; };
 static KmWs km_ws(long long M, int C, int K)
 {
     KmWs w{};
@@ -1236,6 +1281,8 @@ static KmWs km_ws(long long M, int C, int K)
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     w.nblk = (int)((M + KS_SORT_CHUNK - 1) / KS_SORT_CHUNK);
     w.nchmax = (int)((M + KS_SEG - 1) / KS_SEG) + K;
+    w.off_flist = take(sizeof(int) * (size_t)M);                 // fast form: points the screen could not decide
+    w.off_fcnt = take(256);
     w.off_perm = take(sizeof(int) * (size_t)M);
     w.off_bh = take(sizeof(int) * (size_t)w.nblk * K);          // per-chunk histograms, then their exclusive prefix over the chunks
     w.off_tot = take(sizeof(int) * (size_t)K);
@@ -1436,19 +1483,42 @@ static int launch_km_segsums(const float *pts, long long M, int C, int K, const 
     return GFS3D_OK;
 }
 
+// relative part of the screen's error bound for C channels (knn.hip derives the terms): dropped piece products 2^-15 (1 + 2^-6) per
+// dot, the screen's 3 C fp32 accumulations at 2^-23, the exact form's 6 C at 2^-24 - doubled for d = |c|^2 - 2 <c, p>
+static inline float km_screen_rel(int C) { return 2.0f * (3.1e-5f + (float)C * (3.0f * 1.1920929e-7f + 6.0f * 5.9604645e-8f)) * 1.05f; }
+
 template <int NT>
 static int launch_kmeans(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums,
-                         float *counts, double *inertia, hipStream_t st, char *ws = nullptr)
+                         float *counts, double *inertia, hipStream_t st, char *ws = nullptr, bool fast = false)
 {
     ProfScope prof(5, st);
     bool x6 = false;
     if constexpr (NT >= 2) {
         if (C % 32 == 0 && ((reinterpret_cast<uintptr_t>(pts) | reinterpret_cast<uintptr_t>(cent)) & 15) == 0) {
             const size_t lds = (size_t)2 * NT * 32 * PX_ROW + sizeof(float) * (2 * NT * 32 + 8 * 32 * XS_LD);
-            GFS3D_ENSURE_LDS(kmeans_assign_x6_kernel<NT>, lds, "gfs3d_kmeans_assign_f32");
-            hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT>), dim3((unsigned)((M + 255) / 256)), dim3(PX_THREADS), lds, st,
-                               pts, M, C, cent, K, label, counts, inertia);
-            GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel");
+            const dim3 grid((unsigned)((M + 255) / 256));
+            KmFast fa{nullptr, nullptr, 0.f, 0.f};
+            if (fast && ws) {
+                const KmWs w = km_ws(M, C, K);
+                fa = KmFast{reinterpret_cast<int *>(ws + w.off_flist), reinterpret_cast<int *>(ws + w.off_fcnt), km_screen_rel(C), 4e-6f};
+                if (hipMemsetAsync(fa.fcount, 0, sizeof(int), st) != hipSuccess) {
+                    set_error("gfs3d_kmeans_assign_fast_f32: hipMemsetAsync failed");
+                    return GFS3D_ERR_HIP;
+                }
+                GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X3, false>), lds, "gfs3d_kmeans_assign_fast_f32");
+                hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X3, false>), grid, dim3(PX_THREADS), lds, st, pts, M, C, cent, K, label, counts,
+                                   inertia, fa);
+                GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel (screen)");
+                GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X6, true>), lds, "gfs3d_kmeans_assign_fast_f32");
+                hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X6, true>), dim3(min(grid.x, 512u)), dim3(PX_THREADS), lds, st, pts, M, C, cent, K,
+                                   label, counts, inertia, fa);
+                GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel (exact pass over the list)");
+            } else {
+                GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X6, false>), lds, "gfs3d_kmeans_assign_f32");
+                hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X6, false>), grid, dim3(PX_THREADS), lds, st, pts, M, C, cent, K, label, counts,
+                                   inertia, fa);
+                GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel");
+            }
             x6 = true;
         }
     }
@@ -1518,9 +1588,26 @@ extern "C" int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, con
     return gfs3d_kmeans_assign_ws_f32(pts, M, C, cent, K, label, sums, counts, inertia, nullptr, 0, stream);
 }
 
+static int km_assign(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums, float *counts,
+                     double *inertia, void *workspace, size_t workspace_bytes, void *stream, bool fast);
+
 extern "C" int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
                                           int32_t *label, float *sums, float *counts, double *inertia,
                                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    return km_assign(pts, M, C, cent, K, label, sums, counts, inertia, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int gfs3d_kmeans_assign_fast_f32(const float *pts, long long M, int C, const float *cent, int K,
+                                            int32_t *label, float *sums, float *counts, double *inertia,
+                                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    GFS3D_REQUIRE(workspace != nullptr, "gfs3d_kmeans_assign_fast_f32: the screened form needs the workspace");
+    return km_assign(pts, M, C, cent, K, label, sums, counts, inertia, workspace, workspace_bytes, stream, true);
+}
+
+static int km_assign(const float *pts, long long M, int C, const float *cent, int K, int32_t *label, float *sums, float *counts,
+                     double *inertia, void *workspace, size_t workspace_bytes, void *stream, bool fast)
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(pts && cent && label && sums && counts, "gfs3d_kmeans_assign_f32: NULL pointer");
@@ -1537,10 +1624,10 @@ extern "C" int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, 
             }
             ws = static_cast<char *>(workspace);
         }
-        if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
-        if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
-        if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
-        return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws);
+        if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
+        if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
+        if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
+        return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
     }
     const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
     GFS3D_ENSURE_LDS(kmeans_assign_kernel, lds, "gfs3d_kmeans_assign_f32");

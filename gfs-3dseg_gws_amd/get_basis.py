@@ -94,8 +94,11 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
     identical on all ranks (no rank leaves the loop while another still waits in a collective); an empty cluster
     keeps its previous centroid, which is rank-identical too because the start was."""
     n_iter = 0
+    # inside the loop only labels / sums / counts matter: the screened assignment (same labels at about half the matrix work);
+    # the final assignment below is the exact form, whose inertia is the one reported
+    loop_fn = (lambda p, c: ops.kmeans_assign(p, c, fast=True)) if assign_fn is ops.kmeans_assign else assign_fn
     for n_iter in range(1, max_iter + 1):
-        _, sums, counts, _ = assign_fn(points, cent)
+        _, sums, counts, _ = loop_fn(points, cent)
         if sharded:
             packed = torch.cat([sums, counts[:, None]], dim=1)          # one collective per iteration
             torch.distributed.all_reduce(packed)

@@ -1066,9 +1066,10 @@ def capl_train_head(feat, main_proto, bg_proto, y, fake, base_num, ignore_index=
     return CaplTrainHeadFunction.apply(feat, main_proto, bg_proto, y, fake, base_num, ignore_index)
 
 
-def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor):
+def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False):
     """One Lloyd assignment step on device: labels, per-centroid sums/counts and
-    inertia (get_basis.py:210 runs sklearn KMeans on the CPU)."""
+    inertia (get_basis.py:210 runs sklearn KMeans on the CPU).  fast=True: the screened form of the Lloyd loop
+    (gfs3d_kmeans_assign_fast_f32: same labels / sums / counts, inertia from the screened scores)."""
     _need_gpu(pts, "pts")
     _need_gpu(cent, "cent")
     pts, cent = pts.contiguous(), cent.contiguous()
@@ -1083,7 +1084,7 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor):
         L = _lib.lib()
         nbytes = L.gfs3d_kmeans_workspace_bytes(M, C, K)       # > 0: centroid sums as sorted segment sums (fixed order, no atomics)
         ws = _workspace(dev, nbytes) if nbytes else None
-        rc = L.gfs3d_kmeans_assign_ws_f32(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia),
-                                          _p(ws), ws.numel() if ws is not None else 0, _stream())
+        fn = L.gfs3d_kmeans_assign_fast_f32 if (fast and ws is not None) else L.gfs3d_kmeans_assign_ws_f32
+        rc = fn(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "gfs3d_kmeans_assign_ws_f32")
     return label, sums, counts, inertia

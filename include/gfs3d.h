@@ -415,6 +415,15 @@ int gfs3d_kmeans_assign_f32(const float *pts, long long M, int C, const float *c
  * the points sorted by label (stable counting sort, fixed summation order: no float atomics, bit-reproducible; `sums` need
  * not be zeroed) - the points are read once as whole rows instead of going through a one-hot GEMM. */
 size_t gfs3d_kmeans_workspace_bytes(long long M, int C, int K);
+/* The Lloyd-loop form: the same labels, sums and counts at about half the matrix work.  A SCREEN scores every point with
+ * hi + mid bf16 operands (three products instead of six) under a rigorous error bound E; a point whose two best scores
+ * are more than 2 E apart has its arg-min decided, the few others are re-scored at fp32 accuracy from a list.  `inertia`
+ * is summed from the screened scores (each within E of the exact one): use gfs3d_kmeans_assign_ws_f32 for a final, exact
+ * inertia (get_basis.device_kmeans does).  Needs the workspace; C % 32 == 0 and 33 <= K <= 256 take the screened path,
+ * other shapes run the exact form. */
+int gfs3d_kmeans_assign_fast_f32(const float *pts, long long M, int C, const float *cent, int K,
+                                 int32_t *label, float *sums, float *counts, double *inertia,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
                                int32_t *label, float *sums, float *counts, double *inertia,
                                void *workspace, size_t workspace_bytes, void *stream);

@@ -8,7 +8,8 @@ g = torch.Generator().manual_seed(5)
 M = 7 * 300000
 pts = torch.randn(M, 192, generator=g).to(dev)
 cent = pts[torch.randperm(M, generator=g)[:200].to(dev)].contiguous()
-for _ in range(2): ops.kmeans_assign(pts, cent)
-torch.cuda.synchronize(); t = time.time()
-for _ in range(5): ops.kmeans_assign(pts, cent)
-torch.cuda.synchronize(); print("lloyd step ms", round((time.time() - t) / 5 * 1e3, 3))
+for fast in (False, True):
+    for _ in range(2): ops.kmeans_assign(pts, cent, fast=fast)
+    torch.cuda.synchronize(); t = time.time()
+    for _ in range(5): ops.kmeans_assign(pts, cent, fast=fast)
+    torch.cuda.synchronize(); print("lloyd step ms", "screened" if fast else "exact", round((time.time() - t) / 5 * 1e3, 3))

@@ -1457,3 +1457,39 @@ def test_dgcnn_general_shapes_run_through_the_hip_graph_and_match_the_oracle(dev
     (outd.sum() + fd[0].sum()).backward()
     (outr.sum() + fr[0].sum()).backward()
     assert relerr(xd.grad, xr.grad) < 1e-3
+
+
+@pytest.mark.parametrize("M,C,K,kind", [(5000, 192, 200, "clusters"), (70000, 192, 256, "clusters"), (4097, 64, 33, "clusters"),
+                                        (3000, 192, 200, "offset"), (2049, 96, 129, "twins"), (1000, 192, 200, "relu")])
+def test_kmeans_assign_fast_equals_the_exact_form(dev, M, C, K, kind):
+    """The screened Lloyd step (gfs3d_kmeans_assign_fast_f32: hi + mid bf16 screen with an error bound, exact re-scoring of
+    the undecided points from a list) returns the labels, counts and sums of the fp32-accurate form - on well separated
+    clusters (nothing on the list), on features whose norms dwarf their distances (a loose bound: most points re-scored), on
+    duplicated centroids (exact ties: the list pass must pick the lower index) and on ReLU-ed features; inertia within 1e-3."""
+    from gfs3d import ops
+    g = torch.Generator().manual_seed(M + K + len(kind))
+    cent = torch.randn(K, C, generator=g)
+    if kind == "offset":
+        cent = cent * 0.05 + 4.0
+    if kind == "relu":
+        cent = torch.relu(cent) * 3
+    if kind == "twins":
+        cent[K // 2:] = cent[:K - K // 2].clone()          # centroid K // 2 + i is an exact copy of centroid i
+    noise = 0.02 if kind == "offset" else 0.5
+    pts = cent[torch.randint(0, K, (M,), generator=g)] + noise * torch.randn(M, C, generator=g)
+    if kind == "relu":
+        pts = torch.relu(pts)
+    pd, cd = pts.to(dev), cent.to(dev)
+    la, sa, ca, ia = ops.kmeans_assign(pd, cd)
+    lb, sb, cb, ib = ops.kmeans_assign(pd, cd, fast=True)
+    agree = float((la == lb).float().mean())
+    if kind == "twins":                                    # an exact tie goes to the lower twin, in both forms
+        assert not bool(((lb >= K // 2) & (lb < 2 * (K // 2))).any()) and not bool(((la >= K // 2) & (la < 2 * (K // 2))).any())
+    # the two forms may differ only where the exact form's own two best scores are within its rounding
+    d = torch.cdist(pts.double(), cent.double()) ** 2
+    top2 = torch.topk(d, 2, dim=1, largest=False)[0]
+    clear = ((top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 1]).to(dev)
+    assert bool((la[clear] == lb[clear]).all()) and agree > 0.999
+    if agree == 1.0:
+        assert torch.equal(ca, cb) and torch.equal(sa, sb)          # same labels -> the segment sums are bit-identical
+    assert abs(float(ia) - float(ib)) <= 1e-3 * float(ia)
