@@ -168,3 +168,69 @@ def test_capl_head_rejects_unsupported_shapes(dev):
     with pytest.raises(NotImplementedError):
         ops.capl_train_head(feat, torch.randn(13, 64, device=dev), torch.randn(1, 64, device=dev),
                             torch.zeros(2, 100, dtype=torch.int64, device=dev), [1], 7, 255)
+
+
+def _head_dp_rank(rank, world, port, out):
+    import os, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "gfs-3dseg_gws_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gfs3d import ops
+    dev = torch.device("cuda:0")
+    feat, main, bg, y = _dp_case()
+    sel = [rank, rank + 2]                                 # items (0, 2) / (1, 3): the local support halves are items 2 and 3
+    fd = feat[sel].to(dev).requires_grad_(True)
+    md, bd = main.to(dev).requires_grad_(True), bg.to(dev).requires_grad_(True)
+    pred, loss = ops.capl_train_head(fd, md, bd, y[sel].to(dev), [2, 5], 7, 255)
+    loss.backward()
+    for g_ in (md.grad, bd.grad):                          # the step's gradient all-reduce (mean over ranks)
+        dist.all_reduce(g_)
+        g_ /= world
+    torch.cuda.synchronize()
+    out[rank] = {"loss": float(loss.detach()), "pred": pred.cpu().numpy(), "dfeat": fd.grad.cpu().numpy(),
+                 "dmain": md.grad.cpu().numpy(), "dbg": bd.grad.cpu().numpy()}
+    dist.destroy_process_group()
+
+
+def _dp_case():
+    g = torch.Generator().manual_seed(77)
+    feat = torch.randn(4, 128, 384, generator=g)
+    main, bg = torch.randn(13, 128, generator=g), torch.randn(1, 128, generator=g)
+    y = torch.randint(0, 8, (4, 384), generator=g)
+    return feat, main, bg, y
+
+
+def test_fused_train_head_two_block_shards_equal_the_whole_batch(dev):
+    """Block-sharded data parallelism (two gloo ranks on this one GPU): the fake-novel sums (forward) and their gradients
+    (backward) are all-reduced between the phases of the fused head, so two shards whose support halves together are the
+    whole batch's support half reproduce the single-process loss (mean of the two), predictions and gradients."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    from gfs3d import ops
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_head_dp_rank, args=(r, 2, port, out)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(300)
+        assert p_.exitcode == 0
+    feat, main, bg, y = _dp_case()
+    fd = feat.to(dev).requires_grad_(True)
+    md, bd = main.to(dev).requires_grad_(True), bg.to(dev).requires_grad_(True)
+    pred, loss = ops.capl_train_head(fd, md, bd, y.to(dev), [2, 5], 7, 255)
+    loss.backward()
+    assert abs(0.5 * (out[0]["loss"] + out[1]["loss"]) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    for r in range(2):
+        sel = [r, r + 2]
+        assert float((torch.from_numpy(out[r]["pred"]) == pred.cpu()[sel]).float().mean()) > 0.999
+        # a rank's loss is the mean over ITS points: its feature gradients are twice the whole-batch ones (half as many points)
+        assert relmax(0.5 * torch.from_numpy(out[r]["dfeat"]), fd.grad.cpu()[sel]) < 1e-4
+        assert relmax(out[r]["dmain"], md.grad) < 1e-4 and relmax(out[r]["dbg"], bd.grad) < 1e-4
+    assert np.array_equal(out[0]["dmain"], out[1]["dmain"])
