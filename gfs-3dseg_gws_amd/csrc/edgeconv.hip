@@ -1178,8 +1178,15 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 gq1[q] += dy1;
                 const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;
                 if (CSR) {                                  // (a masked row's values are 0 and its row is the wave's scratch row)
-                    dyb[row] = dy0;
-                    dyb[row + 32] = dy1;
+                    if constexpr (PREC == PREC_X6) {
+                        dyb[row] = dy0;
+                        dyb[row + 32] = dy1;
+                    } else {
+                        // reduced modes: the row as 32 dwords of two bf16 (channels i | 32 + i) - half the bytes of the one
+                        // tensor of size N k 64 the backward writes and ec_bwd_segsum_kernel reads back (the kernel is bound by
+                        // exactly that traffic once the matrix work is a single product)
+                        reinterpret_cast<unsigned *>(dyb)[(size_t)mrow[drow(r, h)] * 32 + i] = mm_pack2<PREC_BF16>(dy0, dy1);
+                    }
                 } else if (!(GFS3D_ABL & 1)) {
                     atomicAdd(&GP[row], dy0);
                     atomicAdd(&GP[row + 32], dy1);
@@ -1218,11 +1225,96 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 // and summed in a fixed order - fused with the BN1-backward reductions of ec_bwd_bn1_reduce_kernel (which it replaces):
 //     sum_n GQ  and  sum_e dy1 xhat1 = sum_m P''[m] GP[m] + sum_n Q''[n] GQ[n]
 // wave per target, lane = channel; partial[2][64] doubles.
+// HALF = true (reduced modes): rows of 32 dwords holding two bf16 each (channels i | 32 + i), summed in fp32
+template <bool HALF>
 __global__ void __launch_bounds__(256)
 ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowptr,
                      const float *__restrict__ P, const float *__restrict__ Q, const float *__restrict__ GQ,
                      const float *__restrict__ stats, int BN, float *__restrict__ GP, const BnAcc partial)
 {
+    if constexpr (HALF) {
+        // lane = (row slot sub = lane >> 3, dword quad c4 = lane & 7): one wave instruction reads 8 rows of 128 B; a lane owns
+        // channels 4 c4 .. 4 c4 + 3 (low halves) and 32 + 4 c4 .. (high halves)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __shared__ double red[4][2][EC];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int sub = lane >> 3, c4 = lane & 7;
+        const unsigned *rows = reinterpret_cast<const unsigned *>(dyb);
+        f32x4 mean1[2], rstd1[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            mean1[hf] = *reinterpret_cast<const f32x4 *>(stats + ST_MEAN1 * EC + 32 * hf + 4 * c4);
+            rstd1[hf] = *reinterpret_cast<const f32x4 *>(stats + ST_RSTD1 * EC + 32 * hf + 4 * c4);
+        }
+        double s[8], sx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.0; sx[e] = 0.0; }
+        constexpr int SEG_TPW = 8;
+        const int nchunk = (BN + SEG_TPW - 1) / SEG_TPW;
+        for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
+            const int t0 = ch * SEG_TPW;
+            const int myptr = rowptr[min(t0 + min(lane, SEG_TPW), BN)];
+#pragma unroll 2
+            for (int q = 0; q < SEG_TPW; ++q) {
+                const int tm = t0 + q;
+                if (tm >= BN) break;
+                const int p0 = __shfl(myptr, q, 64), p1 = __shfl(myptr, q + 1, 64);
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                for (int p = p0 + sub; p < p1; p += 32) {          // 32 rows of 128 B in flight per wave and step
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = (p + 8 * u < p1) ? *reinterpret_cast<const uint4 *>(rows + (size_t)(p + 8 * u) * 32 + 4 * c4) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc[e] += __builtin_bit_cast(float, w4[e] << 16);
+                            acc[4 + e] += __builtin_bit_cast(float, w4[e] & 0xffff0000u);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = acc[e];
+                    t += __shfl_xor(t, 8, 64);
+                    t += __shfl_xor(t, 16, 64);
+                    t += __shfl_xor(t, 32, 64);
+                    acc[e] = t;
+                }
+                if (sub == 0) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const size_t o = (size_t)tm * EC + 32 * hf + 4 * c4;
+                        const f32x4 gq = *reinterpret_cast<const f32x4 *>(GQ + o), pv = *reinterpret_cast<const f32x4 *>(P + o),
+                                    qv = *reinterpret_cast<const f32x4 *>(Q + o);
+                        *reinterpret_cast<f32x4 *>(GP + o) = f32x4{acc[4 * hf], acc[4 * hf + 1], acc[4 * hf + 2], acc[4 * hf + 3]};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            s[4 * hf + e] += (double)gq[e];
+                            sx[4 * hf + e] += (double)(pv[e] * rstd1[hf][e] * acc[4 * hf + e]) + (double)((qv[e] - mean1[hf][e]) * rstd1[hf][e] * gq[e]);
+                        }
+                    }
+                }
+            }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { red[wv][0][32 * hf + 4 * c4 + e] = s[4 * hf + e]; red[wv][1][32 * hf + 4 * c4 + e] = sx[4 * hf + e]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6;
+            bn_acc_add(partial, blockIdx.x, which, lane,
+                       red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
+        }
+        return;
+    } else {
     // lane = (row slot sub = lane >> 4, channel quad c4 = lane & 15): one wave instruction reads 4 rows of 256 B as 16-byte
     // pieces; 4 of them in flight = 16 rows per step.  The four row slots are added in a fixed tree at the end.
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1282,6 +1374,7 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
         bn_acc_add(partial, blockIdx.x, which, lane,
                    red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
     }
+    }   // fp32 rows
 }
 
 // B5: BN1 backward reductions: sum_n GQ (= sum_e dy1) and
@@ -1886,8 +1979,12 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
         if (csr) {
             const int sg = min((BN + 31) / 32, 2048);
-            hipLaunchKernelGGL(ec_bwd_segsum_kernel, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
-                               a->stats, BN, GP, BnAcc{acc2, rows});
+            if (prec_of(a->compute, true) != PREC_X6)
+                hipLaunchKernelGGL(ec_bwd_segsum_kernel<true>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
+                                   a->stats, BN, GP, BnAcc{acc2, rows});
+            else
+                hipLaunchKernelGGL(ec_bwd_segsum_kernel<false>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
+                                   a->stats, BN, GP, BnAcc{acc2, rows});
             GFS3D_LAUNCH_CHECK("ec_bwd_segsum_kernel");
             if (int rc = bn_finish(BnAcc{acc2, rows}, sg, st, mid)) return rc;
         } else {
