@@ -247,8 +247,12 @@ def extras(dev, L, gdist):
         ops.capl_train_head(f3, mp, bgp, yh, [2, 4, 7], 7, 255)[1].backward()
     ms = timed_ms(head, 20)
     byts = 4.0 * B * N * 128 * 3                                     # features read by the forward and by the backward, gradient written
+    head_flops = 2.0 * B * N * 128 * (14 * 11 + 3 * 14)             # 11 class-table products of 14 x 128 per point + the three point contractions
     out["capl_train_head"] = {"shape": "B=32x2048, C=128, 13+1 classes, 3 fake-novel classes; forward + backward", "ms": round(ms, 4),
-                              "bound": "hbm", "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                              "bound": "hbm (its bytes are the floor; the passes run at the VALU / LDS-broadcast rate of one wave per SIMD: "
+                                       "65536 points = 1024 waves)",
+                              "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
+                              "executed_TFLOPps_fp32": round(head_flops / ms / 1e9, 2),
                               "note": "generate_fake_proto + 3 x get_pred + post_refine_proto_v2 + 2 x CrossEntropyLoss + arg-max as 11 "
                                       "launches (csrc/head.hip); the tensor-library form it replaces took ~1.45 ms in ~200 launches"}
     del f3, mp, bgp, yh
