@@ -94,6 +94,40 @@ def test_entry_points_reject_bad_arguments_before_touching_a_device():
         and b"head dimension" in L.gfs3d_last_error()
 
 
+def test_round3_entry_points_reject_bad_arguments_before_touching_a_device():
+    """The fused prototype head, its testing form, the screened Lloyd step and the label-presence mask validate their arguments on
+    the host (no GPU: nothing is launched) and the workspace query returns 0 for shapes the head is not built for."""
+    import ctypes
+    from gfs3d import _lib, ops
+    L = _lib.lib()
+    assert L.gfs3d_capl_head_workspace_bytes(32, 2048, 13) > 0 and L.gfs3d_capl_head_workspace_bytes(64, 2048, 21) > 0
+    assert L.gfs3d_capl_head_workspace_bytes(32, 2048, 24) == 0 and L.gfs3d_capl_head_workspace_bytes(0, 2048, 13) == 0
+    assert L.gfs3d_capl_head_forward_phase(None, 0) != 0 and b"args is NULL" in L.gfs3d_last_error()
+    a = _lib.CaplHeadArgs()
+    a.B, a.C, a.N, a.classes, a.base_num = 4, 64, 256, 13, 7
+    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"feature channels" in L.gfs3d_last_error()
+    a.C, a.n_fake = 128, 20
+    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"fake-novel" in L.gfs3d_last_error()
+    a.n_fake, a.half, a.feat_bstride = 2, 2, 128 * 256
+    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"NULL buffer" in L.gfs3d_last_error()
+    for name in ("feat", "label", "main_proto", "bg_proto", "fsum", "workspace", "loss"):
+        setattr(a, name, 1)                             # (non-NULL placeholders: the checks below stop before any use)
+    a.workspace_bytes = 16
+    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"workspace too small" in L.gfs3d_last_error()
+    a.workspace_bytes = 1 << 30
+    a.fake[0], a.fake[1] = 3, 99
+    assert L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 1) != 0 and b"fake-novel label 99" in L.gfs3d_last_error()
+    a.fake[1] = 5
+    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 7) != 0 and b"phase" in L.gfs3d_last_error()
+    assert L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 0) != 0 and b"NULL gradient buffer" in L.gfs3d_last_error()
+    e = _lib.CaplEvalArgs()
+    e.B, e.C, e.N, e.classes, e.base_num, e.Kw = 2, 128, 64, 13, 7, 4000
+    assert L.gfs3d_capl_head_eval(ctypes.byref(e)) != 0 and b"coding" in L.gfs3d_last_error()
+    assert L.gfs3d_label_presence(None, 10, None, None) != 0 and b"bad argument" in L.gfs3d_last_error()
+    assert L.gfs3d_kmeans_assign_fast_f32(1, 100, 64, 1, 40, 1, 1, 1, None, None, 0, None) != 0 and b"workspace" in L.gfs3d_last_error()
+    assert not ops.capl_head_supported(torch.zeros(2, 64, 16), 13, 2)       # (CPU tensor / wrong width: the model keeps its tensor-library head)
+
+
 def test_dgcnn_state_dict_and_seeded_init_match_reference():
     from model.dgcnn import DGCNN
     g = load_golden("dgcnn")
