@@ -276,7 +276,7 @@ def generate_fake_proto(x: Tensor, y: Tensor, main_proto: Tensor, fake_novel: Op
     for fn in fake_novel:
         m = (ty == fn).to(xn.dtype)
         mean = (xn * m).sum(0).sum(-1) / (m.sum(0).sum(-1) + 1e-12)
-        sel = torch.zeros(proto.size(0), 1, dtype=proto.dtype)
+        sel = torch.zeros(proto.size(0), 1, dtype=proto.dtype, device=proto.device)
         sel[int(fn) - 1] = 1
         proto = proto * (1 - sel) + mean.unsqueeze(0) * sel
     return proto, fake_novel

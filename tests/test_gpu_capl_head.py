@@ -96,6 +96,35 @@ def test_fused_train_head_is_bit_reproducible_and_scales_with_the_incoming_gradi
         assert relmax(v, -3.0 * u) < 1e-6
 
 
+def test_fused_train_head_full_size_matches_the_unfused_form(dev):
+    """BASELINE configs[3] size (B = 32 x 2048, 13 + 1 classes): the fused head against the tensor-library form of the same model
+    code on the device (loss 1e-5 relative, gradients 1e-4 of their max), and a second run bit for bit."""
+    from gfs3d import ops
+    from oracle import ref_ops as R
+    B, N, classes, nb, fake = 32, 2048, 13, 7, [2, 4, 7]
+    g = torch.Generator().manual_seed(123)
+    feat = (torch.randn(B, 128, N, generator=g) * 2).to(dev)
+    main, bg = torch.randn(classes, 128, generator=g).to(dev), torch.randn(1, 128, generator=g).to(dev)
+    y = torch.randint(0, nb + 1, (B, N), generator=g).to(dev)
+    y[0, :100] = 255
+    runs = []
+    for _ in range(2):
+        fd, md, bd = (t.clone().requires_grad_(True) for t in (feat, main, bg))
+        pred, loss = ops.capl_train_head(fd, md, bd, y, fake, nb, 255)
+        loss.backward()
+        runs.append((pred, loss.detach(), fd.grad, md.grad, bd.grad))
+    for u, v in zip(*runs):
+        assert torch.equal(u, v)
+    fr, mr, br = (t.clone().requires_grad_(True) for t in (feat, main, bg))
+    logits_ref, loss_ref, _ = R.capl_train_head(fr, y, mr, br, nb, fake_novel=fake, ignore_index=255)      # the oracle chain, fp32 on the device
+    loss_ref.backward()
+    pred, loss, gf, gm, gb = runs[0]
+    assert abs(float(loss) - float(loss_ref.detach())) < 1e-5 * abs(float(loss_ref.detach()))
+    assert float((pred == logits_ref.argmax(1)).float().mean()) > 0.9995
+    assert relmax(gf, fr.grad) < 1e-4 and relmax(gm, mr.grad) < 1e-4 and relmax(gb, br.grad) < 1e-4
+    assert bool(torch.isfinite(gf).all())
+
+
 def test_model_takes_the_fused_head_and_matches_its_unfused_form(dev):
     """mpti_net_Point_GeoAsWeight_v2.train_head: the fused pipeline against the model's own tensor-library form on the same
     features (the form the golden tests pinned in rounds 1-2), gradients through to the features and the prototypes."""
