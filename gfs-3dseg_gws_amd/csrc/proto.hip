@@ -1139,10 +1139,13 @@ kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int w = t * 32 + acc_row(r, h);               // increasing within a lane: '<' keeps the lowest index of a tie
-            if constexpr (SCREEN) {
-                const float d = (w < K) ? cn[w] - 2.f * acc[t][r] : __builtin_inff();      // + |p|^2, constant per point
-                second = fminf(second, fmaxf(d, best));
-                if (d < best) { best = d; bk = w; }
+            if constexpr (SCREEN) {                                  // (branch-free: as `if`s this became 128 guarded blocks with spills)
+                const float d0 = cn[w] - 2.f * acc[t][r];                // + |p|^2, constant per point (cn holds all NT 32 rows)
+                const float d = (w < K) ? d0 : __builtin_inff();         // (select AFTER the read: a guarded read became a branch per row)
+                const bool lt = d < best;
+                second = fminf(second, lt ? best : d);
+                bk = lt ? w : bk;
+                best = lt ? d : best;
             } else {
                 const float d = cn[w] - 2.f * acc[t][r];
                 if (w < K && d < best) { best = d; bk = w; }
