@@ -448,6 +448,18 @@ def main():
             kfl = algorithmic_flops(0, B)[0] / (kms * 1e-3) / 1e12
             roof["knn"] = {"ms_per_step": round(kms, 4), "algorithmic_GBps": round(kb / (kms * 1e-3) / 1e9, 2),
                            "algorithmic_TFLOPps": round(kfl, 2), "frac_of_fp32_peak": round(kfl / PEAK_FP32_TFLOPS, 4)}
+            # "kNN HBM GB/s" as MEASURED by the committed PMC passes: FETCH (x2) + WRITE bytes of the kNN kernels of one
+            # step (C = 9 layer: <20, 1> screen + <20, 16> exact + point-major copy / norms; two C = 64 layers: <20, 4> + <20, 64>)
+            per_step = {"knn_screen_kernel<20, 1>": 1, "knn_exact_kernel<20, 16>": 1, "knn_pm_kernel": 1, "knn_sqnorm_kernel": 1,
+                        "knn_screen_kernel<20, 4>": 2, "knn_exact_kernel<20, 64>": 2}
+            tb, src = 0, None
+            for name, n in per_step.items():
+                t_, s_ = hbm_traffic(name, "r03")
+                if t_:
+                    tb, src = tb + n * t_, s_
+            if tb:
+                roof["knn"].update({"measured_hbm_bytes_per_step": tb, "measured_hbm_GBps": round(tb / (kms * 1e-3) / 1e9, 1),
+                                    "measured_source": src})
         if fwd_ms:
             # SURVEY 8(d) per block: kNN 1.19 GF + EdgeConv fwd 2.44 GF (conv1 counted on the N k edges); compulsory bytes 2.10 MB + 3.80 MB.
             # The kernels run conv1 on the N points (P / Q algebra): executed-equivalent 1.19 + 3 x 0.336 (conv2) + 0.05 (projections) GF.

@@ -125,6 +125,36 @@ def test_fused_train_head_full_size_matches_the_unfused_form(dev):
     assert bool(torch.isfinite(gf).all())
 
 
+def test_fused_train_head_properties_at_full_size(dev):
+    """Size-independent properties at BASELINE size (B = 32 x 2048): (i) relabelling the points of every block (one
+    permutation of the point axis applied to features and labels) leaves the loss unchanged up to summation order and permutes
+    predictions and feature gradients with it; (ii) the cosine heads do not see a positive rescaling of the PROTOTYPES: loss and
+    predictions unchanged, prototype gradients scaled by 1 / s (the refinement blends with the raw main_proto, so this holds for
+    the bg prototype and - with no base class refined, base_num = 0 - for main_proto as well)."""
+    from gfs3d import ops
+    B, N, classes = 32, 2048, 13
+    g = torch.Generator().manual_seed(8)
+    feat = torch.randn(B, 128, N, generator=g).to(dev)
+    main, bg = torch.randn(classes, 128, generator=g).to(dev), torch.randn(1, 128, generator=g).to(dev)
+    y = torch.randint(0, 8, (B, N), generator=g).to(dev)
+
+    def run(f, m, b_, yy, base_num):
+        fd, md, bd = (t.clone().requires_grad_(True) for t in (f, m, b_))
+        pred, loss = ops.capl_train_head(fd, md, bd, yy, [1, 5, 6], base_num, 255)
+        loss.backward()
+        return pred, loss.detach(), fd.grad, md.grad, bd.grad
+    p0, l0, gf0, gm0, gb0 = run(feat, main, bg, y, 7)
+    perm = torch.randperm(N, generator=g).to(dev)
+    p1, l1, gf1, gm1, gb1 = run(feat[:, :, perm].contiguous(), main, bg, y[:, perm].contiguous(), 7)
+    assert abs(float(l1) - float(l0)) < 1e-6 * abs(float(l0))
+    assert float((p1 == p0[:, perm]).float().mean()) > 0.9999
+    assert relmax(gf1, gf0[:, :, perm]) < 1e-5 and relmax(gm1, gm0) < 1e-5 and relmax(gb1, gb0) < 1e-5
+    p2, l2, gf2, gm2, gb2 = run(feat, main, bg, y, 0)
+    p3, l3, gf3, gm3, gb3 = run(feat, main * 4.0, bg * 0.5, y, 0)
+    assert abs(float(l3) - float(l2)) < 1e-6 * abs(float(l2)) and float((p3 == p2).float().mean()) > 0.9999
+    assert relmax(gf3, gf2) < 1e-5 and relmax(gm3 * 4.0, gm2) < 1e-5 and relmax(gb3 * 0.5, gb2) < 1e-5
+
+
 def test_model_takes_the_fused_head_and_matches_its_unfused_form(dev):
     """mpti_net_Point_GeoAsWeight_v2.train_head: the fused pipeline against the model's own tensor-library form on the same
     features (the form the golden tests pinned in rounds 1-2), gradients through to the features and the prototypes."""
