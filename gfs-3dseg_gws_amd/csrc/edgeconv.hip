@@ -75,6 +75,43 @@ __global__ void bn_reduce_final_kernel(const double *__restrict__ mid, double *_
     acc[e] = t;
 }
 
+// XCD-aware dealing of work units (speed only: no result depends on which workgroup takes a unit).  Workgroups go
+// round-robin to the 8 XCDs (blockIdx % 8, MI355X_MICROARCH.md) and each XCD has its own 4 MB L2.  The gather kernels read a
+// cloud's table of 64-channel rows (P', Q, dy1: N x 256 B = 512 KB at N = 2048) k times per point; dealt plainly every XCD
+// touches every cloud (16.8 MB at B = 32) and the row gathers miss its L2.  Dealt by cloud - the workgroups of XCD x take the
+// clouds c with c % 8 == x - one L2 holds B/8 tables.  `upc` = units (super-tiles / points / chunks) per cloud; used when
+// B % 8 == 0, the grid is a multiple of 8 and no unit straddles two clouds, the plain round-robin otherwise.
+struct UnitDeal {
+    int first, stride, count, upc, x;
+    bool xcd;
+    __device__ __forceinline__ UnitDeal(int nunits, int upc_, int B, bool whole, int workers, int worker)
+    {
+#ifdef EC_PLAIN_DEAL
+        xcd = false;
+#else
+        xcd = whole && (B & 7) == 0 && (gridDim.x & 7) == 0;
+#endif
+        upc = upc_;
+        if (xcd) {
+            x = blockIdx.x & 7;
+            first = (blockIdx.x >> 3) * workers + worker;
+            stride = (gridDim.x >> 3) * workers;
+            count = (B >> 3) * upc;
+        } else {
+            x = 0;
+            first = blockIdx.x * workers + worker;
+            stride = gridDim.x * workers;
+            count = nunits;
+        }
+    }
+    __device__ __forceinline__ int unit(int u) const
+    {
+        if (!xcd) return u;
+        const int c = u / upc;
+        return (x + 8 * c) * upc + (u - c * upc);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // F2: BN1 batch statistics of h1 = P[idx] + Q over all edges, and SP (pure gathers).
 // wave per point, lane = channel.  partial: [gridDim.x][2][64] doubles.
@@ -87,7 +124,9 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
     __shared__ double red[ST1_WAVES][2][EC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double s = 0.0, ss = 0.0;
-    for (int pt = blockIdx.x * ST1_WAVES + wv; pt < BN; pt += gridDim.x * ST1_WAVES) {
+    const UnitDeal deal(BN, N, BN / N, true, ST1_WAVES, wv);
+    for (int w = deal.first; w < deal.count; w += deal.stride) {
+        const int pt = deal.unit(w);
         const int b = pt / N;
         const float q = Q[(size_t)pt * EC + lane];
         const int myidx = (lane < k) ? idx[(size_t)pt * k + lane] : 0;
@@ -234,59 +273,112 @@ rev_overflow_kernel(const float *__restrict__ Q, const int *__restrict__ ovf_cnt
 }
 
 // ---------------------------------------------------------------------------
-// The reverse graph in CSR form, one workgroup per point-cloud block (N k < 65536 edges and the tables below within
-// LDS): for every target m its in-edges in ASCENDING edge order (edge e = n k + j), so that everything summed over the
-// in-edges of a point - SQ here, G_P in the backward - has a FIXED order: bit-reproducible, and no float atomics.
+// The reverse graph in CSR form (N k < 65536 edges per point-cloud block and the tables below within LDS): for every
+// target m its in-edges in ASCENDING edge order (edge e = n k + j), so that everything summed over the in-edges of a
+// point - SQ here, G_P in the backward - has a FIXED order: bit-reproducible, and no float atomics.
 //   rowptr[b N + m]      first row of target m in the global CSR order (rows b N k .. (b+1) N k - 1 belong to block b);
 //                        rowptr[B N] = B N k
 //   csr_src[row]         global source point (b N + n) of that in-edge
 //   pos[(b N + n) k + j] the CSR row of edge (n, j)   - where the backward stores that edge's dy1 row
-// A counting sort by (target, source) without a sort: the workgroup's 16 waves own 16 consecutive source ranges.
-//   A  per (source range w, target m) counts, any thread, LDS atomics on packed u16 pairs (order-free);
-//   B  a thread per target turns them into exclusive prefixes over the ranges and the in-degree; block-wide scan -> ptr;
-//   C  wave w walks ITS sources in ascending order, one source (k distinct targets = k lanes, no conflict) per step:
-//      row = ptr[m] + cursor[w][m]++ - the wave is the only writer of its cursors, its LDS operations stay in program
-//      order, so the ranks follow the source order exactly.  A hub's in-edges are spread over the steps like any others.
+// A counting sort by (target, source) without a sort.  A cloud's sources are cut into R ranges, one workgroup each (R = 8
+// at N = 2048: 8 x B workgroups instead of the B of a one-workgroup-per-cloud form, which left 7/8 of the chip idle for
+// ~120 us per layer), a workgroup's 16 waves own 16 consecutive sub-ranges of `span` sources.
+//   csr_count_kernel   per (range r, target m) in-edge counts -> rangecnt[b][r][m] (u16), LDS atomics (order-free);
+//   csr_place_kernel
+//     A  per (wave w, target m) counts of the workgroup's own range, LDS atomics on packed u16 pairs;
+//     B  a thread per target: in-edges from the ranges before r (rangecnt) + exclusive prefix over the waves, and the
+//        total in-degree; block-wide scan -> ptr (every workgroup of the cloud computes the same ptr);
+//     C  wave w walks ITS sources in ascending order, one source (k distinct targets = k lanes, no conflict) per step:
+//        row = ptr[m] + cursor[w][m]++ - the wave is the only writer of its cursors, its LDS operations stay in program
+//        order, so the ranks follow the source order exactly.  A hub's in-edges are spread over the steps like any others.
 // ---------------------------------------------------------------------------
-constexpr int CSR_THREADS = 1024, CSR_WAVES = CSR_THREADS / 64;
+constexpr int CSR_THREADS = 1024, CSR_WAVES = CSR_THREADS / 64, CSR_MAX_RANGES = 8;
 static inline size_t csr_lds_bytes(int N, int k) { (void)k; return sizeof(unsigned) * (CSR_WAVES / 2) * (size_t)N + sizeof(int) * (size_t)N + sizeof(int) * 64; }
+static inline int csr_ranges(int N) { const int r = (N + 255) / 256; return r < 1 ? 1 : (r > CSR_MAX_RANGES ? CSR_MAX_RANGES : r); }
+__host__ __device__ static inline int csr_span(int N, int R) { return (N + R * CSR_WAVES - 1) / (R * CSR_WAVES); }     // sources per wave
+
 __global__ void __launch_bounds__(CSR_THREADS)
-csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__restrict__ rowptr, int *__restrict__ csr_src,
-                 int *__restrict__ pos)
+csr_count_kernel(const int32_t *__restrict__ idx, int N, int k, unsigned short *__restrict__ rangecnt)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char csr_smem[];
-    unsigned *cw = reinterpret_cast<unsigned *>(csr_smem);                 // [8][N]: ranges 2 q (low half) and 2 q + 1 (high half)
-    int *ptr = reinterpret_cast<int *>(cw + (CSR_WAVES / 2) * (size_t)N);  // [N] in-degree, then exclusive scan
-    int *wsum = ptr + N;                                                   // [64] scan scratch
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.x;
-    const int ne = N * k;
-    const int span = (N + CSR_WAVES - 1) / CSR_WAVES;                      // sources per range
-    const int32_t *ib = idx + (size_t)b * ne;
-    for (int q = tid; q < (CSR_WAVES / 2) * N; q += CSR_THREADS) cw[q] = 0u;
+    unsigned *cnt = reinterpret_cast<unsigned *>(csr_smem);                // [N]
+    const int tid = threadIdx.x, r = blockIdx.x, R = gridDim.x, b = blockIdx.y;
+    const int span = csr_span(N, R);
+    const int n_lo = min(N, r * CSR_WAVES * span), n_hi = min(N, n_lo + CSR_WAVES * span);
+    const int32_t *ib = idx + (size_t)b * N * k;
+    for (int m = tid; m < N; m += CSR_THREADS) cnt[m] = 0u;
     __syncthreads();
-    // A: edges tid, tid + 1024, ... (N k < 65536 -> at most 64): all loads in flight at once
-    {
-        int tg[64];
+    const int e_hi = n_hi * k;
+    for (int e0 = n_lo * k + tid; e0 < e_hi; e0 += 8 * CSR_THREADS) {     // 8 loads in flight per thread
+        int tg[8];
 #pragma unroll
-        for (int q = 0; q < 64; ++q) {
-            const int e = tid + q * CSR_THREADS;
-            tg[q] = e < ne ? min(max(ib[e], 0), N - 1) : -1;      // (ids outside [0, N) are a caller error: clamped, so that the LDS tables stay intact)
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * CSR_THREADS;
+            tg[q] = e < e_hi ? min(max(ib[e], 0), N - 1) : -1;      // (ids outside [0, N) are a caller error: clamped, so that the LDS tables stay intact)
         }
 #pragma unroll
-        for (int q = 0; q < 64; ++q)
-            if (tg[q] >= 0) {
-                const int w = ((tid + q * CSR_THREADS) / k) / span;
-                atomicAdd(&cw[(size_t)(w >> 1) * N + tg[q]], (w & 1) ? 0x10000u : 1u);
-            }
+        for (int q = 0; q < 8; ++q)
+            if (tg[q] >= 0) atomicAdd(&cnt[tg[q]], 1u);
     }
     __syncthreads();
-    // B: exclusive prefix over the ranges, per target; thread t owns the `per` consecutive targets t per ..
+    unsigned short *out = rangecnt + ((size_t)b * R + r) * N;
+    for (int m = tid; m < N; m += CSR_THREADS) out[m] = (unsigned short)cnt[m];
+}
+
+__global__ void __launch_bounds__(CSR_THREADS)
+csr_place_kernel(const int32_t *__restrict__ idx, const unsigned short *__restrict__ rangecnt, int B, int N, int k,
+                 int *__restrict__ rowptr, int *__restrict__ csr_src, int *__restrict__ pos)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char csr_smem[];
+    unsigned *cw = reinterpret_cast<unsigned *>(csr_smem);                 // [8][N]: waves 2 q (low half) and 2 q + 1 (high half)
+    int *ptr = reinterpret_cast<int *>(cw + (CSR_WAVES / 2) * (size_t)N);  // [N] in-degree, then exclusive scan
+    int *wsum = ptr + N;                                                   // [64] scan scratch
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = blockIdx.x, R = gridDim.x, b = blockIdx.y;
+    const int ne = N * k;
+    const int span = csr_span(N, R);
+    const int r_lo = min(N, r * CSR_WAVES * span), r_hi = min(N, r_lo + CSR_WAVES * span);      // this workgroup's sources
+    const int32_t *ib = idx + (size_t)b * ne;
+#ifdef CSR_TIMING
+    const long long t0 = wall_clock64();
+#endif
+    for (int q = tid; q < (CSR_WAVES / 2) * N; q += CSR_THREADS) cw[q] = 0u;
+    __syncthreads();
+    // A: the edges of the own range, 8 loads in flight per thread
+    {
+        const int e_hi = r_hi * k;
+        for (int e0 = r_lo * k + tid; e0 < e_hi; e0 += 8 * CSR_THREADS) {
+            int tg[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * CSR_THREADS;
+                tg[q] = e < e_hi ? min(max(ib[e], 0), N - 1) : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (tg[q] >= 0) {
+                    const int w = ((e0 + q * CSR_THREADS) / k - r_lo) / span;
+                    atomicAdd(&cw[(size_t)(w >> 1) * N + tg[q]], (w & 1) ? 0x10000u : 1u);
+                }
+        }
+    }
+    __syncthreads();
+#ifdef CSR_TIMING
+    const long long t1 = wall_clock64();
+#endif
+    // B: per target, the in-edges from earlier ranges + the exclusive prefix over the waves; thread t owns the `per`
+    // consecutive targets t per ..
     const int per = (N + CSR_THREADS - 1) / CSR_THREADS;
+    const unsigned short *rc = rangecnt + (size_t)b * R * N;
     int loc = 0;
     for (int q = 0; q < per; ++q) {
         const int m = tid * per + q;
         if (m < N) {
-            unsigned run = 0;
+            unsigned run = 0, total = 0;
+            for (int r2 = 0; r2 < R; ++r2) {
+                const unsigned c = rc[(size_t)r2 * N + m];
+                run += r2 < r ? c : 0u;
+                total += c;
+            }
 #pragma unroll
             for (int w2 = 0; w2 < CSR_WAVES / 2; ++w2) {
                 const unsigned v = cw[(size_t)w2 * N + m];
@@ -294,8 +386,8 @@ csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__re
                 cw[(size_t)w2 * N + m] = run | ((run + lo) << 16);
                 run += lo + hi;
             }
-            ptr[m] = (int)run;
-            loc += (int)run;
+            ptr[m] = (int)total;
+            loc += (int)total;
         }
     }
     int inc = loc;                                          // inclusive scan inside the wave
@@ -313,15 +405,23 @@ csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__re
     int run = wsum[wv] + inc - loc;
     for (int q = 0; q < per; ++q) {
         const int m = tid * per + q;
-        if (m < N) { const int c = ptr[m]; ptr[m] = run; rowptr[(size_t)b * N + m] = b * ne + run; run += c; }
+        if (m < N) {
+            const int c = ptr[m];
+            ptr[m] = run;
+            if (r == 0) rowptr[(size_t)b * N + m] = b * ne + run;
+            run += c;
+        }
     }
-    if (b == B - 1 && tid == 0) rowptr[(size_t)B * N] = B * ne;
+    if (b == B - 1 && r == 0 && tid == 0) rowptr[(size_t)B * N] = B * ne;
     __syncthreads();
+#ifdef CSR_TIMING
+    const long long t2 = wall_clock64();
+#endif
     // C: ordered placement
     unsigned *cur = cw + (size_t)(wv >> 1) * N;             // this wave's cursors: the low (even wave) or high half of word m
     const unsigned one = (wv & 1) ? 0x10000u : 1u;
     const int sh = (wv & 1) ? 16 : 0;
-    const int n_lo = wv * span, n_hi = min(N, n_lo + span);
+    const int n_lo = min(r_hi, r_lo + wv * span), n_hi = min(r_hi, n_lo + span);
     for (int n0 = n_lo; n0 < n_hi; n0 += 8) {               // the neighbour lists of 8 sources in flight
         int tg[8];
 #pragma unroll
@@ -338,13 +438,17 @@ csr_build_kernel(const int32_t *__restrict__ idx, int B, int N, int k, int *__re
             }
         }
     }
+#ifdef CSR_TIMING
+    __syncthreads();
+    if (tid == 0 && b == 5 && r == 3) printf("csr_place ticks A %lld B %lld C %lld\n", t1 - t0, t2 - t1, wall_clock64() - t2);
+#endif
 }
 // SQ[m] = sum over the in-edges of m, in CSR (= ascending source) order, of Q[source]; in-degree.
 // lane = (row slot sub = lane >> 4, channel quad c4 = lane & 15): a wave instruction gathers 4 rows of 256 B as 16-byte
 // pieces, 8 of them in flight; a wave owns 8 consecutive targets (one load brings their row pointers).
 __global__ void __launch_bounds__(256)
 csr_gather_kernel(const float *__restrict__ Q, const int *__restrict__ rowptr, const int *__restrict__ csr_src,
-                  int BN, float *__restrict__ SQ, float *__restrict__ indeg)
+                  int BN, int N, float *__restrict__ SQ, float *__restrict__ indeg)
 {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -352,8 +456,9 @@ csr_gather_kernel(const float *__restrict__ Q, const int *__restrict__ rowptr, c
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     constexpr int TPW = 8;
     const int nchunk = (BN + TPW - 1) / TPW;
-    for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
-        const int t0 = ch * TPW;
+    const UnitDeal deal(nchunk, N / TPW, BN / N, N % TPW == 0, 4, wv);
+    for (int w = deal.first; w < deal.count; w += deal.stride) {
+        const int t0 = deal.unit(w) * TPW;
         const int myptr = rowptr[min(t0 + min(lane, TPW), BN)];
 #pragma unroll 2
         for (int q = 0; q < TPW; ++q) {
@@ -591,7 +696,9 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     const float sg0 = gamma2[i] < 0.f ? -1.f : 1.f, sg1 = gamma2[32 + i] < 0.f ? -1.f : 1.f;      // C/D layout: lane = channel
 
     const int nst = (BN + 7) >> 3;
-    for (int st = blockIdx.x * 4 + wv; st < nst; st += gridDim.x * 4) {
+    const UnitDeal deal(nst, N >> 3, BN / N, (N & 7) == 0, 4, wv);
+    for (int w = deal.first; w < deal.count; w += deal.stride) {
+        const int st = deal.unit(w);
         const int n0 = st * 8;
         const int ptA = min(n0 + pA, BN - 1);
         const int bA = ptA / N;
@@ -927,7 +1034,7 @@ constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES 
 // CSR = true: the dy1 row of every edge is STORED to row pos[edge] of `dyb` (the edge's place in its target's CSR
 // segment; masked rows go to a per-wave scratch row behind the B N k real ones) and ec_bwd_segsum_kernel sums the
 // segments: plain stores at ~5x the float-atomic rate, a fixed summation order, no memset of G_P.  CSR = false: float
-// atomics into G_P (shapes beyond csr_build_kernel's LDS tables).
+// atomics into G_P (shapes beyond csr_place_kernel's LDS tables).
 template <int PREC, bool CSR>
 __global__ void __launch_bounds__(64 * BWD_WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
@@ -972,8 +1079,9 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     __syncthreads();
 
     const int nst = (BN + 7) >> 3;
-    for (int st = blockIdx.x * BWD_WAVES + wv; st < nst; st += gridDim.x * BWD_WAVES) {
-        const int n0 = st * 8;
+    const UnitDeal deal(nst, N >> 3, BN / N, (N & 7) == 0, BWD_WAVES, wv);
+    for (int w = deal.first; w < deal.count; w += deal.stride) {
+        const int n0 = deal.unit(w) * 8;
         const int ptA = min(n0 + pA, BN - 1);
         const int bA = ptA / N;
         float Ag0[4], Ag1[4], gq0[4], gq1[4];
@@ -1620,8 +1728,8 @@ struct Plan {
     size_t off_acc;                                                      // 4 x 64 fp64 atomic accumulators (BN sums)
     size_t off_g, off_GP, off_GQ, off_coef, off_bpart, off_mu, off_wpart;   // backward
     size_t off_cnt, off_slot, off_ovf;                                       // reverse graph (cnt[BN] | ovf_cnt)
-    size_t off_csrsrc, off_dyb;                                              // CSR mode: sources in CSR order; per-edge dy1 rows
-    bool csr_ok;                                                             // the shape fits csr_build_kernel's LDS tables
+    size_t off_csrsrc, off_rangecnt, off_dyb;                                              // CSR mode: sources in CSR order; per-edge dy1 rows
+    bool csr_ok;                                                             // the shape fits csr_place_kernel's LDS tables
     size_t part_rows;                                                        // rows of the ordered-reduction table at off_part
     size_t total;
 };
@@ -1675,10 +1783,11 @@ static Plan make_plan(int B, int C, int N, int k)
     p.off_slot = take(sizeof(int) * BN * (size_t)REV_CAP);
     p.off_ovf = take(sizeof(int2) * BN * (size_t)k);
     p.off_wpart = take(sizeof(float) * 2 * EC * (size_t)(((C + 31) / 32) * 32) * p.g_pq);
-    // N k < 65536 (strictly): the packed u16 prefixes / cursors of csr_build_kernel hold up to the largest in-degree, which a
+    // N k < 65536 (strictly): the packed u16 prefixes / cursors of csr_place_kernel hold up to the largest in-degree, which a
     // caller's idx with repeated neighbours can push to N k (every edge of the cloud into one target)
     p.csr_ok = (size_t)N * k < 65536 && csr_lds_bytes(N, k) <= 160 * 1024 && (BN * k + 4096) < (size_t)(1u << 24);
     p.off_csrsrc = take(p.csr_ok ? sizeof(int) * BN * k : 0);
+    p.off_rangecnt = take(p.csr_ok ? sizeof(unsigned short) * (size_t)csr_ranges(N) * BN : 0);
     p.off_dyb = take(p.csr_ok ? sizeof(float) * EC * (BN * k + (size_t)p.g_bwd * BWD_WAVES) : 0);
     p.total = o;
     return p;
@@ -1780,11 +1889,15 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
     const int BN = a->B * a->N;
     if (p.csr_ok && a->csr_rowptr && a->csr_pos) {           // CSR form: fixed in-edge order, no float atomics anywhere
         int *csr_src = reinterpret_cast<int *>(ws + p.off_csrsrc);
+        unsigned short *rangecnt = reinterpret_cast<unsigned short *>(ws + p.off_rangecnt);
         const size_t lds = csr_lds_bytes(a->N, a->k);
-        GFS3D_ENSURE_LDS(csr_build_kernel, lds, who);
-        hipLaunchKernelGGL(csr_build_kernel, dim3(a->B), dim3(CSR_THREADS), lds, rs, a->idx, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
-        GFS3D_LAUNCH_CHECK("csr_build_kernel");
-        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, 2048)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->SQ, a->indeg);
+        const dim3 grid((unsigned)csr_ranges(a->N), (unsigned)a->B);
+        GFS3D_ENSURE_LDS(csr_place_kernel, lds, who);
+        hipLaunchKernelGGL(csr_count_kernel, grid, dim3(CSR_THREADS), sizeof(unsigned) * (size_t)a->N, rs, a->idx, a->N, a->k, rangecnt);
+        GFS3D_LAUNCH_CHECK("csr_count_kernel");
+        hipLaunchKernelGGL(csr_place_kernel, grid, dim3(CSR_THREADS), lds, rs, a->idx, rangecnt, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
+        GFS3D_LAUNCH_CHECK("csr_place_kernel");
+        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, 2048)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->N, a->SQ, a->indeg);
         GFS3D_LAUNCH_CHECK("csr_gather_kernel");
         return GFS3D_OK;
     }
