@@ -492,16 +492,9 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 // norms of BatchNorm-ed features (|x|^2 ~ 64) 2 E = 0.03 against neighbour distances of ~10, a fraction of a candidate per query.
 constexpr float KNN_SCREEN_REL = 1.25e-4f;     // > 2 (2^-15 (1 + 2^-6) + 192 2^-23 + 64 2^-24) = 1.18e-4, see above
 constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
-constexpr int KS_QS = 32;                      // queue slots per lane (= per query half)
+constexpr int KS_QS = 32;                      // candidate ids a lane (= query half) may store
 constexpr int KS_CAP = 64;                     // candidate ids kept per query
-// Stage geometry for NKB 16-channel K-blocks.  256 staging threads = (8 NKB channel pairs) x (candidate groups of 4):
-//   NKB = 4: 32 candidates per LDS stage (64 = two MFMA tiles per barrier was measured: 110 -> 153 us), rows of
-//            [hi 64 x bf16 | mid | 16 B pad] = 272 B (17 slots: conflict-free ds_read_b128)
-//   NKB = 1: 128 candidates per stage (four MFMA tiles per barrier), rows of [hi 16 x bf16 | mid | 16 B pad] = 80 B (5 slots)
 template <int V> struct ks_int { static constexpr int value = V; };
-struct ks_rt { int value; };
-constexpr int ks_tc(int nkb) { return 4 * (256 / (8 * nkb)); }
-constexpr int ks_tld(int nkb) { return 64 * nkb + 16; }
 
 // two fp32 values -> their hi and mid bf16 pieces (both roundings to nearest-even), each pair packed in one dword (a low)
 __device__ __forceinline__ void split2_rne(float a, float b, unsigned &hi, unsigned &mid)
@@ -525,123 +518,143 @@ knn_pm_kernel(const float *__restrict__ x, int C, int N, int RW, float *__restri
             if (n0 + q < N) xpm[((size_t)b * N + n0 + q) * RW + p] = tile[q][p];
 }
 
-// NKB = 16-channel K-blocks of the operands: 4 (17..64 channels) or 1 (<= 16 channels: the xyz / colour input of layer 1)
-template <int K, int NKB>
-__global__ void __launch_bounds__(256, NKB == 1 ? 2 : 3)
-knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int B, int C, int N,
-                  int *__restrict__ cand, int *__restrict__ ccnt)
+// ---------------------------------------------------------------------------
+// knn_screen_kernel.  The candidate operands come from a PRE-SPLIT image - one row per point, [hi RW x bf16 | mid RW x bf16]
+// (knn_img_kernel, once per call) - and travel global -> LDS by DMA (global_load_lds: no VGPRs, no VALU; a wave-uniform base
+// + a per-lane offset computed once) through a ring of KS_RING stages, one barrier per stage.
+//   * a stage holds KS_NT MFMA tiles per wave (NKB = 4: 64 rows = 16 KB; NKB = 1: 128 rows = 8 KB);
+//   * the LDS image is lane-linear (DMA lands lane l at base + 16 l), rows of 64 NKB bytes without padding: the XOR swizzle
+//     that makes the ds_read_b128 operand reads conflict-free is applied to the SOURCE slot of each lane and again on the read;
+//   * stage norms arrive by the dword form of the same DMA;
+//   * inside a wave the MFMA chains of stage s are issued together with the selection work on the scores of stage s - 1;
+//   * sweep 1 writes candidate ids straight to `cand` (lane half 0 from the front of the query's KS_CAP slots, half 1 from
+//     the back; ccnt = total | c0 << 16), so the only LDS is the ring: 50 KB (two 4-wave blocks per CU).
+// QW = waves (32 queries each) per block: 8 when the grid then still covers the chip (halves the L2 -> LDS traffic).
+// History (B = 32, N = 2048, C = 64): the round-2 form converted fp32 channel-first columns inside the loop (~40 VALU and 17
+// VGPRs per tile of staging), had a barrier per 32 candidates and an LDS candidate queue of 34 KB per block: 147 us, 28 % of
+// the matrix pipe at 2.4 GHz.  This form: 115 us; in-kernel stamps give 74 k cycles for sweep 0 at 1.78 GHz (66 % of the
+// MFMA cycles) and 97 k for sweep 1 at 1.95 GHz (51 %) - the issue port carries ~6 VALU per MFMA on top of the MFMAs.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char ks_lds_char;
+// 16 B (4 B) per lane, global -> LDS without a VGPR destination: lane l lands at lds_base + 16 l (4 l); wave-uniform base
+// (SGPR pair) + per-lane 32-bit byte offset, so a piece costs no address arithmetic.  Inline asm: see lds_dma16 in edgeconv.hip
+__device__ __forceinline__ void ks_dma16_off(const void *gbase_wave_uniform, unsigned voff, const void *lds_dst_wave_uniform)
 {
-    constexpr int KS_TC = ks_tc(NKB), KS_TLD = ks_tld(NKB), KS_CPT = 4, KS_NG = KS_TC / KS_CPT;     // stage geometry, see ks_tc()
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ks_lds_char *)lds_dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(base), "v"(voff), "s"(gbase_wave_uniform) : "memory");
+}
+__device__ __forceinline__ void ks_dma4_off(const void *gbase_wave_uniform, unsigned voff, const void *lds_dst_wave_uniform)
+{
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(ks_lds_char *)lds_dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(base), "v"(voff), "s"(gbase_wave_uniform) : "memory");
+}
+template <int V> __device__ __forceinline__ void ks_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
+
+constexpr int KS_RING = 3;
+constexpr int KS_SLACK_ROWS = 128;                   // >= rows of a stage
+constexpr int ks_nt(int nkb) { return nkb == 4 ? 2 : 4; }                 // MFMA tiles per wave and stage
+constexpr size_t ks_lds(int nkb) { return (size_t)KS_RING * (32 * ks_nt(nkb) * 64 * nkb + 32 * ks_nt(nkb) * 4) + 16; }
+
+// xpm (B N, RW) fp32 point-major rows -> image rows [hi RW x bf16 | mid RW x bf16]; thread = (row, channel pair)
+__global__ void __launch_bounds__(256)
+knn_img_kernel(const float *__restrict__ xpm, long long rows, int RW, unsigned *__restrict__ img)
+{
+    const int half = RW >> 1;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (rows + KS_SLACK_ROWS) * half) return;
+    const long long row = t / half;
+    const int pi = (int)(t - row * half);
+    float2 v = make_float2(0.f, 0.f);                     // the slack rows behind the last cloud (a ragged last stage reads them)
+    if (row < rows) v = *reinterpret_cast<const float2 *>(xpm + row * RW + 2 * pi);
+    unsigned hh, mm;
+    split2_rne(v.x, v.y, hh, mm);
+    img[row * RW + pi] = hh;
+    img[row * RW + half + pi] = mm;
+}
+
+template <int K, int NKB, int QW>
+__global__ void __launch_bounds__(64 * QW, QW == 4 ? 2 : 1)
+knn_screen_kernel(const unsigned char *__restrict__ img, const float *__restrict__ sqg, int B, int N,
+                   int *__restrict__ cand, int *__restrict__ ccnt)
+{
+    constexpr int RB = 64 * NKB, SPR = 4 * NKB, RPB = 256 / RB;          // row bytes, 16-B slots per row, rows per 256-B bank row
+    constexpr int KS_NT = ks_nt(NKB), SR = 32 * KS_NT, SB = SR * RB;     // tiles / rows / bytes per stage
+    constexpr int NPIECE = SB / 1024, D = NPIECE / QW, NQ = SR / QW;      // 1-KB DMA pieces per stage, per wave; norms per wave
+    static_assert(NPIECE % QW == 0 && D >= 1, "stage pieces must divide over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
-    unsigned char *timg = ks_smem;                                              // [2][KS_TC][KS_TLD] bf16 candidate stages
-    float *tsq = reinterpret_cast<float *>(timg + 2 * KS_TC * KS_TLD);          // [2][KS_TC] their norms
-    float *red = tsq + 2 * KS_TC;                                               // [4]
-    unsigned *queue = reinterpret_cast<unsigned *>(red + 4);                    // [4 waves][KS_QS + 1][64] candidate ids (+ one scratch row)
+    unsigned char *ring = ks_smem;                                              // [KS_RING][SR][RB] swizzled rows
+    float *tsq = reinterpret_cast<float *>(ring + KS_RING * SB);               // [KS_RING][SR] their norms
+    float *red = tsq + KS_RING * SR;                                           // [QW] (QW <= 8 -> 16 floats reserved below)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    // blocks b and b + 8 share an XCD (round-robin dispatch): keep the blocks of one point cloud on one XCD, so that its
-    // 512 KB of rows stay in that XCD's L2 for all of its query blocks (speed only)
-    const int nq = (N + 127) / 128;
+    // blocks b and b + 8 share an XCD (round-robin dispatch): the blocks of one point cloud stay on one XCD (speed only)
+    const int nq = (N + 32 * QW - 1) / (32 * QW);
     const int slot = blockIdx.x >> 3;
     const int b = (slot / nq) * 8 + (blockIdx.x & 7), qblk = slot % nq;
     if (b >= B) return;
-    const int q0 = qblk * 128 + w * 32;
-    const float *xb = x + (size_t)b * C * N;
+    const int q0 = qblk * 32 * QW + w * 32;
+    const unsigned char *imgb = img + (size_t)b * N * RB;
     const float *sqb = sqg + (size_t)b * N;
-    unsigned *myq = queue + (size_t)w * (KS_QS + 1) * 64 + lane;
 
-    // largest norm of the block (the bound E needs max_j |x_j|)
-    float mx = 0.f;
-    for (int n = tid; n < N; n += 256) mx = fmaxf(mx, sqb[n]);
+    float mx = 0.f;                                        // largest norm of the cloud (the bound E needs max_j |x_j|)
+    for (int n = tid; n < N; n += 64 * QW) mx = fmaxf(mx, sqb[n]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     if (lane == 0) red[w] = mx;
     // query operand: K-block kb, element e <-> channel 16 kb + 8 h + e of query q0 + j
     uint4 qph[NKB], qpm[NKB];
     {
-        const int qi = min(q0 + j, N - 1);
+        const unsigned char *qrow = imgb + (size_t)min(q0 + j, N - 1) * RB + 16 * h;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            float v8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = 16 * kb + 8 * h + e;
-                v8[e] = c < C ? xb[(size_t)c * N + qi] : 0.f;
-            }
-            unsigned hh[4], mm[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split2_rne(v8[2 * e], v8[2 * e + 1], hh[e], mm[e]);
-            qph[kb] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
-            qpm[kb] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+            qph[kb] = *reinterpret_cast<const uint4 *>(qrow + 32 * kb);
+            qpm[kb] = *reinterpret_cast<const uint4 *>(qrow + 32 * NKB + 32 * kb);
         }
     }
     const float sqq = sqb[min(q0 + j, N - 1)];
     __syncthreads();
-    const float sqmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sqmax = red[0];
+#pragma unroll
+    for (int q = 1; q < QW; ++q) sqmax = fmaxf(sqmax, red[q]);
     const float E = KNN_SCREEN_REL * sqrtf(sqq * sqmax) + KNN_SCREEN_ABS * (sqq + sqmax);
 
-    // staging of one stage (KS_TC candidates): thread (channel pair cp, candidate group cq) loads 2 channels x KS_CPT
-    // candidates and writes KS_CPT dwords of 2 bf16
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const int cp = tid / KS_NG, cq = tid % KS_NG;
-    const int ns = (N + KS_TC - 1) / KS_TC;
-    // (branch-free: N % 4 == 0 is a precondition of this path; a ragged last stage reads the last KS_CPT valid columns
-    // instead - its rows past N are never scored - and channels past C read row C - 1 and are zeroed by a select)
-    const int ch0 = min(2 * cp, C - 1), ch1 = min(2 * cp + 1, C - 1);
-    const bool z0 = 2 * cp >= C, z1 = 2 * cp + 1 >= C;
-    auto fetch = [&](int st, float (&gv0)[KS_CPT], float (&gv1)[KS_CPT], float &gsq) {
-        const int jb = min(KS_TC * st + KS_CPT * cq, N - KS_CPT);
-        const f32x4_ *r0 = reinterpret_cast<const f32x4_ *>(xb + (size_t)ch0 * N + jb);
-        const f32x4_ *r1 = reinterpret_cast<const f32x4_ *>(xb + (size_t)ch1 * N + jb);
+    const int ns = (N + SR - 1) / SR;
+    // DMA of stage st into ring slot `buf`: piece i = w D + u, lane l fills LDS slot g = 64 i + l = (row r, physical slot p),
+    // which holds the logical slot p ^ f(r) of that row; rows past N re-read row N - 1 (their norms are patched to +inf)
+    // (the image has a zeroed stage of slack behind the last cloud; a stage's rows past N of an earlier cloud are the next cloud's)
+    unsigned soff[D];
 #pragma unroll
-        for (int u = 0; u < KS_CPT / 4; ++u) {
-            const f32x4_ a0 = r0[u], b0 = r1[u];
+    for (int u = 0; u < D; ++u) {
+        const int g = (w * D + u) * 64 + lane;
+        const int r = g / SPR, pslot = g % SPR;
+        soff[u] = (unsigned)(r * RB + 16 * (pslot ^ ((r / RPB) & (SPR - 1))));
+    }
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    auto issue = [&](int st, int buf) {
+        unsigned char *dst = ring + buf * SB + wu * D * 1024;
+        const unsigned char *src = imgb + (size_t)st * SB;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { gv0[4 * u + e] = z0 ? 0.f : a0[e]; gv1[4 * u + e] = z1 ? 0.f : b0[e]; }
-        }
-        const int jr = KS_TC * st + (tid & (KS_TC - 1));
-        gsq = jr < N ? sqb[jr] : __builtin_inff();          // a row past N scores 2 dot - inf = -inf
+        for (int u = 0; u < D; ++u) ks_dma16_off(src, soff[u], dst + u * 1024);
+        if (lane < NQ) ks_dma4_off(sqb, (unsigned)(4 * min(SR * st + wu * NQ + lane, N - 1)), tsq + buf * SR + wu * NQ);
     };
-    auto put = [&](int buf, const float (&gv0)[KS_CPT], const float (&gv1)[KS_CPT], float gsq) {
-        unsigned char *img = timg + buf * KS_TC * KS_TLD;
-#pragma unroll
-        for (int e = 0; e < KS_CPT; ++e) {
-            unsigned hh, mm;
-            split2_rne(gv0[e], gv1[e], hh, mm);
-            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 4 * cp) = hh;
-            *reinterpret_cast<unsigned *>(img + (KS_CPT * cq + e) * KS_TLD + 32 * NKB + 4 * cp) = mm;
-        }
-        if (tid < KS_TC) tsq[buf * KS_TC + tid] = gsq;
-    };
-    // all KS_NT 32-candidate tiles of stage image buf: approximate t_r = 2 <x_j, x_q> - |x_j|^2 for the 16 candidate rows this
-    // lane sees of each (C/D layout of the MFMA).  Branch-free, every operand read issued first and the tiles' MFMA chains
-    // interleaved: with 2-3 waves per SIMD nothing else hides the LDS and MFMA latencies (one tile per basic block, as the
-    // first version had it, ran at ~830 cycles per tile for ~300 of issue).
-    constexpr int KS_NT = KS_TC / 32;
-    auto stage_scores = [&](int buf, float (&tv)[KS_NT][16]) {
-        float4 s4[KS_NT][4];
-        auto load_sq = [&]() {
-#pragma unroll
-            for (int sub = 0; sub < KS_NT; ++sub) {
-                const float *sq = tsq + buf * KS_TC + 32 * sub + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) s4[sub][g] = *reinterpret_cast<const float4 *>(sq + 8 * g);
-            }
-        };
-        if (KS_NT > 1) load_sq();                           // (one tile per stage: after the chain, the registers are needed there)
-        f32x16 acc[KS_NT];
+    // Software pipeline inside a wave: the MFMA chains of stage st are issued together with the selection work on the scores
+    // of stage st - 1 (held in tv), so a wave fills its own MFMA gaps; tv of stage st is formed when its chains have finished.
+    // stage_mfma: all KS_NT tiles of ring slot buf, acc = <x_j, x_q> for the 16 candidate rows this lane sees of each tile (C/D
+    // layout); every operand read of a K-block issued first, the tiles' chains interleaved.
+    const int fsw = (j / RPB) & (SPR - 1);                 // f(row) of this lane's row 32 sub + j
+    auto stage_mfma = [&](int buf, f32x16 (&acc)[KS_NT]) {
 #pragma unroll
         for (int sub = 0; sub < KS_NT; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[sub][r] = 0.f;
+        const unsigned char *rowb = ring + buf * SB + j * RB;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {                  // smallest products first
             uint4 ah[KS_NT], am[KS_NT];
 #pragma unroll
             for (int sub = 0; sub < KS_NT; ++sub) {
-                const unsigned char *img = timg + (buf * KS_TC + 32 * sub + j) * KS_TLD + 16 * h;
-                ah[sub] = *reinterpret_cast<const uint4 *>(img + 32 * kb);
-                am[sub] = *reinterpret_cast<const uint4 *>(img + 32 * NKB + 32 * kb);
+                ah[sub] = *reinterpret_cast<const uint4 *>(rowb + 32 * sub * RB + (((2 * kb + h) ^ fsw) << 4));
+                am[sub] = *reinterpret_cast<const uint4 *>(rowb + 32 * sub * RB + (((2 * NKB + 2 * kb + h) ^ fsw) << 4));
             }
 #pragma unroll
             for (int sub = 0; sub < KS_NT; ++sub) acc[sub] = mm_mfma<PREC_BF16>(am[sub], qph[kb], acc[sub]);
@@ -650,16 +663,21 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
 #pragma unroll
             for (int sub = 0; sub < KS_NT; ++sub) acc[sub] = mm_mfma<PREC_BF16>(ah[sub], qph[kb], acc[sub]);
         }
-        if (KS_NT == 1) load_sq();
+    };
+    // t_r = 2 <x_j, x_q> - |x_j|^2 (approximately)
+    auto stage_tv = [&](int buf, const f32x16 (&acc)[KS_NT], float (&tv)[KS_NT][16]) {
 #pragma unroll
-        for (int sub = 0; sub < KS_NT; ++sub)
+        for (int sub = 0; sub < KS_NT; ++sub) {
+            const float *sq = tsq + buf * SR + 32 * sub + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                tv[sub][4 * g + 0] = __builtin_fmaf(2.0f, acc[sub][4 * g + 0], -s4[sub][g].x);
-                tv[sub][4 * g + 1] = __builtin_fmaf(2.0f, acc[sub][4 * g + 1], -s4[sub][g].y);
-                tv[sub][4 * g + 2] = __builtin_fmaf(2.0f, acc[sub][4 * g + 2], -s4[sub][g].z);
-                tv[sub][4 * g + 3] = __builtin_fmaf(2.0f, acc[sub][4 * g + 3], -s4[sub][g].w);
+                const float4 s4 = *reinterpret_cast<const float4 *>(sq + 8 * g);
+                tv[sub][4 * g + 0] = __builtin_fmaf(2.0f, acc[sub][4 * g + 0], -s4.x);
+                tv[sub][4 * g + 1] = __builtin_fmaf(2.0f, acc[sub][4 * g + 1], -s4.y);
+                tv[sub][4 * g + 2] = __builtin_fmaf(2.0f, acc[sub][4 * g + 2], -s4.z);
+                tv[sub][4 * g + 3] = __builtin_fmaf(2.0f, acc[sub][4 * g + 3], -s4.w);
             }
+        }
     };
 
     float bm[K];                                          // sweep 0: the K largest bucket maxima of this lane (query half)
@@ -672,69 +690,83 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
     };
     float thr = -__builtin_inff(), thr2 = -__builtin_inff();
     int cnt = 0;
-    float a0[KS_CPT], a1[KS_CPT], b0[KS_CPT], b1[KS_CPT], aq = 0.f, bq = 0.f;      // two stages in flight: s + 1 and s + 2
-    // 64-channel form: the two sweeps are two INSTANTIATIONS of this body (sweep a compile-time constant) - as a run-time loop
-    // variable the compiler kept one copy and computed the cheap parts of both branches (bucket maxima AND candidate masks) in
-    // every stage: 67 -> 22 VALU in the scoring block of sweep 0
-    auto run_sweep = [&](auto sweep_c) {
-        const int sweep = sweep_c.value;                   // a constant for ks_int<V>, a run-time value for ks_rt
-        fetch(0, a0, a1, aq);
-        __syncthreads();                                   // (the previous sweep's last stage has been read by every wave)
-        put(0, a0, a1, aq);
-        if (ns > 1) fetch(1, a0, a1, aq);
-        __syncthreads();
-        // stage s is computed from image s & 1 while stage s + 1 (registers, requested one stage ago) is written to the other
-        // image and stage s + 2 is requested: a request has a whole stage of work to land
-        auto one_stage = [&](int st, float (&c0r)[KS_CPT], float (&c1r)[KS_CPT], float &cqr, float (&n0r)[KS_CPT], float (&n1r)[KS_CPT], float &nqr) {
-            if (st + 2 < ns) fetch(st + 2, n0r, n1r, nqr);
-            float tv[KS_NT][16];
-            stage_scores(st & 1, tv);
-            // (rows past N of a ragged last stage carry a norm of +inf - see fetch() - so their score is -inf: never a candidate)
-            if (sweep == 0) {
+    const int qme = q0 + j;
+    int *myc = cand + ((size_t)b * N + min(qme, N - 1)) * KS_CAP + (h ? KS_CAP - 1 : 0);
+    const int cstep = h ? -1 : 1;
+    const bool qvalid = qme < N;
+    // sweep 0, scores of one stage: bucket maxima (rows past N carry a norm of +inf: score -inf, no change)
+    auto select0 = [&](const float (&tv)[KS_NT][16]) {
 #pragma unroll
-                for (int sub = 0; sub < KS_NT; ++sub) {
-                    float mt = fmaxf(fmaxf(tv[sub][0], tv[sub][1]), tv[sub][2]);
+        for (int sub = 0; sub < KS_NT; ++sub) {
+            float mt = fmaxf(fmaxf(tv[sub][0], tv[sub][1]), tv[sub][2]);
 #pragma unroll
-                    for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, tv[sub][r]), tv[sub][r + 1]);       // v_max3_f32
-                    mt = fmaxf(mt, tv[sub][15]);
-                    bm_insert(__fsub_rn(mt, sqq));          // (a tile wholly past N inserts -inf: no change)
-                }
-            } else {
-                // candidates are rare (~12 of a lane's 1024 elements): one compare + one add-with-carry per element builds
-                // a 16-bit mask per tile (element r at bit 15 - r), the queue is touched only for its set bits.  The compare is
-                // on tv against thr2 = thr + |xq|^2 lowered by the roundings of both forms: a superset of {pd >= thr}.
-                unsigned bits[KS_NT];
+            for (int r = 3; r < 15; r += 2) mt = fmaxf(fmaxf(mt, tv[sub][r]), tv[sub][r + 1]);       // v_max3_f32
+            mt = fmaxf(mt, tv[sub][15]);
+            bm_insert(__fsub_rn(mt, sqq));
+        }
+    };
+    // sweep 1: candidates are rare (~12 of a lane's 1024 elements): one compare + one add-with-carry per element builds a
+    // 16-bit mask per tile (element r at bit 15 - r), memory is touched only for its set bits.  The compare is on tv against
+    // thr2 = thr + |xq|^2 lowered by the roundings of both forms: a superset of {pd >= thr}.
+    auto mask1 = [&](const float (&tv)[KS_NT][16], unsigned (&bits)[KS_NT]) {
 #pragma unroll
-                for (int sub = 0; sub < KS_NT; ++sub) {
-                    bits[sub] = 0;
+        for (int sub = 0; sub < KS_NT; ++sub) {
+            bits[sub] = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) bits[sub] = bits[sub] + bits[sub] + (tv[sub][r] >= thr2 ? 1u : 0u);
-                }
+            for (int r = 0; r < 16; ++r) bits[sub] = bits[sub] + bits[sub] + (tv[sub][r] >= thr2 ? 1u : 0u);
+        }
+    };
+    // two tiles' masks in one word (tile sp at bits 16 ..): leading zeros lz = 0..15: tile sp, row lz; 16..31: tile sp + 1, row lz - 16
+    auto extract1 = [&](int st, const unsigned (&bits)[KS_NT]) {
 #pragma unroll
-                for (int sub = 0; sub < KS_NT; ++sub) {
-                    const int cbase = KS_TC * st + 32 * sub + 4 * h;
-                    unsigned bt = bits[sub];
-                    while (__any(bt != 0)) {
-                        if (bt != 0) {
-                            const int hb = 31 - __builtin_clz(bt);              // highest set bit <-> smallest r = 15 - hb
-                            const int r = 15 - hb;
-                            bt &= ~(1u << hb);
-                            myq[(cnt < KS_QS ? cnt : KS_QS) * 64] = (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
-                            ++cnt;
-                        }
-                    }
+        for (int sp = 0; sp < KS_NT; sp += 2) {
+            const int cbase = SR * st + 32 * sp + 4 * h;
+            unsigned bt = qvalid ? ((bits[sp] << 16) | bits[sp + 1]) : 0u;
+            while (__any(bt != 0)) {
+                if (bt != 0) {
+                    const int lz = __builtin_clz(bt);
+                    bt &= ~(0x80000000u >> lz);
+                    const int r = lz & 15;
+                    if (cnt < KS_QS) myc[cstep * cnt] = cbase + 2 * (lz & 16) + (r & 3) + 8 * (r >> 2);
+                    ++cnt;
                 }
             }
-            if (st + 1 < ns) put((st + 1) & 1, c0r, c1r, cqr);
-            __syncthreads();
-        };
-        int st = 0;
-        for (; st + 2 <= ns; st += 2) {
-            one_stage(st, a0, a1, aq, b0, b1, bq);
-            one_stage(st + 1, b0, b1, bq, a0, a1, aq);
         }
-        if (st < ns) one_stage(st, a0, a1, aq, b0, b1, bq);
+    };
+    auto run_sweep = [&](auto sweep_c) {
+        constexpr int sweep = decltype(sweep_c)::value;
+        __syncthreads();                                   // (the previous sweep's last stage has been read by every wave)
+        for (int st = 0; st < KS_RING - 1 && st < ns; ++st) issue(st, st);
+        int buf = 0;
+        float tv[KS_NT][16];                               // scores of the previous stage (none before the first: -inf selects nothing)
+#pragma unroll
+        for (int sub = 0; sub < KS_NT; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tv[sub][r] = -__builtin_inff();
+        for (int st = 0; st < ns; ++st) {
+            // stage st has landed once at most the later stages' operations of this wave are outstanding (vmcnt retires in order;
+            // the candidate stores of sweep 1 only make the wait conservative)
+            if (st + 1 < ns) ks_wait_vm<(KS_RING - 2) * (D + 1)>(); else ks_wait_vm<0>();
+            __syncthreads();                               // ... for every wave, and ring slot (st - 1) % RING is free
+            if (st == ns - 1 && (N % SR) != 0) {           // ragged last stage: rows past N score -inf
+                if (tid < SR && SR * st + tid >= N) tsq[buf * SR + tid] = __builtin_inff();
+                __syncthreads();
+            }
+            if (st + KS_RING - 1 < ns) issue(st + KS_RING - 1, buf == 0 ? KS_RING - 1 : buf - 1);
+            f32x16 acc[KS_NT];
+            stage_mfma(buf, acc);
+            if (sweep == 0) {
+                select0(tv);
+            } else {
+                unsigned bits[KS_NT];
+                mask1(tv, bits);
+                extract1(st - 1, bits);
+            }
+            stage_tv(buf, acc, tv);
+            buf = buf + 1 == KS_RING ? 0 : buf + 1;
+        }
         if (sweep == 0) {
+            select0(tv);
             float other[K];
 #pragma unroll
             for (int t = 0; t < K; ++t) other[t] = __shfl_xor(bm[t], 32, 64);
@@ -745,27 +777,19 @@ knn_screen_kernel(const float *__restrict__ x, const float *__restrict__ sqg, in
             thr = (bm[K - 1] == -__builtin_inff()) ? -__builtin_inff() : next_below(next_below(lo));
             // pd = fl(tv - |xq|^2) >= thr  implies  tv >= thr + |xq|^2 - (roundings of the subtraction and of this sum)
             thr2 = (thr == -__builtin_inff()) ? thr : (thr + sqq) - 4.8e-7f * (fabsf(thr) + fabsf(sqq)) - 1e-37f;
+        } else {
+            unsigned bits[KS_NT];
+            mask1(tv, bits);
+            extract1(ns - 1, bits);
         }
     };
-    if constexpr (NKB == 4) {
-        run_sweep(ks_int<0>{});
-        run_sweep(ks_int<1>{});
-    } else {                                               // (four tiles per stage: two copies of the body do not fit the registers)
-        for (int sw = 0; sw < 2; ++sw) run_sweep(ks_rt{sw});
-    }
-    // ---- publish: the two halves of a query one after the other; overflow (or more than KS_CAP) -> exhaustive scan
+    run_sweep(ks_int<0>{});
+    run_sweep(ks_int<1>{});
+    // ---- publish the counts; a half that overflowed its KS_QS slots (ties, tiny N) -> exhaustive scan in the exact kernel
     const int c0 = __shfl(cnt, j, 64), c1 = __shfl(cnt, j + 32, 64);
     // (no bound - fewer than K buckets in a tiny cloud - also means: rows past N of a ragged tile passed the -inf threshold)
-    const bool bad = c0 > KS_QS || c1 > KS_QS || c0 + c1 > KS_CAP || thr == -__builtin_inff();
-    const int q = q0 + j;
-    if (q < N) {
-        const size_t gq = (size_t)b * N + q;
-        if (h == 0) ccnt[gq] = bad ? -1 : c0 + c1;
-        if (!bad) {
-            int *dst = cand + gq * KS_CAP + (h ? c0 : 0);
-            for (int s = 0; s < cnt; ++s) dst[s] = (int)myq[s * 64];
-        }
-    }
+    const bool bad = c0 > KS_QS || c1 > KS_QS || thr == -__builtin_inff();
+    if (qvalid && h == 0) ccnt[(size_t)b * N + qme] = bad ? -1 : ((c0 + c1) | (c0 << 16));
 }
 
 template <int K, int RW>
@@ -788,8 +812,9 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
     const float *sqb = sqg + (size_t)b * N;
     if (l < RW / 4) *reinterpret_cast<f32x4_ *>(&qrow[w][hq][4 * l]) = *reinterpret_cast<const f32x4_ *>(xpm + gq * RW + 4 * l);
     const float sqq = sqg[gq];
-    const int n = ccnt[gq];
-    const int count = n >= 0 ? n : N;                        // -1: exhaustive
+    const int n = ccnt[gq];                                  // total | (ids stored from the front of the KS_CAP slots) << 16; the rest
+    const int cfront = n >> 16;                              // were stored from the back.  -1: exhaustive
+    const int count = n >= 0 ? (n & 0xffff) : N;
     const int nch_mine = (count + 31) / 32;
     const int nch = max(nch_mine, __shfl_xor(nch_mine, 32, 64));
     __builtin_amdgcn_wave_barrier();
@@ -799,7 +824,7 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
     for (int c = 0; c < nch; ++c) {
         const int pos = c * 32 + l;
         const bool valid = pos < count;
-        const int id = valid ? (n >= 0 ? cand[gq * KS_CAP + pos] : pos) : 0;
+        const int id = valid ? (n >= 0 ? cand[gq * KS_CAP + (pos < cfront ? pos : KS_CAP - 1 - (pos - cfront))] : pos) : 0;
         const float *row = xpm + ((size_t)b * N + id) * RW;
         f32x4_ xr[RW / 4];
 #pragma unroll
@@ -853,7 +878,7 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
     }
 }
 
-struct KnnWs { size_t off_sq, off_pm, off_cand, off_cnt, total; };
+struct KnnWs { size_t off_sq, off_pm, off_cand, off_cnt, off_img, total; };
 static KnnWs knn_ws(int B, int C, int N, int k)
 {
     (void)k;
@@ -865,6 +890,7 @@ static KnnWs knn_ws(int B, int C, int N, int k)
     w.off_pm = take(screened ? sizeof(float) * (size_t)B * N * 64 : 0);
     w.off_cand = take(screened ? sizeof(int) * (size_t)B * N * KS_CAP : 0);
     w.off_cnt = take(screened ? sizeof(int) * (size_t)B * N : 0);
+    w.off_img = take(screened ? ((size_t)B * N + KS_SLACK_ROWS) * (C <= 16 ? 64 : 256) : 0);              // bf16 hi | mid rows of the screen
     w.total = o;
     return w;
 }
@@ -879,7 +905,7 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
         hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
         GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
     }
-    constexpr int RW = 16 * NKB, KS_TC = ks_tc(NKB), KS_TLD = ks_tld(NKB);
+    constexpr int RW = 16 * NKB;
     const float *xpm = (xpm_in && C == 64) ? xpm_in : nullptr;      // the caller's copy is used as it is for 64 channels only
     if (!xpm) {                                             // the exact pass reads zero-padded RW-channel rows
         float *t = reinterpret_cast<float *>(ws + lay.off_pm);
@@ -888,13 +914,23 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
         xpm = t;
     }
     int *cand = reinterpret_cast<int *>(ws + lay.off_cand), *ccnt = reinterpret_cast<int *>(ws + lay.off_cnt);
-    const size_t lds = 2 * KS_TC * KS_TLD + sizeof(float) * (2 * KS_TC + 4) + sizeof(unsigned) * 4 * (KS_QS + 1) * 64;
-    GFS3D_ENSURE_LDS((knn_screen_kernel<K, NKB>), lds, who);
-    hipLaunchKernelGGL((knn_screen_kernel<K, NKB>), dim3(((N + 127) / 128) * ((B + 7) / 8) * 8), dim3(256), lds, st, x, sq, B, C, N, cand, ccnt);
+    static const int qw_env = [] { const char *e = getenv("GFS3D_KNN_SCREEN_QW"); return e ? atoi(e) : 0; }();        // A-B only
+    unsigned char *img = reinterpret_cast<unsigned char *>(ws + lay.off_img);
+    const long long rows = (long long)B * N;
+    hipLaunchKernelGGL(knn_img_kernel, dim3((unsigned)(((rows + KS_SLACK_ROWS) * (RW / 2) + 255) / 256)), dim3(256), 0, st, xpm, rows, RW, reinterpret_cast<unsigned *>(img));
+    GFS3D_LAUNCH_CHECK("knn_img_kernel");
+    const size_t lds = ks_lds(NKB);
+    const int groups = (B + 7) / 8;
+    const bool wide = qw_env ? qw_env == 8 : (long long)((N + 255) / 256) * groups * 8 >= 224;      // 256-query blocks still cover the chip
+    if (wide) {
+        GFS3D_ENSURE_LDS((knn_screen_kernel<K, NKB, 8>), lds, who);
+        hipLaunchKernelGGL((knn_screen_kernel<K, NKB, 8>), dim3(((N + 255) / 256) * groups * 8), dim3(512), lds, st, img, sq, B, N, cand, ccnt);
+    } else {
+        GFS3D_ENSURE_LDS((knn_screen_kernel<K, NKB, 4>), lds, who);
+        hipLaunchKernelGGL((knn_screen_kernel<K, NKB, 4>), dim3(((N + 127) / 128) * groups * 8), dim3(256), lds, st, img, sq, B, N, cand, ccnt);
+    }
     GFS3D_LAUNCH_CHECK("knn_screen_kernel");
-    const long long nq = (long long)B * N;
-    (void)nq;
-    hipLaunchKernelGGL((knn_exact_kernel<K, RW>), dim3((unsigned)(((N + 7) / 8) * ((B + 7) / 8) * 8)), dim3(256), 0, st, xpm, sq, cand, ccnt, B, N, k, idx64, idx32);
+    hipLaunchKernelGGL((knn_exact_kernel<K, RW>), dim3((unsigned)(((N + 7) / 8) * groups * 8)), dim3(256), 0, st, xpm, sq, cand, ccnt, B, N, k, idx64, idx32);
     GFS3D_LAUNCH_CHECK("knn_exact_kernel");
     return GFS3D_OK;
 }
