@@ -1,6 +1,7 @@
 """GPU timeline of a rocprofv3 --kernel-trace run (rocpd database): per step window, the union of the busy intervals of
 all streams, the sum of the kernel durations and the idle gaps - tells a launch-bound step from a device-bound one.
-  python scripts/timeline.py <r_results.db> [marker kernel substring] [skip first N marker hits]
+  python scripts/timeline.py <r_results.db> [marker kernel substring] [skip first N marker hits] [dump]
+With a 4th argument the launches of one step are listed in start order (offset, duration, gap to the previous end, queue).
 Steps are delimited by consecutive launches of the marker kernel (default: the Adam multi_tensor_apply kernel)."""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
@@ -37,3 +38,12 @@ if out:
     n = len(out)
     print("mean: step %.3f  busy %.3f  sum %.3f  idle %.3f" % (sum(o[0] for o in out) / n, sum(o[1] for o in out) / n, sum(o[2] for o in out) / n,
                                                           sum(o[0] - o[1] for o in out) / n))
+
+if len(sys.argv) > 4 and len(steps) > 2:
+    a, b = steps[1], steps[3] if len(steps) > 3 else steps[2]
+    t0, last_end = rows[a][1], rows[a][1]
+    import re
+    for name, st, en, q in rows[a:b]:
+        short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "").replace("void ", ""))[:58]
+        print("%9.1f us  %7.1f us  gap %6.1f  q%d  %s" % ((st - t0) / 1e3, (en - st) / 1e3, (st - last_end) / 1e3, q, short))
+        last_end = max(last_end, en)

@@ -51,6 +51,9 @@ def relerr(a, b):
     # is scanned exhaustively, a ragged last 32-candidate tile, k = 32, C below 64 (zero-padded point rows)
     (2, 64, 1024, 20, "offset"), (2, 64, 2048, 20, "relu"), (1, 64, 512, 20, "tiny_spread"), (2, 64, 1000, 20, "offset"),
     (1, 64, 300, 32, "relu"), (2, 24, 516, 20, "offset"), (1, 48, 2048, 9, "randn"),
+    # DMA-staged screen: a last stage of 64 (C > 16) / 128 (C <= 16) rows that is ragged in every way (rows of the next cloud
+    # and of the zeroed slack behind the last one land in LDS), 256-query blocks (B N / 256 >= 224) with a ragged last block
+    (3, 64, 68, 20, "randn"), (2, 16, 132, 20, "offset"), (9, 40, 1996, 20, "relu"), (16, 9, 3972, 20, "blocks"),
 ])
 def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
     from gfs3d import ops
@@ -143,7 +146,7 @@ def _make_block(p, C, dev):
     return blk.to(dev)
 
 
-@pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (1, 64, 130, 20), (3, 9, 65, 5), (1, 64, 64, 32), (1, 3, 257, 1)])
+@pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (1, 64, 130, 20), (3, 9, 65, 5), (1, 64, 64, 32), (1, 3, 257, 1), (8, 9, 72, 20)])
 def test_edgeconv_eval_forward(dev, B, C, N, k):
     from gfs3d import ops
     p = _block_params(C, 100 + C)
@@ -190,8 +193,10 @@ def test_edgeconv_eval_non_finite_input_stays_confined(dev, bad):
     assert bool(torch.isfinite(y[0][:, others]).all())
 
 
+# (8, 64, 64, 20) / (16, 9, 40, 5): B % 8 == 0 - the XCD-aware dealing of clouds to workgroups; (1, 64, 520, 20) / (2, 9, 1100, 20):
+# the reverse graph built by 3 / 5 workgroups per cloud with a ragged last source range
 @pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (2, 64, 128, 20), (1, 9, 131, 7), (1, 9, 5, 3), (1, 64, 33, 1),
-                                     (2, 9, 70, 32)])
+                                     (2, 9, 70, 32), (8, 64, 64, 20), (16, 9, 40, 5), (1, 64, 520, 20), (2, 9, 1100, 20)])
 def test_edgeconv_train_forward_backward(dev, B, C, N, k):
     from gfs3d import ops
     p = _block_params(C, 200 + C)
