@@ -489,32 +489,6 @@ csr_gather_kernel(const float *__restrict__ Q, const int *__restrict__ rowptr, c
 }
 
 // ---------------------------------------------------------------------------
-// R: out[e] = sum_p partial[p*width + e] in double.  block = 64 outputs x 16 part-groups
-// (the per-block partial sums are few thousand rows; a single thread walking them is a
-// 250 us latency chain, this is ~10 us).
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(1024)
-reduce_parts_kernel(const T *__restrict__ partial, int nparts, int width, double *__restrict__ out, float *__restrict__ fout = nullptr)
-{
-    __shared__ double red[16][64];
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
-    double s = 0.0;
-    if (e < width)
-        for (int p = grp; p < nparts; p += 16) s += (double)partial[(size_t)p * width + e];
-    red[grp][el] = s;
-    __syncthreads();
-    if (grp == 0 && e < width) {
-        double t = 0.0;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) t += red[g][el];
-        out[e] = t;
-        if (fout) fout[e] = (float)t;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // F3: BN statistics of channel c -> (mean, rstd, scale, shift); `writer` also stores them as stats rows
 // row0..row0+3 and updates the running statistics (momentum, unbiased variance) when training.
 // Called from the prologue of the kernel that consumes the constants (every block recomputes its 64 channels
@@ -568,9 +542,12 @@ __device__ __forceinline__ void bn_constants(const BnFin &f, int c, bool writer,
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, int N,
-             float *__restrict__ P, float *__restrict__ Q, const BnFin fin, float *__restrict__ stats, int fold)
+             float *__restrict__ P, float *__restrict__ Q, const BnFin fin, float *__restrict__ stats, int fold,
+             double *__restrict__ zero_acc)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (training: the 4 x 64 BatchNorm accumulators of the passes that follow on this stream start at zero - a memset launch less)
+    if (zero_acc && blockIdx.x == 0 && blockIdx.y == 0) zero_acc[threadIdx.x] = 0.0;
     float *wa = smem;                 // [C][64]
     float *wd = wa + C * EC;          // [C][64]
     float *xs = wd + C * EC;          // [C][64 points]
@@ -610,9 +587,10 @@ ec_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1, int C, i
 // ec_prescale_kernel rides in that GEMM's epilogue instead (P' = P scale1, Q' = Q scale1 + shift1: `eab` = 128 column
 // scales, then 128 column shifts) and the prescale pass disappears.
 __global__ void ec_wpq_kernel(const float *__restrict__ w1, int C, float *__restrict__ wpq, const BnFin fin, float *__restrict__ stats,
-                              float *__restrict__ eab)
+                              float *__restrict__ eab, double *__restrict__ zero_acc)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_acc && blockIdx.x == 0) zero_acc[threadIdx.x] = 0.0;      // (as in ec_pq_kernel: 256 threads, 4 x 64 accumulators)
     if (eab && e < EC) {
         float sc, sh;
         bn_constants(fin, e, true, stats, (int)ST_MEAN1, sc, sh);
@@ -1686,12 +1664,29 @@ ec_bwd_pq_kernel(const float *__restrict__ x, const float *__restrict__ w1,
     }
 }
 // B7: dW1[:, :C] = dWa - dWd ; dW1[:, C:] = dWd, straight from the workgroup partials [nparts][2][64][CP] (summed in double).
-// block = 64 outputs x 16 part-groups
+// block = 64 outputs x 16 part-groups.  The blocks past the dW1 outputs sum the heavy backward's dW2 partials
+// [nparts2][64 x 64] the same way (one launch for both weight gradients; the partials sit in the workspace since phase 1).
 __global__ void __launch_bounds__(1024)
-ec_bwd_dw1_kernel(const float *__restrict__ partial, int nparts, int C, int CP, float *__restrict__ dw1)
+ec_bwd_dw_kernel(const float *__restrict__ partial, int nparts, int C, int CP, float *__restrict__ dw1,
+                 const float *__restrict__ partial2, int nparts2, float *__restrict__ dw2)
 {
     __shared__ double red[16][2][64];
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int nb1 = (EC * C + 63) / 64;
+    if ((int)blockIdx.x >= nb1) {
+        const int e2 = ((int)blockIdx.x - nb1) * 64 + el;     // < 64 x 64 by the grid
+        double s2 = 0.0;
+        for (int p = grp; p < nparts2; p += 16) s2 += (double)partial2[(size_t)p * (EC * EC) + e2];
+        red[grp][0][el] = s2;
+        __syncthreads();
+        if (grp == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g][0][el];
+            dw2[e2] = (float)t;
+        }
+        return;
+    }
     const int e = blockIdx.x * 64 + el;                      // (o, c) pair
     const int o = e / C, c = e - o * C;
     double sa = 0.0, sd = 0.0;
@@ -1949,11 +1944,12 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     // there is no prescale pass
     const bool fold = !a->training;
     if (phase == 0) {
+        double *zero_acc = (a->training && !rows) ? acc : nullptr;          // atomics mode: the projection kernel clears the accumulators
         if (a->x_pm && a->C % 32 == 0) {
             float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
             float *eab = fold ? reinterpret_cast<float *>(ws + p.off_bpart) : nullptr;       // (4, 64); likewise
             const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
-            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq, fin1, a->stats, eab);
+            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq, fin1, a->stats, eab, zero_acc);
             GFS3D_LAUNCH_CHECK("ec_wpq_kernel");
             float *outs[2] = {fold ? Pp : a->P, fold ? Qp : a->Q};
             if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, eab, eab ? eab + 2 * EC : nullptr, st, who)) return rc;
@@ -1962,7 +1958,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_ENSURE_LDS(ec_pq_kernel, lds, who);
             const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
             hipLaunchKernelGGL(ec_pq_kernel, tgrid, dim3(256), lds, st, a->x, a->w1, a->C, a->N, fold ? Pp : a->P, fold ? Qp : a->Q,
-                               fin1, a->stats, fold ? 1 : 0);
+                               fin1, a->stats, fold ? 1 : 0, zero_acc);
             GFS3D_LAUNCH_CHECK("ec_pq_kernel");
         }
         if (a->training) {
@@ -1977,10 +1973,6 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
                 lane->pending = true;                  // joined in phase 2, or by side_join() on any error return
             }
             if (int rc = reverse_graph(a, p, rs, who)) return rc;
-            if (!rows && hipMemsetAsync(acc, 0, sizeof(double) * 4 * EC, st) != hipSuccess) {
-                set_error("%s: hipMemsetAsync failed", who);
-                return GFS3D_ERR_HIP;
-            }
             {
                 ProfScope prof(4, st);
                 hipLaunchKernelGGL(ec_stats1_kernel, dim3((p.g_heavy + 3) / 4), dim3(64 * ST1_WAVES), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
@@ -2037,7 +2029,6 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
     float *g = reinterpret_cast<float *>(ws + p.off_g);
     float *GP = reinterpret_cast<float *>(ws + p.off_GP), *GQ = reinterpret_cast<float *>(ws + p.off_GQ);
     float *bpart = reinterpret_cast<float *>(ws + p.off_bpart);
-    double *dred = reinterpret_cast<double *>(ws + p.off_dred);
     float *wpart = reinterpret_cast<float *>(ws + p.off_wpart);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     // monolithic call: this rank's sums ARE the global sums, no local copies needed
@@ -2088,8 +2079,6 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
 #undef GFS3D_BWD_LAUNCH
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
-        hipLaunchKernelGGL(reduce_parts_kernel<float>, dim3((BWD_PART + 63) / 64), dim3(1024), 0, st, bpart, p.g_bwd, BWD_PART, dred, ba->dw2);
-        GFS3D_LAUNCH_CHECK("reduce_parts_kernel(bwd)");
         if (csr) {
             const int sg = min((BN + 31) / 32, 2048);
             if (prec_of(a->compute, true) != PREC_X6)
@@ -2120,8 +2109,10 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         hipLaunchKernelGGL(ec_bwd_pq_kernel, dim3(p.g_pq), dim3(PQ_THREADS), lds, st, a->x, a->w1, a->P, a->Q, a->SP, a->SQ, a->indeg,
                            GP, GQ, a->stats, fin, a->C, a->N, a->k, tiles_per_b, p.tiles, ba->dx, wpart);
         GFS3D_LAUNCH_CHECK("ec_bwd_pq_kernel");
-        hipLaunchKernelGGL(ec_bwd_dw1_kernel, dim3((EC * a->C + 63) / 64), dim3(1024), 0, st, wpart, p.g_pq, a->C, CP, ba->dw1);
-        GFS3D_LAUNCH_CHECK("ec_bwd_dw1_kernel");
+        static_assert(BWD_PART == EC * EC, "dW2 partials are 64 x 64 per workgroup");
+        hipLaunchKernelGGL(ec_bwd_dw_kernel, dim3((EC * a->C + 63) / 64 + BWD_PART / 64), dim3(1024), 0, st, wpart, p.g_pq, a->C, CP, ba->dw1,
+                           bpart, p.g_bwd, ba->dw2);
+        GFS3D_LAUNCH_CHECK("ec_bwd_dw_kernel");
     }
     return GFS3D_OK;
 }

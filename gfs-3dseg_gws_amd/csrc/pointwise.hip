@@ -887,6 +887,44 @@ int wgrad(const WGrad &wg, bool allow192, hipStream_t st, const char *who)
     return launch_wgrad_t<64, 64, VPRO>(wg, geo, st, who);
 }
 
+// All weight images of one stack pass in ONE launch (a launch per layer and a memset cost ~5 us each on an idle stream, as much
+// as the whole work): up to PW_MAX_SPLIT matrices, entry i covers elements [first[i], first[i + 1]); the same launch clears
+// the BatchNorm accumulators of the pass.
+constexpr int PW_MAX_SPLIT = 8;
+struct SplitJob {
+    const float *w[PW_MAX_SPLIT];
+    unsigned short *w3[PW_MAX_SPLIT];
+    int Nc[PW_MAX_SPLIT], K[PW_MAX_SPLIT];
+    long long sn[PW_MAX_SPLIT], sk[PW_MAX_SPLIT];
+    int first[PW_MAX_SPLIT + 1];
+    int n;
+    double *zero;
+    int nzero;
+};
+template <int PREC>
+__global__ void pw_split_all_kernel(const SplitJob job)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int z = e; z < job.nzero; z += gridDim.x * blockDim.x) job.zero[z] = 0.0;
+    if (e >= job.first[job.n]) return;
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < PW_MAX_SPLIT; ++q) i += (q < job.n && e >= job.first[q]) ? 1 : 0;
+    const int r = e - job.first[i], K = job.K[i];
+    const int n = r / K, k = r - n * K;
+    mm_store1<PREC>(job.w[i][(size_t)n * job.sn[i] + (size_t)k * job.sk[i]], job.w3[i] + ((size_t)n * (K / 32) + k / 32) * 96 + (k & 31), 32);
+}
+static int split_all(const SplitJob &job, hipStream_t st, int prec)
+{
+    const int total = job.first[job.n] > job.nzero / 8 ? job.first[job.n] : job.nzero / 8;
+    const dim3 grid((total + 255) / 256 > 0 ? (total + 255) / 256 : 1);
+    if (prec == PREC_BF16) hipLaunchKernelGGL(pw_split_all_kernel<PREC_BF16>, grid, dim3(256), 0, st, job);
+    else if (prec == PREC_F16) hipLaunchKernelGGL(pw_split_all_kernel<PREC_F16>, grid, dim3(256), 0, st, job);
+    else hipLaunchKernelGGL(pw_split_all_kernel<PREC_X6>, grid, dim3(256), 0, st, job);
+    GFS3D_LAUNCH_CHECK("pw_split_all_kernel");
+    return GFS3D_OK;
+}
+
 int split_weights(const float *w, int Nc, int K, long long sn, long long sk, void *w3, hipStream_t st, int prec)
 {
     const dim3 grid((Nc * K + 255) / 256);
@@ -1024,9 +1062,25 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     const int L = a->n_layers, M = p.M;
     const double count = stat_count > 0.0 ? stat_count : (double)M;
-    if (phase == 0 && a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
-        set_error("%s: hipMemsetAsync failed", who);
-        return GFS3D_ERR_HIP;
+    // phase 0: the weight images of every layer and (training) cleared accumulators, one launch
+    const bool split_once = L <= PW_MAX_SPLIT;
+    if (phase == 0) {
+        if (split_once) {
+            SplitJob job{};
+            job.n = L;
+            for (int l = 0; l < L; ++l) {
+                const int K = l ? a->width[l - 1] : p.in_width;
+                job.w[l] = a->w[l]; job.w3[l] = reinterpret_cast<unsigned short *>(ws + p.off_w3[l]);
+                job.Nc[l] = a->width[l]; job.K[l] = K; job.sn[l] = K; job.sk[l] = 1;
+                job.first[l + 1] = job.first[l] + a->width[l] * K;
+            }
+            job.zero = a->training ? acc : nullptr;
+            job.nzero = a->training ? 2 * p.maxw * L : 0;
+            if (int rc = split_all(job, st, prec_of(a->compute, false))) return rc;
+        } else if (a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
+            set_error("%s: hipMemsetAsync failed", who);
+            return GFS3D_ERR_HIP;
+        }
     }
     if (a->training && phase > 0) {                      // BatchNorm of layer phase - 1: batch statistics are complete (and global)
         const int l = phase - 1, C = a->width[l];
@@ -1042,7 +1096,8 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         rg.w = a->w[l];
         rg.w3 = ws + p.off_w3[l];
         rg.prec = prec_of(a->compute, false);
-        if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st, rg.prec)) return rc;
+        if (!split_once)
+            if (int rc = split_weights(a->w[l], C, rg.K, rg.K, 1, ws + p.off_w3[l], st, rg.prec)) return rc;
         rg.M = M;
         rg.Nc = C;
         rg.slope = a->training ? (l ? pw_slope(a, l - 1) : 1.f) : pw_slope(a, l);    // training: the prologue's activation; eval: the epilogue's
@@ -1139,6 +1194,7 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     const int L = a->n_layers, M = p.M;
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     double *loc = acc_user ? acc_user + (size_t)2 * p.maxw * L : acc;          // monolithic: this rank's sums are the global sums
+    const bool split_once = L <= PW_MAX_SPLIT;
     float *coef = reinterpret_cast<float *>(ws + p.off_coef);
     const double count = stat_count > 0.0 ? stat_count : (double)M;
     auto keep_local = [&](int l) -> int {
@@ -1151,7 +1207,19 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     };
     if (phase == 0) {
         const int C = a->width[L - 1];
-        if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
+        if (split_once) {                                  // the transposed weight images of every layer + cleared accumulators, one launch
+            SplitJob job{};
+            job.n = L;
+            for (int l = 0; l < L; ++l) {
+                const int Ci = l ? a->width[l - 1] : p.in_width;
+                job.w[l] = a->w[l]; job.w3[l] = reinterpret_cast<unsigned short *>(ws + p.off_w3[l]);
+                job.Nc[l] = Ci; job.K[l] = a->width[l]; job.sn[l] = 1; job.sk[l] = Ci;          // pieces of W_l^T (Ci, C)
+                job.first[l + 1] = job.first[l] + a->width[l] * Ci;
+            }
+            job.zero = acc;
+            job.nzero = 2 * p.maxw * L;
+            if (int rc = split_all(job, st, prec_of(a->compute, true))) return rc;
+        } else if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
         double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
         const int gx = ((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES;
         hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(gx, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_pm, a->h[L - 1],
@@ -1192,7 +1260,8 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     }
     if (rc) return rc;
     // dA_{l-1} = dH_l W_l
-    if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st, prec_of(a->compute, true))) return rc2;      // pieces of W_l^T (Ci, C)
+    if (!split_once)
+        if (int rc2 = split_weights(a->w[l], Ci, C, 1, Ci, w3t, st, prec_of(a->compute, true))) return rc2;      // pieces of W_l^T (Ci, C)
     RowGemm rg{};
     rg.a[0] = gl; rg.a2[0] = a->h[l]; rg.a_segw = C; rg.lda = C; rg.K = C;
     rg.pa = coef; rg.pb = coef + C; rg.pc = coef + 2 * C;
