@@ -219,7 +219,9 @@ static inline int ensure_dynamic_lds(const void *kernel, size_t bytes, LdsGrant 
 // pointwise.hip: out(M, Nc) = a(M, K) . w(Nc, K)^T on MFMA, point-major; the Nc columns are written as segments of
 // width o_segw to out[0], out[1], ...  (K % 32 == 0, Nc % 64 == 0, o_segw % 64 == 0, at most 4 segments)
 // ea / eb (Nc floats each, or both NULL): out = fma(acc, ea[col], eb[col])
+// w_pq != 0 (Nc = 128): w is an EdgeConv first convolution (64, 2 K) = [Wa | Wb], the 128 weight rows are [Wa; Wb - Wa], formed
+// while they are staged.  zero / nzero: doubles the first workgroup clears (the caller's BatchNorm accumulators).
 int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw,
-                  const float *ea, const float *eb, hipStream_t st, const char *who);
+                  const float *ea, const float *eb, hipStream_t st, const char *who, int w_pq = 0, double *zero = nullptr, int nzero = 0);
 
 }  // namespace gfs3d

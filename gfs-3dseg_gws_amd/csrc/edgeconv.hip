@@ -1948,11 +1948,16 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
         if (a->x_pm && a->C % 32 == 0) {
             float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
             float *eab = fold ? reinterpret_cast<float *>(ws + p.off_bpart) : nullptr;       // (4, 64); likewise
-            const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
-            hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq, fin1, a->stats, eab, zero_acc);
-            GFS3D_LAUNCH_CHECK("ec_wpq_kernel");
             float *outs[2] = {fold ? Pp : a->P, fold ? Qp : a->Q};
-            if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, eab, eab ? eab + 2 * EC : nullptr, st, who)) return rc;
+            if (fold) {                                   // eval: [Wa; Wb - Wa] and the folded BatchNorm1 constants from a small kernel
+                const BnFin fin1{nullptr, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, 0};
+                hipLaunchKernelGGL(ec_wpq_kernel, dim3((EC * a->C + 255) / 256), dim3(256), 0, st, a->w1, a->C, wpq, fin1, a->stats, eab, zero_acc);
+                GFS3D_LAUNCH_CHECK("ec_wpq_kernel");
+                if (int rc = pw_plain_gemm(a->x_pm, a->C, wpq, BN, a->C, 2 * EC, outs, EC, eab, eab + 2 * EC, st, who)) return rc;
+            } else {                                      // training: the GEMM forms the weight rows itself and clears the accumulators
+                if (int rc = pw_plain_gemm(a->x_pm, a->C, a->w1, BN, a->C, 2 * EC, outs, EC, nullptr, nullptr, st, who, 1, zero_acc,
+                                           zero_acc ? 4 * EC : 0)) return rc;
+            }
         } else {
             const size_t lds = sizeof(float) * (size_t)a->C * 64 * 3;
             GFS3D_ENSURE_LDS(ec_pq_kernel, lds, who);

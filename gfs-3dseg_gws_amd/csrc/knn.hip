@@ -493,6 +493,7 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 constexpr float KNN_SCREEN_REL = 1.25e-4f;     // > 2 (2^-15 (1 + 2^-6) + 192 2^-23 + 64 2^-24) = 1.18e-4, see above
 constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
 constexpr int KS_QS = 32;                      // candidate ids a lane (= query half) may store
+constexpr int KS_SLACK_ROWS = 128;                // zeroed image rows behind the last cloud (>= rows of a screen stage)
 constexpr int KS_CAP = 64;                     // candidate ids kept per query
 template <int V> struct ks_int { static constexpr int value = V; };
 
@@ -504,9 +505,13 @@ __device__ __forceinline__ void split2_rne(float a, float b, unsigned &hi, unsig
     mid = mm_pack2<PREC_BF16>(ra, rb);
 }
 
-// x (B, C, N) channel-first -> xpm (B, N, RW) point-major (RW = 64 or 16), channels >= C zero
+// Everything the screened path derives from a channel-first x (B, C, N), in one pass over a 64-point tile:
+//   xpm (B, N, RW) point-major rows (RW = 64 or 16), channels >= C zero          - the exact kernel's rows
+//   img rows [hi RW x bf16 | mid RW x bf16] + the zeroed slack behind the last    - the screen's operands (as knn_img_kernel)
+//   sq (or NULL) |x_j|^2 in the oracle's order (as knn_sqnorm_kernel)
 __global__ void __launch_bounds__(256)
-knn_pm_kernel(const float *__restrict__ x, int C, int N, int RW, float *__restrict__ xpm)
+knn_prep_kernel(const float *__restrict__ x, int B, int C, int N, int RW, float *__restrict__ xpm, unsigned *__restrict__ img,
+                float *__restrict__ sq)
 {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x, b = blockIdx.y, n0 = blockIdx.x * 64;
@@ -516,6 +521,23 @@ knn_pm_kernel(const float *__restrict__ x, int C, int N, int RW, float *__restri
     if (p < RW)
         for (int q = wv; q < 64; q += 4)
             if (n0 + q < N) xpm[((size_t)b * N + n0 + q) * RW + p] = tile[q][p];
+    const int half = RW >> 1;
+    if (p < half)
+        for (int q = wv; q < 64; q += 4)
+            if (n0 + q < N) {
+                unsigned hh, mm;
+                split2_rne(tile[q][2 * p], tile[q][2 * p + 1], hh, mm);
+                unsigned *row = img + ((size_t)b * N + n0 + q) * RW;
+                row[p] = hh;
+                row[half + p] = mm;
+            }
+    if (sq && wv == 0 && n0 + p < N) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = __fadd_rn(s, __fmul_rn(tile[p][c], tile[p][c]));
+        sq[(size_t)b * N + n0 + p] = s;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int e = tid; e < KS_SLACK_ROWS * RW; e += 256) img[(size_t)B * N * RW + e] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -551,7 +573,6 @@ __device__ __forceinline__ void ks_dma4_off(const void *gbase_wave_uniform, unsi
 template <int V> __device__ __forceinline__ void ks_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V) : "memory"); }
 
 constexpr int KS_RING = 3;
-constexpr int KS_SLACK_ROWS = 128;                   // >= rows of a stage
 constexpr int ks_nt(int nkb) { return nkb == 4 ? 2 : 4; }                 // MFMA tiles per wave and stage
 constexpr size_t ks_lds(int nkb) { return (size_t)KS_RING * (32 * ks_nt(nkb) * 64 * nkb + 32 * ks_nt(nkb) * 4) + 16; }
 
@@ -901,24 +922,26 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
 {
     const char *who = "gfs3d_knn_topk_f32(screened)";
     ProfScope prof(0, st);
-    if (!have_norms) {
-        hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
-        GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
-    }
     constexpr int RW = 16 * NKB;
-    const float *xpm = (xpm_in && C == 64) ? xpm_in : nullptr;      // the caller's copy is used as it is for 64 channels only
-    if (!xpm) {                                             // the exact pass reads zero-padded RW-channel rows
-        float *t = reinterpret_cast<float *>(ws + lay.off_pm);
-        hipLaunchKernelGGL(knn_pm_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, C, N, RW, t);
-        GFS3D_LAUNCH_CHECK("knn_pm_kernel");
-        xpm = t;
-    }
     int *cand = reinterpret_cast<int *>(ws + lay.off_cand), *ccnt = reinterpret_cast<int *>(ws + lay.off_cnt);
     static const int qw_env = [] { const char *e = getenv("GFS3D_KNN_SCREEN_QW"); return e ? atoi(e) : 0; }();        // A-B only
     unsigned char *img = reinterpret_cast<unsigned char *>(ws + lay.off_img);
-    const long long rows = (long long)B * N;
-    hipLaunchKernelGGL(knn_img_kernel, dim3((unsigned)(((rows + KS_SLACK_ROWS) * (RW / 2) + 255) / 256)), dim3(256), 0, st, xpm, rows, RW, reinterpret_cast<unsigned *>(img));
-    GFS3D_LAUNCH_CHECK("knn_img_kernel");
+    const float *xpm = (xpm_in && C == 64) ? xpm_in : nullptr;      // the caller's copy is used as it is for 64 channels only
+    if (!xpm) {                                             // point-major rows (zero-padded to RW channels), image and norms in one pass
+        float *t = reinterpret_cast<float *>(ws + lay.off_pm);
+        hipLaunchKernelGGL(knn_prep_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, B, C, N, RW, t, reinterpret_cast<unsigned *>(img),
+                           have_norms ? nullptr : sq);
+        GFS3D_LAUNCH_CHECK("knn_prep_kernel");
+        xpm = t;
+    } else {
+        if (!have_norms) {
+            hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
+            GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
+        }
+        const long long rows = (long long)B * N;
+        hipLaunchKernelGGL(knn_img_kernel, dim3((unsigned)(((rows + KS_SLACK_ROWS) * (RW / 2) + 255) / 256)), dim3(256), 0, st, xpm, rows, RW, reinterpret_cast<unsigned *>(img));
+        GFS3D_LAUNCH_CHECK("knn_img_kernel");
+    }
     const size_t lds = ks_lds(NKB);
     const int groups = (B + 7) / 8;
     const bool wide = qw_env ? qw_env == 8 : (long long)((N + 255) / 256) * groups * 8 >= 224;      // 256-query blocks still cover the chip

@@ -33,6 +33,9 @@ struct RowGemm {
     int a_segw, lda;
     const float *pa, *pb, *pc;  // prologue coefficients per K channel
     const float *w;           // (Nc, K) row-major, K contiguous
+    int w_pq;                 // plain kernel only, != 0: w is an EdgeConv first convolution (64, 2 K) = [Wa | Wb]; the GEMM's 128 rows are [Wa; Wb - Wa]
+    double *zero;             // plain kernel only: block 0 clears nzero doubles (BatchNorm accumulators of the caller's next passes)
+    int nzero;
     const void *w3;           // bf16x3 image of w for the split kernel: [Nc][K/32][3 planes][32] bf16
     int M, K, Nc;
     float slope;
@@ -246,8 +249,18 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
             }
         }
 #pragma unroll
-        for (int p = 0; p < NB; ++p) rw[p] = ldg4(g.w + (size_t)(col0 + r0 + 32 * p) * g.K + kcol);
+        for (int p = 0; p < NB; ++p) {
+            const int n = col0 + r0 + 32 * p;
+            if (g.w_pq) {
+                const float *wr = g.w + (size_t)(n & 63) * 2 * g.K + kcol;
+                const f32x4 wa = ldg4(wr);
+                rw[p] = n < 64 ? wa : ldg4(wr + g.K) - wa;
+            } else
+                rw[p] = ldg4(g.w + (size_t)n * g.K + kcol);
+        }
     };
+    if (g.zero && blockIdx.x == 0)
+        for (int z = t; z < g.nzero; z += 256) g.zero[z] = 0.0;
     auto store = [&](int kt, int buf) {
         const int kcol = kt * PW_BK + 4 * c4;
         f32x4 ca = zero4, cb4 = zero4, cc = zero4;
@@ -1017,7 +1030,7 @@ void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev
 }  // namespace
 
 int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc, float *const *out, int o_segw,
-                  const float *ea, const float *eb, hipStream_t st, const char *who)
+                  const float *ea, const float *eb, hipStream_t st, const char *who, int w_pq, double *zero, int nzero)
 {
     if (K % PW_BK || Nc % 64 || o_segw % 64 || Nc / o_segw > 4 || Nc % o_segw) {
         set_error("%s: pw_plain_gemm: unsupported shape K=%d Nc=%d segw=%d", who, K, Nc, o_segw);
@@ -1026,6 +1039,7 @@ int pw_plain_gemm(const float *a, int lda, const float *w, int M, int K, int Nc,
     RowGemm rg{};
     rg.a[0] = a; rg.a_segw = K; rg.lda = lda; rg.K = K;
     rg.w = w; rg.M = M; rg.Nc = Nc;
+    rg.w_pq = w_pq; rg.zero = zero; rg.nzero = nzero;
     for (int s = 0; s < Nc / o_segw; ++s) rg.out[s] = out[s];
     rg.o_segw = o_segw;
     if (ea && eb) {                                  // affine epilogue, identity activation
