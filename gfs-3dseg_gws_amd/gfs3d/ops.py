@@ -1049,17 +1049,34 @@ def capl_eval_head(feat, main_proto, gened_proto, word, coding, th, base_num, y=
     return logits, stats[0], stats[1]
 
 
-def label_presence(y: torch.Tensor):
-    """Sorted list of the distinct labels in [0, 64) of an int64 HIP tensor: one small kernel (integer OR) and an 8-byte
-    read-back instead of torch.unique's device sort (generate_fake_proto's `unique(y)`, capl.py:378-386)."""
+def label_presence_begin(y: torch.Tensor):
+    """Queue the label-presence kernel and the 8-byte copy to pinned host memory; label_presence_end() waits for that copy only.
+    Between the two the caller can queue work that does not depend on the answer (capl.forward queues the whole backbone), so
+    the host's wait hides behind device work instead of leaving the device idle while the host reacts."""
     if not (y.is_cuda and y.dtype == torch.int64):
         raise RuntimeError("gfs3d.label_presence: labels must be an int64 HIP tensor")
     y = y.contiguous()
     mask = torch.empty(1, dtype=torch.int64, device=y.device)
     with torch.cuda.device(y.device):
         _lib.check(_lib.lib().gfs3d_label_presence(_p(y), y.numel(), _p(mask), _stream()), "gfs3d_label_presence")
-    m = int(mask.item()) & 0xFFFFFFFFFFFFFFFF
+        host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+        host.copy_(mask, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+    return host, done, mask            # (mask: kept alive until the copy has run)
+
+
+def label_presence_end(handle):
+    host, done, _ = handle
+    done.synchronize()
+    m = int(host.item()) & 0xFFFFFFFFFFFFFFFF
     return [c for c in range(64) if (m >> c) & 1]
+
+
+def label_presence(y: torch.Tensor):
+    """Sorted list of the distinct labels in [0, 64) of an int64 HIP tensor: one small kernel (integer OR) and an 8-byte
+    read-back instead of torch.unique's device sort (generate_fake_proto's `unique(y)`, capl.py:378-386)."""
+    return label_presence_end(label_presence_begin(y))
 
 
 def capl_train_head(feat, main_proto, bg_proto, y, fake, base_num, ignore_index=-100):

@@ -180,12 +180,19 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         nb = self.base_num
         half = x.size(0) // 2
         fake_novel = None
+        pending = None
         if not eval_model:
             # The fake-novel draw needs the set of classes present in the support half ON THE HOST (python RNG, as the
-            # reference): do it BEFORE the backbone is queued, so that the host waits for one tiny kernel on the labels and
-            # not for the whole forward pass (the same draw from the same RNG state: nothing else consumes `random` between)
-            fake_novel = self._draw_fake_novel(y[half:])
+            # reference).  The presence kernel and its 8-byte copy are queued BEFORE the backbone and read AFTER the backbone has
+            # been queued: the host waits for one tiny kernel on the labels while the device has the whole forward pass to run
+            # (waiting right here left the device idle for ~0.15 ms per step while the host reacted; the same draw from the
+            # same RNG state: nothing consumes python's `random` in between).
+            pending = self._present_begin(y[half:])
+            if pending is None:
+                fake_novel = self._draw_fake_novel(y[half:])
         point_feat, _, word = self._features(x, want_semantic=False, want_onehot=False)      # word: (B,N) index
+        if pending is not None:
+            fake_novel = self._draw_fake_novel(y[half:], present=self._present_end(pending))
 
         if eval_model:
             if gened_proto.dim() == 3:
@@ -266,14 +273,29 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             proto = proto.index_copy(0, cls_idx - 1, mean)
         return proto, fake_novel
 
-    def _draw_fake_novel(self, y, n_cls=None):
+    def _present_begin(self, y):
+        """Queue the label presence of y for a later _present_end(); None when the synchronous path has to be taken
+        (block-sharded batch: a collective; labels not on the fused kernel's path)."""
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        if dp or not (y.is_cuda and y.dtype == torch.int64 and self.main_proto.size(0) < 64):
+            return None
+        return ops.label_presence_begin(y)
+
+    def _present_end(self, pending):
+        n_cls = self.main_proto.size(0)
+        return [v for v in ops.label_presence_end(pending) if v != 0 and v <= n_cls]
+
+    def _draw_fake_novel(self, y, n_cls=None, present=None):
         """Half of the foreground classes present in y (python RNG, reference capl.py:384-390).  Block-sharded batch: the
         class set is the union over ranks (one MAX all-reduce of a presence vector); every rank then draws the SAME sample
         (python RNG seeded alike on all ranks, as train.py does)."""
         n_cls = self.main_proto.size(0) if n_cls is None else n_cls
         dp = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
-        if dp:
+        if present is not None:
+            pass
+        elif dp:
             seen = torch.zeros(n_cls + 1, dtype=torch.int32, device=y.device)
             seen[y.unique().long().clamp_max(n_cls)] = 1
             torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
