@@ -429,7 +429,7 @@ def main():
             roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
             if dom == 2:
-                roof["traffic_note"] = ("ec_main_bwd_kernel: ~184 MB read (P', Q', neighbour ids, winners, gradients) + ~357 MB of plain 256-B row "
+                roof["traffic_note"] = ("ec_main_bwd_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients; 184 MB before the clouds were dealt to XCDs, r03_d) + ~357 MB of plain 256-B row "
                                         "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once "
                                         "(the fixed-order replacement of round 1's float-atomic scatter)")
         roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass). f32 mode: against "
@@ -449,9 +449,10 @@ def main():
             roof["knn"] = {"ms_per_step": round(kms, 4), "algorithmic_GBps": round(kb / (kms * 1e-3) / 1e9, 2),
                            "algorithmic_TFLOPps": round(kfl, 2), "frac_of_fp32_peak": round(kfl / PEAK_FP32_TFLOPS, 4)}
             # "kNN HBM GB/s" as MEASURED by the committed PMC passes: FETCH (x2) + WRITE bytes of the kNN kernels of one
-            # step (C = 9 layer: <20, 1> screen + <20, 16> exact + point-major copy / norms; two C = 64 layers: <20, 4> + <20, 64>)
-            per_step = {"knn_screen_kernel<20, 1>": 1, "knn_exact_kernel<20, 16>": 1, "knn_pm_kernel": 1, "knn_sqnorm_kernel": 1,
-                        "knn_screen_kernel<20, 4>": 2, "knn_exact_kernel<20, 64>": 2}
+            # step (C = 9 layer: <20, 1, QW> screen + <20, 16> exact + knn_prep_kernel (rows, image, norms); two C = 64 layers:
+            # knn_img_kernel + <20, 4, QW> + <20, 64>)
+            per_step = {"knn_screen_kernel<20, 1,": 1, "knn_exact_kernel<20, 16>": 1, "knn_prep_kernel": 1, "knn_img_kernel": 2,
+                        "knn_screen_kernel<20, 4,": 2, "knn_exact_kernel<20, 64>": 2}
             tb, src = 0, None
             for name, n in per_step.items():
                 t_, s_ = hbm_traffic(name, "r03")
