@@ -1019,7 +1019,7 @@ static int knn_entry(const char *who, const float *x, const float *x_pm, const f
         GFS3D_REQUIRE((size_t)C * N * 4 < 0x7fffffffull, "%s: C*N too large for 32-bit buffer offsets", who);
         const KnnWs lay = knn_ws(B, C, N, k);
         static const bool screen_on = [] { const char *e = getenv("GFS3D_KNN_SCREEN"); return !(e && e[0] == '0'); }();     // A-B only
-        const bool screened = screen_on && (N & 3) == 0 && N >= 8 && workspace != nullptr && workspace_bytes >= lay.total &&
+        const bool screened = screen_on && N >= 8 && workspace != nullptr && workspace_bytes >= lay.total &&
                               (long long)B * N * KS_CAP < (1ll << 31);
         float *sq = const_cast<float *>(norms);
         if (!norms) {

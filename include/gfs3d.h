@@ -90,7 +90,7 @@ int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, 
                              int64_t *idx64, int32_t *idx32, void *stream);
 
 /* The general form: x_pm, if not NULL, is the point-major copy (B, N, 64) of x with C == 64 (what the EdgeConv entry points
- * leave in y_pm; ignored for other C) and sqnorm, if not NULL, the point norms as above.  With C <= 64, k <= 32, N % 4 == 0
+ * leave in y_pm; ignored for other C) and sqnorm, if not NULL, the point norms as above.  With C <= 64, k <= 32, N >= 8
  * and the full workspace (gfs3d_knn_workspace_bytes) the graph is built by the SCREENED path: all distances approximately
  * on the bf16 matrix cores with a rigorous error bound (operands of <= 16 channels in one K-step, else four), the exact
  * fp32 chain only for the ~k + 10 candidates per point that can reach the result - the same indices bit for bit. */

@@ -54,6 +54,8 @@ def relerr(a, b):
     # DMA-staged screen: a last stage of 64 (C > 16) / 128 (C <= 16) rows that is ragged in every way (rows of the next cloud
     # and of the zeroed slack behind the last one land in LDS), 256-query blocks (B N / 256 >= 224) with a ragged last block
     (3, 64, 68, 20, "randn"), (2, 16, 132, 20, "offset"), (9, 40, 1996, 20, "relu"), (16, 9, 3972, 20, "blocks"),
+    # N of any remainder mod 4 (the round-2 staging needed N % 4 == 0; the image rows do not)
+    (2, 64, 131, 20, "randn"), (3, 9, 1001, 20, "blocks"), (1, 33, 2050, 20, "offset"), (2, 64, 66, 32, "twins"),
 ])
 def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
     from gfs3d import ops
