@@ -223,14 +223,19 @@ class EdgeConvRun:
         f32 = dict(dtype=torch.float32, device=dev)
         if dy is None and dy_pm is None:
             raise RuntimeError("gfs3d.edgeconv: backward without a gradient")
-        self.dy = dy.contiguous() if dy is not None else None
+        # a channel slice of a wider (B, C', N) gradient (torch.cat of the blocks' outputs upstream) is read in place through
+        # its batch stride - .contiguous() was a 17 MB copy per block and step
+        if dy is not None and not (dy.dim() == 3 and dy.dtype == torch.float32 and dy.stride(2) == 1 and dy.stride(1) == self.N
+                                   and dy.stride(0) >= EC_WIDTH * self.N):
+            dy = dy.contiguous()
+        self.dy = dy
         self.dy_pm = dy_pm.contiguous() if dy_pm is not None else None
         self.dx = torch.empty_like(self.x)
         self.dw1, self.dw2 = torch.empty_like(self.w1), torch.empty_like(self.w2)
         self.dg1, self.db1, self.dg2, self.db2 = (torch.empty(EC_WIDTH, **f32) for _ in range(4))
         ba = EdgeConvBwdArgs()
         ws = self._args(ba.f, with_running=False)
-        ba.dy_cf, ba.dy_bstride = (self.dy.data_ptr() if self.dy is not None else None), EC_WIDTH * self.N
+        ba.dy_cf, ba.dy_bstride = (self.dy.data_ptr() if self.dy is not None else None), (self.dy.stride(0) if self.dy is not None else EC_WIDTH * self.N)
         ba.dy_pm = self.dy_pm.data_ptr() if self.dy_pm is not None else None
         ba.dx = self.dx.data_ptr()
         ba.dw1, ba.dbn1_w, ba.dbn1_b = self.dw1.data_ptr(), self.dg1.data_ptr(), self.db1.data_ptr()
