@@ -340,9 +340,6 @@ csr_place_kernel(const int32_t *__restrict__ idx, const unsigned short *__restri
     const int span = csr_span(N, R);
     const int r_lo = min(N, r * CSR_WAVES * span), r_hi = min(N, r_lo + CSR_WAVES * span);      // this workgroup's sources
     const int32_t *ib = idx + (size_t)b * ne;
-#ifdef CSR_TIMING
-    const long long t0 = wall_clock64();
-#endif
     for (int q = tid; q < (CSR_WAVES / 2) * N; q += CSR_THREADS) cw[q] = 0u;
     __syncthreads();
     // A: the edges of the own range, 8 loads in flight per thread
@@ -364,9 +361,6 @@ csr_place_kernel(const int32_t *__restrict__ idx, const unsigned short *__restri
         }
     }
     __syncthreads();
-#ifdef CSR_TIMING
-    const long long t1 = wall_clock64();
-#endif
     // B: per target, the in-edges from earlier ranges + the exclusive prefix over the waves; thread t owns the `per`
     // consecutive targets t per ..
     const int per = (N + CSR_THREADS - 1) / CSR_THREADS;
@@ -416,9 +410,6 @@ csr_place_kernel(const int32_t *__restrict__ idx, const unsigned short *__restri
     }
     if (b == B - 1 && r == 0 && tid == 0) rowptr[(size_t)B * N] = B * ne;
     __syncthreads();
-#ifdef CSR_TIMING
-    const long long t2 = wall_clock64();
-#endif
     // C: ordered placement
     unsigned *cur = cw + (size_t)(wv >> 1) * N;             // this wave's cursors: the low (even wave) or high half of word m
     const unsigned one = (wv & 1) ? 0x10000u : 1u;
@@ -440,10 +431,6 @@ csr_place_kernel(const int32_t *__restrict__ idx, const unsigned short *__restri
             }
         }
     }
-#ifdef CSR_TIMING
-    __syncthreads();
-    if (tid == 0 && b == 5 && r == 3) printf("csr_place ticks A %lld B %lld C %lld\n", t1 - t0, t2 - t1, wall_clock64() - t2);
-#endif
 }
 // SQ[m] = sum over the in-edges of m, in CSR (= ascending source) order, of Q[source]; in-degree.
 // lane = (row slot sub = lane >> 4, channel quad c4 = lane & 15): a wave instruction gathers 4 rows of 256 B as 16-byte
