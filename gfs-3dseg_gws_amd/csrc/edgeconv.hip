@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(256)
 ec_epilogue_kernel(const float *__restrict__ hwin, const uint8_t *__restrict__ jwin,
                    const BnFin fin, float *__restrict__ stats, int N, float slope,
                    float *__restrict__ y_cf, long long y_bstride, float *__restrict__ y_pm,
-                   float *__restrict__ hsel, uint8_t *__restrict__ jsel, float *__restrict__ y_sq)
+                   float *__restrict__ hsel, uint8_t *__restrict__ jsel, float *__restrict__ y_sq, unsigned *__restrict__ y_img, int B)
 {
     __shared__ float tile[64][65];
     __shared__ float scs[EC], shs[EC];
@@ -862,6 +862,19 @@ ec_epilogue_kernel(const float *__restrict__ hwin, const uint8_t *__restrict__ j
         for (int c = wv; c < EC; c += 4) {
             if (n0 + p < N) y_cf[(size_t)b * y_bstride + (size_t)c * N + n0 + p] = tile[p][c];
         }
+    }
+    if (y_img) {       // the next block's screened kNN reads these rows ([hi 64 x bf16 | mid 64 x bf16], knn.hip: knn_img_kernel)
+        if (co < 32)
+            for (int q = wv; q < 64; q += 4)
+                if (n0 + q < N) {
+                    unsigned hh, mm;
+                    mm_split2_rne(tile[q][2 * co], tile[q][2 * co + 1], hh, mm);
+                    unsigned *row = y_img + ((size_t)b * N + n0 + q) * EC;
+                    row[co] = hh;
+                    row[32 + co] = mm;
+                }
+        if (blockIdx.x == 0 && blockIdx.y == 0)
+            for (int e = tid; e < GFS3D_KNN_IMG_SLACK_ROWS * EC; e += 256) y_img[(size_t)B * N * EC + e] = 0u;
     }
 }
 
@@ -2013,7 +2026,7 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
         hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, jmax, fin2, a->stats, a->N, a->slope,
-                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm);
+                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm, static_cast<unsigned *>(a->y_knn_img), a->B);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
         if (a->training)
             if (int rc = side_join(st, who)) return rc;

@@ -493,7 +493,7 @@ knn_mfma_kernel(const float *__restrict__ x, const float *__restrict__ sqg, int 
 constexpr float KNN_SCREEN_REL = 1.25e-4f;     // > 2 (2^-15 (1 + 2^-6) + 192 2^-23 + 64 2^-24) = 1.18e-4, see above
 constexpr float KNN_SCREEN_ABS = 4e-6f;        // the roundings of 2 dot - |xj|^2 - |xi|^2 in both forms, relative to |xi|^2 + max |xj|^2
 constexpr int KS_QS = 32;                      // candidate ids a lane (= query half) may store
-constexpr int KS_SLACK_ROWS = 128;                // zeroed image rows behind the last cloud (>= rows of a screen stage)
+constexpr int KS_SLACK_ROWS = GFS3D_KNN_IMG_SLACK_ROWS;   // zeroed image rows behind the last cloud (>= rows of a screen stage)
 constexpr int KS_CAP = 64;                     // candidate ids kept per query
 template <int V> struct ks_int { static constexpr int value = V; };
 
@@ -917,7 +917,7 @@ static KnnWs knn_ws(int B, int C, int N, int k)
 }
 
 template <int K, int NKB>
-static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, bool have_norms, int B, int C, int N, int k,
+static int launch_knn_screened(const float *x, const float *xpm_in, const void *img_in, float *sq, bool have_norms, int B, int C, int N, int k,
                                int64_t *idx64, int32_t *idx32, char *ws, const KnnWs &lay, hipStream_t st)
 {
     const char *who = "gfs3d_knn_topk_f32(screened)";
@@ -925,12 +925,12 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
     constexpr int RW = 16 * NKB;
     int *cand = reinterpret_cast<int *>(ws + lay.off_cand), *ccnt = reinterpret_cast<int *>(ws + lay.off_cnt);
     static const int qw_env = [] { const char *e = getenv("GFS3D_KNN_SCREEN_QW"); return e ? atoi(e) : 0; }();        // A-B only
-    unsigned char *img = reinterpret_cast<unsigned char *>(ws + lay.off_img);
+    const unsigned char *img = reinterpret_cast<unsigned char *>(ws + lay.off_img);
     const float *xpm = (xpm_in && C == 64) ? xpm_in : nullptr;      // the caller's copy is used as it is for 64 channels only
     if (!xpm) {                                             // point-major rows (zero-padded to RW channels), image and norms in one pass
         float *t = reinterpret_cast<float *>(ws + lay.off_pm);
-        hipLaunchKernelGGL(knn_prep_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, B, C, N, RW, t, reinterpret_cast<unsigned *>(img),
-                           have_norms ? nullptr : sq);
+        hipLaunchKernelGGL(knn_prep_kernel, dim3((N + 63) / 64, B), dim3(256), 0, st, x, B, C, N, RW, t,
+                           reinterpret_cast<unsigned *>(ws + lay.off_img), have_norms ? nullptr : sq);
         GFS3D_LAUNCH_CHECK("knn_prep_kernel");
         xpm = t;
     } else {
@@ -938,9 +938,13 @@ static int launch_knn_screened(const float *x, const float *xpm_in, float *sq, b
             hipLaunchKernelGGL(knn_sqnorm_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, x, C, N, sq);
             GFS3D_LAUNCH_CHECK("knn_sqnorm_kernel");
         }
-        const long long rows = (long long)B * N;
-        hipLaunchKernelGGL(knn_img_kernel, dim3((unsigned)(((rows + KS_SLACK_ROWS) * (RW / 2) + 255) / 256)), dim3(256), 0, st, xpm, rows, RW, reinterpret_cast<unsigned *>(img));
-        GFS3D_LAUNCH_CHECK("knn_img_kernel");
+        if (img_in) img = static_cast<const unsigned char *>(img_in);      // the producer of x_pm wrote the operand rows as well
+        else {
+            const long long rows = (long long)B * N;
+            hipLaunchKernelGGL(knn_img_kernel, dim3((unsigned)(((rows + KS_SLACK_ROWS) * (RW / 2) + 255) / 256)), dim3(256), 0, st, xpm, rows, RW,
+                               reinterpret_cast<unsigned *>(ws + lay.off_img));
+            GFS3D_LAUNCH_CHECK("knn_img_kernel");
+        }
     }
     const size_t lds = ks_lds(NKB);
     const int groups = (B + 7) / 8;
@@ -1004,7 +1008,7 @@ extern "C" size_t gfs3d_knn_workspace_bytes(int B, int C, int N, int k)
     return (B < 1 || N < 1 || C < 1) ? 0 : gfs3d::knn_ws(B, C, N, k).total;
 }
 
-static int knn_entry(const char *who, const float *x, const float *x_pm, const float *norms, int B, int C, int N, int k,
+static int knn_entry(const char *who, const float *x, const float *x_pm, const void *x_img, const float *norms, int B, int C, int N, int k,
                      int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
     using namespace gfs3d;
@@ -1033,11 +1037,11 @@ static int knn_entry(const char *who, const float *x, const float *x_pm, const f
         if (screened) {
             char *ws = static_cast<char *>(workspace);
             if (C <= 16) {
-                if (k <= 20) return launch_knn_screened<20, 1>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
-                return launch_knn_screened<32, 1>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+                if (k <= 20) return launch_knn_screened<20, 1>(x, x_pm, x_img, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+                return launch_knn_screened<32, 1>(x, x_pm, x_img, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
             }
-            if (k <= 20) return launch_knn_screened<20, 4>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
-            return launch_knn_screened<32, 4>(x, x_pm, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            if (k <= 20) return launch_knn_screened<20, 4>(x, x_pm, x_img, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
+            return launch_knn_screened<32, 4>(x, x_pm, x_img, sq, norms != nullptr, B, C, N, k, idx64, idx32, ws, lay, st);
         }
         if (k <= 20 && C <= 10) return launch_knn_mfma<5, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
         if (k <= 20) return launch_knn_mfma<32, 20>(x, sq, norms != nullptr, B, C, N, k, idx64, idx32, st);
@@ -1052,7 +1056,7 @@ static int knn_entry(const char *who, const float *x, const float *x_pm, const f
 extern "C" int gfs3d_knn_topk_f32(const float *x, int B, int C, int N, int k,
                                   int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return knn_entry("gfs3d_knn_topk_f32", x, nullptr, nullptr, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
+    return knn_entry("gfs3d_knn_topk_f32", x, nullptr, nullptr, nullptr, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, int N, int k,
@@ -1060,11 +1064,17 @@ extern "C" int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int
 {
     using namespace gfs3d;
     GFS3D_REQUIRE(sqnorm != nullptr, "gfs3d_knn_topk_norms_f32: sqnorm is NULL");
-    return knn_entry("gfs3d_knn_topk_norms_f32", x, nullptr, sqnorm, B, C, N, k, idx64, idx32, nullptr, 0, stream);
+    return knn_entry("gfs3d_knn_topk_norms_f32", x, nullptr, nullptr, sqnorm, B, C, N, k, idx64, idx32, nullptr, 0, stream);
 }
 
 extern "C" int gfs3d_knn_topk_pm_f32(const float *x, const float *x_pm, const float *sqnorm, int B, int C, int N, int k,
                                      int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return knn_entry("gfs3d_knn_topk_pm_f32", x, x_pm, sqnorm, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
+    return knn_entry("gfs3d_knn_topk_pm_f32", x, x_pm, nullptr, sqnorm, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gfs3d_knn_topk_img_f32(const float *x, const float *x_pm, const void *x_img, const float *sqnorm, int B, int C, int N,
+                                      int k, int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return knn_entry("gfs3d_knn_topk_img_f32", x, x_pm, x_img, sqnorm, B, C, N, k, idx64, idx32, workspace, workspace_bytes, stream);
 }

@@ -16,6 +16,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
 _SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip")
 _lib = None
+KNN_IMG_SLACK_ROWS = 128      # GFS3D_KNN_IMG_SLACK_ROWS
 
 
 class EdgeConvArgs(Structure):
@@ -36,6 +37,7 @@ class EdgeConvArgs(Structure):
         ("y_sqnorm", c_void_p),
         ("compute", c_int),
         ("csr_rowptr", c_void_p), ("csr_pos", c_void_p),
+        ("y_knn_img", c_void_p),
     ]
 
 
@@ -142,6 +144,8 @@ SYMBOLS = {
     "gfs3d_knn_topk_norms_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfs3d_knn_topk_pm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
                                       c_void_p]),
+    "gfs3d_knn_topk_img_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_set_deterministic": (c_int, [c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),

@@ -96,12 +96,13 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 # K1
 # --------------------------------------------------------------------------
 def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = False, sqnorm: Optional[torch.Tensor] = None,
-             x_pm: Optional[torch.Tensor] = None):
+             x_pm: Optional[torch.Tensor] = None, x_img: Optional[torch.Tensor] = None):
     """x (B,C,N) channel-first -> neighbour indices (B,N,k), nearest first.
     Replaces knn() of model/dgcnn.py:17-23.  `sqnorm`: the point norms if the caller has them in the kernel's
     summation order (the third output of `edgeconv_block(..., want_sq=True)` for the previous block's features);
     `x_pm`: the (B,N,64) point-major values of x when C == 64 (the previous block's second output) - the screened
-    path's exact pass reads point rows."""
+    path's exact pass reads point rows; `x_img`: the screen's operand rows of the same features (the fourth output of
+    `edgeconv_block(..., want_img=True)`; used together with x_pm)."""
     _need_gpu(x, "x")
     if x.dim() != 3:
         raise RuntimeError("gfs3d.knn_topk: x must be (B,C,N)")
@@ -114,11 +115,15 @@ def knn_topk(x: torch.Tensor, k: int, want_i64: bool = True, want_i32: bool = Fa
         raise RuntimeError("gfs3d.knn_topk: sqnorm must be a contiguous fp32 tensor of B*N + 16 elements on x's device")
     if x_pm is not None and (C != 64 or tuple(x_pm.shape) != (B, N, 64) or not x_pm.is_contiguous() or x_pm.dtype != torch.float32):
         raise RuntimeError("gfs3d.knn_topk: x_pm must be the contiguous (B,N,64) fp32 point-major copy of a 64-channel x")
+    if x_img is not None and (x_pm is None or x_img.dtype != torch.int32 or not x_img.is_contiguous() or x_img.device != x.device
+                              or x_img.numel() < (B * N + _lib.KNN_IMG_SLACK_ROWS) * 64):
+        raise RuntimeError("gfs3d.knn_topk: x_img must be the int32 operand image (B*N + 128 rows of 64 dwords) that came with x_pm")
     with torch.cuda.device(x.device):
         L = _lib.lib()
         ws = _workspace(x.device, L.gfs3d_knn_workspace_bytes(B, C, N, int(k)))
-        rc = L.gfs3d_knn_topk_pm_f32(_p(x), _p(x_pm), _p(sqnorm), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(), _stream())
-    _lib.check(rc, "gfs3d_knn_topk_pm_f32")
+        rc = L.gfs3d_knn_topk_img_f32(_p(x), _p(x_pm), _p(x_img), _p(sqnorm), B, C, N, int(k), _p(i64), _p(i32), _p(ws), ws.numel(),
+                                      _stream())
+    _lib.check(rc, "gfs3d_knn_topk_img_f32")
     if want_i64 and want_i32:
         return i64, i32
     return i64 if want_i64 else i32
@@ -146,7 +151,7 @@ class EdgeConvRun:
     the C ABI either monolithically or phase by phase (synchronised BatchNorm)."""
 
     def __init__(self, x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope,
-                 private_workspace: bool = False, x_pm: Optional[torch.Tensor] = None):
+                 private_workspace: bool = False, x_pm: Optional[torch.Tensor] = None, want_img: bool = False):
         for t, nme in ((x, "x"), (w1, "conv1.weight"), (w2, "conv2.weight")):
             _need_gpu(t, nme)
         self.x = x.contiguous()
@@ -187,6 +192,8 @@ class EdgeConvRun:
         self.y_pm = torch.empty((B, N, EC_WIDTH), **f32)      # point-major copy: input of the point-wise stack (K4)
         self.y_sq = torch.empty(B * N + 16, **f32)            # |y_n|^2 for the next layer's kNN (+ the slack its 16-B reads need)
         self.y = torch.empty((B, EC_WIDTH, N), **f32)
+        # operand rows of y for the next block's screened kNN ([hi | mid] bf16 pairs, + the zeroed slack rows its last stage reads)
+        self.y_img = torch.empty((B * N + _lib.KNN_IMG_SLACK_ROWS) * EC_WIDTH, dtype=torch.int32, device=dev) if want_img else None
         nbytes = _lib.lib().gfs3d_edgeconv_workspace_bytes(B, C, N, k)
         self._private_ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev) if private_workspace else None
         self._nbytes = nbytes
@@ -216,6 +223,7 @@ class EdgeConvRun:
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         a.x_pm = self.x_pm.data_ptr() if self.x_pm is not None else None
         a.y_sqnorm = self.y_sq.data_ptr() if self.y_sq is not None else None
+        a.y_knn_img = self.y_img.data_ptr() if (self.y_img is not None and with_running) else None     # (forward only)
         return ws
 
     def _bwd_args(self, dy, dy_pm=None):
@@ -313,8 +321,9 @@ class EdgeConvFunction(torch.autograd.Function):
     gradients arriving through either are added."""
 
     @staticmethod
-    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync, x_pm):
-        run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope, x_pm=x_pm)
+    def forward(ctx, x, idx, w1, g1, b1, w2, g2, b2, rm1, rv1, rm2, rv2, training, eps, momentum, slope, sync, x_pm, want_img=False):
+        run = EdgeConvRun(x, idx, w1, g1, b1, rm1, rv1, w2, g2, b2, rm2, rv2, training, eps, momentum, slope, x_pm=x_pm,
+                          want_img=want_img)
         y = run.forward(sync)
         run.y = None                     # outputs must not be reachable from ctx (reference cycle through grad_fn)
         ctx.set_materialize_grads(False)
@@ -324,22 +333,27 @@ class EdgeConvFunction(torch.autograd.Function):
         y_sq = run.y_sq
         run.y_sq = None
         ctx.mark_non_differentiable(y_sq)
+        if want_img:
+            y_img = run.y_img
+            run.y_img = None
+            ctx.mark_non_differentiable(y_img)
+            return y, run.y_pm.detach(), y_sq, y_img
         return y, run.y_pm.detach(), y_sq      # y_pm is an alias: the backward reads it (sign of the activation)
 
     @staticmethod
-    def backward(ctx, dy, dy_pm, _dy_sq=None):
+    def backward(ctx, dy, dy_pm, _dy_sq=None, _dy_img=None):
         if not hasattr(ctx, "c"):
             raise RuntimeError("gfs3d.edgeconv: backward is implemented for training mode (batch statistics) only")
         if dy is None and dy_pm is None:
-            return (None,) * 18
+            return (None,) * 19
         grads = ctx.c.backward(dy, ctx.sync, dy_pm)
         dx, dw1, dg1, db1, dw2, dg2, db2 = grads
-        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 10
+        return (dx, None, dw1, dg1, db1, dw2, dg2, db2) + (None,) * 11
 
 
 def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: float = 0.2,
                    sync: Optional[BNSync] = None, want_pm: bool = False, x_pm: Optional[torch.Tensor] = None,
-                   track: bool = True, want_sq: bool = False):
+                   track: bool = True, want_sq: bool = False, want_img: bool = False):
     """Run one EdgeConv block given the two conv weights and the two
     nn.BatchNorm2d modules (their running stats are updated in place when
     training, like nn.BatchNorm2d does).  `sync`: share the batch statistics between ranks.  `x_pm`: the
@@ -351,10 +365,13 @@ def edgeconv_block(x, idx32, conv1_w, bn1, conv2_w, bn2, training: bool, slope: 
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
     mom = bn1.momentum if bn1.momentum is not None else 0.1
-    y, y_pm, y_sq = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
-                                     bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
-                                     bool(training), float(bn1.eps), float(mom), float(slope), sync,
-                                     x_pm.detach() if x_pm is not None else None)
+    out = EdgeConvFunction.apply(x, idx32, conv1_w, bn1.weight, bn1.bias, conv2_w, bn2.weight, bn2.bias,
+                                 bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var,
+                                 bool(training), float(bn1.eps), float(mom), float(slope), sync,
+                                 x_pm.detach() if x_pm is not None else None, bool(want_img))
+    y, y_pm, y_sq = out[0], out[1], out[2]
+    if want_img:                             # (+ the next block's screen operand rows: `knn_topk(..., x_img=)`)
+        return y, y_pm, y_sq, out[3]
     if want_sq:                              # (y, y_pm, |y|^2 in the kNN kernel's order: `knn_topk(..., sqnorm=)` of the next block)
         return y, y_pm, y_sq
     return (y, y_pm) if want_pm else y

@@ -144,8 +144,8 @@ class DGCNN(nn.Module):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
         with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
         feats, feats_pm, bns = [], [], []
-        x_pm = x_sq = None
-        for block in self.edge_convs:
+        x_pm = x_sq = x_img = None
+        for li, block in enumerate(self.edge_convs):
             # Shapes outside the fused kernel (reference conv2d accepts any layer_dims, dgcnn.py:45-58; k > 32; a backward pass in
             # eval mode): the graph still comes from the HIP kNN kernel (bit-exact contract), the block itself runs as the
             # reference wrote it - gather, cat, the nn.Sequential, max over k - as tensor-library ops on the device.
@@ -154,15 +154,20 @@ class DGCNN(nn.Module):
                 if self.bn_sync is not None and self.training:
                     raise NotImplementedError("gfs3d: synchronised BatchNorm is implemented for the fused EdgeConv shape ([64, 64], k <= 32) only")
                 x = block(get_edge_feature(x, self.k, ops.knn_topk(x.detach(), self.k))).max(dim=-1)[0]
-                x_pm = x_sq = None
+                x_pm = x_sq = x_img = None
                 feats.append(x)
                 feats_pm.append(None)
                 continue
             c1, bn1, c2, bn2 = block.fused_parts()
+            pm_ok = x_pm is not None and x.shape[1] == 64
             idx32 = ops.knn_topk(x.detach(), self.k, want_i64=False, want_i32=True, sqnorm=x_sq,
-                                 x_pm=x_pm.detach() if (x_pm is not None and x.shape[1] == 64) else None)
-            x, x_pm, x_sq = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
-                                               sync=self.bn_sync, x_pm=x_pm, track=False, want_sq=True)
+                                 x_pm=x_pm.detach() if pm_ok else None, x_img=x_img if pm_ok else None)
+            # the block's epilogue leaves what the NEXT block's kNN needs: norms, point-major rows and the screen's operand rows
+            nxt = li + 1 < len(self.edge_convs)
+            x, x_pm, x_sq, x_img = ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
+                                                      sync=self.bn_sync, x_pm=x_pm, track=False, want_sq=True, want_img=True) \
+                if nxt else ops.edgeconv_block(x, idx32, c1.weight, bn1, c2.weight, bn2, self.training, _LRELU,
+                                               sync=self.bn_sync, x_pm=x_pm, track=False, want_sq=True) + (None,)
             bns += [bn1, bn2]
             feats.append(x)
             feats_pm.append(x_pm)

@@ -97,6 +97,13 @@ int gfs3d_knn_topk_norms_f32(const float *x, const float *sqnorm, int B, int C, 
 int gfs3d_knn_topk_pm_f32(const float *x, const float *x_pm, const float *sqnorm, int B, int C, int N, int k,
                           int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the screen's operand image handed over as well: x_img = what gfs3d_edgeconv_forward_f32 leaves in y_knn_img
+ * for the same features (used with C == 64 and x_pm given; ignored otherwise) - the call then launches the screen and the
+ * exact pass only. */
+#define GFS3D_KNN_IMG_SLACK_ROWS 128
+int gfs3d_knn_topk_img_f32(const float *x, const float *x_pm, const void *x_img, const float *sqnorm, int B, int C, int N, int k,
+                           int64_t *idx64, int32_t *idx32, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ K2 --
  * One EdgeConv block = get_edge_feature (dgcnn.py:26-42) + conv2d block
  * [1x1 conv -> BatchNorm2d -> LeakyReLU(0.2)] x2 (dgcnn.py:45-61) + max over
@@ -139,6 +146,9 @@ typedef struct gfs3d_edgeconv_args {
                                      edges per block; idx values outside [0, N) are a caller error - the graph builder clamps them): the training forward builds the reverse kNN graph in CSR form and the
                                      backward stores per-edge rows + sums CSR segments instead of float atomics - every sum over
                                      the in-edges of a point then has a fixed order.  NULL: slot table + float atomics */
+    void *y_knn_img;              /* optional out, (B*N + GFS3D_KNN_IMG_SLACK_ROWS) rows of 256 bytes: the operand rows of y for the
+                                     next block's screened kNN ([hi 64 x bf16 | mid 64 x bf16] per point, the slack rows zeroed) -
+                                     hand it to gfs3d_knn_topk_img_f32 together with y_pm and y_sqnorm instead of an image pass */
 } gfs3d_edgeconv_args;
 
 size_t gfs3d_edgeconv_workspace_bytes(int B, int C, int N, int k);

@@ -1441,6 +1441,21 @@ def test_edgeconv_norm_handoff_is_bit_exact(dev):
         for c in range(64):
             ref = (ref + (yc[:, c, :] * yc[:, c, :]).astype(np.float32)).astype(np.float32)
         assert np.array_equal(y_sq[:B * N].cpu().numpy().reshape(B, N), ref)
+        # the screen's operand rows as well (round 3): [hi | mid] bf16 pairs of y's point-major rows, zeroed slack behind them -
+        # the same rows the kNN call builds itself, hence the same graph
+        with torch.no_grad():
+            y2, y_pm2, y_sq2, y_img = ops.edgeconv_block(x, idx, c1.weight, bn1, c2.weight, bn2, training, want_sq=True, want_img=True)
+        assert torch.equal(y2, y) and torch.equal(y_pm2, y_pm)
+        c = ops.knn_topk(y, k, sqnorm=y_sq2, x_pm=y_pm2, x_img=y_img)
+        assert torch.equal(a, c)
+        rows = y_img[:B * N * 64].view(B * N, 64)
+        hi = (rows[:, :32].to(torch.int64) & 0xFFFFFFFF)
+        lo16 = ((hi & 0xFFFF) << 16).to(torch.int32).view(torch.float32)         # channel 2 p
+        up16 = (hi & 0xFFFF0000).to(torch.int32).view(torch.float32)             # channel 2 p + 1
+        yv = y_pm2.reshape(B * N, 64)
+        assert float((lo16 - yv[:, 0::2]).abs().max()) <= float(yv.abs().max()) * 2.0 ** -8
+        assert float((up16 - yv[:, 1::2]).abs().max()) <= float(yv.abs().max()) * 2.0 ** -8
+        assert int(y_img[B * N * 64:].abs().max()) == 0
 
 
 @pytest.mark.parametrize("widths,k,training", [([[32, 48], [64, 64]], 10, False), ([[64, 64, 32]], 8, True), ([[64, 64], [64, 64]], 40, False)])
