@@ -1013,7 +1013,7 @@ constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-#ifndef GFS3D_ABL          // ablation builds only (scripts/build_ablation.sh): 1 no G_P atomics, 2 gather one fixed row, 4 no dW2 product
+#ifndef GFS3D_ABL          // ablation builds only (scripts/build_ablation.sh): 1 no G_P atomics, 2 gather one fixed row, 4 no dW2 product, 8 no a1 split for the dW2 product
 #define GFS3D_ABL 0
 #endif
 constexpr int BWD_WAVES = 4;
@@ -1204,11 +1204,17 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             for (int kb = 0; kb < 2; ++kb) {
                 float v8[8];
                 uint4 d[NP], x0[NP], x1[NP];
-                pieces(aD0 + 8 * kb, x0);
-                pieces(aD1 + 8 * kb, x1);
+                if (!(GFS3D_ABL & 8)) {
+                    pieces(aD0 + 8 * kb, x0);
+                    pieces(aD1 + 8 * kb, x1);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = acc0[8 * kb + e];
                 pieces(v8, d);
+                if (GFS3D_ABL & 8) {
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) { x0[pc] = d[pc]; x1[pc] = d[(pc + 1) % NP]; }
+                }
 #pragma unroll
                 for (int pc = 0; pc < NP; ++pc)
                     *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + i * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
