@@ -1013,7 +1013,7 @@ constexpr int BWD_PART = EC * EC;
 constexpr int TLD = EC + 4;
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-#ifndef GFS3D_ABL          // ablation builds only (scripts/build_ablation.sh): 1 no G_P atomics, 2 gather one fixed row, 4 no dW2 product, 8 no a1 split for the dW2 product
+#ifndef GFS3D_ABL          // ablation builds only (scripts/build_ablation.sh): 1 no G_P atomics, 2 gather one fixed row, 4 no dW2 product, 8 no a1 split for the dW2 product, 16 no dy1 row stores, 32 / 64 no MFMAs in GEMM 3 / GEMM 1
 #define GFS3D_ABL 0
 #endif
 constexpr int BWD_WAVES = 4;
@@ -1163,7 +1163,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 pieces(a + 8 * kb, ap);
-                mac2(ap, b0, b1, acc0, acc1);
+                if (!(GFS3D_ABL & 64)) mac2(ap, b0, b1, acc0, acc1);
+                else asm volatile("" :: "v"(ap[0].x), "v"(b0[0].x), "v"(b1[0].x));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // a1: A-layout -> C/D layout through the transpose tile
@@ -1264,7 +1265,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                     }
                     ap[pc] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
-                mac2(ap, b0, b1, e0, e1);
+                if (!(GFS3D_ABL & 32)) mac2(ap, b0, b1, e0, e1);
+                else asm volatile("" :: "v"(ap[0].x), "v"(b0[0].x), "v"(b1[0].x));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // dy1 = dA1 * LReLU'(z1); G_Q (in-lane), G_P (atomic 128-B half rows)
@@ -1282,8 +1284,10 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;
                 if (CSR) {                                  // (a masked row's values are 0 and its row is the wave's scratch row)
                     if constexpr (PREC == PREC_X6) {
-                        dyb[row] = dy0;
-                        dyb[row + 32] = dy1;
+                        if (!(GFS3D_ABL & 16)) {
+                            dyb[row] = dy0;
+                            dyb[row + 32] = dy1;
+                        } else asm volatile("" :: "v"(dy0), "v"(dy1));
                     } else {
                         // reduced modes: the row as 32 dwords of two bf16 (channels i | 32 + i) - half the bytes of the one
                         // tensor of size N k 64 the backward writes and ec_bwd_segsum_kernel reads back (the kernel is bound by
