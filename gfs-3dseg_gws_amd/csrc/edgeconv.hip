@@ -1328,6 +1328,348 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
         out[e] = ((smem[e] + smem[EC * EC + e]) + smem[2 * EC * EC + e]) + smem[3 * EC * EC + e];
 }
 
+// B3': the same backward (fp32-accurate mode, CSR form) as a PAIR of waves per SIMD.  In ec_main_bwd_kernel a wave's matrix
+// work (3 x 48 MFMAs per tile = 4.6 k cycles), its ~1200 vector instructions and its LDS / gather round trips are strictly serial
+// (one wave per SIMD: 352 registers) - ablations: the MFMAs are 32 % of the time and overlap with nothing.  Here wave p (FRONT)
+// and wave p + 4 (BACK) of an 8-wave workgroup share SIMD p and split a tile:
+//   FRONT  gather P' rows (registers, one tile ahead), a1 = LReLU(P'[m] + Q'[n]), split, (1) H2 = A1 W2^T, dH2 in place;
+//          hands over, through LDS: the a1 pieces as they stand in the A layout (`aimg`: rows = edges, 128 B per plane),
+//          the dH2 pieces (`dimg`, as before) and the sign masks of a1;
+//   BACK   (2) dW2 += dH2^T A1: A = dimg rows as written, B = aimg read TRANSPOSED (ds_read_b64_tr_b16: lane = channel, 8
+//          edges) - no fp32 transpose of a1 and no second split;  (3) dA1 = dH2 W2: A = dimg transposed (as before), B = the
+//          ONE W2 image read transposed (no W2^T image);  dy1, G_Q, the row stores.
+// The hand-off is single-buffered: FRONT works one tile ahead and keeps its a1 pieces in registers; two workgroup barriers per
+// tile (X: BACK has read tile g - 1, FRONT may write tile g; Y: tile g is in LDS).  Both roles fit 256 registers.
+// LDS: W2 image 25.6 KB + per pair (aimg 12 KB + dimg 12 KB + Q' tile 2 KB + CSR rows 1 KB + masks) = 135 KB.
+constexpr int BP_PAIRS = 4;
+constexpr int BP_AIMG = 3 * 32 * 128;                                       // bytes: a1 piece planes [plane][edge][64 ci], 16-B slots swizzled
+constexpr int BP_PAIR_LDS = BP_AIMG + BWD_DIMG + 8 * EC * 4 + 8 * 32 * 4 + 64 * 4;      // aimg | dimg | Q' tile | CSR rows | sign masks
+constexpr size_t BP_LDS_BYTES = EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS + 192 * 4;
+static_assert(BP_LDS_BYTES >= (size_t)BP_PAIRS * EC * EC * 4, "the dW2 reduction images reuse the workgroup's LDS");
+
+__global__ void __launch_bounds__(128 * BP_PAIRS)
+ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
+                        const float *__restrict__ w2, const CoefIn cin,
+                        const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
+                        int BN, int N, int k, float slope,
+                        float *__restrict__ GQ, float *__restrict__ partial,
+                        const int *__restrict__ pos, float *__restrict__ dyb)
+{
+    constexpr int PREC = PREC_X6, NP = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] pieces of W2
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pair = wv & 3;
+    const bool front = wv < BP_PAIRS;
+    const int i = lane & 31, h = lane >> 5;
+    unsigned char *pbase = sW3 + EC * BWD_WROW + (size_t)pair * BP_PAIR_LDS;
+    unsigned char *aimg = pbase;
+    unsigned char *dimg = aimg + BP_AIMG;
+    float *qt = reinterpret_cast<float *>(dimg + BWD_DIMG);             // [8][64] Q' rows of FRONT's super-tile
+    int *pall = reinterpret_cast<int *>(qt + 8 * EC);                   // [8][32] CSR row of each row of each tile of BACK's super-tile
+    unsigned *smask = reinterpret_cast<unsigned *>(pall + 8 * 32);      // [2][32] sign masks of a1: [channel half][edge]
+    float *sC = reinterpret_cast<float *>(sW3 + EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS);
+    const int trash_row = BN * k + (int)(blockIdx.x * BP_PAIRS + pair);  // where masked rows are stored (never read)
+
+    for (int e = tid; e < EC * EC; e += 128 * BP_PAIRS)
+        mm_store1<PREC>(w2[e], reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * BWD_WROW) + (e & 63), EC);
+    if (tid < EC) bwd_coef(cin, tid, blockIdx.x == 0, sC);
+    __syncthreads();
+
+    const int pA = 4 * ((i >> 2) & 1) + (i >> 3), jjA = i & 3;
+    const int T = (k + 3) >> 2;
+    const int nst = (BN + 7) >> 3;
+    const UnitDeal deal(nst, N >> 3, BN / N, (N & 7) == 0, BP_PAIRS, pair);
+    const int first0 = deal.first - pair;                                 // pair 0's first unit: the longest walk of the workgroup
+    const int nsup = deal.count > first0 ? (deal.count - first0 + deal.stride - 1) / deal.stride : 0;
+    const int G = nsup * T;                                               // tile steps every pair runs (uniform barrier count)
+
+    auto mac2 = [&](const uint4 (&a_)[NP], const uint4 (&b0_)[NP], const uint4 (&b1_)[NP], f32x16 &c0, f32x16 &c1) {
+        constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+            c0 = mm_mfma<PREC>(a_[PA[term]], b0_[PB[term]], c0);
+            c1 = mm_mfma<PREC>(a_[PA[term]], b1_[PB[term]], c1);
+        }
+    };
+
+    if (front) {
+        // ------------------------------------------------------------------ FRONT
+        const unsigned char *wr0 = sW3 + i * BWD_WROW + 64 * h, *wr1 = sW3 + (32 + i) * BWD_WROW + 64 * h;     // + piece * 128 + kb * 16
+        int u = deal.first, t = 0;                 // my unit (super-tile) and tile of step g
+        int n0 = 0, ptA = 0;
+        float Ag0[4], Ag1[4];
+        unsigned js0 = 0, js1 = 0;
+        float4 pn[8];                              // P' half row of the NEXT tile's edge (in flight)
+        auto row_of = [&](int uu, int tt) -> const float * {       // P' half row of edge (point pA, slot 4 tt + jjA) of unit uu
+            const int nn0 = deal.unit(uu) * 8;
+            const int pt = min(nn0 + pA, BN - 1);
+            const int m = idx[(size_t)pt * k + min(4 * tt + jjA, k - 1)];
+            return Pp + ((size_t)(pt / N) * N + m) * EC + 32 * h;
+        };
+        auto fetch = [&](int uu, int tt) {
+            const float4 *src = reinterpret_cast<const float4 *>(row_of(uu, tt));
+#pragma unroll
+            for (int v = 0; v < 8; ++v) pn[v] = src[v];
+        };
+        if (u < deal.count) fetch(u, 0);
+        for (int g = 0; g <= G; ++g) {
+            const bool work = g < G && u < deal.count;
+            uint4 ap[4][NP];
+            f32x16 acc0, acc1;
+            unsigned sbits = 0u;
+            bool okrow[16];
+            if (work) {
+                if (t == 0) {                      // a new super-tile: its routed-gradient terms and Q' rows
+                    n0 = deal.unit(u) * 8;
+                    ptA = min(n0 + pA, BN - 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pt = n0 + 4 * h + q;
+                        const bool ok = pt < BN;
+                        const size_t o = (size_t)min(pt, BN - 1) * EC + i;
+                        Ag0[q] = ok ? sC[CF_A + i] * g_pm[o] : 0.f;
+                        Ag1[q] = ok ? sC[CF_A + 32 + i] * g_pm[o + 32] : 0.f;
+                        if (q == 0) { js0 = 0; js1 = 0; }
+                        js0 |= (ok ? (unsigned)jsel[o] : 255u) << (8 * q);
+                        js1 |= (ok ? (unsigned)jsel[o + 32] : 255u) << (8 * q);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int pt = min(n0 + (lane >> 4) + 4 * c, BN - 1);
+                        *reinterpret_cast<float4 *>(qt + ((lane >> 4) + 4 * c) * EC + 4 * (lane & 15)) =
+                            *reinterpret_cast<const float4 *>(Qp + (size_t)pt * EC + 4 * (lane & 15));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                // a1 of this tile from the rows requested one step ago; request the next tile's
+                float a[32];
+                {
+                    const float4 *q4 = reinterpret_cast<const float4 *>(qt + pA * EC + 32 * h);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const float4 pv = pn[v], qv = q4[v];
+                        float z;
+                        z = pv.x + qv.x; a[4 * v + 0] = fmaxf(z, z * slope);
+                        z = pv.y + qv.y; a[4 * v + 1] = fmaxf(z, z * slope);
+                        z = pv.z + qv.z; a[4 * v + 2] = fmaxf(z, z * slope);
+                        z = pv.w + qv.w; a[4 * v + 3] = fmaxf(z, z * slope);
+                    }
+                }
+                {
+                    int un = u, tn = t + 1;
+                    if (tn == T) { tn = 0; un = u + deal.stride; }
+                    if (un < deal.count) fetch(un, tn);
+                }
+#pragma unroll
+                for (int c = 0; c < 32; ++c) sbits |= (a[c] > 0.f ? 1u : 0u) << c;
+                // (1) H2 = A1 W2^T
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    uint4 b0[NP], b1[NP];
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        b0[pc] = *reinterpret_cast<const uint4 *>(wr0 + pc * 128 + kb * 16);
+                        b1[pc] = *reinterpret_cast<const uint4 *>(wr1 + pc * 128 + kb * 16);
+                    }
+                    mm_pieces8<PREC>(a + 8 * kb, ap[kb]);
+                    mac2(ap[kb], b0, b1, acc0, acc1);
+                }
+                // dH2 in place (C/D layout): Cc*h2 + Bc + routed term; masked rows -> 0
+                const float Bc0 = sC[CF_BC + i], Bc1 = sC[CF_BC + 32 + i], Cc0 = sC[CF_CC + i], Cc1 = sC[CF_CC + 32 + i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r >> 2;
+                    const int j = 4 * t + (r & 3);
+                    const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                    okrow[r] = ok;
+                    const float d0 = fmaf(Cc0, acc0[r], Bc0) + ((int)((js0 >> (8 * q)) & 255u) == j ? Ag0[q] : 0.f);
+                    const float d1 = fmaf(Cc1, acc1[r], Bc1) + ((int)((js1 >> (8 * q)) & 255u) == j ? Ag1[q] : 0.f);
+                    acc0[r] = ok ? d0 : 0.f;
+                    acc1[r] = ok ? d1 : 0.f;
+                }
+            }
+            __syncthreads();                       // X: BACK has read the hand-off of step g - 1
+            if (work) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+                        *reinterpret_cast<uint4 *>(aimg + pc * (32 * 128) + i * 128 + 16 * ((4 * h + kb) ^ (i & 7))) = ap[kb][pc];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    float v8[8];
+                    uint4 d[NP];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v8[e] = acc0[8 * kb + e];
+                    mm_pieces8<PREC>(v8, d);
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+                        *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + i * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v8[e] = acc1[8 * kb + e];
+                    mm_pieces8<PREC>(v8, d);
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc)
+                        *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + (32 + i) * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
+                }
+                smask[h * 32 + i] = sbits;
+                if (++t == T) { t = 0; u += deal.stride; }
+            }
+            __syncthreads();                       // Y: the hand-off of step g is in LDS
+        }
+    } else {
+        // ------------------------------------------------------------------ BACK
+        f32x16 dW00, dW01, dW10, dW11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW00[r] = 0.f; dW01[r] = 0.f; dW10[r] = 0.f; dW11[r] = 0.f; }
+        int u = deal.first, t = 0, n0 = 0;
+        float gq0[4], gq1[4];
+        const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+        // transposed-read lane roles (a 16-lane group transposes 4 rows x 16 columns of 2 bytes: lane 4 q + pq supplies row q,
+        // columns 4 pq .. 4 pq + 3, lane c receives column c of the 4 rows)
+        const int tslot = 2 * (g4 & 1) + (tp & 1);                       // dimg: see ec_main_bwd_kernel
+        for (int g = 0; g <= G; ++g) {
+            const bool work = g >= 1 && u < deal.count;                   // (u, t): the tile of step g - 1
+            f32x16 e0, e1;
+            unsigned pos0 = 0u, pos1 = 0u;
+            if (work) {
+                if (t == 0) {                      // a new super-tile: CSR rows of its edges, G_Q sums
+                    n0 = deal.unit(u) * 8;
+                    const int ptA = min(n0 + pA, BN - 1);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int tl = 2 * tt + h;
+                        if (tl < T) {
+                            const int jc = 4 * tl + jjA;
+                            pall[tl * 32 + i] = (jc < k && n0 + pA < BN) ? pos[(size_t)ptA * k + jc] : trash_row;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { gq0[q] = 0.f; gq1[q] = 0.f; }
+                }
+                // (2) dW2[co][ci] += sum_edges dH2[e][co] a1[e][ci]: K-block kb, K index (h, e) <-> edge 16 kb + 8 (e >> 2) + 4 h + (e & 3)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    uint4 dA0[NP], dA1[NP], x0[NP], x1[NP];
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        dA0[pc] = *reinterpret_cast<const uint4 *>(dimg + pc * (EC * 64) + i * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3)));
+                        dA1[pc] = *reinterpret_cast<const uint4 *>(dimg + pc * (EC * 64) + (32 + i) * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3)));
+                        unsigned w0[4], w1[4];
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const int erow = 16 * kb + 8 * hf + 4 * h + tq;              // edge row this lane addresses
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                const int c0 = 32 * ct + 16 * (g4 & 1) + 4 * tp;         // its 4 channels
+                                const unsigned char *src = aimg + pc * (32 * 128) + erow * 128 + 16 * ((c0 >> 3) ^ (erow & 7)) + 2 * (c0 & 7);
+                                const s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)src);
+                                const uint2 uu = __builtin_bit_cast(uint2, v);
+                                if (ct == 0) { w0[2 * hf] = uu.x; w0[2 * hf + 1] = uu.y; }
+                                else { w1[2 * hf] = uu.x; w1[2 * hf + 1] = uu.y; }
+                            }
+                        }
+                        x0[pc] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+                        x1[pc] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                    }
+                    mac2(dA0, x0, x1, dW00, dW01);
+                    mac2(dA1, x0, x1, dW10, dW11);
+                }
+                // (3) dA1 = dH2 W2 :  K = co, lane half h holds co 32 h + 8 kb ..
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { e0[r] = 0.f; e1[r] = 0.f; }
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    uint4 ap[NP], b0[NP], b1[NP];
+#pragma unroll
+                    for (int pc = 0; pc < NP; ++pc) {
+                        unsigned w4[4], wb0[4], wb1[4];
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const int co = 32 * h + 8 * kb + 4 * hf + tq;
+                            {
+                                const unsigned char *src = dimg + pc * (EC * 64) + co * 64 + 16 * (tslot ^ ((co >> 1) & 3)) + 8 * (tp >> 1);
+                                const s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)src);
+                                const uint2 uu = __builtin_bit_cast(uint2, v);
+                                w4[2 * hf] = uu.x; w4[2 * hf + 1] = uu.y;
+                            }
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct) {
+                                const unsigned char *src = sW3 + co * BWD_WROW + pc * 128 + 2 * (32 * ct + 16 * (g4 & 1) + 4 * tp);
+                                const s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)src);
+                                const uint2 uu = __builtin_bit_cast(uint2, v);
+                                if (ct == 0) { wb0[2 * hf] = uu.x; wb0[2 * hf + 1] = uu.y; }
+                                else { wb1[2 * hf] = uu.x; wb1[2 * hf + 1] = uu.y; }
+                            }
+                        }
+                        ap[pc] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                        b0[pc] = make_uint4(wb0[0], wb0[1], wb0[2], wb0[3]);
+                        b1[pc] = make_uint4(wb1[0], wb1[1], wb1[2], wb1[3]);
+                    }
+                    mac2(ap, b0, b1, e0, e1);
+                }
+                // sign masks of a1 in the C/D layout: bit r <-> edge drow(r, h), channel i (pos0) / 32 + i (pos1)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int er = drow(r, h);
+                    pos0 |= ((smask[er] >> i) & 1u) << r;
+                    pos1 |= ((smask[32 + er] >> i) & 1u) << r;
+                }
+            }
+            __syncthreads();                       // X
+            if (work) {
+                const int *mrow = pall + t * 32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r >> 2;
+                    const int j = 4 * t + (r & 3);
+                    const bool ok = (j < k) && (n0 + 4 * h + q < BN);
+                    const float dy0 = ok ? e0[r] * ((pos0 >> r) & 1u ? 1.f : slope) : 0.f;
+                    const float dy1 = ok ? e1[r] * ((pos1 >> r) & 1u ? 1.f : slope) : 0.f;
+                    gq0[q] += dy0;
+                    gq1[q] += dy1;
+                    const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;      // (a masked row's values are 0 and its row is the pair's scratch row)
+                    dyb[row] = dy0;
+                    dyb[row + 32] = dy1;
+                }
+                if (++t == T) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int pt = n0 + 4 * h + q;
+                        if (pt < BN) {
+                            GQ[(size_t)pt * EC + i] = gq0[q];
+                            GQ[(size_t)pt * EC + 32 + i] = gq1[q];
+                        }
+                    }
+                    t = 0;
+                    u += deal.stride;
+                }
+            }
+            __syncthreads();                       // Y
+        }
+        // the four BACK waves' dW2 accumulators, summed in a FIXED order: one [64][64] image per wave, then one partial per block
+        __syncthreads();
+        float *sD = smem + (size_t)pair * EC * EC;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = drow(r, h);
+            sD[row * EC + i] = dW00[r];
+            sD[row * EC + 32 + i] = dW01[r];
+            sD[(32 + row) * EC + i] = dW10[r];
+            sD[(32 + row) * EC + 32 + i] = dW11[r];
+        }
+    }
+    if (front) __syncthreads();                    // (pairs with BACK's barrier before its image stores)
+    __syncthreads();
+    float *out = partial + (size_t)blockIdx.x * BWD_PART;
+    for (int e = tid; e < EC * EC; e += 128 * BP_PAIRS)
+        out[e] = ((smem[e] + smem[EC * EC + e]) + smem[2 * EC * EC + e]) + smem[3 * EC * EC + e];
+}
+
 // B4 (CSR mode): G_P[m] = sum of the dy1 rows of m's in-edges - one contiguous CSR segment of `dyb`, read as a stream
 // and summed in a fixed order - fused with the BN1-backward reductions of ec_bwd_bn1_reduce_kernel (which it replaces):
 //     sum_n GQ  and  sum_e dy1 xhat1 = sum_m P''[m] GP[m] + sum_n Q''[n] GQ[n]
@@ -2100,7 +2442,13 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 hipLaunchKernelGGL((ec_main_bwd_kernel<PREC_, CSR_>), dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, \
                                    a->w2, cin, g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart, a->csr_pos, dyb);              \
             } while (0)
-            if (reduced) { if (csr) GFS3D_BWD_LAUNCH(PREC_BF16, true); else GFS3D_BWD_LAUNCH(PREC_BF16, false); }
+            static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 0; }();       // A-B only
+            if (!reduced && csr && pair_env) {           // fp32-accurate CSR form as wave pairs (ec_main_bwd_pair_kernel)
+                GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel, BP_LDS_BYTES, who);
+                ProfScope prof(2, st);
+                hipLaunchKernelGGL(ec_main_bwd_pair_kernel, dim3(p.g_bwd), dim3(128 * BP_PAIRS), BP_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin, g,
+                                   a->jsel, BN, a->N, a->k, a->slope, GQ, bpart, a->csr_pos, dyb);
+            } else if (reduced) { if (csr) GFS3D_BWD_LAUNCH(PREC_BF16, true); else GFS3D_BWD_LAUNCH(PREC_BF16, false); }
             else { if (csr) GFS3D_BWD_LAUNCH(PREC_X6, true); else GFS3D_BWD_LAUNCH(PREC_X6, false); }
 #undef GFS3D_BWD_LAUNCH
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
