@@ -1413,7 +1413,13 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
             for (int v = 0; v < 8; ++v) pn[v] = src[v];
         };
         if (u < deal.count) fetch(u, 0);
+#ifdef BP_TIMING
+        long long tk[4] = {0, 0, 0, 0};
+#endif
         for (int g = 0; g <= G; ++g) {
+#ifdef BP_TIMING
+            const long long s0 = __builtin_amdgcn_s_memtime();
+#endif
             const bool work = g < G && u < deal.count;
             uint4 ap[4][NP];
             f32x16 acc0, acc1;
@@ -1492,7 +1498,14 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     acc1[r] = ok ? d1 : 0.f;
                 }
             }
+#ifdef BP_TIMING
+            asm volatile("" : "+v"(acc0[0]), "+v"(acc1[15]));
+            const long long s1 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                       // X: BACK has read the hand-off of step g - 1
+#ifdef BP_TIMING
+            const long long s2 = __builtin_amdgcn_s_memtime();
+#endif
             if (work) {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -1519,8 +1532,19 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                 smask[h * 32 + i] = sbits;
                 if (++t == T) { t = 0; u += deal.stride; }
             }
+#ifdef BP_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const long long s3 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                       // Y: the hand-off of step g is in LDS
+#ifdef BP_TIMING
+            const long long s4 = __builtin_amdgcn_s_memtime();
+            tk[0] += s1 - s0; tk[1] += s2 - s1; tk[2] += s3 - s2; tk[3] += s4 - s3;
+#endif
         }
+#ifdef BP_TIMING
+        if (blockIdx.x == 9 && lane == 0 && pair == 1) printf("bp FRONT steps %d: compute %lld waitX %lld write %lld waitY %lld\n", G + 1, tk[0], tk[1], tk[2], tk[3]);
+#endif
     } else {
         // ------------------------------------------------------------------ BACK
         f32x16 dW00, dW01, dW10, dW11;
@@ -1532,7 +1556,13 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
         // transposed-read lane roles (a 16-lane group transposes 4 rows x 16 columns of 2 bytes: lane 4 q + pq supplies row q,
         // columns 4 pq .. 4 pq + 3, lane c receives column c of the 4 rows)
         const int tslot = 2 * (g4 & 1) + (tp & 1);                       // dimg: see ec_main_bwd_kernel
+#ifdef BP_TIMING
+        long long tk[4] = {0, 0, 0, 0};
+#endif
         for (int g = 0; g <= G; ++g) {
+#ifdef BP_TIMING
+            const long long s0 = __builtin_amdgcn_s_memtime();
+#endif
             const bool work = g >= 1 && u < deal.count;                   // (u, t): the tile of step g - 1
             f32x16 e0, e1;
             unsigned pos0 = 0u, pos1 = 0u;
@@ -1620,7 +1650,14 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     pos1 |= ((smask[32 + er] >> i) & 1u) << r;
                 }
             }
+#ifdef BP_TIMING
+            asm volatile("" : "+v"(e0[0]), "+v"(e1[15]), "+v"(pos0));
+            const long long s1 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                       // X
+#ifdef BP_TIMING
+            const long long s2 = __builtin_amdgcn_s_memtime();
+#endif
             if (work) {
                 const int *mrow = pall + t * 32;
 #pragma unroll
@@ -1649,8 +1686,18 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     u += deal.stride;
                 }
             }
+#ifdef BP_TIMING
+            const long long s3 = __builtin_amdgcn_s_memtime();
+#endif
             __syncthreads();                       // Y
+#ifdef BP_TIMING
+            const long long s4 = __builtin_amdgcn_s_memtime();
+            tk[0] += s1 - s0; tk[1] += s2 - s1; tk[2] += s3 - s2; tk[3] += s4 - s3;
+#endif
         }
+#ifdef BP_TIMING
+        if (blockIdx.x == 9 && lane == 0 && pair == 1) printf("bp BACK  steps %d: gemms %lld waitX %lld dy1 %lld waitY %lld\n", G + 1, tk[0], tk[1], tk[2], tk[3]);
+#endif
         // the four BACK waves' dW2 accumulators, summed in a FIXED order: one [64][64] image per wave, then one partial per block
         __syncthreads();
         float *sD = smem + (size_t)pair * EC * EC;
@@ -2442,7 +2489,7 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                 hipLaunchKernelGGL((ec_main_bwd_kernel<PREC_, CSR_>), dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, \
                                    a->w2, cin, g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart, a->csr_pos, dyb);              \
             } while (0)
-            static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 0; }();       // A-B only
+            static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 1; }();       // 0: the one-wave-per-SIMD form (A-B only)
             if (!reduced && csr && pair_env) {           // fp32-accurate CSR form as wave pairs (ec_main_bwd_pair_kernel)
                 GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel, BP_LDS_BYTES, who);
                 ProfScope prof(2, st);
