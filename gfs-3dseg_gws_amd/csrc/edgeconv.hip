@@ -1334,16 +1334,17 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 // and wave p + 4 (BACK) of an 8-wave workgroup share SIMD p and split a tile:
 //   FRONT  gather P' rows (registers, one tile ahead), a1 = LReLU(P'[m] + Q'[n]), split, (1) H2 = A1 W2^T, dH2 in place;
 //          hands over, through LDS: the a1 pieces as they stand in the A layout (`aimg`: rows = edges, 128 B per plane),
-//          the dH2 pieces (`dimg`, as before) and the sign masks of a1;
+//          the dH2 pieces (`dimg`, as before);
 //   BACK   (2) dW2 += dH2^T A1: A = dimg rows as written, B = aimg read TRANSPOSED (ds_read_b64_tr_b16: lane = channel, 8
 //          edges) - no fp32 transpose of a1 and no second split;  (3) dA1 = dH2 W2: A = dimg transposed (as before), B = the
-//          ONE W2 image read transposed (no W2^T image);  dy1, G_Q, the row stores.
+//          ONE W2 image read transposed (no W2^T image);  dy1 (the sign of a1 from the hi pieces it already holds), G_Q,
+//          the row stores.
 // The hand-off is single-buffered: FRONT works one tile ahead and keeps its a1 pieces in registers; two workgroup barriers per
 // tile (X: BACK has read tile g - 1, FRONT may write tile g; Y: tile g is in LDS).  Both roles fit 256 registers.
-// LDS: W2 image 25.6 KB + per pair (aimg 12 KB + dimg 12 KB + Q' tile 2 KB + CSR rows 1 KB + masks) = 135 KB.
+// LDS: W2 image 25.6 KB + per pair (aimg 12 KB + dimg 12 KB + Q' tile 2 KB + CSR rows 1 KB) = 134 KB.
 constexpr int BP_PAIRS = 4;
 constexpr int BP_AIMG = 3 * 32 * 128;                                       // bytes: a1 piece planes [plane][edge][64 ci], 16-B slots swizzled
-constexpr int BP_PAIR_LDS = BP_AIMG + BWD_DIMG + 8 * EC * 4 + 8 * 32 * 4 + 64 * 4;      // aimg | dimg | Q' tile | CSR rows | sign masks
+constexpr int BP_PAIR_LDS = BP_AIMG + BWD_DIMG + 8 * EC * 4 + 8 * 32 * 4;      // aimg | dimg | Q' tile | CSR rows
 constexpr size_t BP_LDS_BYTES = EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS + 192 * 4;
 static_assert(BP_LDS_BYTES >= (size_t)BP_PAIRS * EC * EC * 4, "the dW2 reduction images reuse the workgroup's LDS");
 
@@ -1367,7 +1368,6 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
     unsigned char *dimg = aimg + BP_AIMG;
     float *qt = reinterpret_cast<float *>(dimg + BWD_DIMG);             // [8][64] Q' rows of FRONT's super-tile
     int *pall = reinterpret_cast<int *>(qt + 8 * EC);                   // [8][32] CSR row of each row of each tile of BACK's super-tile
-    unsigned *smask = reinterpret_cast<unsigned *>(pall + 8 * 32);      // [2][32] sign masks of a1: [channel half][edge]
     float *sC = reinterpret_cast<float *>(sW3 + EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS);
     const int trash_row = BN * k + (int)(blockIdx.x * BP_PAIRS + pair);  // where masked rows are stored (never read)
 
@@ -1423,7 +1423,6 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
             const bool work = g < G && u < deal.count;
             uint4 ap[4][NP];
             f32x16 acc0, acc1;
-            unsigned sbits = 0u;
             bool okrow[16];
             if (work) {
                 if (t == 0) {                      // a new super-tile: its routed-gradient terms and Q' rows
@@ -1468,8 +1467,6 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     if (tn == T) { tn = 0; un = u + deal.stride; }
                     if (un < deal.count) fetch(un, tn);
                 }
-#pragma unroll
-                for (int c = 0; c < 32; ++c) sbits |= (a[c] > 0.f ? 1u : 0u) << c;
                 // (1) H2 = A1 W2^T
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -1529,7 +1526,6 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     for (int pc = 0; pc < NP; ++pc)
                         *reinterpret_cast<uint4 *>(dimg + pc * (EC * 64) + (32 + i) * 64 + 16 * ((2 * kb + h) ^ ((i >> 1) & 3))) = d[pc];
                 }
-                smask[h * 32 + i] = sbits;
                 if (++t == T) { t = 0; u += deal.stride; }
             }
 #ifdef BP_TIMING
@@ -1605,6 +1601,19 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                         }
                         x0[pc] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
                         x1[pc] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+                        if (pc == 0) {
+                            // LReLU'(z1) needs a1 > 0 for the edges of this K-block - the hi pieces just read ARE a1 in this lane's
+                            // C/D row order (register 8 kb + e): positive <=> the bf16 is a positive non-zero number (a1 > 0 rounds to
+                            // +0 only below 4.6e-41).  No sign masks through LDS, no second pass over a1.
+#pragma unroll
+                            for (int wq = 0; wq < 4; ++wq) {
+                                const int r = 8 * kb + 2 * wq;
+                                pos0 |= ((int)(w0[wq] << 16) > 0 ? 1u : 0u) << r;
+                                pos0 |= ((int)w0[wq] >= 0x10000 ? 1u : 0u) << (r + 1);
+                                pos1 |= ((int)(w1[wq] << 16) > 0 ? 1u : 0u) << r;
+                                pos1 |= ((int)w1[wq] >= 0x10000 ? 1u : 0u) << (r + 1);
+                            }
+                        }
                     }
                     mac2(dA0, x0, x1, dW00, dW01);
                     mac2(dA1, x0, x1, dW10, dW11);
@@ -1641,13 +1650,6 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                         b1[pc] = make_uint4(wb1[0], wb1[1], wb1[2], wb1[3]);
                     }
                     mac2(ap, b0, b1, e0, e1);
-                }
-                // sign masks of a1 in the C/D layout: bit r <-> edge drow(r, h), channel i (pos0) / 32 + i (pos1)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int er = drow(r, h);
-                    pos0 |= ((smask[er] >> i) & 1u) << r;
-                    pos1 |= ((smask[32 + er] >> i) & 1u) << r;
                 }
             }
 #ifdef BP_TIMING
