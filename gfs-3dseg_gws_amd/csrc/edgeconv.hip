@@ -1348,6 +1348,7 @@ constexpr int BP_PAIR_LDS = BP_AIMG + BWD_DIMG + 8 * EC * 4 + 8 * 32 * 4;      /
 constexpr size_t BP_LDS_BYTES = EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS + 192 * 4;
 static_assert(BP_LDS_BYTES >= (size_t)BP_PAIRS * EC * EC * 4, "the dW2 reduction images reuse the workgroup's LDS");
 
+template <int PREC>
 __global__ void __launch_bounds__(128 * BP_PAIRS)
 ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                         const float *__restrict__ w2, const CoefIn cin,
@@ -1356,7 +1357,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                         float *__restrict__ GQ, float *__restrict__ partial,
                         const int *__restrict__ pos, float *__restrict__ dyb)
 {
-    constexpr int PREC = PREC_X6, NP = 3;
+    constexpr int NP = Mx<PREC>::NP;               // operand piece planes: 3 (fp32-accurate) or 1 (reduced modes: bf16 operands)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] pieces of W2
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1385,11 +1386,16 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
     const int G = nsup * T;                                               // tile steps every pair runs (uniform barrier count)
 
     auto mac2 = [&](const uint4 (&a_)[NP], const uint4 (&b0_)[NP], const uint4 (&b1_)[NP], f32x16 &c0, f32x16 &c1) {
-        constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
+        if constexpr (PREC == PREC_X6) {
+            constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
-            c0 = mm_mfma<PREC>(a_[PA[term]], b0_[PB[term]], c0);
-            c1 = mm_mfma<PREC>(a_[PA[term]], b1_[PB[term]], c1);
+            for (int term = 0; term < 6; ++term) {
+                c0 = mm_mfma<PREC>(a_[PA[term]], b0_[PB[term]], c0);
+                c1 = mm_mfma<PREC>(a_[PA[term]], b1_[PB[term]], c1);
+            }
+        } else {
+            c0 = mm_mfma<PREC>(a_[0], b0_[0], c0);
+            c1 = mm_mfma<PREC>(a_[0], b1_[0], c1);
         }
     };
 
@@ -1671,9 +1677,12 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
                     const float dy1 = ok ? e1[r] * ((pos1 >> r) & 1u ? 1.f : slope) : 0.f;
                     gq0[q] += dy0;
                     gq1[q] += dy1;
-                    const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;      // (a masked row's values are 0 and its row is the pair's scratch row)
-                    dyb[row] = dy0;
-                    dyb[row + 32] = dy1;
+                    if constexpr (PREC == PREC_X6) {
+                        const unsigned row = (unsigned)mrow[drow(r, h)] * EC + i;  // (a masked row's values are 0 and its row is the pair's scratch row)
+                        dyb[row] = dy0;
+                        dyb[row + 32] = dy1;
+                    } else                                  // reduced modes: the row as 32 dwords of two bf16 (channels i | 32 + i)
+                        reinterpret_cast<unsigned *>(dyb)[(size_t)mrow[drow(r, h)] * 32 + i] = mm_pack2<PREC_BF16>(dy0, dy1);
                 }
                 if (++t == T) {
 #pragma unroll
@@ -2492,11 +2501,17 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
                                    a->w2, cin, g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart, a->csr_pos, dyb);              \
             } while (0)
             static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 1; }();       // 0: the one-wave-per-SIMD form (A-B only)
-            if (!reduced && csr && pair_env) {           // fp32-accurate CSR form as wave pairs (ec_main_bwd_pair_kernel)
-                GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel, BP_LDS_BYTES, who);
+            if (csr && pair_env) {                       // CSR form as wave pairs (ec_main_bwd_pair_kernel)
                 ProfScope prof(2, st);
-                hipLaunchKernelGGL(ec_main_bwd_pair_kernel, dim3(p.g_bwd), dim3(128 * BP_PAIRS), BP_LDS_BYTES, st, Pp, Qp, a->idx, a->w2, cin, g,
-                                   a->jsel, BN, a->N, a->k, a->slope, GQ, bpart, a->csr_pos, dyb);
+                if (reduced) {
+                    GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel<PREC_BF16>, BP_LDS_BYTES, who);
+                    hipLaunchKernelGGL(ec_main_bwd_pair_kernel<PREC_BF16>, dim3(p.g_bwd), dim3(128 * BP_PAIRS), BP_LDS_BYTES, st, Pp, Qp, a->idx, a->w2,
+                                       cin, g, a->jsel, BN, a->N, a->k, a->slope, GQ, bpart, a->csr_pos, dyb);
+                } else {
+                    GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel<PREC_X6>, BP_LDS_BYTES, who);
+                    hipLaunchKernelGGL(ec_main_bwd_pair_kernel<PREC_X6>, dim3(p.g_bwd), dim3(128 * BP_PAIRS), BP_LDS_BYTES, st, Pp, Qp, a->idx, a->w2,
+                                       cin, g, a->jsel, BN, a->N, a->k, a->slope, GQ, bpart, a->csr_pos, dyb);
+                }
             } else if (reduced) { if (csr) GFS3D_BWD_LAUNCH(PREC_BF16, true); else GFS3D_BWD_LAUNCH(PREC_BF16, false); }
             else { if (csr) GFS3D_BWD_LAUNCH(PREC_X6, true); else GFS3D_BWD_LAUNCH(PREC_X6, false); }
 #undef GFS3D_BWD_LAUNCH
