@@ -41,7 +41,7 @@ NPTS, KNN, CIN = 2048, 20, 9
 PEAK_FP32_TFLOPS = 157.3       # MI355X dense fp32 (vector == fp32 MFMA) peak, MI355X_MICROARCH.md
 PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
-KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_kernel", 3: "proto_kernels", 4: "ec_stats1_kernel",
+KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_pair_kernel", 3: "proto_kernels", 4: "ec_stats1_kernel",
            5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd", 8: "attention_fwd", 9: "attention_bwd"}
 WORKLOADS = {
     "c2": dict(model="dgcnn", B=32, dtype="f32", classes=0, base=0, Kw=0,
@@ -429,7 +429,7 @@ def main():
             roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
                          "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
             if dom == 2:
-                roof["traffic_note"] = ("ec_main_bwd_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients; 184 MB before the clouds were dealt to XCDs, r03_d) + ~357 MB of plain 256-B row "
+                roof["traffic_note"] = ("ec_main_bwd_pair_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients; 184 MB before the clouds were dealt to XCDs, r03_d) + ~357 MB of plain 256-B row "
                                         "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once "
                                         "(the fixed-order replacement of round 1's float-atomic scatter)")
         roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass). f32 mode: against "
