@@ -1371,6 +1371,47 @@ def test_rccl_single_rank_exercises_every_collective(dev):
         assert np.abs(r["grads"][mode] - ref).max() < 1e-4 * scale, mode
 
 
+def _one_wave_backward(out):
+    """Child process (GFS3D_EC_BWD_PAIR=0 is read once per process): the one-wave-per-SIMD heavy backward on a fixed problem."""
+    import os
+    os.environ["GFS3D_EC_BWD_PAIR"] = "0"
+    out["grads"] = _edgeconv_grads_for_form_test()
+
+
+def _edgeconv_grads_for_form_test():
+    from gfs3d import ops
+    d = torch.device("cuda:0")
+    B, C, N, k = 8, 64, 264, 20
+    p = _block_params(C, 31)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, N, generator=g).to(d)
+    cot = torch.randn(B, 64, N, generator=g).to(d)
+    idx = ops.knn_topk(x, k, want_i64=False, want_i32=True)
+    blk = _make_block(p, C, d).train()
+    c1, bn1, c2, bn2 = blk.fused_parts()
+    xg = x.clone().requires_grad_(True)
+    y = ops.edgeconv_block(xg, idx, c1.weight, bn1, c2.weight, bn2, True)
+    (y * cot).sum().backward()
+    return [t.detach().cpu().numpy() for t in (xg.grad, c1.weight.grad, c2.weight.grad, bn1.weight.grad, bn1.bias.grad)]
+
+
+def test_edgeconv_backward_wave_pair_form_equals_one_wave_form(dev):
+    """The shipped heavy backward (ec_main_bwd_pair_kernel: a front and a back wave per SIMD) against the one-wave form it replaced
+    (GFS3D_EC_BWD_PAIR=0, run in a child process): the same sums in the same order except the weight gradient's accumulation
+    over tiles - gradients equal to rounding."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    pr = ctx.Process(target=_one_wave_backward, args=(out,))
+    pr.start()
+    pr.join(300)
+    assert pr.exitcode == 0
+    ref = out["grads"]
+    new = _edgeconv_grads_for_form_test()
+    for a, b in zip(new, ref):
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-12)
+
+
 def test_entry_points_are_graph_capture_safe(dev):
     """include/gfs3d.h promises no allocation and no host synchronisation inside the entry points (the side-stream fork /
     join of the training forward is event-based): a DGCNN eval forward and a whole training forward + backward captured
