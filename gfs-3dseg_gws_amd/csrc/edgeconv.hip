@@ -1342,6 +1342,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
 // The hand-off is single-buffered: FRONT works one tile ahead and keeps its a1 pieces in registers; two workgroup barriers per
 // tile (X: BACK has read tile g - 1, FRONT may write tile g; Y: tile g is in LDS).  Both roles fit 256 registers.
 // LDS: W2 image 25.6 KB + per pair (aimg 12 KB + dimg 12 KB + Q' tile 2 KB + CSR rows 1 KB) = 134 KB.
+// the hand-off barriers order LDS traffic only: no wait for the global loads in flight (the next tile's P' rows) or the dy1 stores
+__device__ __forceinline__ void bp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int BP_PAIRS = 4;
 constexpr int BP_AIMG = 3 * 32 * 128;                                       // bytes: a1 piece planes [plane][edge][64 ci], 16-B slots swizzled
 constexpr int BP_PAIR_LDS = BP_AIMG + BWD_DIMG + 8 * EC * 4 + 8 * 32 * 4;      // aimg | dimg | Q' tile | CSR rows
@@ -1505,7 +1507,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
             asm volatile("" : "+v"(acc0[0]), "+v"(acc1[15]));
             const long long s1 = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads();                       // X: BACK has read the hand-off of step g - 1
+            bp_barrier();                          // X: BACK has read the hand-off of step g - 1
 #ifdef BP_TIMING
             const long long s2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1538,7 +1540,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const long long s3 = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads();                       // Y: the hand-off of step g is in LDS
+            bp_barrier();                          // Y: the hand-off of step g is in LDS
 #ifdef BP_TIMING
             const long long s4 = __builtin_amdgcn_s_memtime();
             tk[0] += s1 - s0; tk[1] += s2 - s1; tk[2] += s3 - s2; tk[3] += s4 - s3;
@@ -1662,7 +1664,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
             asm volatile("" : "+v"(e0[0]), "+v"(e1[15]), "+v"(pos0));
             const long long s1 = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads();                       // X
+            bp_barrier();                          // X
 #ifdef BP_TIMING
             const long long s2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1700,7 +1702,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
 #ifdef BP_TIMING
             const long long s3 = __builtin_amdgcn_s_memtime();
 #endif
-            __syncthreads();                       // Y
+            bp_barrier();                          // Y
 #ifdef BP_TIMING
             const long long s4 = __builtin_amdgcn_s_memtime();
             tk[0] += s1 - s0; tk[1] += s2 - s1; tk[2] += s3 - s2; tk[3] += s4 - s3;
