@@ -99,31 +99,40 @@ def hbm_traffic(kernel, tag):
     return None, None
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (torch-CPU restatement of model/dgcnn.py, kind='port') timed on this
-    host's cores on a bounded sample: B=8 blocks of the same workload, fwd+bwd."""
+def cpu_baseline(seconds_budget=60.0):
+    """The oracle (torch-CPU restatement of model/dgcnn.py, kind='port') timed on this host's cores with BASELINE.md
+    section 3's protocol: B = 1 eval forward (BASELINE configs[0]: 3 warm-ups, median of 10) and B = 32 train-mode
+    forward + backward (the metric's own workload; 1 warm-up, median of up to 10 iterations within `seconds_budget`,
+    at least 3).  `value` is the B = 32 forward + backward figure."""
     from oracle import ref_ops as R
     from model.dgcnn import DGCNN
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).state_dict().items()}
-    Bc = 8
-    x = R.synthetic_blocks(Bc, NPTS, seed=0)
     prev_threads = torch.get_num_threads()
     cores = min(32, os.cpu_count() or 1)      # measured on the 2x64-core EPYC host: 8/16/32/64/128 threads -> 4.0/4.4/4.9/3.3/1.8 blocks/s
     torch.set_num_threads(cores)
+
+    def median_time(fn, warm, lo, hi, budget):
+        for _ in range(warm):
+            fn()
+        times, t_start = [], time.time()
+        while len(times) < lo or (len(times) < hi and time.time() - t_start < budget):
+            t0 = time.time()
+            fn()
+            times.append(time.time() - t0)
+        return sorted(times)[len(times) // 2], len(times)
+
+    x1 = R.synthetic_blocks(1, NPTS, seed=0)
+    with torch.no_grad():
+        dt1, n1 = median_time(lambda: R.dgcnn_forward(sd, x1, k=KNN, training=False), 3, 10, 10, 0.0)
+    Bc = 32
+    x = R.synthetic_blocks(Bc, NPTS, seed=0)
 
     def one():
         p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
         _, out = R.dgcnn_forward(p, x, k=KNN, training=True, new_stats={})
         out.mean().backward()
-    one()
-    times = []
-    t_start = time.time()
-    while len(times) < 3 or (time.time() - t_start < seconds_budget * 0.6 and len(times) < 10):
-        t0 = time.time()
-        one()
-        times.append(time.time() - t0)
-    dt = sorted(times)[len(times) // 2]
+    dt, n = median_time(one, 1, 3, 10, seconds_budget)
     torch.set_num_threads(prev_threads)
     model = ""
     try:
@@ -132,7 +141,9 @@ def cpu_baseline(seconds_budget=25.0):
     except OSError:
         pass
     return {"value": round(Bc / dt, 3), "unit": "blocks/s", "cores": cores, "kind": "port", "cpu": model,
-            "sample": f"median of {len(times)} iterations of B={Bc} x {NPTS} x {CIN}, k={KNN}, DGCNN fwd+bwd (torch CPU oracle)"}
+            "sample": f"median of {n} iterations (1 warm-up) of B={Bc} x {NPTS} x {CIN}, k={KNN}, DGCNN train-mode fwd+bwd (torch CPU oracle)",
+            "b1_eval_forward": {"value": round(1.0 / dt1, 3), "unit": "blocks/s", "ms": round(dt1 * 1e3, 2),
+                                "sample": f"BASELINE configs[0]: one 2048 x 9 block, DGCNN eval forward, median of {n1} after 3 warm-ups"}}
 
 
 def capl_args():
@@ -335,9 +346,124 @@ def extras(dev, L, gdist):
     return out
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without an external launcher: start N fresh child interpreters (one rank per GPU) with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, forward rank 0's JSON line, exit non-zero if any child did.  The parent
+    never touches the GPU (no HIP call, not even torch.cuda.is_available()): the children are plain new processes, not
+    an exec of a process that initialised the device."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, GFS3D_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    deadline = time.time() + float(os.environ.get("GFS3D_BENCH_TIMEOUT", "1500"))
+    rc, out0 = 0, ""
+    live = set(range(n))
+    try:
+        while live:
+            for r in sorted(live):
+                try:
+                    if r == 0:
+                        out0 = procs[0].communicate(timeout=0.2)[0] or ""
+                    else:
+                        procs[r].wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                live.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode
+                    print(f"bench.py: rank {r} exited with code {procs[r].returncode}", file=sys.stderr)
+            if (rc or time.time() > deadline) and live:
+                rc = rc or 124
+                break
+    finally:
+        for r in live:                   # a failed or overdue job: end exactly the children started here
+            procs[r].kill()
+        for r in live:
+            procs[r].wait()
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        rc = 1
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    return rc
+
+
+def dry_run(args, world, rank, local):
+    """--dry: the N-rank flow without kernels (runs on a box without a GPU): build the model's flat gradient bucket, run
+    the step's collectives on it (early slice + remainder, mean), the barrier and max-over-ranks of the timed region, and
+    print the line's launch-related fields.  Exercised by tests/test_dist_cpu.py with GFS3D_BENCH_BACKEND=gloo --gpus 8."""
+    import torch.distributed as dist
+    from gfs3d import dist as gdist
+    backend = os.environ.get("GFS3D_BENCH_BACKEND", "nccl")
+    on_gpu = backend == "nccl"
+    if on_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if on_gpu:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("GFS3D_BENCH_DRY_FAIL_RANK") == str(rank):      # tests: a rank that dies must fail the whole job
+        os._exit(3)
+    from model.dgcnn import DGCNN
+    torch.manual_seed(0)
+    net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev)
+    bucket = gdist.FlatGradBucket(net.parameters(), early=list(net.conv.parameters()), overlap=False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bucket.zero()
+        for p in net.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        bucket.all_reduce_mean()
+    if world > 1:
+        dist.barrier()
+    elapsed = gdist.max_over_ranks(time.perf_counter() - t0, dev)
+    want = (world + 1) / 2.0
+    ok = world == 1 or bool(torch.allclose(bucket.flat, torch.full_like(bucket.flat, want)))
+    devices = rank_devices(dev, world)
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                          "devices": devices, "steps": args.steps, "bucket_elems": int(bucket.flat.numel()),
+                          "collectives_ok": ok, "elapsed_s": round(elapsed, 4)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def rank_devices(dev, world):
+    """Device of every rank, gathered to all ranks (evidence that N ranks drove N cards)."""
+    import torch.distributed as dist
+    mine = f"{dev.type}:{dev.index}" if dev.type == "cuda" else "cpu"
+    if world == 1:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry", action="store_true", help="launch + collectives only, no kernels (works without a GPU under "
+                                                       "GFS3D_BENCH_BACKEND=gloo)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
@@ -347,9 +473,15 @@ def main():
     ap.add_argument("--sync-bn", action="store_true", help="whole-batch BatchNorm statistics across ranks (N>1)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # no external launcher: this process becomes one (no GPU call before this)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        raise SystemExit(dry_run(args, world, rank, local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # GFS3D_BENCH_BACKEND=gloo: rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks then share devices)
@@ -392,6 +524,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = gdist.max_over_ranks(elapsed, dev)
+    devices = rank_devices(dev, world)
 
     # second pass, outside the timed region: the same K steps with the library's hipEvent brackets on (all ranks: the
     # steps hold collectives)
@@ -478,7 +611,8 @@ def main():
                  "point-cloud blocks/sec (2048 pts, k=20) CAPL training step"
         line = {
             "metric": metric, "value": round(world * B / (elapsed / args.steps), 2),
-            "unit": "blocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "blocks/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "devices": devices,
+            "backend": backend if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": cfg["text"], "blocks_per_gpu": B, "points": NPTS, "k": KNN,

@@ -178,3 +178,55 @@ def test_dp_helpers_world2_gloo():
     # every rank back-propagates the same global prototype: summed shard gradients = 2x the single-process one
     full = a["fake_grad"] + b["fake_grad"]
     assert np.abs(full - 2 * pf.grad.numpy()).max() < 1e-5 * max(1.0, np.abs(pf.grad.numpy()).max())
+
+
+def _run_bench(argv, **env):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(GFS3D_BENCH_BACKEND="gloo", GFS3D_BENCH_TIMEOUT="240", **env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=e, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_gpus_8_launches_eight_ranks_by_itself():
+    """a plain `python bench.py --gpus 8` (no torchrun) is an 8-rank job: the parent spawns the ranks,
+    rank 0's single JSON line comes back, n_gpus = ranks in the process group = 8.  --dry: bucket + collectives, no kernels."""
+    rc, lines, err = _run_bench(["--gpus", "8", "--dry", "--steps", "2"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["rccl_ranks"] == 8 and len(ln["devices"]) == 8 and ln["collectives_ok"]
+    assert ln["bucket_elems"] == 261504                    # the DGCNN backbone's parameters (SURVEY 8a a5)
+
+
+def test_bench_self_launch_fails_when_a_rank_dies():
+    rc, lines, err = _run_bench(["--gpus", "3", "--dry", "--steps", "1"], GFS3D_BENCH_DRY_FAIL_RANK="1")
+    assert rc != 0 and not lines
+    assert "rank 1 exited with code 3" in err
+
+
+def test_bench_under_an_external_launcher_keeps_working():
+    """The torchrun form: WORLD_SIZE / RANK set from outside -> no second level of spawning; --gpus must agree."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, GFS3D_BENCH_BACKEND="gloo", WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--steps", "1"], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    e = dict(os.environ, GFS3D_BENCH_BACKEND="gloo", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry"], env=e, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
