@@ -8,6 +8,7 @@
 
 namespace gfs3d {
 bool g_deterministic = false;
+bool g_bn_tail = [] { const char *e = getenv("GFS3D_PW_TAIL"); return !(e && e[0] == '0'); }();     // GFS3D_PW_TAIL=0: field bisection
 
 static thread_local char g_err[512] = "";
 
@@ -85,6 +86,12 @@ extern "C" int gfs3d_profile_read(int kernel_id, double *total_ms, long long *la
     g_recs.swap(keep);
     *total_ms = ms;
     *launches = n;
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_set_bn_tail(int on)
+{
+    gfs3d::g_bn_tail = on != 0;
     return GFS3D_OK;
 }
 

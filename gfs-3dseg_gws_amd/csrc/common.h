@@ -13,6 +13,7 @@ namespace gfs3d {
 constexpr int WAVE = 64;
 
 void set_error(const char *fmt, ...);
+extern bool g_bn_tail;            // gfs3d_set_bn_tail: BatchNorm finalisation in the producing kernel's last workgroup (pointwise.hip: bn_tail)
 extern bool g_deterministic;      // gfs3d_set_deterministic: ordered reductions instead of fp64 atomics (api.hip)
 
 // measurement hooks (api.hip): no-ops unless gfs3d_profile_enable(1)

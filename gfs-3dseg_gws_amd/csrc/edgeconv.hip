@@ -1362,9 +1362,12 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
     constexpr int NP = Mx<PREC>::NP;               // operand piece planes: 3 (fp32-accurate) or 1 (reduced modes: bf16 operands)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] pieces of W2
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the wave index as a SCALAR (readfirstlane): role, pair and the walk derived from it are wave-uniform to the compiler, so the
+    // role bodies are entered by s_cbranch_scc and a wave can only ever execute the barriers of its own role
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wv & 3;
     const bool front = wv < BP_PAIRS;
+    static_assert(BWD_WAVES == BP_PAIRS, "the trash rows behind dyb are sized by BWD_WAVES per workgroup (edgeconv plan: off_dyb)");
     const int i = lane & 31, h = lane >> 5;
     unsigned char *pbase = sW3 + EC * BWD_WROW + (size_t)pair * BP_PAIR_LDS;
     unsigned char *aimg = pbase;

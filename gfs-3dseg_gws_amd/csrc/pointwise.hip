@@ -898,7 +898,11 @@ int launch_rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 template <int PRO, int EPI, bool OUT_CF>
 int rowgemm(const RowGemm &rg, hipStream_t st, const char *who)
 {
+#ifdef PW_ABL
     static const int force_bn = getenv("GFS3D_PW_BN") ? atoi(getenv("GFS3D_PW_BN")) : 0;      // experiments: GFS3D_PW_BN=64
+#else
+    constexpr int force_bn = 0;
+#endif
     if (rg.Nc % 128 == 0 && force_bn != 64) return launch_rowgemm<128, PRO, EPI, OUT_CF>(rg, st, who);
     return launch_rowgemm<64, PRO, EPI, OUT_CF>(rg, st, who);
 }
@@ -1157,11 +1161,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         }
     }
     // monolithic call in atomics mode: the producing GEMM's last workgroup finalises its BatchNorm (bn_tail), no launch for it
-#ifdef PW_NO_TAIL
-    const bool use_tail = false;
-#else
-    const bool use_tail = a->training && !acc_user && !g_deterministic && split_once;
-#endif
+    const bool use_tail = g_bn_tail && a->training && !acc_user && !g_deterministic && split_once;
     unsigned *tickets = reinterpret_cast<unsigned *>(acc + (size_t)2 * p.maxw * L);          // slot 2 l: layer l
     if (a->training && phase > 0 && !use_tail) {         // BatchNorm of layer phase - 1: batch statistics are complete (and global)
         const int l = phase - 1, C = a->width[l];
@@ -1284,11 +1284,7 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     const bool split_once = L <= PW_MAX_SPLIT;
     // monolithic call in atomics mode: the kernel that completes the sums of layer l computes that layer's coefficients and
     // BatchNorm parameter gradients in its last workgroup (bn_tail), no pw_bwd_coef_kernel launch
-#ifdef PW_NO_TAIL
-    const bool use_tail = false;
-#else
-    const bool use_tail = !acc_user && !g_deterministic && split_once;
-#endif
+    const bool use_tail = g_bn_tail && !acc_user && !g_deterministic && split_once;
     unsigned *tickets = reinterpret_cast<unsigned *>(acc + (size_t)2 * p.maxw * L);
     float *coef = reinterpret_cast<float *>(ws + p.off_coef);
     const double count_ = stat_count > 0.0 ? stat_count : (double)M;

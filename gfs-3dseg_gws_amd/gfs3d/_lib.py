@@ -148,6 +148,7 @@ SYMBOLS = {
                                        c_size_t, c_void_p]),
     "gfs3d_edgeconv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "gfs3d_set_deterministic": (c_int, [c_int]),
+    "gfs3d_set_bn_tail": (c_int, [c_int]),
     "gfs3d_edgeconv_forward_f32": (c_int, [POINTER(EdgeConvArgs), c_void_p]),
     "gfs3d_edgeconv_backward_f32": (c_int, [POINTER(EdgeConvBwdArgs), c_void_p]),
     "gfs3d_edgeconv_forward_phase_f32": (c_int, [POINTER(EdgeConvArgs), c_int, c_void_p, c_double, c_void_p]),

@@ -1003,22 +1003,36 @@ class CaplTrainHeadFunction(torch.autograd.Function):
             if fake and _dp_world() > 1:
                 torch.distributed.all_reduce(fsum)
             _lib.check(L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 1), "gfs3d_capl_head_forward_phase(1)")
-        ctx.args = a
-        ctx.keep = (feat, main_proto, bg_proto, y, fsum, loss, ws)       # the pointers in `a` stay valid as long as these do
+        # tensor inputs through save_for_backward (autograd's version counters catch an in-place update of the features or
+        # prototypes between forward and backward); the scalar fields of the args struct are kept, its pointers are rebuilt
+        ctx.save_for_backward(feat, main_proto, bg_proto, y, fsum, loss, ws)
+        ctx.scalars = (B, C, N, int(ignore_index), classes, int(base_num), fake)
         ctx.has_fake = bool(fake)
         ctx.mark_non_differentiable(pred)
         return pred, loss[0]
 
     @staticmethod
     def backward(ctx, _dpred, dloss):
-        a = ctx.args
-        feat, main_proto, bg_proto = ctx.keep[0], ctx.keep[1], ctx.keep[2]
+        feat, main_proto, bg_proto, y, fsum, loss, ws = ctx.saved_tensors
+        B, C, N, ignore_index, classes, base_num, fake = ctx.scalars
         dev = feat.device
         dloss = dloss.to(device=dev, dtype=torch.float32).contiguous()
         dfeat = torch.empty_like(feat)
         dmain = torch.empty_like(main_proto)
         dbg = torch.empty_like(bg_proto)
-        dfsum = torch.zeros((HEAD_MAX_FAKE, feat.shape[1] + 1), dtype=torch.float32, device=dev)
+        dfsum = torch.zeros((HEAD_MAX_FAKE, C + 1), dtype=torch.float32, device=dev)
+        a = _lib.CaplHeadArgs()                    # a struct of its own: backward is re-entrant and never sees a stale pointer
+        a.B, a.C, a.N = B, C, N
+        a.feat, a.feat_bstride = feat.data_ptr(), C * N
+        a.label, a.ignore_index = y.data_ptr(), ignore_index
+        a.main_proto, a.classes = main_proto.data_ptr(), classes
+        a.bg_proto, a.base_num = bg_proto.data_ptr(), base_num
+        a.n_fake = len(fake)
+        for i, c in enumerate(fake):
+            a.fake[i] = c
+        a.half = B // 2
+        a.fsum, a.workspace, a.workspace_bytes = fsum.data_ptr(), ws.data_ptr(), ws.numel()
+        a.loss, a.pred = loss.data_ptr(), None     # the predictions belong to the caller and are not read by the backward
         a.dloss, a.dfsum = dloss.data_ptr(), dfsum.data_ptr()
         a.dfeat, a.dmain, a.dbg = dfeat.data_ptr(), dmain.data_ptr(), dbg.data_ptr()
         with torch.cuda.device(dev):

@@ -251,6 +251,14 @@ size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, co
 size_t gfs3d_pointwise_workspace_bytes_ex(int B, int N, int n_seg, int seg_width, int n_layers, const int *width);
 int gfs3d_pointwise_forward_f32(const gfs3d_pointwise_args *a, void *stream);
 int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream);
+/* In a monolithic (non-phased, non-deterministic) training call the LAST workgroup of the kernel that completes a layer's
+ * BatchNorm column sums also finalises that layer (scale / shift / running statistics in the forward; coefficients, dgamma,
+ * dbeta in the backward) instead of a tiny launch of its own.  gfs3d_set_bn_tail(0) - or GFS3D_PW_TAIL=0 in the
+ * environment at load time - selects the separate finalisation kernels (same results up to the order of the fp64 atomic
+ * sums): a field switch for bisecting, and what tests/test_gpu_stress.py flips.  Diagnostic contract used by that test:
+ * after either call the first n_layers * 2 * maxw doubles of `workspace` (maxw = the largest width[l]) still hold the
+ * column sums [layer][2][maxw] the finalisation was computed from. */
+int gfs3d_set_bn_tail(int on);
 
 /* Phased variants for SYNCHRONISED BatchNorm (see the EdgeConv phases above).  L = n_layers, maxw = the largest layer
  * width, `acc` a caller-owned device buffer of 2 * L * 2 * maxw doubles: rows [l][2][maxw] of global sums, followed by

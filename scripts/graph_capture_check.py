@@ -1,5 +1,5 @@
 import sys, os
-ROOT = "/root/repo"
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gfs-3dseg_gws_amd"))
 import torch, time
 from gfs3d.synthetic import synthetic_blocks

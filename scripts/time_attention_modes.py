@@ -1,5 +1,7 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/gfs-3dseg_gws_amd"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "gfs-3dseg_gws_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, _p)
 import torch
 from gfs3d import ops
 from test_gpu_reduced import cosine

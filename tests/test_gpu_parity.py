@@ -200,6 +200,10 @@ def test_edgeconv_eval_non_finite_input_stays_confined(dev, bad):
 @pytest.mark.parametrize("B,C,N,k", [(2, 9, 256, 20), (2, 64, 128, 20), (1, 9, 131, 7), (1, 9, 5, 3), (1, 64, 33, 1),
                                      (2, 9, 70, 32), (8, 64, 64, 20), (16, 9, 40, 5), (1, 64, 520, 20), (2, 9, 1100, 20)])
 def test_edgeconv_train_forward_backward(dev, B, C, N, k):
+    _edgeconv_train_case(dev, B, C, N, k)
+
+
+def _edgeconv_train_case(dev, B, C, N, k):
     from gfs3d import ops
     p = _block_params(C, 200 + C)
     g = torch.Generator().manual_seed(N + k)
@@ -1358,8 +1362,8 @@ def test_rccl_single_rank_exercises_every_collective(dev):
     out = ctx.Manager().dict()
     pr = ctx.Process(target=_rccl_rank, args=(0, 1, port, out))
     pr.start()
-    pr.join(600)
-    assert pr.exitcode == 0
+    _join_child(pr, 600, "single-rank RCCL child")
+    assert 0 in out, "the RCCL child ended without writing its results"
     r = out[0]
     assert r["backend"] == "nccl" and r["f64"] and r["i32max"] == [0, 1, 0, 1] and r["i64"] == sum(range(39))
     assert r["diff"] == [2.0] * 5 and r["bcast"] and r["max"] == 3.5
@@ -1395,6 +1399,19 @@ def _edgeconv_grads_for_form_test():
     return [t.detach().cpu().numpy() for t in (xg.grad, c1.weight.grad, c2.weight.grad, bn1.weight.grad, bn1.bias.grad)]
 
 
+def _join_child(pr, seconds, what):
+    """Wait for a spawned child; a child that overran is ended (it holds the GPU and a Manager process) before the test fails."""
+    pr.join(seconds)
+    if pr.is_alive():
+        pr.terminate()
+        pr.join(30)
+        if pr.is_alive():
+            pr.kill()
+            pr.join()
+        pytest.fail(f"{what}: child process still running after {seconds} s (terminated)")
+    assert pr.exitcode == 0, f"{what}: child exit code {pr.exitcode}"
+
+
 def test_edgeconv_backward_wave_pair_form_equals_one_wave_form(dev):
     """The shipped heavy backward (ec_main_bwd_pair_kernel: a front and a back wave per SIMD) against the one-wave form it replaced
     (GFS3D_EC_BWD_PAIR=0, run in a child process): the same sums in the same order except the weight gradient's accumulation
@@ -1404,12 +1421,35 @@ def test_edgeconv_backward_wave_pair_form_equals_one_wave_form(dev):
     out = ctx.Manager().dict()
     pr = ctx.Process(target=_one_wave_backward, args=(out,))
     pr.start()
-    pr.join(300)
-    assert pr.exitcode == 0
+    _join_child(pr, 300, "one-wave backward")
+    assert "grads" in out, "the child ended without writing its gradients"
     ref = out["grads"]
     new = _edgeconv_grads_for_form_test()
     for a, b in zip(new, ref):
         assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-12)
+
+
+def _one_wave_vs_oracle(out):
+    """Child process with GFS3D_EC_BWD_PAIR=0: the oracle comparison of test_edgeconv_train_forward_backward on the one-wave form."""
+    import os
+    os.environ["GFS3D_EC_BWD_PAIR"] = "0"
+    d = torch.device("cuda:0")
+    for case in ((2, 64, 128, 20), (2, 9, 1100, 20), (8, 64, 64, 20)):
+        _edgeconv_train_case(d, *case)
+    out["ok"] = True
+
+
+def test_edgeconv_backward_one_wave_form_matches_the_oracle(dev):
+    """the one-wave-per-SIMD heavy backward (still the form for N k >= 65536 / no CSR buffers, and
+    GFS3D_EC_BWD_PAIR=0) stays pinned to the ORACLE, not only to the pair form: forward, running statistics and all seven
+    gradients at 1e-4 on three shapes, in a child process (the switch is read once per process)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    pr = ctx.Process(target=_one_wave_vs_oracle, args=(out,))
+    pr.start()
+    _join_child(pr, 300, "one-wave backward vs oracle")
+    assert out.get("ok") is True
 
 
 def test_entry_points_are_graph_capture_safe(dev):
