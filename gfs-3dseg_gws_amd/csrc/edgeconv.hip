@@ -1742,7 +1742,7 @@ template <bool HALF>
 __global__ void __launch_bounds__(256)
 ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowptr,
                      const float *__restrict__ P, const float *__restrict__ Q, const float *__restrict__ GQ,
-                     const float *__restrict__ stats, int BN, float *__restrict__ GP, const BnAcc partial)
+                     const float *__restrict__ stats, int BN, float *__restrict__ GP, const BnAcc partial, int rev)
 {
     if constexpr (HALF) {
         // lane = (row slot sub = lane >> 3, dword quad c4 = lane & 7): one wave instruction reads 8 rows of 128 B; a lane owns
@@ -1763,7 +1763,8 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
         for (int e = 0; e < 8; ++e) { s[e] = 0.0; sx[e] = 0.0; }
         constexpr int SEG_TPW = 8;
         const int nchunk = (BN + SEG_TPW - 1) / SEG_TPW;
-        for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
+        for (int c_ = blockIdx.x * 4 + wv; c_ < nchunk; c_ += gridDim.x * 4) {
+            const int ch = rev ? nchunk - 1 - c_ : c_;
             const int t0 = ch * SEG_TPW;
             const int myptr = rowptr[min(t0 + min(lane, SEG_TPW), BN)];
 #pragma unroll 2
@@ -1840,7 +1841,9 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
     // a wave owns SEG_TPW consecutive targets = one contiguous run of CSR rows; their row pointers come in with one load
     constexpr int SEG_TPW = 8;
     const int nchunk = (BN + SEG_TPW - 1) / SEG_TPW;
-    for (int ch = blockIdx.x * 4 + wv; ch < nchunk; ch += gridDim.x * 4) {
+    // rev: the clouds written LAST by the heavy kernel are read FIRST (their rows are the ones still in the memory-side cache)
+    for (int c_ = blockIdx.x * 4 + wv; c_ < nchunk; c_ += gridDim.x * 4) {
+        const int ch = rev ? nchunk - 1 - c_ : c_;
         const int t0 = ch * SEG_TPW;
         const int myptr = rowptr[min(t0 + min(lane, SEG_TPW), BN)];
 #pragma unroll 2
@@ -2524,12 +2527,13 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         }
         if (csr) {
             const int sg = min((BN + 31) / 32, 2048);
+            static const int seg_rev = [] { const char *e = getenv("GFS3D_EC_SEGSUM_REV"); return e ? atoi(e) : 1; }();       // A-B only
             if (prec_of(a->compute, true) != PREC_X6)
                 hipLaunchKernelGGL(ec_bwd_segsum_kernel<true>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
-                                   a->stats, BN, GP, BnAcc{acc2, rows});
+                                   a->stats, BN, GP, BnAcc{acc2, rows}, seg_rev);
             else
                 hipLaunchKernelGGL(ec_bwd_segsum_kernel<false>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
-                                   a->stats, BN, GP, BnAcc{acc2, rows});
+                                   a->stats, BN, GP, BnAcc{acc2, rows}, seg_rev);
             GFS3D_LAUNCH_CHECK("ec_bwd_segsum_kernel");
             if (int rc = bn_finish(BnAcc{acc2, rows}, sg, st, mid)) return rc;
         } else {

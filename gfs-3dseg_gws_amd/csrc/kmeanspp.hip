@@ -1,0 +1,265 @@
+// k-means++ seeding on the device (configs[2]: 200 centroids over up to 2.1 M x 192 fp32 points).
+// Replaces the seeding half of sklearn's KMeans(init='k-means++') in get_basis.py:210 of the reference (a third-party
+// dependency, not vendored; the D^2 sampling of Arthur & Vassilvitskii is restated here: the next centre is point i with
+// probability d2[i] / sum d2, d2[i] = squared distance to the nearest centre so far).
+//
+// The K - 1 picks are sequential by nature; each costs one pass over the points.  Everything stays on the device and nothing
+// waits for the host: the uniform variates are drawn on the host up front (numpy RandomState - the same stream the host form
+// consumed one at a time) and uploaded once.
+//   kpp_update_kernel  d2[i] = min(d2[i], |p_i - c_t|^2), nearest[i], and the fp64 sum of d2 per block of 1024 points.  A point
+//                      whose nearest centre a satisfies |c_t - c_a|^2 >= 4 d2[i] cannot move (triangle inequality): its 768-byte
+//                      row is not read at all - late picks read a small part of the array.
+//   kpp_pick_kernel    one workgroup: cdf over the block sums -> block; cdf over that block's d2 -> the first point whose
+//                      cumulative mass exceeds u * total (numpy's searchsorted(cdf, u, side='right')); copies its row to
+//                      centers[t + 1] and leaves |c_new - c_a|^2 for the next update's pruning test.
+// Fixed summation orders everywhere: the picks are a pure function of (points, first, u).
+#include "common.h"
+
+namespace gfs3d {
+namespace {
+
+constexpr int KPP_BLOCK = 1024;          // points per workgroup of the update kernel = granularity of the two-level cdf
+constexpr int KPP_PICK_THREADS = 1024;
+constexpr float KPP_PRUNE_MARGIN = 1.0f + 1e-3f;       // skip only when the bound holds with room for the roundings of both sides
+
+typedef float kf4 __attribute__((ext_vector_type(4)));
+
+// 16 lanes per row (float4 each per piece), 4 rows per wave step; the 64 rows of a wave chunk are filtered first and only the
+// rows that can move are visited.
+template <int C4MAX>       // float4 pieces of a row handled per lane: ceil(C / 64)
+__global__ void __launch_bounds__(256)
+kpp_update_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ centers, int t,
+                  const float *__restrict__ cc, int prune, float *__restrict__ d2, int *__restrict__ nearest, double *__restrict__ bsum)
+{
+    __shared__ double wsum[4];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 15, grp = lane >> 4;
+    const int c4n = C >> 2;
+    kf4 cen[C4MAX];
+#pragma unroll
+    for (int s = 0; s < C4MAX; ++s) {
+        const int pc = q + 16 * s;
+        cen[s] = pc < c4n ? *reinterpret_cast<const kf4 *>(centers + (size_t)t * C + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long long base = (long long)blockIdx.x * KPP_BLOCK + wv * 256;
+    double acc = 0.0;
+    for (int ch = 0; ch < 4; ++ch) {
+        const long long row0 = base + 64 * ch;
+        if (row0 >= M) break;
+        const long long mine = row0 + lane;
+        const bool have = mine < M;
+        float myd = 0.f;
+        int mya = 0;
+        bool need = have;
+        if (t > 0 && have) {
+            myd = d2[mine];
+            mya = nearest[mine];
+            // |p - c_t| >= |c_t - c_a| - |p - c_a| >= 2 r - r = r when |c_t - c_a|^2 >= 4 r^2
+            if (prune && cc[mya] >= 4.f * myd * KPP_PRUNE_MARGIN) need = false;
+        }
+        unsigned long long mask = __ballot(need);
+        float newd = 0.f;
+        while (mask) {                                             // wave-uniform: up to 4 rows per trip
+            int b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                b[g] = mask ? (int)__builtin_ctzll(mask) : -1;
+                mask &= mask - 1;
+            }
+            const int r = grp == 0 ? b[0] : grp == 1 ? b[1] : grp == 2 ? b[2] : b[3];
+            float s_ = 0.f;
+            if (r >= 0) {
+                const float *row = pts + (size_t)(row0 + r) * C;
+                kf4 v[C4MAX];
+#pragma unroll
+                for (int s = 0; s < C4MAX; ++s) {
+                    const int pc = q + 16 * s;
+                    v[s] = pc < c4n ? *reinterpret_cast<const kf4 *>(row + 4 * pc) : cen[s];
+                }
+#pragma unroll
+                for (int s = 0; s < C4MAX; ++s) {
+                    const kf4 d = v[s] - cen[s];
+                    s_ = fmaf(d.x, d.x, s_);
+                    s_ = fmaf(d.y, d.y, s_);
+                    s_ = fmaf(d.z, d.z, s_);
+                    s_ = fmaf(d.w, d.w, s_);
+                }
+            }
+            s_ += __shfl_xor(s_, 1, 64);
+            s_ += __shfl_xor(s_, 2, 64);
+            s_ += __shfl_xor(s_, 4, 64);
+            s_ += __shfl_xor(s_, 8, 64);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float dg = __shfl(s_, 16 * g, 64);
+                if (lane == b[g]) newd = dg;
+            }
+        }
+        if (have) {
+            if (t == 0) { myd = newd; mya = 0; d2[mine] = myd; nearest[mine] = 0; }
+            else if (need && newd < myd) { myd = newd; mya = t; d2[mine] = myd; nearest[mine] = t; }
+            acc += (double)myd;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+}
+
+// inclusive scan of one double per thread over the workgroup (Hillis-Steele in LDS: a fixed tree)
+__device__ __forceinline__ double block_scan_incl(double v, double *buf, int tid, int n)
+{
+    buf[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < n; o <<= 1) {
+        const double add = tid >= o ? buf[tid - o] : 0.0;
+        __syncthreads();
+        buf[tid] += add;
+        __syncthreads();
+    }
+    return buf[tid];
+}
+
+__global__ void __launch_bounds__(KPP_PICK_THREADS)
+kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, long long first, const double *__restrict__ u,
+                const float *__restrict__ d2, const double *__restrict__ bsum, int nblk, float *__restrict__ centers,
+                long long *__restrict__ picks, float *__restrict__ cc)
+{
+    __shared__ double buf[KPP_PICK_THREADS];
+    __shared__ long long s_pick;
+    __shared__ int s_blk, s_win, s_last;
+    __shared__ double s_before, s_target;
+    const int tid = threadIdx.x;
+    if (t_new == 0) {
+        if (tid == 0) s_pick = first;
+        __syncthreads();
+    } else {
+        // level 1: thread j owns `per` consecutive blocks
+        const int per = (nblk + KPP_PICK_THREADS - 1) / KPP_PICK_THREADS;
+        double mine = 0.0;
+        for (int e = 0; e < per; ++e) {
+            const int b = tid * per + e;
+            if (b < nblk) mine += bsum[b];
+        }
+        const double incl = block_scan_incl(mine, buf, tid, KPP_PICK_THREADS);
+        const double total = buf[KPP_PICK_THREADS - 1];
+        const double target = u[t_new - 1] * total;
+        if (tid == 0) { s_blk = -1; s_target = target; s_win = KPP_PICK_THREADS; }
+        __syncthreads();
+        const double before = incl - mine;
+        if (total > 0.0 && incl > target && before <= target) atomicMin(&s_win, tid);   // (rounding of incl - mine: the lowest match wins)
+        __syncthreads();
+        if (tid == s_win) {
+            double run = before;
+            int pickb = -1;
+            for (int e = 0; e < per; ++e) {
+                const int b = tid * per + e;
+                if (b >= nblk) break;
+                const double nxt = run + bsum[b];
+                if (nxt > target) { pickb = b; break; }
+                run = nxt;
+            }
+            if (pickb < 0) {                                        // rounding at the range's end: its last non-empty block
+                run = before;
+                for (int e = 0; e < per; ++e) {
+                    const int b = tid * per + e;
+                    if (b >= nblk) break;
+                    if (bsum[b] > 0.0) { pickb = b; s_before = run; }
+                    run += bsum[b];
+                }
+            } else {
+                s_before = run;
+            }
+            s_blk = pickb;
+        }
+        __syncthreads();
+        if (s_blk < 0) {                                            // no mass left (every point coincides with a centre), or u == 1
+            if (tid == 0) {
+                long long i = total > 0.0 ? M - 1 : (long long)(u[t_new - 1] * (double)M);
+                s_pick = i < 0 ? 0 : (i >= M ? M - 1 : i);
+            }
+            __syncthreads();
+        } else {
+            // level 2: the block's 1024 values, one per thread
+            const long long i = (long long)s_blk * KPP_BLOCK + tid;
+            const double v = i < M ? (double)d2[i] : 0.0;
+            const double in2 = s_before + block_scan_incl(v, buf, tid, KPP_PICK_THREADS);
+            if (tid == 0) { s_win = KPP_PICK_THREADS; s_last = -1; }
+            __syncthreads();
+            if (v > 0.0 && in2 > s_target && in2 - v <= s_target) atomicMin(&s_win, tid);
+            if (v > 0.0) atomicMax(&s_last, tid);
+            __syncthreads();
+            // (no match: rounding between the two levels put the target past the block's end - its last point with mass)
+            if (tid == 0) s_pick = (long long)s_blk * KPP_BLOCK + (s_win < KPP_PICK_THREADS ? s_win : (s_last < 0 ? 0 : s_last));
+            __syncthreads();
+        }
+    }
+    const long long pk = s_pick;
+    if (tid == 0) picks[t_new] = pk;
+    // the new centre's row, and its squared distance to every earlier centre (the next update's pruning table)
+    float *crow = centers + (size_t)t_new * C;
+    for (int c = tid; c < C; c += KPP_PICK_THREADS) crow[c] = pts[(size_t)pk * C + c];
+    __syncthreads();                                                // (global writes of this workgroup are visible to it after the barrier)
+    for (int a = tid; a <= t_new; a += KPP_PICK_THREADS) {
+        float s_ = 0.f;
+        const float *ar = centers + (size_t)a * C, *nr = pts + (size_t)pk * C;
+        for (int c = 0; c < C; ++c) {
+            const float d = ar[c] - nr[c];
+            s_ = fmaf(d, d, s_);
+        }
+        cc[a] = a == t_new ? 0.f : s_;
+    }
+}
+
+}  // namespace
+}  // namespace gfs3d
+
+using namespace gfs3d;
+
+extern "C" size_t gfs3d_kmeanspp_workspace_bytes(long long M, int K)
+{
+    if (M < 1 || K < 1) return 0;
+    const size_t nblk = (size_t)((M + KPP_BLOCK - 1) / KPP_BLOCK);
+    return align_up(sizeof(float) * (size_t)M, 256) + align_up(sizeof(int) * (size_t)M, 256) + align_up(sizeof(double) * nblk, 256) +
+           align_up(sizeof(float) * (size_t)K, 256);
+}
+
+extern "C" int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int K, long long first, const double *u, float *centers,
+                                       long long *picks, void *workspace, size_t workspace_bytes, int prune, void *stream)
+{
+    const char *who = "gfs3d_kmeanspp_seed_f32";
+    GFS3D_REQUIRE(pts && u && centers && picks, "%s: NULL argument", who);
+    GFS3D_REQUIRE(M >= 1 && K >= 1 && K <= M, "%s: need 1 <= K <= M (M=%lld K=%d)", who, M, K);
+    GFS3D_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, "%s: C=%d unsupported (a multiple of 4, <= 1024)", who, C);
+    GFS3D_REQUIRE(first >= 0 && first < M, "%s: first=%lld out of range", who, first);
+    GFS3D_REQUIRE((M + KPP_BLOCK - 1) / KPP_BLOCK < (1ll << 30), "%s: M too large", who);
+    GFS3D_REQUIRE(workspace && workspace_bytes >= gfs3d_kmeanspp_workspace_bytes(M, K), "%s: workspace too small", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nblk = (int)((M + KPP_BLOCK - 1) / KPP_BLOCK);
+    char *ws = static_cast<char *>(workspace);
+    float *d2 = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)M, 256);
+    int *nearest = reinterpret_cast<int *>(ws);
+    ws += align_up(sizeof(int) * (size_t)M, 256);
+    double *bsum = reinterpret_cast<double *>(ws);
+    ws += align_up(sizeof(double) * (size_t)nblk, 256);
+    float *cc = reinterpret_cast<float *>(ws);
+    const int c4 = (C / 4 + 15) / 16;                          // float4 pieces per lane
+    for (int t = 0; t < K; ++t) {
+        hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_PICK_THREADS), 0, st, pts, M, C, t, first, u, d2, bsum, nblk, centers, picks, cc);
+        GFS3D_LAUNCH_CHECK("kpp_pick_kernel");
+        if (t == K - 1) break;
+#define KPP_LAUNCH(N_)                                                                                                          \
+    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t, cc, prune, d2, nearest, bsum)
+        if (c4 <= 1) KPP_LAUNCH(1);
+        else if (c4 <= 2) KPP_LAUNCH(2);
+        else if (c4 <= 3) KPP_LAUNCH(3);
+        else if (c4 <= 4) KPP_LAUNCH(4);
+        else if (c4 <= 8) KPP_LAUNCH(8);
+        else KPP_LAUNCH(16);
+#undef KPP_LAUNCH
+        GFS3D_LAUNCH_CHECK("kpp_update_kernel");
+    }
+    return GFS3D_OK;
+}

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
-_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip", "kmeanspp.hip")
 _lib = None
 KNN_IMG_SLACK_ROWS = 128      # GFS3D_KNN_IMG_SLACK_ROWS
 
@@ -188,6 +188,9 @@ SYMBOLS = {
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfs3d_kmeans_assign_fast_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gfs3d_kmeanspp_workspace_bytes": (c_size_t, [c_longlong, c_int]),
+    "gfs3d_kmeanspp_seed_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_int, c_void_p]),
     "gfs3d_proto_backward_proto_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfs3d_proto_backward_proto_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),

@@ -1141,3 +1141,27 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False):
         rc = fn(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "gfs3d_kmeans_assign_ws_f32")
     return label, sums, counts, inertia
+
+
+def kmeanspp_seed(pts: torch.Tensor, K: int, first: int, u, prune: bool = True):
+    """k-means++ seeding on the device (gfs3d_kmeanspp_seed_f32; the `init='k-means++'` of get_basis.py:210): pts (M,C)
+    fp32, `first` the first centre's index, `u` the K - 1 uniform variates of the picks (host array: numpy RandomState draws).
+    Returns (centers (K,C), picks (K,) int64) - device tensors, nothing waits for the host."""
+    _need_gpu(pts, "pts")
+    pts = pts.contiguous()
+    M, C = pts.shape
+    dev = pts.device
+    u = torch.as_tensor(u, dtype=torch.float64).reshape(-1)
+    if u.numel() != K - 1:
+        raise ValueError("gfs3d.kmeanspp_seed: K - 1 uniform variates are needed")
+    u_dev = (u if u.numel() else torch.zeros(1, dtype=torch.float64)).to(dev)
+    centers = torch.empty((K, C), dtype=torch.float32, device=dev)
+    picks = torch.empty(K, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        L = _lib.lib()
+        nbytes = L.gfs3d_kmeanspp_workspace_bytes(M, K)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        rc = L.gfs3d_kmeanspp_seed_f32(_p(pts), M, C, K, int(first), _p(u_dev), _p(centers), _p(picks), _p(ws), ws.numel(),
+                                       1 if prune else 0, _stream())
+    _lib.check(rc, "gfs3d_kmeanspp_seed_f32")
+    return centers, picks

@@ -257,7 +257,7 @@ int gfs3d_pointwise_backward_f32(const gfs3d_pointwise_bwd_args *a, void *stream
  * environment at load time - selects the separate finalisation kernels (same results up to the order of the fp64 atomic
  * sums): a field switch for bisecting, and what tests/test_gpu_stress.py flips.  Diagnostic contract used by that test:
  * after either call the first n_layers * 2 * maxw doubles of `workspace` (maxw = the largest width[l]) still hold the
- * column sums [layer][2][maxw] the finalisation was computed from. */
+ * column sums the finalisation was computed from: layer l's two rows of width[l] doubles at [2 maxw l] and [2 maxw l + width[l]]. */
 int gfs3d_set_bn_tail(int on);
 
 /* Phased variants for SYNCHRONISED BatchNorm (see the EdgeConv phases above).  L = n_layers, maxw = the largest layer
@@ -445,6 +445,19 @@ int gfs3d_kmeans_assign_fast_f32(const float *pts, long long M, int C, const flo
 int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
                                int32_t *label, float *sums, float *counts, double *inertia,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* k-means++ seeding on the device: the `init='k-means++'` half of `KMeans(n_clusters=num_cnt, init='k-means++').fit(point_feat)`,
+ * get_basis.py:210 of the reference (sklearn, not vendored; restated as the plain D^2 sampling of Arthur & Vassilvitskii 2007:
+ * centre t + 1 is point i with probability d2[i] / sum d2, d2 = squared distance to the nearest of the centres so far).
+ *   pts (M, C) row-major fp32, C % 4 == 0, C <= 1024;  first = index of the first centre (the caller's uniform draw);
+ *   u  K - 1 uniform variates in [0, 1) on the DEVICE (drawn on the host, uploaded once): pick t + 1 is
+ *      searchsorted(cumsum(d2), u[t] * sum(d2), side='right') - numpy's RandomState.choice(M, p = d2 / sum d2) on the same variate;
+ *   centers (K, C) out: the picked rows;  picks (K) out: their indices.
+ * 2 K - 1 launches on `stream`, no host synchronisation, fixed summation orders (the picks are a pure function of the
+ * arguments).  prune != 0: a point whose nearest centre a has |c_new - c_a|^2 >= 4 d2 is not re-read (triangle
+ * inequality: it cannot move) - same picks up to rounding-level ties, a fraction of the memory traffic. */
+size_t gfs3d_kmeanspp_workspace_bytes(long long M, int K);
+int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int K, long long first, const double *u, float *centers,
+                            long long *picks, void *workspace, size_t workspace_bytes, int prune, void *stream);
 /* gfs3d_word_assign_f32 / gfs3d_proto_backward_feat_f32 with the matrix-core operand form chosen by the caller
  * (`compute` = GFS3D_COMPUTE_*; tensors stay fp32).  The reduced forms apply to the geometric-word shapes (more than 32
  * prototypes, C % 32 == 0); get_pred-sized calls (<= 32 prototypes) are HBM-bound on fp32 MFMAs and ignore it. */

@@ -32,18 +32,20 @@ def _make_run(dev, B, N, nseg, widths, seed):
 
 
 def _sums(run):
+    """Per layer l the pair (sum, sum of squares | sum g, sum g h): rows of C doubles at [2 maxw l] and [2 maxw l + C]."""
     L, maxw = len(run.widths), max(run.widths)
-    return run._private_ws[:L * 2 * maxw * 8].view(torch.float64).view(L, 2, maxw).clone()
+    flat = run._private_ws[:L * 2 * maxw * 8].view(torch.float64).clone()
+    return [(flat[2 * maxw * l:2 * maxw * l + C], flat[2 * maxw * l + C:2 * maxw * l + 2 * C]) for l, C in enumerate(run.widths)]
 
 
 def _fwd_dev(run, acc):
     """max over layers of the relative deviation of the finalised (mean, rstd, scale, shift) from the sums in `acc`."""
     count = float(run.B * run.N)
-    worst = torch.zeros((), dtype=torch.float64, device=acc.device)
+    worst = torch.zeros((), dtype=torch.float64, device=run.stats[0].device)
     for l, C in enumerate(run.widths):
         _w, gam, bet, _rm, _rv = run.layers[l]
-        mean = acc[l, 0, :C] / count
-        var = (acc[l, 1, :C] / count - mean * mean).clamp_min(0.0)
+        mean = acc[l][0] / count
+        var = (acc[l][1] / count - mean * mean).clamp_min(0.0)
         rstd = 1.0 / torch.sqrt(var + 1e-5)
         scale = gam.double() * rstd
         ref = torch.stack([scale, bet.double() - mean * scale, mean, rstd])
@@ -53,9 +55,9 @@ def _fwd_dev(run, acc):
 
 
 def _bwd_dev(run, acc, dgs, dbs):
-    worst = torch.zeros((), dtype=torch.float64, device=acc.device)
+    worst = torch.zeros((), dtype=torch.float64, device=run.stats[0].device)
     for l, C in enumerate(run.widths):
-        s1, sgh = acc[l, 0, :C], acc[l, 1, :C]
+        s1, sgh = acc[l]
         mean, rstd = run.stats[l][2].double(), run.stats[l][3].double()
         dgamma = rstd * (sgh - mean * s1)
         for got, ref in ((dgs[l].double(), dgamma), (dbs[l].double(), s1)):
