@@ -43,6 +43,10 @@ PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_pair_kernel", 3: "proto_kernels", 4: "ec_stats1_kernel",
            5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd", 8: "attention_fwd", 9: "attention_bwd"}
+# kernel names as the PMC summaries (profiles/*_hbm_traffic.json) spell them, by (kernel id, reduced mode)
+# (ids 6-9 bracket GROUPS of kernels: no single PMC figure)
+KERNEL_PMC_NAME = {(2, False): "ec_main_bwd_pair_kernel<0>", (2, True): "ec_main_bwd_pair_kernel<1>", (1, False): "ec_main_fwd_kernel<true, 0>",
+                   (1, True): "ec_main_fwd_kernel<true, 2>"}
 WORKLOADS = {
     "c2": dict(model="dgcnn", B=32, dtype="f32", classes=0, base=0, Kw=0,
                text="configs[1]: S3DIS-shaped blocks, batch=32x2048x9 per GPU, k=20, DGCNN+EdgeConv fwd/bwd (train mode, BN batch stats) "
@@ -87,7 +91,7 @@ def hbm_traffic(kernel, tag):
     scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
     import glob
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_hbm_traffic.json")))
-    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r02_e", "r01_e"]:
+    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r03_g", "r02_e"]:
         try:
             with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
                 d = json.load(f)
@@ -97,6 +101,53 @@ def hbm_traffic(kernel, tag):
         except OSError:
             continue
     return None, None
+
+
+def pipe_of(kid, dtype):
+    """(name, peak TFLOP/s) of the pipe kernel `kid` EXECUTES on: the fp32-accurate GEMMs run as six bf16 piece products per
+    fp32 product on the bf16 matrix cores (dense bf16 peak / 6), the reduced modes as one 16-bit product; kNN stays on the
+    fp32 MFMA chain (bit-exact contract) behind a bf16 screen, priced at the fp32 peak only."""
+    if kid == 0:
+        return "fp32 MFMA chain + bf16 screen", None
+    if dtype == "f32":
+        return "bf16 matrix cores, 6 piece products per fp32 product (dense bf16 peak / 6)", PEAK_16BIT_TFLOPS / 6
+    return "16-bit matrix cores, one product per fp32 product (dense 16-bit peak)", PEAK_16BIT_TFLOPS
+
+
+def roofline_of(prof, steps, B, cfg, tag="r04"):
+    """Roofline block of one profiled workload: the library kernel with the largest device time among those with a flop model,
+    its role flops / average launch time against (a) the fp32 peak the results are priced at and (b) the pipe it executes on,
+    and its HBM bytes per launch from the committed PMC passes."""
+    cand = [k for k in prof if algorithmic_flops(k, B, cfg)[1] > 0]
+    roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+    if not cand:
+        return roof
+    dom = max(cand, key=lambda k: prof[k][0])
+    ms, n = prof[dom]
+    flops_step, launches_step = algorithmic_flops(dom, B, cfg)
+    avg_ms = ms / n
+    achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
+    pipe_name, pipe_peak = pipe_of(dom, cfg["dtype"])
+    name = KERNELS[dom] + ("<1>" if (dom == 2 and cfg["dtype"] != "f32") else "")
+    pmc_name = KERNEL_PMC_NAME.get((dom, cfg["dtype"] != "f32"))
+    traffic, src = hbm_traffic(pmc_name, tag) if pmc_name else (None, None)
+    roof.update({"kernel": name, "achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                 "frac_fp32": round(achieved / PEAK_FP32_TFLOPS, 4), "executed_pipe": pipe_name,
+                 "peak_executed_pipe": round(pipe_peak, 1) if pipe_peak else None,
+                 "frac_executed_pipe": round(achieved / pipe_peak, 4) if pipe_peak else None,
+                 "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                 "role_flops_per_launch": int(flops_step / launches_step)})
+    roof["per_kernel"] = {}
+    for kid in sorted(prof):
+        fl, nl = algorithmic_flops(kid, B, cfg)
+        ent = {"ms_per_step": round(prof[kid][0] / steps, 4)}
+        if nl:
+            tf = fl / (prof[kid][0] / steps * 1e-3) / 1e12
+            _, pk = pipe_of(kid, cfg["dtype"])
+            ent.update({"algorithmic_TFLOPps": round(tf, 2), "frac_fp32": round(tf / PEAK_FP32_TFLOPS, 4),
+                        "frac_executed_pipe": round(tf / pk, 4) if pk else None})
+        roof["per_kernel"][KERNELS[kid]] = ent
+    return roof
 
 
 def cpu_baseline(seconds_budget=60.0):
@@ -224,6 +275,40 @@ def timed_ms(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+def c3_end_to_end(dev, n_blocks=1400, num_cnt=200):
+    """configs[2] end to end (reference get_basis.py:162-222): M synthetic base-split blocks -> EdgeConv features of every
+    point (resident) -> <= 300 000 points per foreground class -> k-means++ seeding -> Lloyd to sklearn's tolerance ->
+    per-cluster means -> rank-truncated SVD (host numpy).  1400 blocks x 2048 points with labels in 0..7 give
+    7 classes x ~358 000 points -> the full 7 x 300 000 x 192 k-means problem."""
+    import types as _t
+    from get_basis import DGCNNSeg, extract_geometric_words
+    from gfs3d.synthetic import synthetic_blocks
+    a = _t.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=CIN, dgcnn_k=KNN)
+    torch.manual_seed(0)
+    seg = DGCNNSeg(a, num_classes=8).to(dev).eval()
+    blocks = torch.cat([synthetic_blocks(100, NPTS, seed=100 + i) for i in range(n_blocks // 100)]).to(dev)   # resident: no PCIe in the flow
+    labels = torch.randint(0, 8, (blocks.shape[0], NPTS), generator=torch.Generator().manual_seed(1)).to(dev)
+    extract_geometric_words(seg, blocks[:64], labels[:64], 8, 16, max_per_class=2000, max_iter=3)                # warm-up (first-use costs)
+    torch.cuda.synchronize()
+    tm = {}
+    t0 = time.perf_counter()
+    words = extract_geometric_words(seg, blocks, labels, 8, num_cnt, max_per_class=300000, batch=64, seed=0, max_iter=300, timings=tm)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    host = tm["svd_host"] + tm["means_to_host"]
+    it = tm["lloyd_iterations"]
+    return {"workload": f"configs[2]: {blocks.shape[0]} synthetic blocks x {NPTS} pts, 7 foreground classes -> {tm['points']} x 192 points, "
+                        f"{num_cnt} centroids, k-means++ then Lloyd to tol 1e-4 ({it} iterations), means, SVD",
+            "total_ms": round(total * 1e3, 1),
+            "stage_ms": {k: round(tm[k] * 1e3, 2) for k in ("features", "subsample", "seeding", "lloyd", "means_to_host", "svd_host")},
+            "lloyd_ms_per_iteration": round(tm["lloyd"] * 1e3 / max(it + 1, 1), 3),
+            "features_blocks_per_s": round(blocks.shape[0] / tm["features"], 1),
+            "host_share": round(host / total, 4),
+            "words_shape": list(words.shape),
+            "note": "each stage closed by a device synchronisation; host = the 150 KB read-back of the means + numpy SVD (the only host "
+                    "arithmetic); the Lloyd loop reads one scalar per iteration for its stopping test"}
+
+
 def extras(dev, L, gdist):
     """The other kernels of the path on their BASELINE shapes, each against its BINDING roof (word cosine,
     get_pred and the Lloyd step are HBM-bound, attention is bound by the fp32 matrix rate)."""
@@ -278,10 +363,17 @@ def extras(dev, L, gdist):
                                  "form) + centroid sums as sorted segment sums; the points are read twice"),
                                 ("lloyd_step_exact", False, "every point scored at fp32 accuracy (bf16x6 GEMM): the final assignment, whose inertia is reported")):
             ms = timed_ms(lambda: ops.kmeans_assign(pts, cent, fast=fast), 5, warm=2)
-            out[key] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3), "bound": "hbm",
-                        "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
-                        "algorithmic_TFLOPps": round(2.0 * M * 192 * 200 / ms / 1e9, 2), "note": note}
-        del pts
+            fl = 2.0 * M * 192 * 200
+            out[key] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3),
+                        "bound": "mfma (bf16x6: the scoring GEMM is 2 K = 400 flop per 4 B read = 100 flop/B, above the fp32 balance; "
+                                 "the screened form executes 3 of the 6 piece products)",
+                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2),
+                        "frac_fp32": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
+                        "frac_executed_pipe": round(fl / ms / 1e9 / (PEAK_16BIT_TFLOPS / (3 if fast else 6)), 4),
+                        "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac_hbm": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "note": note}
+        del pts, cent
+        torch.cuda.empty_cache()
+        out["c3_end_to_end"] = c3_end_to_end(dev)
     q, k_, v = (torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
     cot = torch.randn(B, 64, N, generator=g).to(dev)
 
@@ -304,9 +396,9 @@ def extras(dev, L, gdist):
             fl = algorithmic_flops(kid, B)[0]
             # fp32 results on the bf16 matrix cores (6 piece products per fp32 product): roof = dense bf16 peak / 6
             out[key] = {"shape": "B=32x2048, d=64, dropout 0.1", "ms": round(ms, 4), "bound": "mfma (bf16x6: dense bf16 peak / 6)",
-                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2), "peak": round(PEAK_16BIT_TFLOPS / 6, 1),
-                        "frac": round(fl / ms / 1e9 / (PEAK_16BIT_TFLOPS / 6), 4),
-                        "frac_of_fp32_peak": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4)}
+                        "algorithmic_TFLOPps": round(fl / ms / 1e9, 2), "peak_executed_pipe": round(PEAK_16BIT_TFLOPS / 6, 1),
+                        "frac_fp32": round(fl / ms / 1e9 / PEAK_FP32_TFLOPS, 4),
+                        "frac_executed_pipe": round(fl / ms / 1e9 / (PEAK_16BIT_TFLOPS / 6), 4)}
     del q, k_, v, cot
     for name in ("c4", "c5"):
         cfg = WORKLOADS[name]
@@ -328,7 +420,8 @@ def extras(dev, L, gdist):
         prof = read_profile(L)
         out["step_" + name] = {"workload": cfg["text"], "dtype": cfg["dtype"], "ms_per_step": round(dt * 1e3, 3),
                                "blocks_per_s": round(cfg["B"] / dt, 1),
-                               "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / 3, 4) for k, v in prof.items()}}
+                               "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / 3, 4) for k, v in prof.items()},
+                               "roofline": roofline_of(prof, 3, cfg["B"], cfg)}
         if name == "c4":       # the testing path of the reference (train.py test loop): capl.forward(eval_model=True), fp32 results
             net.eval()
             ncls = cfg["classes"]
@@ -548,33 +641,14 @@ def main():
         net.train()
 
     if rank == 0:
-        reduced = cfg["dtype"] != "f32"
-        heavy = [k for k in prof if k in (0, 1, 2)]
-        roof = {"bound": "mfma", "kernel": None, "achieved": None, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
-        if heavy:
-            dom = max(heavy, key=lambda k: prof[k][0])
-            ms, n = prof[dom]
-            flops_step, launches_step = algorithmic_flops(dom, B)
-            avg_ms = ms / n
-            achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
-            peak = PEAK_16BIT_TFLOPS if (reduced and dom in (1, 2)) else PEAK_FP32_TFLOPS
-            traffic, src = hbm_traffic(KERNELS[dom], "r03")
-            roof.update({"kernel": KERNELS[dom], "achieved": round(achieved, 3), "peak": peak, "frac": round(achieved / peak, 4),
-                         "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n})
-            if dom == 2:
-                roof["traffic_note"] = ("ec_main_bwd_pair_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients; 184 MB before the clouds were dealt to XCDs, r03_d) + ~357 MB of plain 256-B row "
-                                        "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once "
-                                        "(the fixed-order replacement of round 1's float-atomic scatter)")
-        roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass). f32 mode: against "
-                        "the fp32 (vector == fp32-MFMA) peak; the EdgeConv / point-wise GEMMs run on the bf16 matrix cores at fp32 accuracy "
-                        "(exact 3-way bf16 split, 6 piece products per fp32 product); kNN stays on the bit-exact fp32 MFMA chain. Reduced "
-                        "modes: conv2 kernels against the dense 16-bit MFMA peak")
-        roof["per_kernel_ms_per_step"] = {KERNELS[k]: round(v[0] / args.steps, 4) for k, v in prof.items()}
-        for kid in (6, 7, 8, 9):
-            if kid in prof:
-                fl, _ = algorithmic_flops(kid, B, cfg)
-                roof[KERNELS[kid]] = {"ms_per_step": round(prof[kid][0] / args.steps, 4),
-                                      "algorithmic_TFLOPps": round(fl / (prof[kid][0] / args.steps * 1e-3) / 1e12, 2)}
+        roof = roofline_of(prof, args.steps, B, cfg)
+        if roof["kernel"] and roof["kernel"].startswith("ec_main_bwd_pair_kernel"):
+            roof["traffic_note"] = ("ec_main_bwd_pair_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients) + ~357 MB of plain 256-B row "
+                                    "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once, last-written "
+                                    "clouds first (the fixed-order, atomic-free form of the scatter_add_ in get_edge_feature's backward)")
+        roof["note"] = ("achieved = algorithmic flops of the kernel's role / its average launch time (second, instrumented pass, hipEvents on the "
+                        "launch stream). `frac` = `frac_fp32`: against the fp32 peak the results are priced at (they are fp32-accurate); "
+                        "`frac_executed_pipe`: against the pipe the kernel runs on (`executed_pipe`).  kNN stays on the bit-exact fp32 MFMA chain")
         if 0 in prof:       # "kNN HBM GB/s" of the metric: algorithmic bytes 4CN + 8Nk per block and layer
             kb = B * sum(4 * C * NPTS + 8 * NPTS * KNN for C in (CIN, 64, 64))
             kms = prof[0][0] / args.steps
@@ -588,7 +662,7 @@ def main():
                         "knn_screen_kernel<20, 4,": 2, "knn_exact_kernel<20, 64>": 2}
             tb, src = 0, None
             for name, n in per_step.items():
-                t_, s_ = hbm_traffic(name, "r03")
+                t_, s_ = hbm_traffic(name, "r04")
                 if t_:
                     tb, src = tb + n * t_, s_
             if tb:
@@ -601,10 +675,12 @@ def main():
             gf, mb = B * (1.19 + 2.44), B * (2.10 + 3.80)
             gf_exec = B * (1.19 + 3 * NPTS * KNN * 2 * 64 * 64 / 1e9 + 2 * NPTS * 64 * (2 * CIN + 4 * 64) / 1e9)
             roof["fwd_knn_edgeconv_eval"] = {"ms": round(fwd_ms, 4), "blocks_per_s": round(B / (fwd_ms * 1e-3), 1),
-                                             "algorithmic_TFLOPps": round(gf / fwd_ms, 2),
-                                             "frac_of_fp32_peak": round(gf / fwd_ms / PEAK_FP32_TFLOPS, 4),
                                              "executed_equivalent_TFLOPps": round(gf_exec / fwd_ms, 2),
-                                             "frac_of_fp32_peak_executed": round(gf_exec / fwd_ms / PEAK_FP32_TFLOPS, 4),
+                                             "frac_fp32": round(gf_exec / fwd_ms / PEAK_FP32_TFLOPS, 4),
+                                             "survey_priced_TFLOPps": round(gf / fwd_ms, 2),
+                                             "survey_priced_note": "SURVEY 8(d) prices conv1 on the N k edges and all N^2 distances; the kernels run conv1 on the "
+                                                                   "N points and screen 98 % of the distance work away - a throughput figure on the survey's "
+                                                                   "flop count, NOT a roofline fraction (it can exceed the peak)",
                                              "algorithmic_GBps": round(mb / fwd_ms, 1)}
         ms_step = elapsed / args.steps * 1e3
         metric = "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd" if cfg["model"] == "dgcnn" else \

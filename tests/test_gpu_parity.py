@@ -428,6 +428,97 @@ def test_dgcnn_full_size_train_step_is_finite_and_repeatable(dev):
     assert all(bool(torch.isfinite(q.grad).all()) for q in net.parameters())
 
 
+def test_dgcnn_bench_workload_train_fwd_bwd_vs_oracle_stage_by_stage(dev):
+    """The workload bench.py times - full DGCNN, B = 32 x 2048 x 9, k = 20, train mode (batch statistics), forward +
+    backward of a mean loss - against the oracle STAGE BY STAGE on identical inputs (the structure of
+    test_dgcnn_full_size_eval_stage_by_stage): every block and the point-wise stack get the device's own input of that stage
+    and the device's graph, so near-tie neighbour swaps and kink flips of an EARLIER stage cannot leak into the comparison.
+      forward   each stage's output and its BatchNorm running statistics within 1e-4 / 1e-5; the graphs bit-exact vs the C oracle;
+      backward  each stage's oracle autograd is fed the cotangent the DEVICE delivered at that stage's output
+                (feats[i].grad) and must reproduce the device's parameter gradients (1e-3: sums over 1.3 M edges, a
+                handful of inner pre-activations within an ulp of the LeakyReLU kink take the other slope) and the gradient
+                flowing to the stage's input (all but 1e-3 of the elements within 1e-4 of the tensor's max, none beyond 5e-2).
+    The loss is bench.py's `out.mean()` with the kink-masked cotangent of test_edgeconv_large_train_forward_backward_vs_oracle
+    (outputs within 1e-4 of the LeakyReLU kink get no cotangent)."""
+    from gfs3d import ops
+    from model.dgcnn import DGCNN
+    B, N, k = 32, 2048, 20
+    torch.manual_seed(0)
+    net = DGCNN([[64, 64]] * 3, [512, 256], 9, k=k, return_edgeconvs=True)
+    sd = {kk: v.clone() for kk, v in net.state_dict().items()}
+    net = net.to(dev).train()
+    x = R.synthetic_blocks(B, N, seed=0)
+    xg = x.to(dev).requires_grad_(True)
+    # DGCNN.forward, spelled out so that both views of every block output can keep their gradient: the channel-first one feeds the
+    # next block, the point-major one the point-wise stack (model/dgcnn.py: forward)
+    feats, feats_pm = net.edgeconv_features(xg, with_point_major=True)
+    out = ops.pointwise_stack(feats_pm, net.conv.fused_parts(), True, 0.2)
+    for f in list(feats) + list(feats_pm):
+        f.retain_grad()
+    ins = [x] + [f.detach().cpu() for f in feats[:-1]]
+
+    def out_grad(i):            # the cotangent the device delivered at block i's output, channel-first
+        g_ = feats_pm[i].grad.detach().transpose(1, 2)
+        return (g_ + feats[i].grad.detach() if feats[i].grad is not None else g_).cpu()
+
+    def near(dev_t, ref_t, what, frac=0.999, worst=5e-2):
+        """all but 1e-3 of the elements within 1e-4 of the tensor's max; the rest - of a block's 84 M inner pre-activations about
+        ten sit within an ulp of the LeakyReLU kink and take the other slope in one of the two implementations, each moving the
+        128 gradient entries of its two end points by that unit's whole share (measured: 3e-4 of the elements, worst 1e-2) -
+        bounded by 5 % of the max"""
+        e = (dev_t.detach().cpu().double() - ref_t.double()).abs() / float(ref_t.abs().max())
+        good, mx = float((e < TOL).double().mean()), float(e.max())
+        assert good > frac and mx < worst, f"{what}: {good:.6f} of the elements within 1e-4, worst {mx:.2e}"
+
+    # ---- forward, stage by stage (no autograd: the 32 x 128 x 2048 x 20 edge tensors are freed per stage)
+    graphs, stats = [], {}
+    with torch.no_grad():
+        for i in range(3):
+            idx = ops.knn_topk(ins[i].to(dev), k).cpu()
+            assert np.array_equal(idx.numpy(), c_oracle.knn(ins[i].numpy(), k)), f"graph of block {i}"
+            graphs.append(idx)
+            yr, jr = R.conv_stack(R.edge_feature(ins[i], k, idx), sd, f"edge_convs.{i}", 2, training=True, new_stats=stats).max(dim=-1)
+            assert maxerr(feats[i], yr) < TOL, f"block {i} forward on its own input"
+            _force_routing(feats[i], torch.gather(idx.unsqueeze(1).expand(B, 64, N, k), 3, jr.unsqueeze(-1)).squeeze(-1))
+            del yr, jr
+        out_ref = R.conv_stack(torch.cat([f.detach().cpu() for f in feats], dim=1), sd, "conv", 2, training=True, new_stats=stats)
+        assert maxerr(out, out_ref) < TOL
+    for name, buf in net.named_buffers():
+        if "running" in name:
+            assert maxerr(buf, stats[name]) < 1e-5, name
+    cot = (out_ref.abs() > 1e-4).float() / out_ref.numel()
+    del out_ref
+    (out * cot.to(dev)).sum().backward()
+    dev_grads = {n_: p_.grad.detach().cpu() for n_, p_ in net.named_parameters()}
+
+    # ---- backward of the point-wise stack on the device's block outputs
+    pr = {kk: v.clone().requires_grad_("running" not in kk and v.dtype.is_floating_point) for kk, v in sd.items() if kk.startswith("conv.")}
+    fin = [f.detach().cpu().requires_grad_(True) for f in feats]
+    (R.conv_stack(torch.cat(fin, dim=1), pr, "conv", 2, training=True, new_stats={}) * cot).sum().backward()
+    for kk, v in pr.items():
+        if v.grad is not None:
+            assert relerr(dev_grads[kk], v.grad) < 1e-3, kk
+    from_stack = [f.grad for f in fin]
+    near(out_grad(2), from_stack[2], "gradient reaching block 3's output")
+    del pr, fin
+
+    # ---- backward of every block, fed the device's own cotangent at its output
+    for i in (2, 1, 0):
+        pref = f"edge_convs.{i}"
+        pr = {kk: v.clone().requires_grad_("running" not in kk and v.dtype.is_floating_point) for kk, v in sd.items() if kk.startswith(pref)}
+        xin = ins[i].clone().requires_grad_(True)
+        yr = R.conv_stack(R.edge_feature(xin, k, graphs[i]), pr, pref, 2, training=True, new_stats={}).max(dim=-1)[0]
+        (yr * out_grad(i)).sum().backward()
+        for kk, v in pr.items():
+            if v.grad is not None:
+                assert relerr(dev_grads[kk], v.grad) < 1e-3, kk
+        if i > 0:       # the block's input is the previous block's output, which also feeds the point-wise stack
+            near(out_grad(i - 1), xin.grad + from_stack[i - 1], f"gradient reaching block {i}'s output")
+        else:
+            near(xg.grad, xin.grad, "gradient w.r.t. the input blocks")
+        del pr, xin, yr
+
+
 # ------------------------------------------------------------------ K3
 @pytest.mark.parametrize("B,C,N,Kw", [(2, 192, 256, 200), (1, 192, 100, 180), (2, 64, 130, 20), (1, 192, 64, 256), (2, 32, 300, 33),
                                       (1, 96, 513, 70)])

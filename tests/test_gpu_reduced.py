@@ -14,7 +14,8 @@ what one operand rounding does (relative 2^-12 for half, 2^-9 for bf16):
                           the LeakyReLU pre-activations across the kink, and each flipped unit changes its gradient by
                           80 % - an rms error of sqrt(fraction) * 0.8 (1.5 % / 5 %) that no arithmetic can avoid.  Per
                           kernel: cosine with the fp32-accurate gradient >= 0.999 (half) / 0.99 (bf16); whole model:
-                          >= 0.95 / 0.8 for every parameter tensor.
+                          >= 0.97 / 0.85 for every parameter tensor (measured 0.979 / 0.873), AND a 60-step training run whose
+                          loss curve stays within 8 % of the fp32 curve at every step (measured 3 %).
 The fp32-accurate mode (default) is untouched by all this: tests/test_gpu_parity.py runs in it.
 """
 import random
@@ -236,7 +237,9 @@ def test_capl_scannet_reduced_vs_reference_golden(dev, mode, word_agree, pred_ag
     assert float(err.max()) < 20 * FWD_TOL[mode] * 1.2
 
 
-@pytest.mark.parametrize("mode,loss_tol,min_cos", [("f16", 1e-3, 0.95), ("bf16", 2e-3, 0.8)])
+# cosine floors: measured lowest per-parameter cosines on MI355X 0.979 (f16) / 0.873 (bf16) - scripts/exp_reduced_cos.py; that these
+# directions TRAIN is what test_reduced_modes_train_like_fp32_over_60_steps shows (loss curves within 3 % of fp32 over 60 steps)
+@pytest.mark.parametrize("mode,loss_tol,min_cos", [("f16", 1e-3, 0.97), ("bf16", 2e-3, 0.85)])
 def test_capl_train_step_reduced_vs_reference_golden(dev, mode, loss_tol, min_cos):
     """A whole CAPL training step (capl.py:194-242) in a reduced mode: loss, predictions and the direction of every
     parameter gradient against the reference's fp32 step."""
@@ -260,6 +263,52 @@ def test_capl_train_step_reduced_vs_reference_golden(dev, mode, loss_tol, min_co
         assert cosine(p.grad, g[key]) >= min_cos, n
         checked += 1
     assert checked >= 30
+
+
+def _capl_training_run(mode, steps, dev, B=8, N=1024, classes=21, base=15, Kw=180):
+    """`steps` Adam steps of the CAPL model (configs[4] shapes: ScanNet, 21 + 1 classes, K_w = 180) on one fixed synthetic batch
+    whose labels are a function of the geometry (height x colour bins), so the loss falls; everything seeded."""
+    import contextlib
+    import io
+    from gfs3d import ops
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    args = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                                 base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(0)
+    gp = torch.randn(Kw, 192, generator=torch.Generator().manual_seed(2)).to(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mpti_net_Point_GeoAsWeight_v2(classes=classes, args=args, base_num=base, gp=gp, energy=0.9)
+    net = net.to(dev).train()
+    x = R.synthetic_blocks(B, N, seed=3).to(dev)
+    y = ((x[:, 2] * 0.999 * 4).long() * 4 + (x[:, 3] * 0.999 * 4).long()).clamp(0, base)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    losses = []
+    torch.manual_seed(1)
+    for s in range(steps):
+        opt.zero_grad(set_to_none=True)
+        random.seed(s)
+        with ops.compute(mode):
+            _, loss = net(x, y=y)
+            loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    return np.array(losses)
+
+
+def test_reduced_modes_train_like_fp32_over_60_steps(dev):
+    """does a reduced mode TRAIN?  60 optimiser steps of the CAPL model from one seed in f32, f16 (half
+    forward / bf16 backward) and bf16: the reduced loss curves must follow the fp32 curve step by step - the band is defined
+    here as 8 % of the fp32 loss at every step and 3 % on the mean of the last 10 steps (measured on MI355X: 2.9 % / 0.4 %
+    for f16, 3.0 % / 1.0 % for bf16; a second fp32 run repeats the first to the last digit) - and the loss must actually fall
+    (2.30 -> < 0.35).  A mode whose gradients only pointed 'roughly downhill' would drift out of this band within ~10 steps."""
+    ref = _capl_training_run("f32", 60, dev)
+    assert ref[0] > 2.0 and ref[-10:].mean() < 0.35 and np.isfinite(ref).all()
+    for mode in ("f16", "bf16"):
+        c = _capl_training_run(mode, 60, dev)
+        assert np.isfinite(c).all(), mode
+        dev_ = np.abs(c - ref) / ref
+        assert dev_.max() < 0.08, (mode, float(dev_.max()), int(dev_.argmax()))
+        assert abs(c[-10:].mean() - ref[-10:].mean()) < 0.03 * ref[-10:].mean(), mode
 
 
 def test_reduced_modes_full_size_step_is_finite(dev):
