@@ -124,9 +124,11 @@ def roofline_of(prof, steps, B, cfg, tag="r04"):
         return roof
     dom = max(cand, key=lambda k: prof[k][0])
     ms, n = prof[dom]
+    # ids 0-2 bracket ONE launch each (3 per step: the EdgeConv layers); ids 6-9 bracket whole passes, several per step in the
+    # CAPL model (backbone stack, BaseLearner, fusion, q|k|v): their flop model is per STEP, so is the time it is divided by
     flops_step, launches_step = algorithmic_flops(dom, B, cfg)
     avg_ms = ms / n
-    achieved = (flops_step / launches_step) / (avg_ms * 1e-3) / 1e12
+    achieved = flops_step / (ms / steps * 1e-3) / 1e12
     pipe_name, pipe_peak = pipe_of(dom, cfg["dtype"])
     name = KERNELS[dom] + ("<1>" if (dom == 2 and cfg["dtype"] != "f32") else "")
     pmc_name = KERNEL_PMC_NAME.get((dom, cfg["dtype"] != "f32"))
@@ -136,7 +138,7 @@ def roofline_of(prof, steps, B, cfg, tag="r04"):
                  "peak_executed_pipe": round(pipe_peak, 1) if pipe_peak else None,
                  "frac_executed_pipe": round(achieved / pipe_peak, 4) if pipe_peak else None,
                  "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n,
-                 "role_flops_per_launch": int(flops_step / launches_step)})
+                 "launches_per_step": round(n / steps, 2), "role_flops_per_step": int(flops_step)})
     roof["per_kernel"] = {}
     for kid in sorted(prof):
         fl, nl = algorithmic_flops(kid, B, cfg)

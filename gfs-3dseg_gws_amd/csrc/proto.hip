@@ -752,6 +752,227 @@ static int launch_proto_bwd_x6(const float *feat, long long bs, int B, int C, in
     return launch_proto_bwd_x6p<NT, CT, MODE, PREC_X6>(feat, bs, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who);
 }
 
+// ---------------------------------------------------------------------------
+// The same kernel fed from a PER-CALL IMAGE of the words (shared prototypes, a caller workspace): proto_bwd_x6_kernel has every
+// workgroup transpose and split the words itself - 2-byte LDS stores, 72 per thread and tile - at ONE workgroup per CU, so its
+// memory phases (softmax-dot pre-pass, tile loads, feature loads, stores) run one after the other with nothing beside them
+// (DESIGN: 20 + 26 + 46 + 27 us around a 65 us core).  Here `proto_words_image_kernel` writes, once per call, the transposed
+// piece image [tile][channel][hi | mid | lo][32 words at their K positions] (192-B rows) and 1 / |g_w|; a workgroup of FOUR
+// waves (128 points, 81 KB of LDS: two per CU, their phases overlap) copies a tile's rows with 16-byte moves.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) char px_lds_char;
+// 16 B per lane, global -> LDS without a VGPR destination (see ks_dma16_off in knn.hip): lane l lands at lds_base + 16 l
+__device__ __forceinline__ void px_dma16_off(const void *gbase_wave_uniform, unsigned voff, const void *lds_dst_wave_uniform)
+{
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(px_lds_char *)lds_dst_wave_uniform);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(base), "v"(voff), "s"(gbase_wave_uniform) : "memory");
+}
+constexpr int PXI_THREADS = 256;
+constexpr int PXI_GROW = 192;            // bytes per image row in global memory (three 64-B piece planes)
+
+template <int PREC>
+__global__ void __launch_bounds__(256)
+proto_words_image_kernel(const float *__restrict__ proto, int K, int C, unsigned short *__restrict__ img, float *__restrict__ ginv)
+{
+    const int ntile = (K + 31) / 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < ntile * 32 * C) {
+        const int w = e / C, c = e - w * C;
+        const int t = w >> 5, wl = w & 31;
+        const float v = w < K ? proto[(size_t)w * C + c] : 0.f;
+        unsigned short *dst = img + ((size_t)t * C + c) * (PXI_GROW / 2) + 16 * (wl >> 4) + px_kpos(wl & 15);
+        if constexpr (PREC == PREC_X6) mm_store1<PREC_X6>(v, dst, 32);
+        else { dst[0] = mm_cvt1<PREC>(v); dst[32] = 0; dst[64] = 0; }
+    }
+    if (blockIdx.x == 0)
+        for (int w = threadIdx.x; w < ntile * 32; w += 256) {
+            float gsq = 0.f;
+            if (w < K)
+                for (int c = 0; c < C; ++c) gsq = fmaf(proto[(size_t)w * C + c], proto[(size_t)w * C + c], gsq);
+            ginv[w] = w < K ? 1.0f / fmaxf(sqrtf(gsq), NORM_EPS) : 0.f;
+        }
+}
+
+template <int NT, int CT, int MODE, int PREC>
+__global__ void __launch_bounds__(PXI_THREADS, 2)
+proto_bwd_x6i_kernel(const float *__restrict__ feat, long long feat_bstride, int C, int N, int K, float scale,
+                     const unsigned char *__restrict__ gimg, const float *__restrict__ gginv,
+                     const float *__restrict__ soft, const float *__restrict__ dup, float *__restrict__ dfeat)
+{
+    constexpr int NROW = CT * 32;                        // image rows = channels
+    constexpr int NP = Mx<PREC>::NP, PARTS = 4 * NP;     // 16-byte parts of an image row that this mode reads
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][NROW][PX_ROW]
+    float *ginv = reinterpret_cast<float *>(img + 2 * NROW * PX_ROW);         // [NT*32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * (PXI_THREADS / 2) + wv * 32 + j;
+    const int nc = min(n, N - 1);
+    const float *fb = feat + (size_t)b * feat_bstride;
+    const float *sb = soft ? soft + (size_t)b * K * N + nc : nullptr;
+    const float *ub = dup + (size_t)b * K * N + nc;
+    for (int w = tid; w < NT * 32; w += PXI_THREADS) ginv[w] = gginv[w];
+
+    float dot = 0.f;
+    if (MODE == MODE_SOFTMAX) {
+#pragma unroll 4
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);
+                if (w < K) dot = fmaf(sb[(size_t)w * N], ub[(size_t)w * N], dot);
+            }
+        dot += __shfl_xor(dot, 32, 64);
+    }
+
+    // a tile's LDS image ([NROW][PX_ROW] bytes) arrives by LDS-DMA (global_load_lds: no VGPR destination - the kernel sits at its
+    // register budget): 1-KB pieces, lane l of piece i fills image bytes 1024 i + 16 l .. + 15 = (row, 16-byte part) and reads that
+    // part of the 192-byte global row (the pad part of a 208-byte LDS row re-reads part 0)
+    constexpr int NPIECE = (NROW * PX_ROW + 1023) / 1024, ND = (NPIECE + PXI_THREADS / 64 - 1) / (PXI_THREADS / 64);
+    static_assert((NROW * PX_ROW) % 1024 == 0, "the tile image is a whole number of DMA pieces");
+    unsigned soff[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+        const int d = ((wv * ND + u) * 64 + lane) * 16, row = d / PX_ROW, within = d - row * PX_ROW;
+        soff[u] = (unsigned)(row * PXI_GROW + (within < PXI_GROW ? within : 0));
+    }
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    auto dma = [&](int t, unsigned char *dst_img) {
+        const unsigned char *src = gimg + (size_t)t * C * PXI_GROW;
+#pragma unroll
+        for (int u = 0; u < ND; ++u)
+            if (wvu * ND + u < NPIECE) px_dma16_off(src, soff[u], dst_img + (wvu * ND + u) * 1024);
+    };
+    float sv[16], uv[16];
+    auto load = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = t * 32 + acc_row(r, h);
+            const bool ok = w < K;
+            uv[r] = ok ? ub[(size_t)w * N] : 0.f;
+            sv[r] = (MODE == MODE_SOFTMAX && ok) ? sb[(size_t)w * N] : 0.f;
+        }
+    };
+    uint4 bp[2][NP];                                     // pieces of d[t]: K-step s <-> registers 8 s .. 8 s + 7
+    auto split_d = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int r = 8 * s + e, w = t * 32 + acc_row(r, h);
+                const float v = (MODE == MODE_SOFTMAX) ? sv[r] * (uv[r] - dot) : uv[r];
+                v8[e] = v * (scale * ginv[min(w, NT * 32 - 1)]);
+            }
+            mm_pieces8<PREC>(v8, bp[s]);
+        }
+    };
+
+    f32x16 G[CT];                               // dfhat, rows = channel 32 ct + acc_row(r, h), column = point
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[ct][r] = 0.f;
+    const int ntile = (K + 31) / 32;
+    dma(0, img);
+    load(0);
+    __syncthreads();                                     // ginv
+    split_d(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile 0 have landed ...
+    __syncthreads();                                     // ... and everyone's
+    for (int t = 0; t < ntile; ++t) {
+        const unsigned char *cur = img + (t & 1) * NROW * PX_ROW;
+        if (t + 1 < ntile) {
+            dma(t + 1, img + ((t + 1) & 1) * NROW * PX_ROW);       // (the other image was last read before the previous barrier)
+            load(t + 1);
+        }
+        const unsigned char *pa = cur + j * PX_ROW + h * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                uint4 af[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    af[pl] = *reinterpret_cast<const uint4 *>(pa + ct * 32 * PX_ROW + pl * 64 + s * 32);
+                mm_mac<PREC>(af, bp[s], G[ct]);
+            }
+        }
+        if (t + 1 < ntile) split_d(t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // normalisation backward, in-lane: |f|^2 and <f, dfhat> over this lane's channels, then the other lane half's
+    const unsigned voff = (unsigned)(4 * h * N + nc) * 4u;                   // + (32 ct + acc_row(r, 0)) N 4 bytes
+    const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fb), 0, (int)min((size_t)C * N * 4, (size_t)0x7fffffff), 0x00020000);
+    float fsq = 0.f, fd = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, (ct * 32 + acc_row(r, 0)) * N * 4, 0));
+            fsq = fmaf(fv, fv, fsq);
+            fd = fmaf(fv, G[ct][r], fd);
+        }
+    fsq += __shfl_xor(fsq, 32, 64);
+    fd += __shfl_xor(fd, 32, 64);
+    const float finv = 1.0f / fmaxf(sqrtf(fsq), NORM_EPS);
+    const float coef = fd * finv * finv;         // <fhat, dfhat> / |f|
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(dfeat + (size_t)b * C * N, 0, (int)min((size_t)C * N * 4, (size_t)0x7fffffff), 0x00020000);
+    const int ovoff = (n < N) ? (int)voff : 0x7fffffff;                     // a lane past N: dropped by the range check
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int so = (ct * 32 + acc_row(r, 0)) * N * 4;
+            const float fv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff, so, 0));
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (G[ct][r] - fv * coef) * finv), rs_o, ovoff, so, 0);
+        }
+}
+
+static size_t proto_bwd_image_bytes(int C, int K)
+{
+    const int ntile = (K + 31) / 32;
+    return align_up((size_t)ntile * C * PXI_GROW, 256) + align_up(sizeof(float) * ntile * 32, 256);
+}
+
+template <int NT, int CT, int MODE, int PREC>
+static int launch_proto_bwd_x6i(const float *feat, long long bs, int B, int C, int N, const float *proto, int K, float scale,
+                                const float *soft, const float *dup, float *dfeat, void *ws, hipStream_t st, const char *who)
+{
+    unsigned char *gimg = static_cast<unsigned char *>(ws);
+    const int ntile = (K + 31) / 32;
+    float *gginv = reinterpret_cast<float *>(gimg + align_up((size_t)ntile * C * PXI_GROW, 256));
+    ProfScope prof(3, st);
+    hipLaunchKernelGGL(proto_words_image_kernel<PREC>, dim3((ntile * 32 * C + 255) / 256), dim3(256), 0, st, proto, K, C,
+                       reinterpret_cast<unsigned short *>(gimg), gginv);
+    GFS3D_LAUNCH_CHECK("proto_words_image_kernel");
+    const size_t lds = (size_t)2 * CT * 32 * PX_ROW + sizeof(float) * NT * 32;
+    GFS3D_ENSURE_LDS((proto_bwd_x6i_kernel<NT, CT, MODE, PREC>), lds, who);
+    dim3 grid((N + PXI_THREADS / 2 - 1) / (PXI_THREADS / 2), B);
+    hipLaunchKernelGGL((proto_bwd_x6i_kernel<NT, CT, MODE, PREC>), grid, dim3(PXI_THREADS), lds, st, feat, bs, C, N, K, scale, gimg, gginv, soft, dup,
+                       dfeat);
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
+// shapes the image form covers: shared words (P == 1), more than 32 of them, C in {64, 128, 192}
+template <int MODE>
+static int dispatch_proto_bwd_image(const float *feat, long long bs, int B, int C, int N, const float *proto, int K, float scale,
+                                    const float *soft, const float *dup, float *dfeat, void *ws, hipStream_t st, const char *who, int prec)
+{
+    const int nt = (K + 31) / 32;
+#define GFS3D_PXI(NT_, CT_)                                                                                                                  \
+    return prec != PREC_X6 ? launch_proto_bwd_x6i<NT_, CT_, MODE, PREC_BF16>(feat, bs, B, C, N, proto, K, scale, soft, dup, dfeat, ws, st, who) \
+                           : launch_proto_bwd_x6i<NT_, CT_, MODE, PREC_X6>(feat, bs, B, C, N, proto, K, scale, soft, dup, dfeat, ws, st, who)
+    if (C == 64) { if (nt <= 2) GFS3D_PXI(2, 2); if (nt <= 4) GFS3D_PXI(4, 2); GFS3D_PXI(8, 2); }
+    if (C == 128) { if (nt <= 2) GFS3D_PXI(2, 4); if (nt <= 4) GFS3D_PXI(4, 4); GFS3D_PXI(8, 4); }
+    if (nt <= 2) GFS3D_PXI(2, 6); if (nt <= 4) GFS3D_PXI(4, 6); GFS3D_PXI(8, 6);
+#undef GFS3D_PXI
+}
+
 template <int MODE>
 static int dispatch_proto_bwd(const float *feat, long long bs, int B, int C, int N, const float *proto, int P, int K, float scale,
                               const float *soft, const float *dup, float *dfeat, hipStream_t st, const char *who, int prec = PREC_X6)
@@ -1668,6 +1889,32 @@ extern "C" int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (soft) return dispatch_proto_bwd<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, st, who, prec);
     return dispatch_proto_bwd<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, P, K, scale, nullptr, dup, dfeat, st, who, prec);
+}
+
+extern "C" size_t gfs3d_proto_backward_feat_workspace_bytes(int C, int K)
+{
+    if (C < 1 || K < 1 || K > 256) return 0;
+    return gfs3d::proto_bwd_image_bytes(C, K);
+}
+
+extern "C" int gfs3d_proto_backward_feat_ws(const float *feat, long long feat_bstride, int B, int C, int N,
+                                            const float *proto, int P, int K, float scale,
+                                            const float *soft, const float *dup, float *dfeat, int compute,
+                                            void *workspace, size_t workspace_bytes, void *stream)
+{
+    using namespace gfs3d;
+    const char *who = "gfs3d_proto_backward_feat_ws";
+    static const bool image_on = [] { const char *e = getenv("GFS3D_PROTO_IMAGE"); return !(e && e[0] == '0'); }();     // A-B only
+    const bool image = image_on && workspace && P == 1 && K > 32 && K <= 256 && (C == 64 || C == 128 || C == 192) && B >= 1 && B <= 65535 && N >= 1 &&
+                       feat && proto && dup && dfeat && feat_bstride >= (long long)C * N && (long long)N * 256 * 4 < 0x7fffffffll &&
+                       (compute == GFS3D_COMPUTE_F32 || compute == GFS3D_COMPUTE_BF16 || compute == GFS3D_COMPUTE_F16);
+    if (!image)        // other shapes (get_pred-sized heads, per-sample prototypes) and argument errors: the form without a workspace
+        return gfs3d_proto_backward_feat_mixed(feat, feat_bstride, B, C, N, proto, P, K, scale, soft, dup, dfeat, compute, stream);
+    GFS3D_REQUIRE(workspace_bytes >= proto_bwd_image_bytes(C, K), "%s: workspace too small", who);
+    const int prec = prec_of(compute, true);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (soft) return dispatch_proto_bwd_image<MODE_SOFTMAX>(feat, feat_bstride, B, C, N, proto, K, scale, soft, dup, dfeat, workspace, st, who, prec);
+    return dispatch_proto_bwd_image<MODE_LOGITS>(feat, feat_bstride, B, C, N, proto, K, scale, nullptr, dup, dfeat, workspace, st, who, prec);
 }
 
 extern "C" size_t gfs3d_proto_backward_proto_workspace_bytes(int B, int C, int N)

@@ -203,6 +203,9 @@ SYMBOLS = {
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gfs3d_proto_backward_feat_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
                                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gfs3d_proto_backward_feat_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gfs3d_proto_backward_feat_ws": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                             c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
 }
 
 

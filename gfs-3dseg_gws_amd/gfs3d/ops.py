@@ -839,10 +839,13 @@ def proto_backward_feat(feat: torch.Tensor, proto: torch.Tensor, scale: float, d
     dup = dup.contiguous()
     dfeat = torch.empty((B, C, N), dtype=torch.float32, device=feat.device)
     with torch.cuda.device(feat.device):
-        rc = _lib.lib().gfs3d_proto_backward_feat_mixed(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
-                                                        _p(soft), _p(dup), _p(dfeat), _compute if compute is None else compute,
-                                                        _stream())
-    _lib.check(rc, "gfs3d_proto_backward_feat_mixed")
+        L = _lib.lib()
+        nbytes = L.gfs3d_proto_backward_feat_workspace_bytes(C, K) if P == 1 else 0     # shared words: a per-call piece image
+        ws = _workspace(feat.device, nbytes) if nbytes else None
+        rc = L.gfs3d_proto_backward_feat_ws(_p(feat), _bstride(feat), B, C, N, _p(proto), P, K, float(scale),
+                                            _p(soft), _p(dup), _p(dfeat), _compute if compute is None else compute,
+                                            _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _lib.check(rc, "gfs3d_proto_backward_feat_ws")
     return dfeat
 
 
@@ -1007,6 +1010,7 @@ class CaplTrainHeadFunction(torch.autograd.Function):
         # prototypes between forward and backward); the scalar fields of the args struct are kept, its pointers are rebuilt
         ctx.save_for_backward(feat, main_proto, bg_proto, y, fsum, loss, ws)
         ctx.scalars = (B, C, N, int(ignore_index), classes, int(base_num), fake)
+        ctx.args_blob = bytes(a)
         ctx.has_fake = bool(fake)
         ctx.mark_non_differentiable(pred)
         return pred, loss[0]
@@ -1021,16 +1025,9 @@ class CaplTrainHeadFunction(torch.autograd.Function):
         dmain = torch.empty_like(main_proto)
         dbg = torch.empty_like(bg_proto)
         dfsum = torch.zeros((HEAD_MAX_FAKE, C + 1), dtype=torch.float32, device=dev)
-        a = _lib.CaplHeadArgs()                    # a struct of its own: backward is re-entrant and never sees a stale pointer
-        a.B, a.C, a.N = B, C, N
-        a.feat, a.feat_bstride = feat.data_ptr(), C * N
-        a.label, a.ignore_index = y.data_ptr(), ignore_index
-        a.main_proto, a.classes = main_proto.data_ptr(), classes
-        a.bg_proto, a.base_num = bg_proto.data_ptr(), base_num
-        a.n_fake = len(fake)
-        for i, c in enumerate(fake):
-            a.fake[i] = c
-        a.half = B // 2
+        # a struct of its own (a byte copy of the forward's scalar fields): backward is re-entrant and never sees a stale pointer
+        a = _lib.CaplHeadArgs.from_buffer_copy(ctx.args_blob)
+        a.feat, a.label, a.main_proto, a.bg_proto = feat.data_ptr(), y.data_ptr(), main_proto.data_ptr(), bg_proto.data_ptr()
         a.fsum, a.workspace, a.workspace_bytes = fsum.data_ptr(), ws.data_ptr(), ws.numel()
         a.loss, a.pred = loss.data_ptr(), None     # the predictions belong to the caller and are not read by the backward
         a.dloss, a.dfsum = dloss.data_ptr(), dfsum.data_ptr()

@@ -467,6 +467,15 @@ int gfs3d_word_assign_mixed(const float *feat, long long feat_bstride, int B, in
 int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
                                     const float *proto, int P, int K, float scale,
                                     const float *soft, const float *dup, float *dfeat, int compute, void *stream);
+/* The same with a caller workspace (gfs3d_proto_backward_feat_workspace_bytes(C, K); 0 = no such form): for SHARED words
+ * (P == 1, 32 < K <= 256, C in {64, 128, 192}) the transposed bf16 piece image of the words and 1 / |g_w| are built ONCE per call
+ * into the workspace and every workgroup copies tiles of it instead of transposing and splitting the words itself (smaller
+ * workgroups, two per CU).  Other shapes run gfs3d_proto_backward_feat_mixed.  Same results up to fp32 summation order. */
+size_t gfs3d_proto_backward_feat_workspace_bytes(int C, int K);
+int gfs3d_proto_backward_feat_ws(const float *feat, long long feat_bstride, int B, int C, int N,
+                                 const float *proto, int P, int K, float scale,
+                                 const float *soft, const float *dup, float *dfeat, int compute,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }
