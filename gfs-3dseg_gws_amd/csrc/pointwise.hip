@@ -123,6 +123,9 @@ struct RowGemm {
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// workgroup barrier that orders LDS traffic only: global stores / loads in flight are NOT waited for (__syncthreads() would: on
+// CDNA4 vmcnt counts stores too, so the second epilogue pass waited for the first pass's stores to reach memory)
+__device__ __forceinline__ void pw_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Shared epilogue of the row GEMMs: acc[TM][TN] are 32x32 MFMA result tiles (column on the lane, rows in the 16
 // registers); wave (wm, wn) owns rows wm*WM.. and columns wn*64.. of the block tile at (row0, col0).
@@ -168,7 +171,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = ldg4(g.ea + gcol); eb = ldg4(g.eb + gcol); }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            __syncthreads();
+            pw_lds_barrier();
             if (wm == ps) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -178,7 +181,8 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                         for (int r = 0; r < 16; ++r)
                             smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ELD + wn * 64 + j * 32 + li] = acc[i][j][r];
             }
-            __syncthreads();
+            pw_lds_barrier();
+            float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // fp32 over the 8 rows of a pass, fp64 beyond
             f32x4 hv[8];
             if (EPI == EPI_BWD_ACT) {
 #pragma unroll
@@ -194,15 +198,19 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&smem[(rr + 8 * jj) * ELD + c4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (EPI == EPI_RAW_STATS) { ts1[e] += (double)v[e]; ts2[e] += (double)v[e] * (double)v[e]; }
+                    if (EPI == EPI_RAW_STATS) { p1[e] += v[e]; p2[e] = fmaf(v[e], v[e], p2[e]); }
                     if (EPI == EPI_AFFINE_ACT) v[e] = lrelu(fmaf(v[e], ea[e], eb[e]), g.slope);
                     if (EPI == EPI_BWD_ACT) {
                         const float hh = hv[jj][e];
                         v[e] = fmaf(hh, ea[e], eb[e]) > 0.f ? v[e] : v[e] * g.slope;
-                        ts1[e] += (double)v[e]; ts2[e] += (double)v[e] * (double)hh;
+                        p1[e] += v[e]; p2[e] = fmaf(v[e], hh, p2[e]);
                     }
                 }
                 *reinterpret_cast<f32x4 *>(op + (size_t)row * g.o_segw) = v;
+            }
+            if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ts1[e] += (double)p1[e]; ts2[e] += (double)p2[e]; }
             }
         }
         if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
