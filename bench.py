@@ -3,13 +3,17 @@
 over synthetic B x 2048 x 9 blocks, k = 20 (config 2: B = 32 per GPU), blocks/s.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps K --warmup W          # N > 1 without WORLD_SIZE in the environment: this process starts N
+                                                         # fresh rank processes itself (before any GPU call) and forwards rank 0's line
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  GFS3D_BENCH_BACKEND=gloo python bench.py --gpus 8 --dry   # the launch + the step's collectives without kernels (no GPU needed)
 
 One process per GPU; ranks own disjoint shards of the block batch (weak scaling:
 32 blocks per GPU); the only data-path collective is one flat-bucket gradient
 all-reduce (RCCL) per step.  A step = zero grads, train-mode forward (BatchNorm
-batch statistics), backward, gradient all-reduce, Adam update.  Rank 0 prints ONE JSON line.
+batch statistics), backward, gradient all-reduce, Adam update.  Rank 0 prints ONE JSON line
+(with `rccl_ranks` = the size of the process group and the device of every rank).
 
 --workload c2 (default)  BASELINE configs[1]: DGCNN + EdgeConv fwd/bwd, B = 32 per GPU, fp32 accuracy
 --workload c4            configs[3]: the whole CAPL training step (S3DIS shapes, 13 + 1 classes, K_w = 200), B = 32 per GPU
