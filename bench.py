@@ -638,12 +638,13 @@ def main():
 
     # north-star side figure (BASELINE.json: "kNN + EdgeConv forward at B=32 x 2048"): the three kNN + EdgeConv
     # blocks alone, eval mode (running statistics), after and outside the timed region
-    fwd_ms = None
+    fwd_ms = c1_ms = None
     if rank == 0 and cfg["model"] == "dgcnn":
         from gfs3d import ops
         net.eval()
         with torch.no_grad(), ops.compute(cfg["dtype"]):
             fwd_ms = timed_ms(lambda: net.edgeconv_features(x), 20)
+            c1_ms = timed_ms(lambda: net(x[:1]), 20)          # BASELINE configs[0] on the device: one 2048 x 9 block, DGCNN eval forward
         net.train()
 
     if rank == 0:
@@ -688,6 +689,10 @@ def main():
                                                                    "N points and screen 98 % of the distance work away - a throughput figure on the survey's "
                                                                    "flop count, NOT a roofline fraction (it can exceed the peak)",
                                              "algorithmic_GBps": round(mb / fwd_ms, 1)}
+        if c1_ms:
+            roof["c1_single_block_eval_forward"] = {"ms": round(c1_ms, 4), "blocks_per_s": round(1e3 / c1_ms, 1),
+                                                    "note": "BASELINE configs[0] on the device (latency-bound: 32 of 256 CUs have work); "
+                                                            "the CPU oracle's figure is cpu_baseline.b1_eval_forward"}
         ms_step = elapsed / args.steps * 1e3
         metric = "point-cloud blocks/sec (2048 pts, k=20) DGCNN fwd+bwd" if cfg["model"] == "dgcnn" else \
                  "point-cloud blocks/sec (2048 pts, k=20) CAPL training step"
