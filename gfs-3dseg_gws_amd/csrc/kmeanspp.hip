@@ -107,18 +107,29 @@ kpp_update_kernel(const float *__restrict__ pts, long long M, int C, const float
     if (threadIdx.x == 0) bsum[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
 }
 
-// inclusive scan of one double per thread over the workgroup (Hillis-Steele in LDS: a fixed tree)
-__device__ __forceinline__ double block_scan_incl(double v, double *buf, int tid, int n)
+// inclusive scan of one double per thread over the workgroup: shuffle scan inside each wave, the 16 wave totals through LDS (a
+// fixed tree: two barriers).  buf[KPP_PICK_THREADS - 1 .. ] is not used: the total is returned through `total`.
+__device__ __forceinline__ double block_scan_incl(double v, double *buf, int tid, int n, double &total)
 {
-    buf[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < n; o <<= 1) {
-        const double add = tid >= o ? buf[tid - o] : 0.0;
-        __syncthreads();
-        buf[tid] += add;
-        __syncthreads();
+    (void)n;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(v, o, 64);
+        if (lane >= o) v += up;
     }
-    return buf[tid];
+    __syncthreads();                                    // (buf may still be read from a previous scan)
+    if (lane == 63) buf[wv] = v;
+    __syncthreads();
+    double before = 0.0, tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < KPP_PICK_THREADS / 64; ++w) {
+        const double x = buf[w];
+        if (w < wv) before += x;
+        tot += x;
+    }
+    total = tot;
+    return v + before;
 }
 
 __global__ void __launch_bounds__(KPP_PICK_THREADS)
@@ -142,8 +153,8 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
             const int b = tid * per + e;
             if (b < nblk) mine += bsum[b];
         }
-        const double incl = block_scan_incl(mine, buf, tid, KPP_PICK_THREADS);
-        const double total = buf[KPP_PICK_THREADS - 1];
+        double total;
+        const double incl = block_scan_incl(mine, buf, tid, KPP_PICK_THREADS, total);
         const double target = u[t_new - 1] * total;
         if (tid == 0) { s_blk = -1; s_target = target; s_win = KPP_PICK_THREADS; }
         __syncthreads();
@@ -184,7 +195,8 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
             // level 2: the block's 1024 values, one per thread
             const long long i = (long long)s_blk * KPP_BLOCK + tid;
             const double v = i < M ? (double)d2[i] : 0.0;
-            const double in2 = s_before + block_scan_incl(v, buf, tid, KPP_PICK_THREADS);
+            double btot;
+            const double in2 = s_before + block_scan_incl(v, buf, tid, KPP_PICK_THREADS, btot);
             if (tid == 0) { s_win = KPP_PICK_THREADS; s_last = -1; }
             __syncthreads();
             if (v > 0.0 && in2 > s_target && in2 - v <= s_target) atomicMin(&s_win, tid);
@@ -200,15 +212,22 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
     // the new centre's row, and its squared distance to every earlier centre (the next update's pruning table)
     float *crow = centers + (size_t)t_new * C;
     for (int c = tid; c < C; c += KPP_PICK_THREADS) crow[c] = pts[(size_t)pk * C + c];
-    __syncthreads();                                                // (global writes of this workgroup are visible to it after the barrier)
-    for (int a = tid; a <= t_new; a += KPP_PICK_THREADS) {
-        float s_ = 0.f;
-        const float *ar = centers + (size_t)a * C, *nr = pts + (size_t)pk * C;
-        for (int c = 0; c < C; ++c) {
-            const float d = ar[c] - nr[c];
-            s_ = fmaf(d, d, s_);
+    // |c_new - c_a|^2 for every earlier centre: a wave per centre, lanes along the channels (coalesced rows, one shuffle tree)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const float *nr = pts + (size_t)pk * C;
+        for (int a = wv; a <= t_new; a += KPP_PICK_THREADS / 64) {
+            float s_ = 0.f;
+            if (a < t_new) {
+                const float *ar = centers + (size_t)a * C;
+                for (int c = lane; c < C; c += 64) {
+                    const float d = ar[c] - nr[c];
+                    s_ = fmaf(d, d, s_);
+                }
+            }
+            s_ = wave_sum(s_);
+            if (lane == 0) cc[a] = s_;
         }
-        cc[a] = a == t_new ? 0.f : s_;
     }
 }
 
