@@ -128,3 +128,12 @@ def test_extract_geometric_words_timings_and_host_share(dev):
     assert w.shape == (16, 192) and np.isfinite(w).all()
     assert {"features", "subsample", "seeding", "lloyd", "means_to_host", "svd_host", "lloyd_iterations", "points"} <= set(tm)
     assert tm["points"] <= 3 * 600
+
+
+def test_bench_c3_end_to_end_line_small(dev):
+    """`extra.c3_end_to_end` of the bench line on a small instance: every stage timed, host share = SVD + read-back."""
+    import bench
+    r = bench.c3_end_to_end(dev, n_blocks=100, num_cnt=16)
+    assert set(r["stage_ms"]) == {"features", "subsample", "seeding", "lloyd", "means_to_host", "svd_host"}
+    assert r["words_shape"] == [16, 192] and 0.0 < r["host_share"] < 1.0
+    assert abs(sum(r["stage_ms"].values()) - r["total_ms"]) < 0.25 * r["total_ms"]

@@ -225,3 +225,26 @@ def test_basis_host_numerics_match_reference():
     assert np.abs(Kmean2Proto(g["pts"], g["km_labels"], 12) - g["proto"]).max() < 1e-6
     assert np.abs(compute_svd(g["proto"]) - g["basis"]).max() < 1e-5
     assert np.abs(compute_svd(g["p200"]) - g["basis200"]).max() < 1e-4
+
+
+def test_bench_roofline_block_reports_both_fractions():
+    """bench.py's roofline block: role flops / time against the fp32 peak AND the pipe the kernel executes on, per launch for
+    the single-kernel ids, per step for the ids that bracket whole passes (several launches per step)."""
+    import bench
+    cfg = dict(bench.WORKLOADS["c2"])
+    B = cfg["B"]
+    # 3 steps: the heavy backward 9 launches of 0.2 ms, the point-wise backward one 0.6-ms pass per step
+    prof = {2: (9 * 0.2, 9), 7: (3 * 0.6, 3), 0: (3 * 0.4, 9)}
+    r = bench.roofline_of(prof, 3, B, cfg, tag="r04")
+    assert r["kernel"].startswith("pointwise_stack_bwd") or r["kernel"].startswith("ec_main_bwd_pair_kernel")
+    pk = r["per_kernel"]
+    conv2 = 32 * 2048 * 20 * 2 * (2 * 64 * 64)                               # one layer's dgrad + wgrad
+    want = 3 * conv2 / (0.6e-3) / 1e12                                        # 3 launches in 0.6 ms per step
+    assert abs(pk["ec_main_bwd_pair_kernel"]["algorithmic_TFLOPps"] - round(want, 2)) < 0.02
+    assert abs(pk["ec_main_bwd_pair_kernel"]["frac_fp32"] - want / 157.3) < 1e-3
+    assert abs(pk["ec_main_bwd_pair_kernel"]["frac_executed_pipe"] - want / (2500.0 / 6)) < 1e-3
+    assert pk["knn_topk_kernel"]["frac_executed_pipe"] is None                # the bit-exact fp32 chain: priced at the fp32 peak only
+    c5 = dict(bench.WORKLOADS["c5"])
+    r5 = bench.roofline_of({2: (9 * 0.3, 9)}, 3, c5["B"], c5)
+    assert r5["kernel"] == "ec_main_bwd_pair_kernel<1>" and r5["peak_executed_pipe"] == 2500.0
+    assert abs(r5["frac_executed_pipe"] - r5["achieved"] / 2500.0) < 1e-4
