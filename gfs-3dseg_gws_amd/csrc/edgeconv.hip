@@ -2528,7 +2528,10 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             GFS3D_LAUNCH_CHECK("ec_main_bwd_kernel");
         }
         if (csr) {
-            const int sg = min((BN + 31) / 32, 2048);
+            // every workgroup ends in 128 same-address fp64 atomics (the BN1-backward sums): few, long-lived workgroups
+            // (2048 -> 512 at B = 32: 93 -> 85 us per launch; 256: slower again)
+            static const int sg_env = [] { const char *e = getenv("GFS3D_EC_SEGSUM_GRID"); return e ? atoi(e) : 512; }();       // A-B only
+            const int sg = min((BN + 31) / 32, sg_env > 0 ? sg_env : 512);
             static const int seg_rev = [] { const char *e = getenv("GFS3D_EC_SEGSUM_REV"); return e ? atoi(e) : 1; }();       // A-B only
             if (prec_of(a->compute, true) != PREC_X6)
                 hipLaunchKernelGGL(ec_bwd_segsum_kernel<true>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
