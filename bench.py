@@ -494,9 +494,16 @@ def launch_ranks(n, argv):
             procs[r].kill()
         for r in live:
             procs[r].wait()
-    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    lines = []
+    for ln in out0.splitlines():                 # rank 0's result line (library chatter on its stdout is not forwarded)
+        if ln.startswith("{"):
+            try:
+                if "n_gpus" in json.loads(ln):
+                    lines.append(ln)
+            except ValueError:
+                pass
     if rc == 0 and len(lines) != 1:
-        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        print(f"bench.py: rank 0 printed {len(lines)} result lines", file=sys.stderr)
         rc = 1
     for ln in lines[-1:]:
         print(ln, flush=True)
