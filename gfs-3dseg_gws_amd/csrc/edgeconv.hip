@@ -2323,7 +2323,9 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
         GFS3D_LAUNCH_CHECK("csr_count_kernel");
         hipLaunchKernelGGL(csr_place_kernel, grid, dim3(CSR_THREADS), lds, rs, a->idx, rangecnt, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
         GFS3D_LAUNCH_CHECK("csr_place_kernel");
-        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, 2048)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->N, a->SQ, a->indeg);
+        // (512 long-lived workgroups beside the main stream's kernels instead of 2048: c2 step -0.7 %, A/B on one box)
+        static const int cg_env = [] { const char *e = getenv("GFS3D_EC_CSRGATHER_GRID"); return e ? atoi(e) : 512; }();       // A-B only
+        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, cg_env > 0 ? cg_env : 512)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->N, a->SQ, a->indeg);
         GFS3D_LAUNCH_CHECK("csr_gather_kernel");
         return GFS3D_OK;
     }
