@@ -293,6 +293,14 @@ def segmenter_fusable(seg):
 def segmenter_forward_pm(seg, packed_pm, training, sync=None):
     """packed_pm (B, N, C_in) point-major -> logits (B, num_classes, N)."""
     c1, b1, a1, c2, b2, a2, dr, c3 = list(seg)
-    h = ops.pointwise_stack([packed_pm], [(c1, b1), (c2, b2)], training, _LRELU, sync=sync,
-                            slopes=[float(a1.negative_slope), float(a2.negative_slope)])
+    slopes = [float(a1.negative_slope), float(a2.negative_slope)]
+    if c3.kernel_size == (1,) and c3.in_channels % 64 == 0 and c3.in_channels <= 1024 and c3.out_channels <= 64:
+        # the classifier (reference dgcnn.py:176-177 / get_basis.py:92-93: Dropout, Conv1d(128, classes)) on the library's GEMM
+        # too: the stack hands its output over point-major, the weight is padded to one 64-row tile
+        h_pm = ops.pointwise_stack([packed_pm], [(c1, b1), (c2, b2)], training, _LRELU, sync=sync, slopes=slopes,
+                                   want_cf=False, want_pm=True)
+        w = F.pad(c3.weight[:, :, 0], (0, 0, 0, 64 - c3.out_channels))
+        logits = ops.linear_cf(dr(h_pm), w)[0][:, :c3.out_channels]
+        return logits + c3.bias[None, :, None] if c3.bias is not None else logits
+    h = ops.pointwise_stack([packed_pm], [(c1, b1), (c2, b2)], training, _LRELU, sync=sync, slopes=slopes)
     return c3(dr(h))
