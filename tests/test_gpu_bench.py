@@ -1,0 +1,46 @@
+"""bench.py's contract on the device: one JSON line with the fields the driver and the judge read (metric / value / unit / n_gpus /
+steps / warmup / ms_per_step / scaling / dtype / data / config.workload, `roofline` with both fractions and the PMC traffic,
+`cpu_baseline` only when asked for), from a short run as a child process - the way the driver calls it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_schema_single_gpu():
+    d = _bench("--gpus", "1", "--steps", "3", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert d["metric"].startswith("point-cloud blocks/sec") and d["unit"] == "blocks/s" and d["n_gpus"] == 1 and d["rccl_ranks"] == 1
+    assert d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "configs[1]" in d["config"]["workload"] and d["config"]["blocks_per_gpu"] == 32
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_fp32", "frac_executed_pipe", "kernel", "per_kernel"):
+        assert key in r, key
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] < 1.0
+    assert r["kernel"].startswith("ec_main_bwd_pair_kernel") and r["traffic"] and r["traffic"] > 1e8
+    assert {"knn", "fwd_knn_edgeconv_eval", "c1_single_block_eval_forward"} <= set(r)
+    assert 5000 < d["value"] < 20000                     # an MI355X runs this step at ~10 k blocks/s
+
+
+def test_bench_two_gloo_ranks_share_the_card():
+    """N > 1 through the self-launcher with the real kernels (gloo: both ranks on the one card): n_gpus = ranks = 2, weak scaling."""
+    d = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", GFS3D_BENCH_BACKEND="gloo")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["devices"] == ["cuda:0", "cuda:0"] and d["backend"] == "gloo"
+    assert d["config"]["parallelism"] == "block-sharded dp2" and "cpu_baseline" not in d
