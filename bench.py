@@ -137,7 +137,12 @@ def roofline_of(prof, steps, B, cfg, tag="r04"):
     name = KERNELS[dom] + ("<1>" if (dom == 2 and cfg["dtype"] != "f32") else "")
     pmc_name = KERNEL_PMC_NAME.get((dom, cfg["dtype"] != "f32"))
     traffic, src = hbm_traffic(pmc_name, tag) if pmc_name else (None, None)
-    roof.update({"kernel": name, "achieved": round(achieved, 3), "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+    # `frac` / `peak` follow the arithmetic the results are priced at: the fp32 peak for the fp32-accurate path; for the reduced
+    # dtypes (configs[4]) the executed 16-bit pipe - `frac_fp32` and `frac_executed_pipe` stay as the explicit fields
+    reduced = cfg["dtype"] != "f32" and pipe_peak
+    if reduced:
+        roof["peak"] = round(pipe_peak, 1)
+    roof.update({"kernel": name, "achieved": round(achieved, 3), "frac": round(achieved / (pipe_peak if reduced else PEAK_FP32_TFLOPS), 4),
                  "frac_fp32": round(achieved / PEAK_FP32_TFLOPS, 4), "executed_pipe": pipe_name,
                  "peak_executed_pipe": round(pipe_peak, 1) if pipe_peak else None,
                  "frac_executed_pipe": round(achieved / pipe_peak, 4) if pipe_peak else None,

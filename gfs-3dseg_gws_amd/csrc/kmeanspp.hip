@@ -185,9 +185,22 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
             s_blk = pickb;
         }
         __syncthreads();
-        if (s_blk < 0) {                                            // no mass left (every point coincides with a centre), or u == 1
+        if (s_blk < 0 && total > 0.0) {
+            // u * total rounded up to the total: no range matched.  The host form's searchsorted is clipped to the last index WITH
+            // mass: the last block with a positive sum, then (target past its end) its last point with d2 > 0 - never a point
+            // that already is a centre (M - 1 could be one, giving a duplicate centre and an empty cluster)
+            int lastb = -1;
+            for (int e = 0; e < per; ++e) {
+                const int b = tid * per + e;
+                if (b < nblk && bsum[b] > 0.0) lastb = b;
+            }
+            if (lastb >= 0) atomicMax(&s_blk, lastb);
+            if (tid == 0) { s_before = 0.0; s_target = 1.0e300; }
+            __syncthreads();
+        }
+        if (s_blk < 0) {                                            // no mass left: every point coincides with a centre
             if (tid == 0) {
-                long long i = total > 0.0 ? M - 1 : (long long)(u[t_new - 1] * (double)M);
+                long long i = (long long)(u[t_new - 1] * (double)M);
                 s_pick = i < 0 ? 0 : (i >= M ? M - 1 : i);
             }
             __syncthreads();
@@ -229,6 +242,263 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
             if (lane == 0) cc[a] = s_;
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// GREEDY k-means++ : what sklearn's KMeans(init='k-means++') actually runs (sklearn/cluster/_kmeans.py `_kmeans_plusplus`,
+// scikit-learn 1.7.2; called by get_basis.py:210 of the reference).  Per pick: T = 2 + int(log K) candidates are drawn by D^2
+// sampling from T variates (`searchsorted(cumsum(d2), u * potential)`, side 'left'), each candidate's potential
+// sum_i min(d2[i], |p_i - x_cand|^2) is evaluated and the candidate with the lowest potential becomes the centre.
+//   kpp_cand_kernel    one workgroup: the two-level cdf search for the T variates; candidate rows; |x_cand - c_a|^2 for every
+//                      earlier centre (per candidate, and the minimum over the candidates: the gain pass's pruning table)
+//   kpp_gain_kernel    one pass over the points: gain_j = sum_i max(0, d2[i] - |p_i - x_cand_j|^2) in fp64 per block of 1024
+//                      points (potential_j = potential - gain_j).  A point whose nearest centre a has
+//                      min_j |x_cand_j - c_a|^2 >= 4 d2[i] cannot gain from any candidate: its row is not read.
+//   kpp_choose_kernel  block gains added in block order -> the first candidate with the largest gain (numpy's argmin of the
+//                      potentials); its row, index and centre distances become centre t.
+//   kpp_update_kernel  (above) then folds the new centre into d2 / nearest / block sums.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int KPP_TMAX = 8;
+
+template <int CS>           // channels per lane in the centre-distance loop: ceil(C / 64)
+__global__ void __launch_bounds__(KPP_PICK_THREADS)
+kpp_cand_kernel(const float *__restrict__ pts, long long M, int C, int K, int t_new, int T, const double *__restrict__ u,
+                const float *__restrict__ d2, const double *__restrict__ bsum, int nblk, const float *__restrict__ centers,
+                long long *__restrict__ cand, float *__restrict__ candrows, float *__restrict__ cct, float *__restrict__ ccmin)
+{
+    __shared__ double buf[KPP_PICK_THREADS];
+    __shared__ long long s_cand[KPP_TMAX];
+    __shared__ int s_blk, s_win, s_last;
+    __shared__ double s_before, s_target;
+    const int tid = threadIdx.x;
+    // level 1 once: thread j owns `per` consecutive blocks
+    const int per = (nblk + KPP_PICK_THREADS - 1) / KPP_PICK_THREADS;
+    double mine = 0.0;
+    for (int e = 0; e < per; ++e) {
+        const int b = tid * per + e;
+        if (b < nblk) mine += bsum[b];
+    }
+    double total;
+    const double incl = block_scan_incl(mine, buf, tid, KPP_PICK_THREADS, total);
+    for (int j = 0; j < T; ++j) {
+        const double target = u[j] * total;
+        __syncthreads();
+        if (tid == 0) { s_blk = -1; s_target = target; s_win = KPP_PICK_THREADS; }
+        __syncthreads();
+        if (target > 0.0 && incl >= target) atomicMin(&s_win, tid);           // first range whose inclusive mass reaches the target
+        __syncthreads();
+        if (tid == s_win) {
+            double run = incl - mine;
+            int pickb = -1;
+            for (int e = 0; e < per; ++e) {
+                const int b = tid * per + e;
+                if (b >= nblk) break;
+                const double nxt = run + bsum[b];
+                if (nxt >= target) { pickb = b; break; }
+                run = nxt;
+            }
+            if (pickb < 0) {                                        // rounding at the range's end: its last block with mass
+                run = incl - mine;
+                for (int e = 0; e < per; ++e) {
+                    const int b = tid * per + e;
+                    if (b >= nblk) break;
+                    if (bsum[b] > 0.0) { pickb = b; s_before = run; }
+                    run += bsum[b];
+                }
+            } else {
+                s_before = run;
+            }
+            s_blk = pickb;
+        }
+        __syncthreads();
+        if (s_blk < 0) {
+            // target <= 0 (u == 0 or no mass left: every point coincides with a centre): searchsorted(cs, 0) = 0, as sklearn
+            if (tid == 0) s_cand[j] = 0;
+        } else {
+            const long long i = (long long)s_blk * KPP_BLOCK + tid;
+            const double v = i < M ? (double)d2[i] : 0.0;
+            double btot;
+            const double in2 = s_before + block_scan_incl(v, buf, tid, KPP_PICK_THREADS, btot);
+            if (tid == 0) { s_win = KPP_PICK_THREADS; s_last = -1; }
+            __syncthreads();
+            if (v > 0.0 && in2 >= s_target) atomicMin(&s_win, tid);
+            if (v > 0.0) atomicMax(&s_last, tid);
+            __syncthreads();
+            // (no match: rounding between the two levels put the target past the block's end - its last point with mass)
+            if (tid == 0) s_cand[j] = (long long)s_blk * KPP_BLOCK + (s_win < KPP_PICK_THREADS ? s_win : (s_last < 0 ? 0 : s_last));
+        }
+    }
+    __syncthreads();
+    if (tid < T) cand[tid] = s_cand[tid];
+    for (int e = tid; e < T * C; e += KPP_PICK_THREADS) {
+        const int j = e / C, c = e - j * C;
+        candrows[e] = pts[(size_t)s_cand[j] * C + c];
+    }
+    // |x_cand_j - c_a|^2 for every earlier centre a: a wave per centre, the T candidate rows in registers
+    const int lane = tid & 63, wv = tid >> 6;
+    float cr[KPP_TMAX][CS];
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) {
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const int c = lane + 64 * s;
+            cr[j][s] = (j < T && c < C) ? pts[(size_t)s_cand[j < T ? j : 0] * C + c] : 0.f;
+        }
+    }
+    for (int a = wv; a < t_new; a += KPP_PICK_THREADS / 64) {
+        float ar[CS];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            const int c = lane + 64 * s;
+            ar[s] = c < C ? centers[(size_t)a * C + c] : 0.f;
+        }
+        float mn = 3.0e38f;
+#pragma unroll
+        for (int j = 0; j < KPP_TMAX; ++j) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int s = 0; s < CS; ++s) {
+                const float d = ar[s] - cr[j][s];
+                s_ = fmaf(d, d, s_);
+            }
+            s_ = wave_sum(s_);
+            if (j < T) {
+                if (lane == 0) cct[j * K + a] = s_;
+                mn = fminf(mn, s_);
+            }
+        }
+        if (lane == 0) ccmin[a] = mn;
+    }
+}
+
+template <int C4MAX>
+__global__ void __launch_bounds__(256)
+kpp_gain_kernel(const float *__restrict__ pts, long long M, int C, int T, const float *__restrict__ candrows,
+                const float *__restrict__ ccmin, int prune, const float *__restrict__ d2, const int *__restrict__ nearest,
+                double *__restrict__ gsum)
+{
+    __shared__ double wsum[4][KPP_TMAX];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane & 15, grp = lane >> 4;
+    const int c4n = C >> 2;
+    kf4 cen[KPP_TMAX][C4MAX];
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) {
+#pragma unroll
+        for (int s = 0; s < C4MAX; ++s) {
+            const int pc = q + 16 * s;
+            cen[j][s] = (j < T && pc < c4n) ? *reinterpret_cast<const kf4 *>(candrows + (size_t)j * C + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    double acc[KPP_TMAX];
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) acc[j] = 0.0;
+    const long long base = (long long)blockIdx.x * KPP_BLOCK + wv * 256;
+    for (int ch = 0; ch < 4; ++ch) {
+        const long long row0 = base + 64 * ch;
+        if (row0 >= M) break;
+        const long long mine = row0 + lane;
+        const bool have = mine < M;
+        float myd = 0.f;
+        bool need = false;
+        if (have) {
+            myd = d2[mine];
+            need = myd > 0.f;
+            // |p - x| >= |x - c_a| - |p - c_a| >= r for every candidate x when min_j |x_j - c_a|^2 >= 4 r^2: no candidate gains here
+            if (need && prune && ccmin[nearest[mine]] >= 4.f * myd * KPP_PRUNE_MARGIN) need = false;
+        }
+        unsigned long long mask = __ballot(need);
+        while (mask) {                                             // wave-uniform: up to 4 rows per trip, 16 lanes per row
+            int b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                b[g] = mask ? (int)__builtin_ctzll(mask) : -1;
+                mask &= mask - 1;
+            }
+            const int r = grp == 0 ? b[0] : grp == 1 ? b[1] : grp == 2 ? b[2] : b[3];
+            const float rd = __shfl(myd, r < 0 ? 0 : r, 64);      // the row's current d2
+            kf4 v[C4MAX];
+            if (r >= 0) {
+                const float *row = pts + (size_t)(row0 + r) * C;
+#pragma unroll
+                for (int s = 0; s < C4MAX; ++s) {
+                    const int pc = q + 16 * s;
+                    v[s] = pc < c4n ? *reinterpret_cast<const kf4 *>(row + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < C4MAX; ++s) v[s] = kf4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < KPP_TMAX; ++j) {
+                float s_ = 0.f;
+#pragma unroll
+                for (int s = 0; s < C4MAX; ++s) {
+                    const kf4 d = v[s] - cen[j][s];
+                    s_ = fmaf(d.x, d.x, s_);
+                    s_ = fmaf(d.y, d.y, s_);
+                    s_ = fmaf(d.z, d.z, s_);
+                    s_ = fmaf(d.w, d.w, s_);
+                }
+                s_ += __shfl_xor(s_, 1, 64);
+                s_ += __shfl_xor(s_, 2, 64);
+                s_ += __shfl_xor(s_, 4, 64);
+                s_ += __shfl_xor(s_, 8, 64);
+                if (q == 0 && r >= 0 && j < T && s_ < rd) acc[j] += (double)(rd - s_);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) {
+        const double w = wave_sum(acc[j]);
+        if (lane == 0) wsum[wv][j] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < KPP_TMAX)
+        gsum[(size_t)blockIdx.x * KPP_TMAX + threadIdx.x] = ((wsum[0][threadIdx.x] + wsum[1][threadIdx.x]) + wsum[2][threadIdx.x]) + wsum[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256)
+kpp_choose_kernel(int C, int K, int t_new, int T, const double *__restrict__ gsum, int nblk, const long long *__restrict__ cand,
+                  const float *__restrict__ candrows, const float *__restrict__ cct, float *__restrict__ centers,
+                  long long *__restrict__ picks, float *__restrict__ cc)
+{
+    __shared__ double part[256][KPP_TMAX + 1];
+    __shared__ int s_best;
+    const int tid = threadIdx.x;
+    double a[KPP_TMAX];
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) a[j] = 0.0;
+    const int per = (nblk + 255) / 256;                      // consecutive blocks per thread, then a fixed tree: one summation order
+    for (int e = 0; e < per; ++e) {
+        const int b = tid * per + e;
+        if (b < nblk) {
+#pragma unroll
+            for (int j = 0; j < KPP_TMAX; ++j) a[j] += gsum[(size_t)b * KPP_TMAX + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KPP_TMAX; ++j) part[tid][j] = a[j];
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) {
+#pragma unroll
+            for (int j = 0; j < KPP_TMAX; ++j) part[tid][j] += part[tid + h][j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int best = 0;
+        for (int j = 1; j < T; ++j)
+            if (part[0][j] > part[0][best]) best = j;            // the first of equal potentials, as numpy's argmin
+        s_best = best;
+        picks[t_new] = cand[best];
+    }
+    __syncthreads();
+    const int best = s_best;
+    for (int c = tid; c < C; c += 256) centers[(size_t)t_new * C + c] = candrows[(size_t)best * C + c];
+    for (int a2 = tid; a2 <= t_new; a2 += 256) cc[a2] = a2 < t_new ? cct[best * K + a2] : 0.f;
 }
 
 }  // namespace
@@ -280,5 +550,87 @@ extern "C" int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int
 #undef KPP_LAUNCH
         GFS3D_LAUNCH_CHECK("kpp_update_kernel");
     }
+    return GFS3D_OK;
+}
+
+// workspace: the plain form's (d2 | nearest | block sums | cc) + candidate ids, rows, centre-distance tables, block gains
+extern "C" size_t gfs3d_kmeanspp_greedy_workspace_bytes(long long M, int C, int K)
+{
+    if (M < 1 || K < 1 || C < 1) return 0;
+    const size_t nblk = (size_t)((M + KPP_BLOCK - 1) / KPP_BLOCK);
+    return gfs3d_kmeanspp_workspace_bytes(M, K) + align_up(sizeof(long long) * KPP_TMAX, 256) +
+           align_up(sizeof(float) * (size_t)KPP_TMAX * C, 256) + align_up(sizeof(float) * (size_t)KPP_TMAX * K, 256) +
+           align_up(sizeof(float) * (size_t)K, 256) + align_up(sizeof(double) * nblk * KPP_TMAX, 256);
+}
+
+extern "C" int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, int K, long long first, const double *u, int n_trials,
+                                         float *centers, long long *picks, void *workspace, size_t workspace_bytes, int prune,
+                                         void *stream)
+{
+    const char *who = "gfs3d_kmeanspp_greedy_f32";
+    GFS3D_REQUIRE(pts && u && centers && picks, "%s: NULL argument", who);
+    GFS3D_REQUIRE(M >= 1 && K >= 1 && K <= M, "%s: need 1 <= K <= M (M=%lld K=%d)", who, M, K);
+    GFS3D_REQUIRE(C >= 4 && C % 4 == 0 && C <= 256, "%s: C=%d unsupported (a multiple of 4, <= 256)", who, C);
+    GFS3D_REQUIRE(n_trials >= 1 && n_trials <= KPP_TMAX, "%s: n_trials=%d unsupported (1..%d)", who, n_trials, KPP_TMAX);
+    GFS3D_REQUIRE(first >= 0 && first < M, "%s: first=%lld out of range", who, first);
+    GFS3D_REQUIRE((M + KPP_BLOCK - 1) / KPP_BLOCK < (1ll << 30), "%s: M too large", who);
+    GFS3D_REQUIRE(workspace && workspace_bytes >= gfs3d_kmeanspp_greedy_workspace_bytes(M, C, K), "%s: workspace too small", who);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nblk = (int)((M + KPP_BLOCK - 1) / KPP_BLOCK);
+    char *ws = static_cast<char *>(workspace);
+    float *d2 = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)M, 256);
+    int *nearest = reinterpret_cast<int *>(ws);
+    ws += align_up(sizeof(int) * (size_t)M, 256);
+    double *bsum = reinterpret_cast<double *>(ws);
+    ws += align_up(sizeof(double) * (size_t)nblk, 256);
+    float *cc = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)K, 256);
+    long long *cand = reinterpret_cast<long long *>(ws);
+    ws += align_up(sizeof(long long) * KPP_TMAX, 256);
+    float *candrows = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)KPP_TMAX * C, 256);
+    float *cct = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)KPP_TMAX * K, 256);
+    float *ccmin = reinterpret_cast<float *>(ws);
+    ws += align_up(sizeof(float) * (size_t)K, 256);
+    double *gsum = reinterpret_cast<double *>(ws);
+    const int c4 = (C / 4 + 15) / 16;                          // float4 pieces per lane of the row kernels (<= 4)
+    const int cs = (C + 63) / 64;                              // channels per lane of the centre-distance loop (<= 4)
+#define KPP_UPDATE(N_, t_)                                                                                                      \
+    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t_, cc, prune, d2, nearest, bsum)
+#define KPP_GAIN(N_)                                                                                                            \
+    hipLaunchKernelGGL(kpp_gain_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, n_trials, candrows, ccmin, prune, d2, nearest, gsum)
+#define KPP_CAND(N_, t_)                                                                                                        \
+    hipLaunchKernelGGL(kpp_cand_kernel<N_>, dim3(1), dim3(KPP_PICK_THREADS), 0, st, pts, M, C, K, t_, n_trials,                  \
+                       u + (size_t)(t_ - 1) * n_trials, d2, bsum, nblk, centers, cand, candrows, cct, ccmin)
+    // centre 0: the given index (its row through the plain pick kernel), then the first distances
+    hipLaunchKernelGGL(kpp_pick_kernel, dim3(1), dim3(KPP_PICK_THREADS), 0, st, pts, M, C, 0, first, u, d2, bsum, nblk, centers, picks, cc);
+    GFS3D_LAUNCH_CHECK("kpp_pick_kernel");
+    for (int t = 0; t < K; ++t) {
+        if (t > 0) {
+            if (cs <= 1) KPP_CAND(1, t);
+            else if (cs <= 2) KPP_CAND(2, t);
+            else if (cs <= 3) KPP_CAND(3, t);
+            else KPP_CAND(4, t);
+            GFS3D_LAUNCH_CHECK("kpp_cand_kernel");
+            if (c4 <= 1) KPP_GAIN(1);
+            else if (c4 <= 2) KPP_GAIN(2);
+            else if (c4 <= 3) KPP_GAIN(3);
+            else KPP_GAIN(4);
+            GFS3D_LAUNCH_CHECK("kpp_gain_kernel");
+            hipLaunchKernelGGL(kpp_choose_kernel, dim3(1), dim3(256), 0, st, C, K, t, n_trials, gsum, nblk, cand, candrows, cct, centers, picks, cc);
+            GFS3D_LAUNCH_CHECK("kpp_choose_kernel");
+        }
+        if (t == K - 1) break;
+        if (c4 <= 1) KPP_UPDATE(1, t);
+        else if (c4 <= 2) KPP_UPDATE(2, t);
+        else if (c4 <= 3) KPP_UPDATE(3, t);
+        else KPP_UPDATE(4, t);
+        GFS3D_LAUNCH_CHECK("kpp_update_kernel");
+    }
+#undef KPP_UPDATE
+#undef KPP_GAIN
+#undef KPP_CAND
     return GFS3D_OK;
 }

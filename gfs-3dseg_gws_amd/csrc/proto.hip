@@ -813,7 +813,8 @@ proto_bwd_x6i_kernel(const float *__restrict__ feat, long long feat_bstride, int
     const float *fb = feat + (size_t)b * feat_bstride;
     const float *sb = soft ? soft + (size_t)b * K * N + nc : nullptr;
     const float *ub = dup + (size_t)b * K * N + nc;
-    for (int w = tid; w < NT * 32; w += PXI_THREADS) ginv[w] = gginv[w];
+    // the workspace holds ceil(K / 32) * 32 inverse norms (proto_bwd_image_bytes); the tiles past them are never used: zero
+    for (int w = tid; w < NT * 32; w += PXI_THREADS) ginv[w] = w < ((K + 31) / 32) * 32 ? gginv[w] : 0.f;
 
     float dot = 0.f;
     if (MODE == MODE_SOFTMAX) {

@@ -71,9 +71,9 @@ class DGCNNSeg(nn.Module):
 
 
 def kmeans_plus_plus_host(points, n_clusters, rng):
-    """k-means++ seeding with the D^2 sampling drawn on the host (numpy `rng.choice(M, p=...)`): one device -> host copy of the
-    M probabilities per pick.  The form of rounds 1-3; kept as the restatement the device form is tested against and for
-    CPU tensors (the gloo logic tests)."""
+    """PLAIN k-means++ seeding (one D^2 draw per pick, numpy `rng.choice(M, p=...)` on the host: one device -> host copy of the
+    M probabilities per pick).  The form of rounds 1-3; kept as the restatement `gfs3d_kmeanspp_seed_f32` is tested against.
+    Not what sklearn runs - see `kmeans_plus_plus`."""
     M = points.shape[0]
     first = int(rng.randint(M))
     centers = [points[first]]
@@ -86,18 +86,63 @@ def kmeans_plus_plus_host(points, n_clusters, rng):
     return torch.stack(centers, 0)
 
 
-def kmeans_plus_plus(points, n_clusters, rng, return_picks=False):
-    """k-means++ seeding (the `init='k-means++'` of the reference's KMeans call, get_basis.py:210).  Device tensors: the whole
-    loop runs on the device (gfs3d_kmeanspp_seed_f32) - the host draws the first index and the K - 1 uniform variates from
-    `rng` up front, exactly the variates `rng.choice(M, p=...)` would have consumed one per pick, so the picks are those of
-    `kmeans_plus_plus_host` (up to a pick whose variate lands within rounding of a cdf step)."""
-    if not points.is_cuda:
-        cent = kmeans_plus_plus_host(points, n_clusters, rng)
-        return (cent, None) if return_picks else cent
+def sklearn_local_trials(n_clusters):
+    """`n_local_trials = 2 + int(np.log(n_clusters))` (sklearn/cluster/_kmeans.py `_kmeans_plusplus`)."""
+    return 2 + int(np.log(n_clusters))
+
+
+def _draw_seeding_variates(M, n_clusters, n_trials, rng):
+    """The variates sklearn's `_kmeans_plusplus` consumes from `rng`, in its order: the first centre through
+    `choice(n_samples, p=sample_weight / sample_weight.sum())` with unit float32 weights (one variate), then
+    `uniform(size=n_local_trials)` per pick."""
+    w = np.ones(M, dtype=np.float32)
+    first = int(rng.choice(M, p=w / w.sum()))
+    return first, rng.uniform(size=(n_clusters - 1, n_trials))
+
+
+def kmeans_plus_plus_greedy_host(points, n_clusters, rng, n_local_trials=None):
+    """sklearn's greedy k-means++ in tensor ops on whatever device `points` lives on (float64 potentials).  For CPU tensors
+    (the gloo logic tests); HIP tensors go through gfs3d_kmeanspp_greedy_f32."""
     M = points.shape[0]
-    first = int(rng.randint(M))
-    u = rng.random_sample(n_clusters - 1)
-    cent, picks = ops.kmeanspp_seed(points, n_clusters, first, u)
+    T = sklearn_local_trials(n_clusters) if n_local_trials is None else int(n_local_trials)
+    first, u = _draw_seeding_variates(M, n_clusters, T, rng)
+    picks = [first]
+    d2 = ((points - points[first]) ** 2).sum(1)
+    for t in range(1, n_clusters):
+        cs = torch.cumsum(d2.double(), 0)
+        r = torch.as_tensor(u[t - 1], dtype=torch.float64, device=points.device) * cs[-1]
+        cand = torch.searchsorted(cs, r).clamp_(max=M - 1)
+        cand = torch.where(r > 0, cand, torch.zeros_like(cand))
+        dc = torch.minimum(((points[None, :, :] - points[cand][:, None, :]) ** 2).sum(2), d2[None, :])
+        best = int(torch.argmin(dc.double().sum(1)))
+        d2 = dc[best]
+        picks.append(int(cand[best]))
+    picks = torch.as_tensor(picks, dtype=torch.int64, device=points.device)
+    return points[picks], picks
+
+
+def kmeans_plus_plus(points, n_clusters, rng, return_picks=False, n_local_trials=None):
+    """k-means++ seeding as `KMeans(n_clusters, init='k-means++')` of the reference runs it (get_basis.py:210): sklearn's GREEDY
+    form - `n_local_trials` = 2 + int(log K) D^2-sampled candidates per pick, the one that lowers the potential most is kept
+    (sklearn/cluster/_kmeans.py `_kmeans_plusplus`).  The host draws from `rng` exactly the variates sklearn would, in its
+    order, up front; HIP tensors run the whole loop on the device (gfs3d_kmeanspp_greedy_f32), so the picks are sklearn's for
+    `random_state=rng` up to rounding-level ties (a variate within ~1e-8 of a cdf step, two candidate potentials within ~1e-7).
+    n_local_trials=0: the plain one-draw-per-pick form of rounds 1-4 (`gfs3d_kmeanspp_seed_f32`)."""
+    M = points.shape[0]
+    if n_local_trials == 0:
+        if not points.is_cuda:
+            cent = kmeans_plus_plus_host(points, n_clusters, rng)
+            return (cent, None) if return_picks else cent
+        first = int(rng.randint(M))
+        u = rng.random_sample(n_clusters - 1)
+        cent, picks = ops.kmeanspp_seed(points, n_clusters, first, u)
+        return (cent, picks) if return_picks else cent
+    T = sklearn_local_trials(n_clusters) if n_local_trials is None else int(n_local_trials)
+    if not points.is_cuda:
+        cent, picks = kmeans_plus_plus_greedy_host(points, n_clusters, rng, T)
+        return (cent, picks) if return_picks else cent
+    first, u = _draw_seeding_variates(M, n_clusters, T, rng)
+    cent, picks = ops.kmeanspp_greedy(points, n_clusters, first, u, T)
     return (cent, picks) if return_picks else cent
 
 
@@ -105,26 +150,77 @@ def _dist_on():
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 
+def _point_to_centre_sq(points, cent, label, chunk=1 << 18):
+    out = torch.empty(points.shape[0], dtype=torch.float32, device=points.device)
+    for s in range(0, points.shape[0], chunk):
+        out[s:s + chunk] = ((points[s:s + chunk] - cent[label[s:s + chunk].long()]) ** 2).sum(1)
+    return out
+
+
+def _relocate_empty_clusters(points, cent_old, label, sums, counts, sharded):
+    """sklearn's `_relocate_empty_clusters_dense` (sklearn/cluster/_k_means_common.pyx; `KMeans.fit` of get_basis.py:210 runs it
+    inside every Lloyd iteration): each empty cluster receives one of the n_empty points FARTHEST from their own centres
+    (largest first, empty clusters in ascending order); the point leaves its old cluster's sum and count.  `sums` / `counts`
+    are the GLOBAL ones under sharding; the candidates are gathered from all ranks so every rank applies the same moves.
+    A rare path (a seeding from data points leaves no cluster empty at first): tensor ops, one host read."""
+    empty = torch.nonzero(counts == 0).reshape(-1)
+    n_empty = int(empty.numel())
+    dist = _point_to_centre_sq(points, cent_old, label)
+    k = min(n_empty, points.shape[0])
+    top = torch.topk(dist, k)
+    C = points.shape[1]
+    rec = torch.full((n_empty, C + 2), -1.0, dtype=torch.float32, device=points.device)      # distance | old cluster | row
+    rec[:k, 0], rec[:k, 1], rec[:k, 2:] = top.values, label[top.indices].float(), points[top.indices]
+    if sharded:
+        ws = torch.distributed.get_world_size()
+        allrec = [torch.empty_like(rec) for _ in range(ws)]
+        torch.distributed.all_gather(allrec, rec)
+        rec = torch.cat(allrec, 0)
+        rec = rec[torch.topk(rec[:, 0], n_empty).indices]          # rank-major order breaks exact ties identically everywhere
+    sums, counts = sums.clone(), counts.clone()
+    for e in range(n_empty):
+        if float(rec[e, 0]) < 0:
+            break
+        old, row = int(rec[e, 1]), rec[e, 2:]
+        sums[old] -= row
+        counts[old] -= 1
+        sums[int(empty[e])] = row
+        counts[int(empty[e])] = 1
+    return sums, counts
+
+
 def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
-    """Lloyd iterations from `cent`.  With `sharded` points every quantity a decision depends on is global: the
-    (K x D sums, K counts) are all-reduced each iteration, so `new`, `shift` and hence the stopping iteration are
-    identical on all ranks (no rank leaves the loop while another still waits in a collective); an empty cluster
-    keeps its previous centroid, which is rank-identical too because the start was."""
+    """Lloyd iterations from `cent` as sklearn's `_kmeans_single_lloyd` runs them (`KMeans.fit`, get_basis.py:210): labels from
+    the current centres, member means with empty clusters relocated, stop when the labels repeat (strict convergence) or the
+    squared centre shift is <= `scale`; then one exact assignment (labels, sums, counts, inertia of the final centres).
+    ONE host read per iteration: (shift, labels changed, empty clusters).  With `sharded` points every quantity a decision
+    depends on is global - (K x D sums, K counts, the changed-label count) go through one all-reduce per iteration - so the
+    stopping iteration is identical on all ranks (no rank leaves the loop while another still waits in a collective)."""
     n_iter = 0
     # inside the loop only labels / sums / counts matter: the screened assignment (same labels at about half the matrix work);
     # the final assignment below is the exact form, whose inertia is the one reported
     loop_fn = (lambda p, c: ops.kmeans_assign(p, c, fast=True)) if assign_fn is ops.kmeans_assign else assign_fn
+    old_label = None
     for n_iter in range(1, max_iter + 1):
-        _, sums, counts, _ = loop_fn(points, cent)
+        label, sums, counts, _ = loop_fn(points, cent)
+        changed = (label != old_label).sum().float().reshape(1) if old_label is not None else torch.ones(1, device=points.device)
         if sharded:
-            packed = torch.cat([sums, counts[:, None]], dim=1)          # one collective per iteration
+            K, D = sums.shape
+            packed = torch.zeros((K + 1, D + 1), dtype=sums.dtype, device=sums.device)   # sums | counts ; changed: one collective
+            packed[:K, :D], packed[:K, D], packed[K, 0] = sums, counts, changed[0].clamp(max=1.0)
             torch.distributed.all_reduce(packed)
-            sums, counts = packed[:, :-1], packed[:, -1]
+            sums, counts, changed = packed[:K, :D], packed[:K, D], packed[K, :1]
         new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
-        shift = float(((new - cent) ** 2).sum())
+        state = torch.cat([((new - cent) ** 2).sum().reshape(1), changed.to(new.dtype), (counts == 0).sum().reshape(1).to(new.dtype)])
+        shift, n_changed, n_empty = state.tolist()                                      # the iteration's one host read
+        if n_empty > 0:
+            sums, counts = _relocate_empty_clusters(points, cent, label, sums, counts, sharded)
+            new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
+            shift = float(((new - cent) ** 2).sum())
         cent = new.contiguous()
-        if shift <= scale:
+        if n_changed == 0 or shift <= scale:
             break
+        old_label = label
     label, sums, counts, inertia = assign_fn(points, cent)
     if sharded:
         K, D = sums.shape
@@ -136,37 +232,46 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
 
 
 def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0, n_init=1, assign_fn=None, return_means=False,
-                  timings=None):
-    """Lloyd's algorithm on the GPU.  points (M,D) float32 device tensor - under torch.distributed THIS RANK'S SHARD of
-    the points.  Returns (centroids (K,D), labels (M,) int64 of the local points, inertia float (global), n_iter).
+                  timings=None, rng=None, center=True, n_local_trials=None):
+    """`KMeans(n_clusters, init='k-means++').fit(points)` (get_basis.py:210) on the GPU, step for step as sklearn's `fit`:
+    centre the data on its mean, greedy k-means++ from `rng` (default `RandomState(seed)`), Lloyd iterations with empty-cluster
+    relocation, stop on repeated labels or a centre shift <= tol * mean(var(points, axis=0)), final assignment, centres shifted
+    back.  points (M,D) float32 device tensor - under torch.distributed THIS RANK'S SHARD of the points.  Returns
+    (centroids (K,D), labels (M,) int64 of the local points, inertia float (global), n_iter).
 
     `n_init` > 1: that many k-means++ restarts, best inertia wins (the reference's sklearn KMeans ran 10 by default in
-    its era, get_basis.py:210; ignored when `init` is given).  return_means: also the per-cluster MEANS of the final assignment
-    and its member counts (what Kmean2Proto computes on the host, get_basis.py:27-44, from the final assignment's own
+    its era, sklearn >= 1.4 runs 1; ignored when `init` is given).  return_means: also the per-cluster MEANS of the final
+    assignment and its member counts (what Kmean2Proto computes on the host, get_basis.py:27-44, from the final assignment's own
     segment sums) - (centroids, labels, inertia, n_iter, means (K,D), counts (K,)).  `timings`: dict receiving the seconds
-    spent seeding and in Lloyd's loop.  Sharded points: the start centroids come from rank 0
-    (k-means++ on rank 0's shard, then broadcast), the stop threshold from the all-reduced variance, so every rank runs
-    the same number of iterations.  `assign_fn` replaces gfs3d.ops.kmeans_assign (CPU logic tests only)."""
+    spent seeding and in Lloyd's loop.  Sharded points: the start centroids come from rank 0 (k-means++ on rank 0's shard,
+    then broadcast), mean and stop threshold from all-reduced moments, so every rank runs the same number of iterations.
+    `assign_fn` replaces gfs3d.ops.kmeans_assign (CPU logic tests only).  center=False: iterate on the data as given."""
     assign_fn = assign_fn or ops.kmeans_assign
     sharded = _dist_on()
-    rng = np.random.RandomState(seed)
-    if sharded:                      # global per-feature variance from (count, sum, sum of squares)
+    rng = rng if rng is not None else np.random.RandomState(seed)
+    if sharded:                      # global per-feature mean and (biased, as numpy's) variance from (count, sum, sum of squares)
         st = torch.stack([torch.full_like(points[0], float(points.shape[0])).double(), points.double().sum(0),
                           (points.double() ** 2).sum(0)])
         torch.distributed.all_reduce(st)
-        n_glob, mean = st[0], st[1] / st[0]
-        var = ((st[2] / n_glob - mean ** 2) * n_glob / (n_glob - 1).clamp_min(1)).mean()
+        mean = st[1] / st[0]
+        var = (st[2] / st[0] - mean ** 2).mean()
+        mean = mean.to(points.dtype)
     else:
-        var = points.var(dim=0).mean()
+        var = points.var(dim=0, unbiased=False).mean()
+        mean = points.mean(dim=0)
     scale = float(var) * tol
+    if center:
+        points = points - mean
     import time
     best = None
     for _ in range(1 if init is not None else max(1, int(n_init))):
         t0 = time.perf_counter()
         if init is not None:
             cent = torch.as_tensor(init).to(points)
+            if center:
+                cent = cent - mean
         elif not sharded or torch.distributed.get_rank() == 0:
-            cent = kmeans_plus_plus(points, n_clusters, rng)
+            cent = kmeans_plus_plus(points, n_clusters, rng, n_local_trials=n_local_trials)
         else:
             cent = torch.empty((n_clusters, points.shape[1]), dtype=points.dtype, device=points.device)
         cent = cent.contiguous().float()
@@ -185,8 +290,11 @@ def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0,
         if best is None or res[2] < best[2]:
             best = res
     cent, label, inertia, n_iter, sums, counts = best
+    means = sums / counts.clamp_min(1)[:, None]
+    if center:
+        cent, means = cent + mean, means + mean
     if return_means:
-        return cent, label.long(), inertia, n_iter, sums / counts.clamp_min(1)[:, None], counts
+        return cent, label.long(), inertia, n_iter, means, counts
     return cent, label.long(), inertia, n_iter
 
 
@@ -220,7 +328,10 @@ def subsample_per_class(feat, labels, num_classes, max_per_class=300000, seed=0,
     stable sort of the labels (ascending point order inside a class, as the reference's block-order concatenation gives).
     sampler "device": `torch.randperm` on the device from a seeded generator; "numpy": the host draw
     `RandomState(seed).choice(arange(n), max, replace=False)` of rounds 1-3 (a full host permutation per class)."""
-    y = labels.reshape(-1).to(feat.device)
+    y = labels.reshape(-1).to(feat.device).long()
+    # labels outside [0, num_classes) - an ignore index such as -100, float labels - match no `y == c` mask of the reference
+    # (get_basis.py:176-181): they are skipped, i.e. counted with the background
+    y = torch.where((y < 0) | (y >= num_classes), torch.zeros_like(y), y)
     counts = torch.bincount(y, minlength=num_classes)[:num_classes].tolist()           # the one sync
     order = torch.argsort(y, stable=True)
     starts = np.concatenate([[0], np.cumsum(counts)])

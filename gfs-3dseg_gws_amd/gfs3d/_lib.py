@@ -191,6 +191,9 @@ SYMBOLS = {
     "gfs3d_kmeanspp_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "gfs3d_kmeanspp_seed_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                         c_int, c_void_p]),
+    "gfs3d_kmeanspp_greedy_workspace_bytes": (c_size_t, [c_longlong, c_int, c_int]),
+    "gfs3d_kmeanspp_greedy_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_size_t, c_int, c_void_p]),
     "gfs3d_proto_backward_proto_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gfs3d_proto_backward_proto_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),

@@ -1162,3 +1162,27 @@ def kmeanspp_seed(pts: torch.Tensor, K: int, first: int, u, prune: bool = True):
                                        1 if prune else 0, _stream())
     _lib.check(rc, "gfs3d_kmeanspp_seed_f32")
     return centers, picks
+
+
+def kmeanspp_greedy(pts: torch.Tensor, K: int, first: int, u, n_trials: int, prune: bool = True):
+    """sklearn's greedy k-means++ on the device (gfs3d_kmeanspp_greedy_f32; what `KMeans(init='k-means++')` of get_basis.py:210
+    runs): pts (M,C) fp32, `first` the first centre's index, `u` (K - 1, n_trials) uniform variates in sklearn's consumption
+    order (host array).  Returns (centers (K,C), picks (K,) int64) - device tensors, nothing waits for the host."""
+    _need_gpu(pts, "pts")
+    pts = pts.contiguous()
+    M, C = pts.shape
+    dev = pts.device
+    u = torch.as_tensor(u, dtype=torch.float64).reshape(-1)
+    if u.numel() != (K - 1) * n_trials:
+        raise ValueError("gfs3d.kmeanspp_greedy: (K - 1) * n_trials uniform variates are needed")
+    u_dev = (u if u.numel() else torch.zeros(1, dtype=torch.float64)).to(dev)
+    centers = torch.empty((K, C), dtype=torch.float32, device=dev)
+    picks = torch.empty(K, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        L = _lib.lib()
+        nbytes = L.gfs3d_kmeanspp_greedy_workspace_bytes(M, C, K)
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        rc = L.gfs3d_kmeanspp_greedy_f32(_p(pts), M, C, K, int(first), _p(u_dev), int(n_trials), _p(centers), _p(picks), _p(ws), ws.numel(),
+                                         1 if prune else 0, _stream())
+    _lib.check(rc, "gfs3d_kmeanspp_greedy_f32")
+    return centers, picks

@@ -66,11 +66,38 @@ def augment_draws(cfg: dict, num_point: int, device, generator: Optional[torch.G
     return m.to(device), jit
 
 
+def augment_draws_batch(cfg: dict, B: int, num_point: int, device, generator: Optional[torch.Generator] = None):
+    """augment_draws for a whole batch in tensor ops (no host reads): (B,3,3) float64 matrices
+    M = mirror_y mirror_x R_z(angle) zoom(s) (the reference's order of composition, loader.py:134-145) and the (B,n,3) jitter."""
+    gen = generator if generator is not None and generator.device == torch.device(device) else None
+    u = torch.rand((B, 4), dtype=torch.float64, device=device, generator=gen)
+    one, zero = torch.ones(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.float64, device=device)
+    s = one
+    if cfg.get("scale", 0) > 1:
+        s = 1.0 / cfg["scale"] + u[:, 0] * (cfg["scale"] - 1.0 / cfg["scale"])
+    c, s_ = one, zero
+    if cfg.get("rot", 0) == 1:
+        ang = u[:, 1] * (2.0 * math.pi)
+        c, s_ = torch.cos(ang), torch.sin(ang)
+    sx = sy = one
+    if cfg.get("mirror_prob", 0) > 0:
+        sx = torch.where(u[:, 2] < cfg["mirror_prob"] / 2, -one, one)
+        sy = torch.where(u[:, 3] < cfg["mirror_prob"] / 2, -one, one)
+    m = torch.stack([torch.stack([sx * c, -sx * s_, zero], 1), torch.stack([sy * s_, sy * c, zero], 1),
+                     torch.stack([zero, zero, one], 1)], 1) * s[:, None, None]
+    jit = None
+    if cfg.get("jitter", 0):
+        jit = (0.01 * torch.randn((B, num_point, 3), device=device, generator=gen)).clamp(-0.05, 0.05).float()
+    return m, jit
+
+
 def assemble(rows: torch.Tensor, pc_attribs: str = "xyzrgbXYZ", sampled_classes: Sequence[int] = (), sampled_class: int = 0,
              support: bool = False, use_all_classes: bool = False, augm_matrix: Optional[torch.Tensor] = None,
-             jitter: Optional[torch.Tensor] = None):
+             jitter: Optional[torch.Tensor] = None, num_labels: Optional[int] = None):
     """Gathered rows (..., n, 7|8) -> (ptcloud (..., 3A, n) fp32 channel-first as the Dataset classes return it,
-    groundtruth (..., n) int64, segment_label (..., n) fp32)   (loader.py:84-129, 200)."""
+    groundtruth (..., n) int64, segment_label (..., n) fp32)   (loader.py:84-129, 200).
+    num_labels: an upper bound (exclusive) of the label ids in `rows`, known to the caller (BlockSampler reads it once at
+    construction); without it the label table is sized from `labels.max()`, a device -> host read."""
     xyz = rows[..., 0:3]
     xyz = xyz - xyz.amin(dim=-2, keepdim=True)
     if augm_matrix is not None:
@@ -93,39 +120,82 @@ def assemble(rows: torch.Tensor, pc_attribs: str = "xyzrgbXYZ", sampled_classes:
     else:
         # table lookup instead of the per-point Python loop (loader.py:108-112): class id -> position (+1: 0 = background)
         off = 0 if use_all_classes else 1
-        hi = int(max([int(labels.max())] + [int(c) for c in sampled_classes])) + 1
-        table = torch.zeros(hi, dtype=torch.long, device=rows.device)
+        top = int(labels.max()) + 1 if num_labels is None else int(num_labels)
+        hi = max([top] + [int(c) + 1 for c in sampled_classes])
+        table = torch.zeros(hi, dtype=torch.long)
         for i, c in enumerate(sampled_classes):
             table[int(c)] = i + off
-        gt = table[labels]
+        gt = table.to(rows.device)[labels]
     seg = rows[..., 7].float() if rows.shape[-1] == 8 else torch.zeros(rows.shape[:-1], dtype=torch.float32, device=rows.device)
     return pc, gt, seg
 
 
 class BlockSampler:
-    """Blocks resident in HBM; `batch()` = sample_pointcloud for a list of block ids, one gather + one assemble."""
+    """Blocks resident in HBM as ONE (sum M_i, 7|8) table; `batch()` = sample_pointcloud (loader.py:39-129) for a list of block
+    ids as a fixed sequence of batch-wide tensor ops - random keys, two top-k selections, one row gather, one assemble - with
+    NO device -> host read (block sizes and the label range are host-side facts taken at construction), so the sampler
+    runs ahead of the training step on its stream.  The draws have the reference's distributions: uniform subsets without
+    replacement (the num_point smallest of M_i uniform keys, in key order: a uniformly random ordered subset), uniform draws
+    with replacement for blocks smaller than num_point, the class share `int(n_class / M_i * num_point)` of loader.py:71-76."""
 
     def __init__(self, blocks: List[torch.Tensor], device="cuda"):
-        self.blocks = [b.to(device) for b in blocks]
         self.device = torch.device(device)
+        cols = {int(b.shape[1]) for b in blocks}
+        if len(cols) != 1:
+            raise RuntimeError("gfs3d.pipeline: blocks must have the same number of columns (7 or 8)")
+        self.sizes = [int(b.shape[0]) for b in blocks]
+        self.offsets = [0]
+        for m in self.sizes:
+            self.offsets.append(self.offsets[-1] + m)
+        self.data = torch.cat([b.to(self.device) for b in blocks], dim=0).contiguous()
+        self.blocks = [self.data[o:o + m] for o, m in zip(self.offsets[:-1], self.sizes)]      # views of the table
+        self.num_labels = int(self.data[:, 6].max()) + 1                                         # the one read, at construction
+
+    def sample_batch_indices(self, block_ids: Sequence[int], num_point: int, sampled_class: Optional[int] = None,
+                             generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """(B, num_point) row numbers into `self.data`: the point draw of sample_pointcloud for every block of the batch."""
+        dev = self.device
+        gen = generator if generator is not None and generator.device == dev else None
+        B, n = len(block_ids), int(num_point)
+        sizes = [self.sizes[int(b)] for b in block_ids]
+        mmax = max(sizes)
+        kk = min(n, mmax)
+        host = torch.tensor([sizes, [self.offsets[int(b)] for b in block_ids]], dtype=torch.long)
+        size_t, off_t = host.to(dev, non_blocking=True).unbind(0)
+        pos = torch.arange(mmax, device=dev)[None, :]
+        inside = pos < size_t[:, None]
+        small = (size_t < n)[:, None]                                  # drawn WITH replacement (loader.py:66, 79)
+        col = torch.arange(n, device=dev)[None, :]
+
+        def ordered_subset(mask):
+            keys = torch.rand((B, mmax), device=dev, generator=gen)
+            order = torch.where(mask, keys, torch.full_like(keys, 2.0)).topk(kk, dim=1, largest=False).indices
+            if kk < n:                                                 # every block of the batch is small: padded, never read
+                order = torch.cat([order, order.new_zeros((B, n - kk))], dim=1)
+            return order
+
+        with_repl = (torch.rand((B, n), device=dev, generator=gen).double() * size_t[:, None]).long().clamp_(max=mmax - 1)
+        with_repl = torch.minimum(with_repl, size_t[:, None] - 1)
+        if sampled_class is None:                                      # random_sample=True
+            idx = torch.where(small, with_repl, ordered_subset(inside))
+        else:
+            flat = (off_t[:, None] + pos).clamp_(max=self.data.shape[0] - 1)
+            valid = inside & (self.data[:, 6][flat] == sampled_class)
+            nv = valid.sum(dim=1)
+            share = (nv.double() / size_t.double() * n).long()         # int(valid_ratio * num_point), the same IEEE operations
+            n_valid = torch.where(small[:, 0], nv, share)[:, None]
+            first = ordered_subset(valid)
+            rest = torch.where(small, with_repl, ordered_subset(inside))
+            idx = torch.where(col < n_valid, first, rest.gather(1, (col - n_valid).clamp_(min=0)))
+        return off_t[:, None] + idx
 
     def batch(self, block_ids: Sequence[int], num_point: int = 2048, pc_attribs: str = "xyzrgbXYZ",
               sampled_classes: Sequence[int] = (), sampled_class: Optional[int] = None, support: bool = False,
               use_all_classes: bool = False, pc_augm: bool = False, pc_augm_config: Optional[dict] = None,
               generator: Optional[torch.Generator] = None):
-        rows = []
-        for bid in block_ids:
-            blk = self.blocks[int(bid)]
-            idx = sample_indices(blk[:, 6], num_point, sampled_class, random_sample=sampled_class is None, generator=generator)
-            rows.append(blk[idx])
-        cols = {r.shape[1] for r in rows}
-        if len(cols) != 1:
-            raise RuntimeError("gfs3d.pipeline: blocks of one batch must have the same number of columns (7 or 8)")
-        rows = torch.stack(rows, dim=0)                                           # (B, n, 7|8)
+        rows = self.data[self.sample_batch_indices(block_ids, num_point, sampled_class, generator)]      # (B, n, 7|8)
         m = jit = None
         if pc_augm:
-            ms, js = zip(*[augment_draws(pc_augm_config, num_point, self.device, generator) for _ in block_ids])
-            m = torch.stack(ms, dim=0)
-            jit = torch.stack(js, dim=0) if js[0] is not None else None
+            m, jit = augment_draws_batch(pc_augm_config, len(block_ids), num_point, self.device, generator)
         return assemble(rows, pc_attribs, sampled_classes, 0 if sampled_class is None else sampled_class, support,
-                        use_all_classes, m, jit)
+                        use_all_classes, m, jit, num_labels=self.num_labels)

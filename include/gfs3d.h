@@ -458,6 +458,21 @@ int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float
 size_t gfs3d_kmeanspp_workspace_bytes(long long M, int K);
 int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int K, long long first, const double *u, float *centers,
                             long long *picks, void *workspace, size_t workspace_bytes, int prune, void *stream);
+/* GREEDY k-means++: the seeding sklearn's `KMeans(init='k-means++')` really runs (get_basis.py:210 of the reference calls it
+ * with the defaults; sklearn/cluster/_kmeans.py `_kmeans_plusplus`, scikit-learn 1.7.2): every pick draws
+ * n_trials = 2 + int(log K) candidates by D^2 sampling and keeps the one that lowers the potential sum_i d2[i] most.
+ *   pts (M, C) row-major fp32, C % 4 == 0, C <= 256;  first = index of the first centre (sklearn:
+ *      `random_state.choice(n_samples, p=uniform)`, the caller's draw);
+ *   u  (K - 1) x n_trials uniform variates on the DEVICE in sklearn's consumption order (`random_state.uniform(size=n_trials)`
+ *      per pick): candidate j of pick t is searchsorted(cumsum(d2), u[t - 1][j] * sum(d2)) (side 'left', 0 when no mass is left);
+ *   the winner is the first candidate with the smallest potential (numpy's argmin);  potentials are summed in fp64 in a fixed
+ *   order (sklearn: a float32 BLAS dot), so the picks are a pure function of the arguments and equal sklearn's except where a
+ *   variate lands within rounding of a cdf step or two candidates' potentials tie to ~1e-7.
+ *   centers (K, C) out;  picks (K) out.  4 K - 2 launches on `stream`, no host synchronisation.  prune as above (the gain
+ *   pass skips a point when no candidate can come closer than its nearest centre). */
+size_t gfs3d_kmeanspp_greedy_workspace_bytes(long long M, int C, int K);
+int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, int K, long long first, const double *u, int n_trials,
+                              float *centers, long long *picks, void *workspace, size_t workspace_bytes, int prune, void *stream);
 /* gfs3d_word_assign_f32 / gfs3d_proto_backward_feat_f32 with the matrix-core operand form chosen by the caller
  * (`compute` = GFS3D_COMPUTE_*; tensors stay fp32).  The reduced forms apply to the geometric-word shapes (more than 32
  * prototypes, C % 32 == 0); get_pred-sized calls (<= 32 prototypes) are HBM-bound on fp32 MFMAs and ignore it. */

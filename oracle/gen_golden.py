@@ -324,6 +324,70 @@ def g_basis():
          logits=logits.numpy(), feat=feat.numpy())
 
 
+# ---------------------------------------------------------------- (12b) sklearn's own seeding and fit (get_basis.py:210)
+def g_kmeanspp():
+    """What `KMeans(n_clusters, init='k-means++')` (get_basis.py:210) does, from scikit-learn itself (third-party, version
+    printed into the fixture): `sklearn.cluster.kmeans_plusplus` picks and whole `KMeans(init='k-means++', n_init=1,
+    random_state=s).fit` results on seeded inputs.  The inputs are NOT stored (up to 38 MB): the tests rebuild them with
+    oracle.ref_ops.clustered_points from the recorded parameters.  Per case the RandomState seed is the one of a few tried
+    whose picks keep the largest distance from a rounding tie (margins measured by the float64 restatement), so that an
+    implementation that rounds differently can be asked for EQUAL picks."""
+    import sklearn
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    from oracle.ref_ops import clustered_points, greedy_kmeans_plusplus, sklearn_lloyd
+    out = {"sklearn_version": np.array(sklearn.__version__)}
+    cases = [("a", 3000, 192, 200, 40, True), ("b", 10000, 192, 200, 60, True), ("c", 50000, 192, 200, 120, True),
+             ("d", 20000, 64, 33, 25, False), ("e", 5000, 192, 8, 6, False), ("f", 4000, 192, 200, 3, True)]
+    for name, M, C, K, blobs, fit in cases:
+        X = clustered_points(M, C, blobs, seed=1000 + ord(name))
+        best = None
+        for s in range(6):
+            _, ind = kmeans_plusplus(X, K, random_state=np.random.RandomState(s))
+            mine, marg = greedy_kmeans_plusplus(X, K, np.random.RandomState(s), with_margins=True)
+            same = bool((mine == ind).all())
+            score = marg[1:].min() if same else -1.0
+            print(name, "seed", s, "oracle == sklearn:", same, "min margins", marg[1:].min(0))
+            if best is None or score > best[0]:
+                best = (score, s, ind, marg)
+        score, s, ind, marg = best
+        assert score > 0, "no seed on which the float64 restatement reproduces sklearn's picks"
+        out[f"{name}_params"] = np.array([M, C, K, blobs, 1000 + ord(name), s], dtype=np.int64)
+        out[f"{name}_indices"] = ind.astype(np.int64)
+        out[f"{name}_margins"] = marg
+        if fit:
+            km = KMeans(n_clusters=K, init="k-means++", n_init=1, random_state=s).fit(X)
+            # KMeans.fit seeds on the CENTRED data from the same stream: record its picks too (recovered from its first centres)
+            Xc = X - X.mean(axis=0)
+            _, ind_fit = kmeans_plusplus(Xc, K, random_state=np.random.RandomState(s))
+            km1 = KMeans(n_clusters=K, init="k-means++", n_init=1, random_state=s, max_iter=1).fit(X)
+            c_or, lab_or, inertia_or, it_or = sklearn_lloyd(Xc, Xc[ind_fit])
+            print(name, "fit: n_iter", km.n_iter_, "inertia", km.inertia_, "| oracle from sklearn's picks: n_iter", it_or, "inertia", inertia_or,
+                  "labels equal", float((lab_or == km.labels_).mean()))
+            out[f"{name}_fit_indices"] = ind_fit.astype(np.int64)
+            out[f"{name}_fit_centers"] = km.cluster_centers_.astype(np.float32)
+            out[f"{name}_fit_labels"] = km.labels_.astype(np.int16)
+            out[f"{name}_fit_inertia"] = np.float64(km.inertia_)
+            out[f"{name}_fit_n_iter"] = np.int64(km.n_iter_)
+            out[f"{name}_fit1_centers"] = km1.cluster_centers_.astype(np.float32)       # after ONE Lloyd iteration
+    # empty clusters: a fixed init with three centres far from every point - sklearn relocates them to the farthest points
+    X = clustered_points(3000, 192, 10, seed=77)
+    g = np.random.RandomState(5)
+    init = X[g.choice(3000, 12, replace=False)].copy()
+    init[3] += 50.0
+    init[7] -= 40.0
+    init[9] += 45.0
+    km = KMeans(n_clusters=12, init=init, n_init=1).fit(X)
+    c_or, lab_or, inertia_or, it_or = sklearn_lloyd(X - X.mean(axis=0), init - X.mean(axis=0))
+    print("relocation: n_iter", km.n_iter_, it_or, "inertia", km.inertia_, inertia_or, "labels equal", float((lab_or == km.labels_).mean()))
+    out["g_params"] = np.array([3000, 192, 12, 10, 77, 0], dtype=np.int64)
+    out["g_init"] = init
+    out["g_fit_centers"] = km.cluster_centers_.astype(np.float32)
+    out["g_fit_labels"] = km.labels_.astype(np.int16)
+    out["g_fit_inertia"] = np.float64(km.inertia_)
+    out["g_fit_n_iter"] = np.int64(km.n_iter_)
+    save("kmeanspp", **out)
+
+
 # ---------------------------------------------------------------- (13) metric
 def g_metric():
     g = np.random.RandomState(1)
@@ -426,6 +490,6 @@ def g_loader():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["knn", "edge_feature", "dgcnn", "capl", "basis", "metric", "harness", "loader"]
+    which = sys.argv[1:] or ["knn", "edge_feature", "dgcnn", "capl", "basis", "kmeanspp", "metric", "harness", "loader"]
     for w in which:
         globals()["g_" + w]()

@@ -361,6 +361,127 @@ def lloyd_kmeans(pts: np.ndarray, init: np.ndarray, iters: int) -> Tuple[np.ndar
     return c.astype(np.float32), lab, float(d[np.arange(len(x)), lab].sum())
 
 
+# --------------------------------------------------------------------------
+# sklearn.cluster.KMeans(n_clusters, init='k-means++') as the reference calls it (get_basis.py:210).
+# scikit-learn is a third-party dependency of the reference, not vendored under /root/reference and not pinned by it
+# (README names no version); the algorithm restated here is scikit-learn 1.7.2's (the version in the build container, the
+# one oracle/gen_golden.py ran): sklearn/cluster/_kmeans.py `_kmeans_plusplus`, `_kmeans_single_lloyd`,
+# `_relocate_empty_clusters` (sklearn/cluster/_k_means_common.pyx) and `KMeans.fit`.  Pinned by tests/golden/kmeanspp.npz,
+# which holds what sklearn itself returned.
+# --------------------------------------------------------------------------
+def clustered_points(M: int, C: int, n_blobs: int, seed: int, spread: float = 0.35) -> np.ndarray:
+    """Input recipe of the k-means fixtures (legacy numpy RandomState: the same bytes on every platform): `n_blobs` Gaussian
+    blobs of unequal size around an offset mean, float32 (M,C) - shaped like EdgeConv features (not centred)."""
+    g = np.random.RandomState(seed)
+    cent = g.randn(n_blobs, C) * g.uniform(0.2, 1.0, size=(1, C)) + g.uniform(-0.5, 1.5, size=(1, C))
+    w = g.uniform(0.2, 1.0, size=n_blobs)
+    which = g.choice(n_blobs, size=M, p=w / w.sum())
+    return (cent[which] + spread * g.randn(M, C) * g.uniform(0.5, 1.5, size=(n_blobs, 1))[which]).astype(np.float32)
+
+
+def sklearn_first_center(M: int, rs: np.random.RandomState) -> int:
+    """`random_state.choice(n_samples, p=sample_weight / sample_weight.sum())` with unit float32 weights
+    (_kmeans_plusplus): consumes ONE uniform variate."""
+    w = np.ones(M, dtype=np.float32)
+    return int(rs.choice(M, p=w / w.sum()))
+
+
+def _sqdist_rows(X: np.ndarray, rows: np.ndarray, chunk: int = 8192) -> np.ndarray:
+    """(T,M) squared distances of X[rows] to every point, evaluated in float64 and rounded to float32 - what sklearn's
+    `_euclidean_distances` returns for float32 input (it upcasts blocks to float64, `_euclidean_distances_upcast`)."""
+    Y = X[rows].astype(np.float64)
+    out = np.empty((len(rows), X.shape[0]), dtype=np.float32)
+    for s in range(0, X.shape[0], chunk):
+        x = X[s:s + chunk].astype(np.float64)
+        out[:, s:s + chunk] = ((x[None, :, :] - Y[:, None, :]) ** 2).sum(2)
+    return out
+
+
+def greedy_kmeans_plusplus(X: np.ndarray, K: int, rs: np.random.RandomState, n_local_trials: Optional[int] = None,
+                           with_margins: bool = False):
+    """sklearn's greedy k-means++ (`_kmeans_plusplus`): per pick `2 + int(log K)` candidates drawn by D^2 sampling
+    (`searchsorted(cumsum(d2), uniform * potential)`, side 'left', clipped), the one that lowers the potential most is kept.
+    The potentials are summed in float64 here (sklearn: a float32 BLAS dot, whose summation order is the library's own).
+    Returns (indices (K,), [margins (K,2)]): margins[c] = (smallest distance of a scaled variate to a cdf step, gap between
+    the two lowest distinct candidate potentials), both relative to the potential - how close pick c came to a rounding tie."""
+    M = X.shape[0]
+    T = 2 + int(np.log(K)) if n_local_trials is None else int(n_local_trials)
+    idx = np.full(K, -1, dtype=np.int64)
+    idx[0] = sklearn_first_center(M, rs)
+    d2 = _sqdist_rows(X, idx[:1])[0]
+    pot = float(d2.astype(np.float64).sum())
+    margins = np.ones((K, 2))
+    for c in range(1, K):
+        r = rs.uniform(size=T) * pot
+        cs = np.cumsum(d2, dtype=np.float64)
+        cand = np.searchsorted(cs, r)
+        np.clip(cand, None, M - 1, out=cand)
+        dc = np.minimum(_sqdist_rows(X, cand), d2[None, :])
+        pots = dc.astype(np.float64).sum(1)
+        best = int(np.argmin(pots))
+        if with_margins and pot > 0:
+            lo = np.where(cand > 0, cs[np.maximum(cand - 1, 0)], 0.0)
+            step = np.minimum(r - lo, cs[cand] - r).min() / pot
+            up = np.unique(pots)
+            margins[c] = (step, (up[1] - up[0]) / pot if len(up) > 1 else 1.0)
+        pot, d2, idx[c] = float(pots[best]), dc[best], cand[best]
+    return (idx, margins) if with_margins else idx
+
+
+def sklearn_lloyd(X: np.ndarray, init: np.ndarray, max_iter: int = 300, tol: float = 1e-4, chunk: int = 16384):
+    """`KMeans.fit` after the seeding: Lloyd iterations as `_kmeans_single_lloyd` runs them.  Per iteration: labels from the
+    current centres, new centres = member means with EMPTY clusters relocated to the points farthest from their centres
+    (`_relocate_empty_clusters`: the n_empty largest distances, each point leaves its old cluster), stop when the labels
+    repeat (strict convergence) or the squared centre shift is <= tol * mean(var(X, axis=0)); a last assignment when the
+    stop was the shift.  float64 arithmetic (sklearn: float32 GEMM chunks).  Returns (centres, labels, inertia, n_iter)."""
+    x = X.astype(np.float64)
+    c = np.asarray(init, dtype=np.float64).copy()
+    K = len(c)
+    tol_abs = float(np.mean(np.var(X, axis=0))) * tol
+    xx = (x * x).sum(1)
+
+    def assign(cen):
+        lab = np.empty(len(x), dtype=np.int64)
+        dist = np.empty(len(x))
+        cc = (cen * cen).sum(1)
+        for s in range(0, len(x), chunk):
+            d = xx[s:s + chunk, None] - 2.0 * x[s:s + chunk] @ cen.T + cc[None, :]
+            lab[s:s + chunk] = d.argmin(1)
+            dist[s:s + chunk] = np.maximum(d[np.arange(d.shape[0]), lab[s:s + chunk]], 0.0)
+        return lab, dist
+
+    old = np.full(len(x), -1, dtype=np.int64)
+    strict = False
+    n_iter = 0
+    for n_iter in range(1, max_iter + 1):
+        lab, dist = assign(c)
+        sums = np.zeros_like(c)
+        np.add.at(sums, lab, x)
+        cnt = np.bincount(lab, minlength=K).astype(np.float64)
+        empty = np.nonzero(cnt == 0)[0]
+        if len(empty):
+            far = np.argsort(-dist, kind="stable")[:len(empty)]
+            for e, f in zip(empty, far):
+                sums[lab[f]] -= x[f]
+                cnt[lab[f]] -= 1
+                sums[e] = x[f]
+                cnt[e] = 1
+        new = sums / cnt[:, None]
+        shift = float(((new - c) ** 2).sum())
+        c = new
+        if np.array_equal(lab, old):
+            strict = True
+            break
+        if shift <= tol_abs:
+            break
+        old = lab
+    if not strict:
+        lab, dist = assign(c)
+    else:
+        dist = ((x - c[lab]) ** 2).sum(1)
+    return c.astype(np.float32), lab, float(dist.sum()), n_iter
+
+
 def dgcnnseg_features(p: Params, x: Tensor, k: int = 20, knn_fn=knn) -> Tensor:
     """get_basis.DGCNNSeg.forward(return_feat=True)[1] (get_basis.py:95-104):
     the three EdgeConv outputs concatenated, (B,192,N)."""

@@ -103,6 +103,12 @@ def _worker(rank, world, port, out):
                                                 assign_fn=_torch_assign)
     res["km"] = (cent.numpy(), lab.numpy(), inertia, n_iter)
     res["km_pp"] = (cent2.numpy(), inertia2, n_iter2)
+    #    ... and from a start that leaves a cluster EMPTY: the relocation (sklearn's rule: the globally farthest point) gathers
+    #    its candidates from both ranks, so both apply the same move
+    far = init.clone()
+    far[2] += 100.0
+    cent3, lab3, inertia3, n_iter3 = device_kmeans(pts_all[lo:hi], 6, init=far, max_iter=50, tol=1e-4, assign_fn=_torch_assign)
+    res["km_far"] = (cent3.numpy(), lab3.numpy(), inertia3, n_iter3)
     # 7. overlap=False: the early slice is exchanged from all_reduce_mean() (the order synchronised BatchNorm needs)
     late = gd.FlatGradBucket(lin.parameters(), early=lin[1].parameters(), overlap=False)
     late.zero()
@@ -157,6 +163,14 @@ def test_dp_helpers_world2_gloo():
     assert np.array_equal(np.concatenate([a["km"][1], b["km"][1]]), lab.numpy())
     assert abs(a["km"][2] - inertia) < 1e-6 * inertia and a["km"][2] == b["km"][2]
     assert np.array_equal(a["km_pp"][0], b["km_pp"][0]) and a["km_pp"][1] == b["km_pp"][1] and a["km_pp"][2] == b["km_pp"][2]
+    far = init.clone()
+    far[2] += 100.0
+    cent, lab, inertia, n_iter = device_kmeans(pts_all, 6, init=far, max_iter=50, tol=1e-4, assign_fn=_torch_assign)
+    assert a["km_far"][3] == b["km_far"][3] == n_iter
+    assert np.array_equal(a["km_far"][0], b["km_far"][0]) and np.abs(a["km_far"][0] - cent.numpy()).max() < 1e-5
+    assert np.array_equal(np.concatenate([a["km_far"][1], b["km_far"][1]]), lab.numpy())
+    assert abs(a["km_far"][2] - inertia) < 1e-6 * inertia
+    assert len(np.unique(lab.numpy())) == 6                     # the far centre was relocated, not left empty
     assert np.allclose(a["late_grad"], mean, atol=1e-6) and np.allclose(b["late_grad"], mean, atol=1e-6)
     assert a["late_launches"] == 0
     # single-process reference for (4)

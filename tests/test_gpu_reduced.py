@@ -239,7 +239,8 @@ def test_capl_scannet_reduced_vs_reference_golden(dev, mode, word_agree, pred_ag
 
 # cosine floors: measured lowest per-parameter cosines on MI355X 0.979 (f16) / 0.873 (bf16) - scripts/exp_reduced_cos.py; that these
 # directions TRAIN is what test_reduced_modes_train_like_fp32_over_60_steps shows (loss curves within 3 % of fp32 over 60 steps)
-@pytest.mark.parametrize("mode,loss_tol,min_cos", [("f16", 1e-3, 0.97), ("bf16", 2e-3, 0.85)])
+# (floors kept a few hundredths under the measured minima: the fp64-atomic BatchNorm sums order differently per card / driver)
+@pytest.mark.parametrize("mode,loss_tol,min_cos", [("f16", 1e-3, 0.95), ("bf16", 2e-3, 0.82)])
 def test_capl_train_step_reduced_vs_reference_golden(dev, mode, loss_tol, min_cos):
     """A whole CAPL training step (capl.py:194-242) in a reduced mode: loss, predictions and the direction of every
     parameter gradient against the reference's fp32 step."""

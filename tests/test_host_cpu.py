@@ -248,3 +248,123 @@ def test_bench_roofline_block_reports_both_fractions():
     r5 = bench.roofline_of({2: (9 * 0.3, 9)}, 3, c5["B"], c5)
     assert r5["kernel"] == "ec_main_bwd_pair_kernel<1>" and r5["peak_executed_pipe"] == 2500.0
     assert abs(r5["frac_executed_pipe"] - r5["achieved"] / 2500.0) < 1e-4
+
+
+# ---------------------------------------------------------------- the seeding / Lloyd host logic (get_basis.py:210)
+def _kpp_case(g, name):
+    from oracle import ref_ops as R
+    M, C, K, blobs, data_seed, rs_seed = (int(v) for v in g[name + "_params"])
+    return R.clustered_points(M, C, blobs, seed=data_seed), K, rs_seed
+
+
+@pytest.mark.parametrize("name", ["a", "e"])
+def test_greedy_seeding_host_form_equals_sklearn_picks(name):
+    """get_basis.kmeans_plus_plus on CPU tensors (the tensor-op form of the greedy seeding the gloo logic tests use) draws
+    sklearn's variates in sklearn's order: the picks are those sklearn.cluster.kmeans_plusplus returned."""
+    from get_basis import kmeans_plus_plus
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, name)
+    cent, picks = kmeans_plus_plus(torch.from_numpy(X), K, np.random.RandomState(s), return_picks=True)
+    assert np.array_equal(picks.numpy(), g[name + "_indices"])
+    assert np.array_equal(cent.numpy(), X[g[name + "_indices"]])
+
+
+def _cpu_assign(pts, cent):
+    d = torch.cdist(pts.double(), cent.double()) ** 2
+    lab = d.argmin(1)
+    sums = torch.zeros_like(cent).index_add_(0, lab, pts)
+    counts = torch.bincount(lab, minlength=cent.shape[0]).to(pts.dtype)
+    return lab, sums, counts, d.gather(1, lab[:, None]).sum().reshape(1)
+
+
+def test_lloyd_host_logic_equals_sklearn_fit_incl_relocation():
+    """get_basis.device_kmeans' host logic (centring, strict-convergence / shift stop, empty-cluster relocation) with a CPU
+    stand-in for the assignment kernel == sklearn's fit: case a from k-means++ (same RandomState -> same picks), case g from a
+    start with three empty clusters."""
+    from get_basis import device_kmeans
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, "a")
+    cent, lab, inertia, n_iter = device_kmeans(torch.from_numpy(X), K, rng=np.random.RandomState(s), assign_fn=_cpu_assign)
+    assert n_iter == int(g["a_fit_n_iter"])
+    assert np.array_equal(lab.numpy(), g["a_fit_labels"].astype(np.int64))
+    assert abs(inertia - float(g["a_fit_inertia"])) < 1e-5 * inertia
+    assert np.abs(cent.numpy() - g["a_fit_centers"]).max() < 1e-4
+    X, K, _ = _kpp_case(g, "g")
+    cent, lab, inertia, n_iter = device_kmeans(torch.from_numpy(X), K, init=g["g_init"], assign_fn=_cpu_assign)
+    assert n_iter == int(g["g_fit_n_iter"])
+    assert np.array_equal(lab.numpy(), g["g_fit_labels"].astype(np.int64))
+    assert abs(inertia - float(g["g_fit_inertia"])) < 1e-5 * inertia
+    assert np.abs(cent.numpy() - g["g_fit_centers"]).max() < 1e-4
+
+
+# ---------------------------------------------------------------- batched block sampler (loader.py:39-151)
+def _toy_blocks(sizes, n_classes=6, seed=0, cols=7):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for m in sizes:
+        b = torch.rand(m, cols, generator=g)
+        b[:, 6] = torch.randint(0, n_classes, (m,), generator=g).float()
+        out.append(b)
+    return out
+
+
+def test_batched_sampler_has_the_reference_draw_distributions():
+    """gfs3d.pipeline.BlockSampler.sample_batch_indices (one set of batch-wide tensor ops, no per-block Python) against
+    the rules of sample_pointcloud (loader.py:64-82): indices inside the block; without replacement when the block has
+    >= num_point points, with replacement otherwise; the class share int(n_class / M * num_point) (all class points for a
+    small block) drawn from the class without replacement; every point equally likely."""
+    from gfs3d import pipeline
+    sizes = [500, 3000, 9000, 2048, 1500, 12000]
+    blocks = _toy_blocks(sizes)
+    smp = pipeline.BlockSampler(blocks, "cpu")
+    ids = [5, 0, 1, 2, 3, 4, 1]
+    idx = smp.sample_batch_indices(ids, 2048, None, torch.Generator().manual_seed(1))
+    assert tuple(idx.shape) == (len(ids), 2048)
+    for r, b in enumerate(ids):
+        loc = idx[r] - smp.offsets[b]
+        assert int(loc.min()) >= 0 and int(loc.max()) < sizes[b]
+        if sizes[b] >= 2048:
+            assert loc.unique().numel() == 2048
+    for cls in (3, 0):
+        idx = smp.sample_batch_indices(ids, 2048, cls, torch.Generator().manual_seed(2))
+        for r, b in enumerate(ids):
+            loc = idx[r] - smp.offsets[b]
+            lab = blocks[b][:, 6]
+            n_cls = int((lab == cls).sum())
+            want = n_cls if sizes[b] < 2048 else int(n_cls / float(sizes[b]) * 2048)
+            assert int(loc.min()) >= 0 and int(loc.max()) < sizes[b]
+            assert int((lab[loc[:want]] == cls).sum()) == want and loc[:want].unique().numel() == want
+            if sizes[b] >= 2048:
+                assert loc[want:].unique().numel() == 2048 - want
+    # uniformity: inclusion frequency of every point of a 3000-point block over 300 draws of 2048 (expected 0.683 +- 0.027)
+    gen = torch.Generator().manual_seed(3)
+    hits = torch.zeros(3000)
+    for _ in range(300):
+        loc = smp.sample_batch_indices([1], 2048, None, gen)[0] - smp.offsets[1]
+        hits[loc] += 1
+    freq = hits / 300
+    assert abs(float(freq.mean()) - 2048 / 3000) < 1e-6 and float((freq - 2048 / 3000).abs().max()) < 0.14
+    # same generator state -> same batch; the x / y / seg triple has the Dataset's shapes
+    a = smp.batch([0, 5, 2], 2048, sampled_classes=[1, 2, 3], generator=torch.Generator().manual_seed(4))
+    b = smp.batch([0, 5, 2], 2048, sampled_classes=[1, 2, 3], generator=torch.Generator().manual_seed(4))
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert tuple(a[0].shape) == (3, 9, 2048) and tuple(a[1].shape) == (3, 2048) and a[1].dtype == torch.int64
+    assert float(a[0][:, 6:9].min()) == 0.0 and float(a[0][:, 6:9].max()) == 1.0 and int(a[1].max()) <= 3
+
+
+def test_batched_augmentation_matrices_compose_like_the_reference():
+    """augment_draws_batch: M = mirror_y mirror_x R_z zoom (loader.py:134-145) from four uniforms per block."""
+    from gfs3d import pipeline
+    from oracle import ref_ops as R
+    cfg = {"scale": 1.3, "rot": 1, "mirror_prob": 0.8, "jitter": 1}
+    m, jit = pipeline.augment_draws_batch(cfg, 64, 100, "cpu", torch.Generator().manual_seed(5))
+    u = torch.rand((64, 4), dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+    seen = set()
+    for b in range(64):
+        s = 1.0 / 1.3 + float(u[b, 0]) * (1.3 - 1.0 / 1.3)
+        mx, my = bool(u[b, 2] < 0.4), bool(u[b, 3] < 0.4)
+        seen.add((mx, my))
+        ref = R.loader_augment_matrix(s, float(u[b, 1]) * 2.0 * np.pi, mx, my)
+        assert np.abs(m[b].numpy() - ref).max() < 1e-12
+    assert len(seen) == 4
+    assert tuple(jit.shape) == (64, 100, 3) and float(jit.abs().max()) <= 0.05 and 0.005 < float(jit.std()) < 0.012

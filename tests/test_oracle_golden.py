@@ -239,3 +239,50 @@ def test_loader_restatement_matches_reference_sample_pointcloud():
         assert np.array_equal(pc, g[f"r{i}_pc"]) and pc.dtype == g[f"r{i}_pc"].dtype, i
         assert np.array_equal(gt, g[f"r{i}_gt"]), i
         assert np.array_equal(seg, g[f"r{i}_seg"]), i
+
+
+# ---------------------------------------------------------------- sklearn's KMeans(init='k-means++') (get_basis.py:210)
+def _kpp_case(g, name):
+    M, C, K, blobs, data_seed, rs_seed = (int(v) for v in g[name + "_params"])
+    return R.clustered_points(M, C, blobs, seed=data_seed), K, rs_seed
+
+
+@pytest.mark.parametrize("name", ["a", "b", "d", "e", "f"])
+def test_greedy_kmeanspp_restatement_equals_sklearn_picks(name):
+    """oracle.ref_ops.greedy_kmeans_plusplus == what sklearn.cluster.kmeans_plusplus returned (tests/golden/kmeanspp.npz) from the
+    same RandomState; the recorded margins are the restatement's own."""
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, name)
+    idx, marg = R.greedy_kmeans_plusplus(X, K, np.random.RandomState(s), with_margins=True)
+    assert np.array_equal(idx, g[name + "_indices"])
+    assert np.allclose(marg, g[name + "_margins"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["a", "f"])
+def test_lloyd_restatement_equals_sklearn_fit(name):
+    """oracle.ref_ops.sklearn_lloyd from sklearn's own picks == KMeans(init='k-means++', n_init=1, random_state=s).fit: the same
+    iteration count, labels, centres and inertia (sklearn works on the centred data in float32 GEMM chunks)."""
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, name)
+    mean = X.mean(axis=0)
+    Xc = X - mean
+    cent, lab, inertia, n_iter = R.sklearn_lloyd(Xc, Xc[g[name + "_fit_indices"]])
+    assert n_iter == int(g[name + "_fit_n_iter"])
+    assert np.array_equal(lab, g[name + "_fit_labels"].astype(np.int64))
+    assert abs(inertia - float(g[name + "_fit_inertia"])) < 1e-6 * inertia
+    close(cent + mean, g[name + "_fit_centers"], 1e-5)
+    c1, _, _, _ = R.sklearn_lloyd(Xc, Xc[g[name + "_fit_indices"]], max_iter=1)
+    close(c1 + mean, g[name + "_fit1_centers"], 1e-5)
+
+
+def test_lloyd_restatement_relocates_empty_clusters_like_sklearn():
+    """Three start centres far from every point: sklearn moves each empty cluster onto one of the points farthest from
+    their centres (fixture case g); the restatement takes the same points and ends in the same clustering."""
+    g = load_golden("kmeanspp")
+    X, K, _ = _kpp_case(g, "g")
+    mean = X.mean(axis=0)
+    cent, lab, inertia, n_iter = R.sklearn_lloyd(X - mean, g["g_init"] - mean)
+    assert n_iter == int(g["g_fit_n_iter"])
+    assert np.array_equal(lab, g["g_fit_labels"].astype(np.int64))
+    assert abs(inertia - float(g["g_fit_inertia"])) < 1e-6 * inertia
+    close(cent + mean, g["g_fit_centers"], 1e-5)
