@@ -320,6 +320,42 @@ def c3_end_to_end(dev, n_blocks=1400, num_cnt=200):
                     "arithmetic); the Lloyd loop reads one scalar per iteration for its stopping test"}
 
 
+def pipeline_throughput(dev, n_blocks=256, batch=32, iters=30):
+    """blocks/s of the device input pipeline (gfs3d.pipeline.BlockSampler.batch: point draw, row gather, min-shift,
+    augmentation, unit-box normalisation, label remap for a batch of 32 blocks = what 32 calls of the reference's
+    sample_pointcloud do on the host, loader.py:39-151) on a resident synthetic dataset of S3DIS-like blocks (3 000 - 12 000
+    points x 7 columns).  Both draw modes; the figure to hold against the training step's block rate."""
+    from gfs3d import pipeline
+    g = torch.Generator().manual_seed(11)
+    blocks = []
+    for _ in range(n_blocks):
+        m = int(torch.randint(3000, 12001, (1,), generator=g))
+        b = torch.rand(m, 7, generator=g)
+        b[:, 3:6] *= 255.0
+        b[:, 6] = torch.randint(0, 13, (m,), generator=g).float()
+        blocks.append(b)
+    smp = pipeline.BlockSampler(blocks, dev)
+    cfg = {"scale": 0, "rot": 1, "mirror_prob": 0, "jitter": 1}                      # the reference's training augmentation (train.py:787-790)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    ids = torch.randint(0, n_blocks, (iters + 5, batch), generator=g).tolist()
+    out = {}
+    for key, cls in (("random_sample", None), ("class_guided", 3)):
+        def one(i):
+            return smp.batch(ids[i], NPTS, sampled_classes=list(range(1, 8)), sampled_class=cls, pc_augm=True, pc_augm_config=cfg, generator=gen)
+        for i in range(5):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5, 5 + iters):
+            one(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[key] = {"ms_per_batch": round(dt * 1e3, 4), "blocks_per_s": round(batch / dt, 1)}
+    return {"dataset": f"{n_blocks} resident blocks of 3 000 - 12 000 points x 7 columns, batches of {batch} x {NPTS} points, z-rotation + jitter",
+            "blocks_per_s": out["random_sample"]["blocks_per_s"], **out,
+            "note": "wall clock of back-to-back batches (host launch cost included); no device -> host read inside a batch"}
+
+
 def extras(dev, L, gdist):
     """The other kernels of the path on their BASELINE shapes, each against its BINDING roof (word cosine,
     get_pred and the Lloyd step are HBM-bound, attention is bound by the fp32 matrix rate)."""
@@ -385,6 +421,8 @@ def extras(dev, L, gdist):
         del pts, cent
         torch.cuda.empty_cache()
         out["c3_end_to_end"] = c3_end_to_end(dev)
+        out["pipeline"] = pipeline_throughput(dev)
+        out["pipeline_blocks_per_s"] = out["pipeline"]["blocks_per_s"]
     q, k_, v = (torch.randn(B, 64, N, generator=g).to(dev).requires_grad_(True) for _ in range(3))
     cot = torch.randn(B, 64, N, generator=g).to(dev)
 
@@ -534,29 +572,83 @@ def dry_run(args, world, rank, local):
             dist.init_process_group(backend, rank=rank, world_size=world)
     if os.environ.get("GFS3D_BENCH_DRY_FAIL_RANK") == str(rank):      # tests: a rank that dies must fail the whole job
         os._exit(3)
-    from model.dgcnn import DGCNN
+    cfg = WORKLOADS[args.workload]
+    sync_bn = bool(args.sync_bn and world > 1)
     torch.manual_seed(0)
-    net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev)
-    bucket = gdist.FlatGradBucket(net.parameters(), early=list(net.conv.parameters()), overlap=False)
+    if cfg["model"] == "dgcnn":
+        from model.dgcnn import DGCNN
+        net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev)
+        early = list(net.conv.parameters())
+    else:                                         # the CAPL model of configs[3] / configs[4], as build_step() makes it
+        import contextlib
+        import io
+        from model.capl import mpti_net_Point_GeoAsWeight_v2
+        gp = torch.randn(cfg["Kw"], 192, generator=torch.Generator().manual_seed(2)).to(dev)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = mpti_net_Point_GeoAsWeight_v2(classes=cfg["classes"], args=capl_args(), base_num=cfg["base"], gp=gp, energy=0.9).to(dev)
+        edge = {id(p) for p in net.encoder.edge_convs.parameters()}
+        early = [p for p in net.parameters() if id(p) not in edge]
+    n_sync = 0
+    if sync_bn:                                   # what `--sync-bn` turns on in build_step(): SyncBatchNorm heads + BNSync on the EdgeConv phases
+        net = gdist.enable_sync_batchnorm(net)
+        n_sync = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
+    bucket = gdist.FlatGradBucket(net.parameters(), early=early, overlap=not sync_bn)
+    encoder = net if cfg["model"] == "dgcnn" else net.encoder
+    ok = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
         bucket.zero()
+        if sync_bn:
+            # the order of one synchronised step: two fp64 phase sums per EdgeConv layer forward, two backward (gfs3d.ops.BNSync:
+            # the all-reduces the phased K2 entry points wait for), all on the bucket's communicator - hence overlap=False above
+            for _ in range(4 * len(encoder.edge_convs)):
+                acc = torch.full((128,), float(rank + 1), dtype=torch.float64, device=dev)
+                encoder.bn_sync.all_reduce(acc)
+                ok = ok and bool((acc == world * (world + 1) / 2.0).all())
+        if cfg["model"] == "capl":
+            # the two data-path collectives of capl.forward under block-sharded DP, through the model's own code: label
+            # presence (MAX) and the fake-novel (feature sum, count) all-reduce of generate_fake_proto (capl.py:364-411)
+            import random
+            g = torch.Generator().manual_seed(100 * it + rank)
+            feat = torch.randn(2, net.main_proto.shape[1], 64, generator=g).to(dev)
+            y = torch.randint(rank % 3, cfg["base"] + 1, (2, 64), generator=g).to(dev)
+            random.seed(0)
+            proto, chosen = net.generate_fake_proto(feat, y, net.main_proto.detach())
+            got = [None] * world
+            if world > 1:
+                dist.all_gather_object(got, (sorted(int(c) for c in chosen), float(proto.double().sum())))
+                ok = ok and all(g_[0] == got[0][0] and abs(g_[1] - got[0][1]) < 1e-4 for g_ in got)
         for p in net.parameters():
             p.grad = torch.full_like(p, float(rank + 1))
         bucket.all_reduce_mean()
+    mine = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     elapsed = gdist.max_over_ranks(time.perf_counter() - t0, dev)
     want = (world + 1) / 2.0
-    ok = world == 1 or bool(torch.allclose(bucket.flat, torch.full_like(bucket.flat, want)))
+    ok = ok and (world == 1 or bool(torch.allclose(bucket.flat, torch.full_like(bucket.flat, want))))
     devices = rank_devices(dev, world)
+    per_rank = rank_values(mine / max(args.steps, 1) * 1e3, world)
     if rank == 0:
         print(json.dumps({"dry": True, "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                          "workload": args.workload, "sync_bn": sync_bn, "sync_batchnorm_layers": n_sync,
                           "devices": devices, "steps": args.steps, "bucket_elems": int(bucket.flat.numel()),
-                          "collectives_ok": ok, "elapsed_s": round(elapsed, 4)}), flush=True)
+                          "bucket_early_elems": int(bucket.n_early), "bucket_overlap": bool(bucket.overlap),
+                          "collectives_ok": ok, "elapsed_s": round(elapsed, 4),
+                          "rank_ms_per_step": {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4)}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
+
+
+def rank_values(value, world):
+    """One float per rank, gathered to all ranks (rank 0 prints min / max: a straggler shows)."""
+    import torch.distributed as dist
+    if world == 1:
+        return [float(value)]
+    got = [None] * world
+    dist.all_gather_object(got, float(value))
+    return got
 
 
 def rank_devices(dev, world):
@@ -630,10 +722,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = rank_values(mine / args.steps * 1e3, world)          # each rank's own K steps, before it waited for the others
     elapsed = gdist.max_over_ranks(elapsed, dev)
     devices = rank_devices(dev, world)
 
@@ -712,7 +806,8 @@ def main():
             "metric": metric, "value": round(world * B / (elapsed / args.steps), 2),
             "unit": "blocks/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "devices": devices,
             "backend": backend if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 4), "rank_ms_per_step": {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4)},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": cfg["text"], "blocks_per_gpu": B, "points": NPTS, "k": KNN,
                        "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and world > 1 else "")},

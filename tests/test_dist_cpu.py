@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -215,6 +216,27 @@ def test_bench_gpus_8_launches_eight_ranks_by_itself():
     ln = lines[0]
     assert ln["n_gpus"] == 8 and ln["rccl_ranks"] == 8 and len(ln["devices"]) == 8 and ln["collectives_ok"]
     assert ln["bucket_elems"] == 261504                    # the DGCNN backbone's parameters
+
+
+@pytest.mark.parametrize("argv,bucket,overlap,sync_layers", [
+    (["--gpus", "8", "--workload", "c4"], 404544, True, 0),
+    (["--gpus", "2", "--workload", "c4", "--sync-bn"], 404544, False, 11),
+    (["--gpus", "2", "--sync-bn"], 261504, False, 8)])
+def test_bench_dry_rehearses_what_a_scaling_run_launches(argv, bucket, overlap, sync_layers):
+    """the launcher with `--workload c4` (the CAPL model's bucket: 404 544 gradients, everything outside the
+    EdgeConv blocks in the early slice; capl.forward's own data-path collectives - label-presence MAX and the fake-novel
+    (sum, count) all-reduce of generate_fake_proto - every rank ending with the same classes and prototypes) and with
+    `--sync-bn` (the BatchNorm phase all-reduces on the bucket's communicator, hence NO overlapped early slice).  Rank 0's line
+    carries every rank's own time per step (min / max): a straggler is visible."""
+    rc, lines, err = _run_bench(argv + ["--dry", "--steps", "2"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    ln = lines[0]
+    n = int(argv[1])
+    assert ln["n_gpus"] == n and ln["rccl_ranks"] == n and ln["collectives_ok"]
+    assert ln["bucket_elems"] == bucket and ln["bucket_overlap"] is overlap and ln["sync_batchnorm_layers"] == sync_layers
+    assert 0 < ln["bucket_early_elems"] < bucket
+    assert 0.0 < ln["rank_ms_per_step"]["min"] <= ln["rank_ms_per_step"]["max"]
 
 
 def test_bench_self_launch_fails_when_a_rank_dies():

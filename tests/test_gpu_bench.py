@@ -44,3 +44,14 @@ def test_bench_two_gloo_ranks_share_the_card():
     d = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", GFS3D_BENCH_BACKEND="gloo")
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["devices"] == ["cuda:0", "cuda:0"] and d["backend"] == "gloo"
     assert d["config"]["parallelism"] == "block-sharded dp2" and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("argv,parallelism", [(["--workload", "c4"], "block-sharded dp2"), (["--sync-bn"], "block-sharded dp2+syncbn"),
+                                              (["--workload", "c4", "--sync-bn"], "block-sharded dp2+syncbn")])
+def test_bench_two_gloo_ranks_run_the_capl_step_and_synchronised_batchnorm(argv, parallelism):
+    """What a scaling run launches besides the default: `--workload c4` (the CAPL step's collectives: label presence,
+    fake-novel sums, the flat bucket) and `--sync-bn` (phase all-reduces inside forward and backward, bucket without overlap),
+    two ranks through the self-launcher with the REAL kernels on the one card (gloo)."""
+    d = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", *argv, GFS3D_BENCH_BACKEND="gloo")
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["config"]["parallelism"] == parallelism
+    assert d["value"] > 0 and 0.0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001

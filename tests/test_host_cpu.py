@@ -67,64 +67,17 @@ def test_args_structs_match_header_field_order_and_size():
 
 
 def test_entry_points_reject_bad_arguments_before_touching_a_device():
-    """Argument validation of the round-2 entry points happens on the host: wrong shapes / NULL pointers come back as an
-    error code with a message (no GPU needed, nothing is launched), and the workspace queries return 0 for unsupported shapes."""
-    import ctypes
-    from gfs3d import _lib
-    L = _lib.lib()
-    arr = (ctypes.c_int * 2)(128, 64)
-    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 1, 256, 2, arr) > 0
-    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 1, 100, 2, arr) == 0          # segment width not a multiple of 64
-    assert L.gfs3d_pointwise_workspace_bytes_ex(2, 256, 5, 64, 2, arr) == 0           # too many segments
-    assert L.gfs3d_linear_workspace_bytes(2, 256, 256, 192) > 0
-    assert L.gfs3d_linear_workspace_bytes(2, 256, 100, 192) == 0 and L.gfs3d_linear_workspace_bytes(2, 256, 256, 320) == 0
-    a = _lib.PackArgs()
-    assert L.gfs3d_pack_rows_f32(None, None) != 0 and b"NULL args" in L.gfs3d_last_error()
-    a.B, a.N, a.n_src = 1, 64, 0
-    assert L.gfs3d_pack_rows_f32(ctypes.byref(a), None) != 0 and b"n_src" in L.gfs3d_last_error()
-    a.n_src, a.dst, a.dst_ld = 1, 1, 16
-    a.src[0], a.width[0] = 1, 64
-    assert L.gfs3d_unpack_rows_f32(ctypes.byref(a), None) != 0 and b"dst_ld" in L.gfs3d_last_error()
-    ptrs = (ctypes.c_void_p * 3)(None, None, None)
-    assert L.gfs3d_linear_forward_f32(None, 1, 64, 256, None, 192, ptrs, 0, None, 0, None) != 0
-    assert L.gfs3d_linear_forward_f32(1, 1, 64, 100, 1, 192, ptrs, 0, 1, 1 << 30, None) != 0 and b"K=100" in L.gfs3d_last_error()
-    assert L.gfs3d_attention_forward_mixed(1, 1, 1, 1, 64, 64, 0.125, 0.0, 0, None, 1, 1, 7, None) != 0 \
-        and b"compute" in L.gfs3d_last_error()
-    assert L.gfs3d_attention_forward_mixed(1, 1, 1, 1, 32, 64, 0.125, 0.0, 0, None, 1, 1, 0, None) != 0 \
-        and b"head dimension" in L.gfs3d_last_error()
-
-
-def test_round3_entry_points_reject_bad_arguments_before_touching_a_device():
-    """The fused prototype head, its testing form, the screened Lloyd step and the label-presence mask validate their arguments on
-    the host (no GPU: nothing is launched) and the workspace query returns 0 for shapes the head is not built for."""
-    import ctypes
+    """Argument validation of the entry points happens on the host: wrong shapes / NULL pointers come back as an error code
+    with a message (no GPU needed, nothing is launched), and the workspace queries return 0 for unsupported shapes.  The
+    calls live in tests/host_cases.py: test_host_sanitizer.py replays them against an AddressSanitizer / UBSan build of the
+    launch code."""
+    import host_cases
     from gfs3d import _lib, ops
     L = _lib.lib()
-    assert L.gfs3d_capl_head_workspace_bytes(32, 2048, 13) > 0 and L.gfs3d_capl_head_workspace_bytes(64, 2048, 21) > 0
-    assert L.gfs3d_capl_head_workspace_bytes(32, 2048, 24) == 0 and L.gfs3d_capl_head_workspace_bytes(0, 2048, 13) == 0
-    assert L.gfs3d_capl_head_forward_phase(None, 0) != 0 and b"args is NULL" in L.gfs3d_last_error()
-    a = _lib.CaplHeadArgs()
-    a.B, a.C, a.N, a.classes, a.base_num = 4, 64, 256, 13, 7
-    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"feature channels" in L.gfs3d_last_error()
-    a.C, a.n_fake = 128, 20
-    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"fake-novel" in L.gfs3d_last_error()
-    a.n_fake, a.half, a.feat_bstride = 2, 2, 128 * 256
-    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"NULL buffer" in L.gfs3d_last_error()
-    for name in ("feat", "label", "main_proto", "bg_proto", "fsum", "workspace", "loss"):
-        setattr(a, name, 1)                             # (non-NULL placeholders: the checks below stop before any use)
-    a.workspace_bytes = 16
-    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 0) != 0 and b"workspace too small" in L.gfs3d_last_error()
-    a.workspace_bytes = 1 << 30
-    a.fake[0], a.fake[1] = 3, 99
-    assert L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 1) != 0 and b"fake-novel label 99" in L.gfs3d_last_error()
-    a.fake[1] = 5
-    assert L.gfs3d_capl_head_forward_phase(ctypes.byref(a), 7) != 0 and b"phase" in L.gfs3d_last_error()
-    assert L.gfs3d_capl_head_backward_phase(ctypes.byref(a), 0) != 0 and b"NULL gradient buffer" in L.gfs3d_last_error()
-    e = _lib.CaplEvalArgs()
-    e.B, e.C, e.N, e.classes, e.base_num, e.Kw = 2, 128, 64, 13, 7, 4000
-    assert L.gfs3d_capl_head_eval(ctypes.byref(e)) != 0 and b"coding" in L.gfs3d_last_error()
-    assert L.gfs3d_label_presence(None, 10, None, None) != 0 and b"bad argument" in L.gfs3d_last_error()
-    assert L.gfs3d_kmeans_assign_fast_f32(1, 100, 64, 1, 40, 1, 1, 1, None, None, 0, None) != 0 and b"workspace" in L.gfs3d_last_error()
+    host_cases.round2_cases(L, _lib)
+    host_cases.round3_cases(L, _lib)
+    host_cases.round5_cases(L, _lib)
+    host_cases.workspace_sweep(L)
     assert not ops.capl_head_supported(torch.zeros(2, 64, 16), 13, 2)       # (CPU tensor / wrong width: the model keeps its tensor-library head)
 
 
