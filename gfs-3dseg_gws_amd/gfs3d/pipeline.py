@@ -91,13 +91,25 @@ def augment_draws_batch(cfg: dict, B: int, num_point: int, device, generator: Op
     return m, jit
 
 
+def label_lookup_table(sampled_classes: Sequence[int], use_all_classes: bool, num_labels: int, device) -> torch.Tensor:
+    """class id -> position in `sampled_classes` (+1 unless use_all_classes: 0 is the background), 0 for every other id
+    (loader.py:105-120), as a device tensor of length max(num_labels, largest class id + 1)."""
+    off = 0 if use_all_classes else 1
+    hi = max([int(num_labels)] + [int(c) + 1 for c in sampled_classes])
+    table = torch.zeros(hi, dtype=torch.long)
+    for i, c in enumerate(sampled_classes):
+        table[int(c)] = i + off
+    return table.to(device, non_blocking=True)
+
+
 def assemble(rows: torch.Tensor, pc_attribs: str = "xyzrgbXYZ", sampled_classes: Sequence[int] = (), sampled_class: int = 0,
              support: bool = False, use_all_classes: bool = False, augm_matrix: Optional[torch.Tensor] = None,
-             jitter: Optional[torch.Tensor] = None, num_labels: Optional[int] = None):
+             jitter: Optional[torch.Tensor] = None, num_labels: Optional[int] = None, label_table: Optional[torch.Tensor] = None):
     """Gathered rows (..., n, 7|8) -> (ptcloud (..., 3A, n) fp32 channel-first as the Dataset classes return it,
     groundtruth (..., n) int64, segment_label (..., n) fp32)   (loader.py:84-129, 200).
     num_labels: an upper bound (exclusive) of the label ids in `rows`, known to the caller (BlockSampler reads it once at
-    construction); without it the label table is sized from `labels.max()`, a device -> host read."""
+    construction); without it the label table is sized from `labels.max()`, a device -> host read.  label_table: the
+    class id -> ground-truth id table already on the device (`label_lookup_table`; BlockSampler keeps one per class list)."""
     xyz = rows[..., 0:3]
     xyz = xyz - xyz.amin(dim=-2, keepdim=True)
     if augm_matrix is not None:
@@ -119,13 +131,10 @@ def assemble(rows: torch.Tensor, pc_attribs: str = "xyzrgbXYZ", sampled_classes:
         gt = (labels == sampled_class).long()
     else:
         # table lookup instead of the per-point Python loop (loader.py:108-112): class id -> position (+1: 0 = background)
-        off = 0 if use_all_classes else 1
-        top = int(labels.max()) + 1 if num_labels is None else int(num_labels)
-        hi = max([top] + [int(c) + 1 for c in sampled_classes])
-        table = torch.zeros(hi, dtype=torch.long)
-        for i, c in enumerate(sampled_classes):
-            table[int(c)] = i + off
-        gt = table.to(rows.device)[labels]
+        if label_table is None:
+            top = int(labels.max()) + 1 if num_labels is None else int(num_labels)
+            label_table = label_lookup_table(sampled_classes, use_all_classes, top, rows.device)
+        gt = label_table[labels]
     seg = rows[..., 7].float() if rows.shape[-1] == 8 else torch.zeros(rows.shape[:-1], dtype=torch.float32, device=rows.device)
     return pc, gt, seg
 
@@ -150,6 +159,7 @@ class BlockSampler:
         self.data = torch.cat([b.to(self.device) for b in blocks], dim=0).contiguous()
         self.blocks = [self.data[o:o + m] for o, m in zip(self.offsets[:-1], self.sizes)]      # views of the table
         self.num_labels = int(self.data[:, 6].max()) + 1                                         # the one read, at construction
+        self._tables = {}
 
     def sample_batch_indices(self, block_ids: Sequence[int], num_point: int, sampled_class: Optional[int] = None,
                              generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -197,5 +207,8 @@ class BlockSampler:
         m = jit = None
         if pc_augm:
             m, jit = augment_draws_batch(pc_augm_config, len(block_ids), num_point, self.device, generator)
+        key = (tuple(int(c) for c in sampled_classes), bool(use_all_classes))
+        if key not in self._tables:
+            self._tables[key] = label_lookup_table(sampled_classes, use_all_classes, self.num_labels, self.device)
         return assemble(rows, pc_attribs, sampled_classes, 0 if sampled_class is None else sampled_class, support,
-                        use_all_classes, m, jit, num_labels=self.num_labels)
+                        use_all_classes, m, jit, num_labels=self.num_labels, label_table=self._tables[key])
