@@ -649,13 +649,22 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    const float *__restrict__ w2, const float *__restrict__ gamma2,
                    int BN, int N, int k, float slope,
                    float *__restrict__ hsel, uint8_t *__restrict__ jsel,
-                   const BnAcc partial)
+                   const BnAcc partial,
+                   const BnFin fin1, float *__restrict__ stats, float *__restrict__ Pp_out, float *__restrict__ Qp_out)
 {
+    // FOLD (training form, Pp_out != NULL): `Pp` / `Qp` are the RAW projections P, Q and BatchNorm1 is applied here -
+    //   Q'[n] = scale1 Q[n] + shift1 once per point, z = fma(scale1, P[m], Q'[n]) per edge (the fma replaces the add: no extra
+    //   vector instruction per edge, 32 more registers for this lane's scales) - and the folded rows P'[n], Q'[n] of the
+    //   super-tile's own 8 points are stored for the backward.  What ec_prescale_kernel did in a 92 MB pass of its own now rides
+    //   inside a kernel the matrix pipe bounds; the fp64 finalisation of the batch statistics happens in this prologue.
+    constexpr bool FOLD = STATS;
     constexpr int WROW = 3 * 2 * EC + 16;               // bytes per W2 row image
     __shared__ __attribute__((aligned(16))) unsigned char sW3[EC * WROW];
     __shared__ double red[4][2][2][EC];                 // [wave][half][s|ss][64]
+    __shared__ __attribute__((aligned(16))) float sc1[EC], sh1[EC];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
+    if (FOLD && Pp_out && tid < EC) bn_constants(fin1, tid, blockIdx.x == 0, stats, (int)ST_MEAN1, sc1[tid], sh1[tid]);
     // max_j LReLU(BN2(h_j)) is reached at max_j h_j where scale2 >= 0 and at min_j h_j elsewhere, and sign(scale2) =
     // sign(gamma2) whatever the batch statistics turn out to be: the rows of W2 with a negative gamma go into the image
     // NEGATED, the kernel tracks one maximum (of +-h, exactly the negation) and undoes the sign where it stores.
@@ -670,6 +679,12 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     const unsigned char *wrow0 = sW3 + i * WROW + 64 * h;            // + piece * 128 + kb * 16
     const unsigned char *wrow1 = sW3 + (32 + i) * WROW + 64 * h;
     const float sg0 = gamma2[i] < 0.f ? -1.f : 1.f, sg1 = gamma2[32 + i] < 0.f ? -1.f : 1.f;      // C/D layout: lane = channel
+    const bool fold = FOLD && Pp_out != nullptr;          // (kernel-uniform)
+    float sA[FOLD ? 32 : 1];                              // scale1 of this lane's 32 channels (fold only)
+    if constexpr (FOLD) {                                 // (sc1 / sh1 were written before the barrier that closes the W2 staging)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sA[c] = fold ? sc1[32 * h + c] : 1.f;
+    }
 
     const int nst = (BN + 7) >> 3;
     const UnitDeal deal(nst, N >> 3, BN / N, (N & 7) == 0, 4, wv);
@@ -687,6 +702,35 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             for (int v = 0; v < 8; ++v) {
                 const float4 t4 = q4[v];
                 qA[4 * v + 0] = t4.x; qA[4 * v + 1] = t4.y; qA[4 * v + 2] = t4.z; qA[4 * v + 3] = t4.w;
+            }
+        }
+        if constexpr (FOLD) {
+            if (fold) {
+                // Q' of this lane's point, kept in registers and (one lane of the four that hold the same half row) stored for
+                // the backward; another of the four folds and stores the point's own P half row
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(sh1 + 32 * h + 4 * v);
+                    qA[4 * v + 0] = fmaf(qA[4 * v + 0], sA[4 * v + 0], t4.x);
+                    qA[4 * v + 1] = fmaf(qA[4 * v + 1], sA[4 * v + 1], t4.y);
+                    qA[4 * v + 2] = fmaf(qA[4 * v + 2], sA[4 * v + 2], t4.z);
+                    qA[4 * v + 3] = fmaf(qA[4 * v + 3], sA[4 * v + 3], t4.w);
+                }
+                if (n0 + pA < BN) {
+                    if (jjA == 0) {
+                        float4 *qo = reinterpret_cast<float4 *>(Qp_out + (size_t)ptA * EC + 32 * h);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) qo[v] = make_float4(qA[4 * v + 0], qA[4 * v + 1], qA[4 * v + 2], qA[4 * v + 3]);
+                    } else if (jjA == 1) {
+                        const float4 *pi = reinterpret_cast<const float4 *>(Pp + (size_t)ptA * EC + 32 * h);
+                        float4 *po = reinterpret_cast<float4 *>(Pp_out + (size_t)ptA * EC + 32 * h);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            const float4 t4 = pi[v];
+                            po[v] = make_float4(t4.x * sA[4 * v + 0], t4.y * sA[4 * v + 1], t4.z * sA[4 * v + 2], t4.w * sA[4 * v + 3]);
+                        }
+                    }
+                }
             }
         }
         float mx0[4], mx1[4];
@@ -720,7 +764,17 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                 {
                     const float4 x0 = pf[2 * kb], x1 = pf[2 * kb + 1];
                     float z;
-                    z = x0.x + qA[8 * kb + 0]; av[0] = fmaxf(z, z * slope);          // LeakyReLU, 0 < slope < 1
+                    if constexpr (FOLD) {                                            // (scale 1 when the rows come in folded)
+                        z = fmaf(sA[8 * kb + 0], x0.x, qA[8 * kb + 0]); av[0] = fmaxf(z, z * slope);          // LeakyReLU, 0 < slope < 1
+                        z = fmaf(sA[8 * kb + 1], x0.y, qA[8 * kb + 1]); av[1] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 2], x0.z, qA[8 * kb + 2]); av[2] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 3], x0.w, qA[8 * kb + 3]); av[3] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 4], x1.x, qA[8 * kb + 4]); av[4] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 5], x1.y, qA[8 * kb + 5]); av[5] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 6], x1.z, qA[8 * kb + 6]); av[6] = fmaxf(z, z * slope);
+                        z = fmaf(sA[8 * kb + 7], x1.w, qA[8 * kb + 7]); av[7] = fmaxf(z, z * slope);
+                    } else {
+                    z = x0.x + qA[8 * kb + 0]; av[0] = fmaxf(z, z * slope);
                     z = x0.y + qA[8 * kb + 1]; av[1] = fmaxf(z, z * slope);
                     z = x0.z + qA[8 * kb + 2]; av[2] = fmaxf(z, z * slope);
                     z = x0.w + qA[8 * kb + 3]; av[3] = fmaxf(z, z * slope);
@@ -728,6 +782,7 @@ ec_main_fwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                     z = x1.y + qA[8 * kb + 5]; av[5] = fmaxf(z, z * slope);
                     z = x1.z + qA[8 * kb + 6]; av[6] = fmaxf(z, z * slope);
                     z = x1.w + qA[8 * kb + 7]; av[7] = fmaxf(z, z * slope);
+                    }
                 }
                 pf[2 * kb] = p4n[2 * kb];
                 pf[2 * kb + 1] = p4n[2 * kb + 1];
@@ -2365,8 +2420,10 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
     const double count = stat_count > 0.0 ? stat_count : (double)BN * a->k;
-    float *hmax = reinterpret_cast<float *>(ws + p.off_hmax);          // winning pre-BN2 value / neighbour slot per (point, channel)
-    uint8_t *jmax = reinterpret_cast<uint8_t *>(ws + p.off_jmax);
+    // winning pre-BN2 value / neighbour slot per (point, channel): training writes them where the backward reads them (the
+    // epilogue used to copy them there: 21 MB of stores per layer)
+    float *hmax = a->training ? a->hsel : reinterpret_cast<float *>(ws + p.off_hmax);
+    uint8_t *jmax = a->training ? a->jsel : reinterpret_cast<uint8_t *>(ws + p.off_jmax);
     double *acc = acc_user ? acc_user : reinterpret_cast<double *>(ws + p.off_acc);
     double *acc1 = acc, *acc2 = acc + 2 * EC;
     double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_part) : nullptr;      // ordered BN reductions
@@ -2422,16 +2479,23 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     } else if (phase == 1) {
         const BnFin fin1{acc1, count, a->bn1_w, a->bn1_b, a->bn1_rm, a->bn1_rv, a->eps, a->momentum, a->training};
         const size_t total = (size_t)BN * EC;
-        if (!fold) {
+        // training: BatchNorm1 is folded into the projections INSIDE the heavy kernel (it reads the raw P / Q, finalises the
+        // batch statistics in its prologue and leaves P' / Q' behind for the backward); GFS3D_EC_PRESCALE=1 keeps the separate
+        // pass of rounds 1-4 (A-B only)
+        static const int prescale_env = [] { const char *e = getenv("GFS3D_EC_PRESCALE"); return e ? atoi(e) : 0; }();
+        const bool in_kernel = !fold && !prescale_env;
+        if (!fold && !in_kernel) {
             hipLaunchKernelGGL(ec_prescale_kernel, dim3((unsigned)min((size_t)2048, (total / 4 + 255) / 256)), dim3(256), 0, st, a->P, a->Q, fin1, a->stats, total, Pp, Qp);
             GFS3D_LAUNCH_CHECK("ec_prescale_kernel");
         }
         ProfScope prof(1, st);
         const dim3 g_fwd(min(p.g_mfma + p.g_mfma / 2, (BN + 31) / 32));       // eval: 3 resident workgroups per CU
         const int prec = prec_of(a->compute, false);
+        const float *Pin = in_kernel ? a->P : Pp, *Qin = in_kernel ? a->Q : Qp;
+        float *Pout = in_kernel ? Pp : nullptr, *Qout = in_kernel ? Qp : nullptr;
 #define GFS3D_FWD_LAUNCH(STATS_, PREC_, GRID_)                                                                                \
-        hipLaunchKernelGGL((ec_main_fwd_kernel<STATS_, PREC_>), GRID_, dim3(256), 0, st, Pp, Qp, a->idx, a->w2, a->bn2_w,     \
-                           BN, a->N, a->k, a->slope, hmax, jmax, BnAcc{acc2, rows})
+        hipLaunchKernelGGL((ec_main_fwd_kernel<STATS_, PREC_>), GRID_, dim3(256), 0, st, Pin, Qin, a->idx, a->w2, a->bn2_w,   \
+                           BN, a->N, a->k, a->slope, hmax, jmax, BnAcc{acc2, rows}, fin1, a->stats, Pout, Qout)
         if (a->training) {
             if (prec == PREC_BF16) GFS3D_FWD_LAUNCH(true, PREC_BF16, dim3(p.g_mfma));
             else if (prec == PREC_F16) GFS3D_FWD_LAUNCH(true, PREC_F16, dim3(p.g_mfma));
@@ -2448,7 +2512,8 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     } else {
         const BnFin fin2{acc2, count, a->bn2_w, a->bn2_b, a->bn2_rm, a->bn2_rv, a->eps, a->momentum, a->training};
         hipLaunchKernelGGL(ec_epilogue_kernel, tgrid, dim3(256), 0, st, hmax, jmax, fin2, a->stats, a->N, a->slope,
-                           a->y_cf, a->y_cf_bstride, a->y_pm, a->hsel, a->jsel, a->y_sqnorm, static_cast<unsigned *>(a->y_knn_img), a->B);
+                           a->y_cf, a->y_cf_bstride, a->y_pm, a->training ? nullptr : a->hsel, a->training ? nullptr : a->jsel, a->y_sqnorm,
+                           static_cast<unsigned *>(a->y_knn_img), a->B);
         GFS3D_LAUNCH_CHECK("ec_epilogue_kernel");
         if (a->training)
             if (int rc = side_join(st, who)) return rc;
