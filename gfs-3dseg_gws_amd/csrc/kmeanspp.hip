@@ -24,12 +24,26 @@ constexpr float KPP_PRUNE_MARGIN = 1.0f + 1e-3f;       // skip only when the bou
 
 typedef float kf4 __attribute__((ext_vector_type(4)));
 
+// sum over the 16 lanes of a DPP row, every lane receiving it: the xor butterfly 1, 2, 4, 8 as four v_add_f32 with DPP operands
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror).  Bit for bit the butterfly's value (after each step all
+// lanes of the exchanged groups hold the same partial, and a + b == b + a), without the LDS crossbar: __shfl_xor compiles to
+// ds_bpermute_b32, and four DEPENDENT ones per candidate row made kpp_gain_kernel run at the LDS pipe's latency (491 us per pass).
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+
 // 16 lanes per row (float4 each per piece), 4 rows per wave step; the 64 rows of a wave chunk are filtered first and only the
 // rows that can move are visited.
 template <int C4MAX>       // float4 pieces of a row handled per lane: ceil(C / 64)
 __global__ void __launch_bounds__(256)
 kpp_update_kernel(const float *__restrict__ pts, long long M, int C, const float *__restrict__ centers, int t,
-                  const float *__restrict__ cc, int prune, float *__restrict__ d2, int *__restrict__ nearest, double *__restrict__ bsum)
+                  const float *__restrict__ cc, int prune, float *__restrict__ d2, int *__restrict__ nearest, double *__restrict__ bsum,
+                  const unsigned char *__restrict__ cmask, const int *__restrict__ cbest)
 {
     __shared__ double wsum[4];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -55,7 +69,8 @@ kpp_update_kernel(const float *__restrict__ pts, long long M, int C, const float
             myd = d2[mine];
             mya = nearest[mine];
             // |p - c_t| >= |c_t - c_a| - |p - c_a| >= 2 r - r = r when |c_t - c_a|^2 >= 4 r^2
-            if (prune && cc[mya] >= 4.f * myd * KPP_PRUNE_MARGIN) need = false;
+            if (cmask) need = (cmask[mine] >> *cbest) & 1;         // greedy form: the gain pass already knows which rows move
+            else if (prune && cc[mya] >= 4.f * myd * KPP_PRUNE_MARGIN) need = false;
         }
         unsigned long long mask = __ballot(need);
         float newd = 0.f;
@@ -85,10 +100,7 @@ kpp_update_kernel(const float *__restrict__ pts, long long M, int C, const float
                     s_ = fmaf(d.w, d.w, s_);
                 }
             }
-            s_ += __shfl_xor(s_, 1, 64);
-            s_ += __shfl_xor(s_, 2, 64);
-            s_ += __shfl_xor(s_, 4, 64);
-            s_ += __shfl_xor(s_, 8, 64);
+            s_ = row16_sum(s_);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float dg = __shfl(s_, 16 * g, 64);
@@ -257,11 +269,12 @@ kpp_pick_kernel(const float *__restrict__ pts, long long M, int C, int t_new, lo
 //                      min_j |x_cand_j - c_a|^2 >= 4 d2[i] cannot gain from any candidate: its row is not read.
 //   kpp_choose_kernel  block gains added in block order -> the first candidate with the largest gain (numpy's argmin of the
 //                      potentials); its row, index and centre distances become centre t.
-//   kpp_update_kernel  (above) then folds the new centre into d2 / nearest / block sums.
+//   kpp_update_kernel  (above) then folds the new centre into d2 / nearest / block sums, reading ONLY the rows the winner moves:
+//                      the gain pass leaves one byte per point (bit j = candidate j comes closer than the nearest centre).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int KPP_TMAX = 8;
 
-template <int CS>           // channels per lane in the centre-distance loop: ceil(C / 64)
+template <int CS>           // 16-byte pieces per lane of a 16-lane group in the centre-distance loop: ceil(C / 64)
 __global__ void __launch_bounds__(KPP_PICK_THREADS)
 kpp_cand_kernel(const float *__restrict__ pts, long long M, int C, int K, int t_new, int T, const double *__restrict__ u,
                 const float *__restrict__ d2, const double *__restrict__ bsum, int nblk, const float *__restrict__ centers,
@@ -269,10 +282,11 @@ kpp_cand_kernel(const float *__restrict__ pts, long long M, int C, int K, int t_
 {
     __shared__ double buf[KPP_PICK_THREADS];
     __shared__ long long s_cand[KPP_TMAX];
-    __shared__ int s_blk, s_win, s_last;
-    __shared__ double s_before, s_target;
+    __shared__ int s_win[KPP_TMAX], s_blk[KPP_TMAX];
+    __shared__ double s_before[KPP_TMAX];
     const int tid = threadIdx.x;
-    // level 1 once: thread j owns `per` consecutive blocks
+    // level 1, all T variates at once: thread i owns `per` consecutive blocks; the first thread whose inclusive mass reaches a
+    // target walks its blocks for it
     const int per = (nblk + KPP_PICK_THREADS - 1) / KPP_PICK_THREADS;
     double mine = 0.0;
     for (int e = 0; e < per; ++e) {
@@ -281,94 +295,124 @@ kpp_cand_kernel(const float *__restrict__ pts, long long M, int C, int K, int t_
     }
     double total;
     const double incl = block_scan_incl(mine, buf, tid, KPP_PICK_THREADS, total);
+    if (tid < KPP_TMAX) { s_win[tid] = KPP_PICK_THREADS; s_blk[tid] = -1; s_before[tid] = 0.0; }
+    __syncthreads();
     for (int j = 0; j < T; ++j) {
         const double target = u[j] * total;
-        __syncthreads();
-        if (tid == 0) { s_blk = -1; s_target = target; s_win = KPP_PICK_THREADS; }
-        __syncthreads();
-        if (target > 0.0 && incl >= target) atomicMin(&s_win, tid);           // first range whose inclusive mass reaches the target
-        __syncthreads();
-        if (tid == s_win) {
-            double run = incl - mine;
-            int pickb = -1;
+        if (target > 0.0 && incl >= target) atomicMin(&s_win[j], tid);
+    }
+    __syncthreads();
+    for (int j = 0; j < T; ++j) {
+        if (tid != s_win[j]) continue;
+        const double target = u[j] * total;
+        double run = incl - mine;
+        int pickb = -1;
+        for (int e = 0; e < per; ++e) {
+            const int b = tid * per + e;
+            if (b >= nblk) break;
+            const double nxt = run + bsum[b];
+            if (nxt >= target) { pickb = b; break; }
+            run = nxt;
+        }
+        if (pickb < 0) {                                        // rounding at the range's end: its last block with mass
+            run = incl - mine;
             for (int e = 0; e < per; ++e) {
                 const int b = tid * per + e;
                 if (b >= nblk) break;
-                const double nxt = run + bsum[b];
-                if (nxt >= target) { pickb = b; break; }
-                run = nxt;
+                if (bsum[b] > 0.0) { pickb = b; s_before[j] = run; }
+                run += bsum[b];
             }
-            if (pickb < 0) {                                        // rounding at the range's end: its last block with mass
-                run = incl - mine;
-                for (int e = 0; e < per; ++e) {
-                    const int b = tid * per + e;
-                    if (b >= nblk) break;
-                    if (bsum[b] > 0.0) { pickb = b; s_before = run; }
-                    run += bsum[b];
-                }
-            } else {
-                s_before = run;
-            }
-            s_blk = pickb;
-        }
-        __syncthreads();
-        if (s_blk < 0) {
-            // target <= 0 (u == 0 or no mass left: every point coincides with a centre): searchsorted(cs, 0) = 0, as sklearn
-            if (tid == 0) s_cand[j] = 0;
         } else {
-            const long long i = (long long)s_blk * KPP_BLOCK + tid;
-            const double v = i < M ? (double)d2[i] : 0.0;
-            double btot;
-            const double in2 = s_before + block_scan_incl(v, buf, tid, KPP_PICK_THREADS, btot);
-            if (tid == 0) { s_win = KPP_PICK_THREADS; s_last = -1; }
-            __syncthreads();
-            if (v > 0.0 && in2 >= s_target) atomicMin(&s_win, tid);
-            if (v > 0.0) atomicMax(&s_last, tid);
-            __syncthreads();
-            // (no match: rounding between the two levels put the target past the block's end - its last point with mass)
-            if (tid == 0) s_cand[j] = (long long)s_blk * KPP_BLOCK + (s_win < KPP_PICK_THREADS ? s_win : (s_last < 0 ? 0 : s_last));
+            s_before[j] = run;
+        }
+        s_blk[j] = pickb;
+    }
+    __syncthreads();
+    // level 2: wave j searches its block's 1024 values - lane l owns values 16 l .. 16 l + 15 (a running sum), the lane totals are
+    // scanned across the wave, the first lane holding a crossing names the point
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        if (wv < T) {
+            const int jq = wv;
+            if (s_blk[jq] < 0) {
+                // target <= 0 (u == 0 or no mass left: every point coincides with a centre): searchsorted(cs, 0) = 0, as sklearn
+                if (lane == 0) s_cand[jq] = 0;
+            } else {
+                const double target = u[jq] * total;
+                const long long i0 = (long long)s_blk[jq] * KPP_BLOCK + 16 * lane;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = (i0 + e < M) ? d2[i0 + e] : 0.f;
+                double tot = 0.0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tot += (double)v[e];
+                double inc = tot;                                   // inclusive scan of the lane totals
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double up = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += up;
+                }
+                double run = s_before[jq] + (inc - tot);
+                int hit = -1, lastmass = -1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    run += (double)v[e];
+                    if (v[e] > 0.f) {
+                        lastmass = 16 * lane + e;
+                        if (hit < 0 && run >= target) hit = 16 * lane + e;
+                    }
+                }
+                const unsigned long long any = __ballot(hit >= 0);
+                int pos;
+                if (any) pos = __shfl(hit, (int)__builtin_ctzll(any), 64);
+                else pos = max(wave_max(lastmass), 0);              // rounding put the target past the block's end: its last point with mass
+                if (lane == 0) s_cand[jq] = (long long)s_blk[jq] * KPP_BLOCK + pos;
+            }
         }
     }
     __syncthreads();
     if (tid < T) cand[tid] = s_cand[tid];
     for (int e = tid; e < T * C; e += KPP_PICK_THREADS) {
-        const int j = e / C, c = e - j * C;
-        candrows[e] = pts[(size_t)s_cand[j] * C + c];
+        const int jj = e / C, c = e - jj * C;
+        candrows[e] = pts[(size_t)s_cand[jj] * C + c];
     }
-    // |x_cand_j - c_a|^2 for every earlier centre a: a wave per centre, the T candidate rows in registers
-    const int lane = tid & 63, wv = tid >> 6;
-    float cr[KPP_TMAX][CS];
-#pragma unroll
-    for (int j = 0; j < KPP_TMAX; ++j) {
-#pragma unroll
-        for (int s = 0; s < CS; ++s) {
-            const int c = lane + 64 * s;
-            cr[j][s] = (j < T && c < C) ? pts[(size_t)s_cand[j < T ? j : 0] * C + c] : 0.f;
-        }
-    }
-    for (int a = wv; a < t_new; a += KPP_PICK_THREADS / 64) {
-        float ar[CS];
-#pragma unroll
-        for (int s = 0; s < CS; ++s) {
-            const int c = lane + 64 * s;
-            ar[s] = c < C ? centers[(size_t)a * C + c] : 0.f;
-        }
-        float mn = 3.0e38f;
-#pragma unroll
-        for (int j = 0; j < KPP_TMAX; ++j) {
+    // |x_cand_j - c_a|^2 for every (candidate j, earlier centre a) pair: a 16-lane group per pair (64 pairs per step of the
+    // workgroup), 16-byte pieces q + 16 s of both rows, one 4-step shuffle tree; then min_j per centre
+    __shared__ float s_cct[KPP_TMAX][256];
+    __syncthreads();                                     // (s_cand is complete; the rows themselves are read from `pts`)
+    {
+        const int lane = tid & 63, q = lane & 15;
+        const int gidx = tid >> 4, ngrp = KPP_PICK_THREADS / 16;
+        const int c4n = C >> 2;
+        const int npair = T * t_new;
+        for (int pr = gidx; pr < ((npair + ngrp - 1) / ngrp) * ngrp; pr += ngrp) {
+            const bool live = pr < npair;
+            const int jj = live ? pr / t_new : 0, a = live ? pr - jj * t_new : 0;
+            const float *xr = pts + (size_t)s_cand[jj] * C, *ar = centers + (size_t)a * C;
             float s_ = 0.f;
 #pragma unroll
-            for (int s = 0; s < CS; ++s) {
-                const float d = ar[s] - cr[j][s];
-                s_ = fmaf(d, d, s_);
+            for (int sgm = 0; sgm < CS; ++sgm) {
+                const int pc = q + 16 * sgm;
+                if (pc < c4n) {
+                    const kf4 d = *reinterpret_cast<const kf4 *>(ar + 4 * pc) - *reinterpret_cast<const kf4 *>(xr + 4 * pc);
+                    s_ = fmaf(d.x, d.x, s_);
+                    s_ = fmaf(d.y, d.y, s_);
+                    s_ = fmaf(d.z, d.z, s_);
+                    s_ = fmaf(d.w, d.w, s_);
+                }
             }
-            s_ = wave_sum(s_);
-            if (j < T) {
-                if (lane == 0) cct[j * K + a] = s_;
-                mn = fminf(mn, s_);
+            s_ = row16_sum(s_);
+            if (live && q == 0) {
+                cct[jj * K + a] = s_;
+                if (a < 256) s_cct[jj][a] = s_;
             }
         }
-        if (lane == 0) ccmin[a] = mn;
+    }
+    __syncthreads();
+    for (int a = tid; a < t_new; a += KPP_PICK_THREADS) {
+        float mn = 3.0e38f;
+        for (int jj = 0; jj < T; ++jj) mn = fminf(mn, a < 256 ? s_cct[jj][a] : cct[jj * K + a]);
+        ccmin[a] = mn;
     }
 }
 
@@ -376,21 +420,20 @@ template <int C4MAX>
 __global__ void __launch_bounds__(256)
 kpp_gain_kernel(const float *__restrict__ pts, long long M, int C, int T, const float *__restrict__ candrows,
                 const float *__restrict__ ccmin, int prune, const float *__restrict__ d2, const int *__restrict__ nearest,
-                double *__restrict__ gsum)
+                double *__restrict__ gsum, unsigned char *__restrict__ cmask)
 {
     __shared__ double wsum[4][KPP_TMAX];
+    // the candidate rows are staged through LDS once; the compiler keeps this lane's pieces of them in registers across the trips
+    // (measured: re-reading them from LDS every trip - 7 waves per SIMD instead of 3 - made the pass LDS-bound: 367 -> 605 us)
+    __shared__ kf4 scand[KPP_TMAX][C4MAX * 16];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane & 15, grp = lane >> 4;
     const int c4n = C >> 2;
-    kf4 cen[KPP_TMAX][C4MAX];
-#pragma unroll
-    for (int j = 0; j < KPP_TMAX; ++j) {
-#pragma unroll
-        for (int s = 0; s < C4MAX; ++s) {
-            const int pc = q + 16 * s;
-            cen[j][s] = (j < T && pc < c4n) ? *reinterpret_cast<const kf4 *>(candrows + (size_t)j * C + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int e = threadIdx.x; e < KPP_TMAX * C4MAX * 16; e += 256) {
+        const int j = e / (C4MAX * 16), pc = e - j * (C4MAX * 16);
+        scand[j][pc] = (j < T && pc < c4n) ? *reinterpret_cast<const kf4 *>(candrows + (size_t)j * C + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
     }
+    __syncthreads();
     double acc[KPP_TMAX];
 #pragma unroll
     for (int j = 0; j < KPP_TMAX; ++j) acc[j] = 0.0;
@@ -409,45 +452,65 @@ kpp_gain_kernel(const float *__restrict__ pts, long long M, int C, int T, const 
             if (need && prune && ccmin[nearest[mine]] >= 4.f * myd * KPP_PRUNE_MARGIN) need = false;
         }
         unsigned long long mask = __ballot(need);
-        while (mask) {                                             // wave-uniform: up to 4 rows per trip, 16 lanes per row
-            int b[4];
+        unsigned mymask = 0u;                                      // this lane's row: bit j = candidate j comes closer than d2
+        // wave-uniform trips of up to 4 rows (16 lanes per row); the rows of trip n + 1 are requested before trip n is computed
+        int b[4], bn[4];
+        kf4 v[C4MAX], vn[C4MAX];
+        auto take = [&](int (&bb)[4]) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                b[g] = mask ? (int)__builtin_ctzll(mask) : -1;
+                bb[g] = mask ? (int)__builtin_ctzll(mask) : -1;
                 mask &= mask - 1;
             }
+        };
+        auto fetch = [&](const int (&bb)[4], kf4 (&vv)[C4MAX]) {
+            const int r = grp == 0 ? bb[0] : grp == 1 ? bb[1] : grp == 2 ? bb[2] : bb[3];
+            const float *row = pts + (size_t)(row0 + max(r, 0)) * C;
+#pragma unroll
+            for (int s = 0; s < C4MAX; ++s) {
+                const int pc = q + 16 * s;
+                vv[s] = (r >= 0 && pc < c4n) ? *reinterpret_cast<const kf4 *>(row + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        bool more = mask != 0;
+        if (more) { take(b); fetch(b, v); }
+        while (more) {
+            const bool next = mask != 0;
+            if (next) { take(bn); fetch(bn, vn); }
             const int r = grp == 0 ? b[0] : grp == 1 ? b[1] : grp == 2 ? b[2] : b[3];
             const float rd = __shfl(myd, r < 0 ? 0 : r, 64);      // the row's current d2
-            kf4 v[C4MAX];
-            if (r >= 0) {
-                const float *row = pts + (size_t)(row0 + r) * C;
-#pragma unroll
-                for (int s = 0; s < C4MAX; ++s) {
-                    const int pc = q + 16 * s;
-                    v[s] = pc < c4n ? *reinterpret_cast<const kf4 *>(row + 4 * pc) : kf4{0.f, 0.f, 0.f, 0.f};
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < C4MAX; ++s) v[s] = kf4{0.f, 0.f, 0.f, 0.f};
-            }
+            unsigned gm = 0u;
 #pragma unroll
             for (int j = 0; j < KPP_TMAX; ++j) {
                 float s_ = 0.f;
 #pragma unroll
                 for (int s = 0; s < C4MAX; ++s) {
-                    const kf4 d = v[s] - cen[j][s];
+                    const kf4 d = v[s] - scand[j][q + 16 * s];
                     s_ = fmaf(d.x, d.x, s_);
                     s_ = fmaf(d.y, d.y, s_);
                     s_ = fmaf(d.z, d.z, s_);
                     s_ = fmaf(d.w, d.w, s_);
                 }
-                s_ += __shfl_xor(s_, 1, 64);
-                s_ += __shfl_xor(s_, 2, 64);
-                s_ += __shfl_xor(s_, 4, 64);
-                s_ += __shfl_xor(s_, 8, 64);
-                if (q == 0 && r >= 0 && j < T && s_ < rd) acc[j] += (double)(rd - s_);
+                s_ = row16_sum(s_);
+                if (r >= 0 && j < T && s_ < rd) {
+                    if (q == 0) acc[j] += (double)(rd - s_);
+                    gm |= 1u << j;
+                }
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                          // the row's candidate bits go to the lane that owns the row
+                const unsigned mg = (unsigned)__shfl((int)gm, 16 * g, 64);
+                if (lane == b[g]) mymask = mg;
+            }
+            more = next;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[g] = bn[g];
+#pragma unroll
+            for (int s = 0; s < C4MAX; ++s) v[s] = vn[s];
         }
+        // which candidates MOVE this point: the winner's update then reads only the rows that change (one byte per point
+        // written here instead of a second full pass over the 4 C M bytes of points)
+        if (have) cmask[mine] = (unsigned char)mymask;
     }
 #pragma unroll
     for (int j = 0; j < KPP_TMAX; ++j) {
@@ -462,7 +525,7 @@ kpp_gain_kernel(const float *__restrict__ pts, long long M, int C, int T, const 
 __global__ void __launch_bounds__(256)
 kpp_choose_kernel(int C, int K, int t_new, int T, const double *__restrict__ gsum, int nblk, const long long *__restrict__ cand,
                   const float *__restrict__ candrows, const float *__restrict__ cct, float *__restrict__ centers,
-                  long long *__restrict__ picks, float *__restrict__ cc)
+                  long long *__restrict__ picks, float *__restrict__ cc, int *__restrict__ best_out)
 {
     __shared__ double part[256][KPP_TMAX + 1];
     __shared__ int s_best;
@@ -494,6 +557,7 @@ kpp_choose_kernel(int C, int K, int t_new, int T, const double *__restrict__ gsu
             if (part[0][j] > part[0][best]) best = j;            // the first of equal potentials, as numpy's argmin
         s_best = best;
         picks[t_new] = cand[best];
+        *best_out = best;
     }
     __syncthreads();
     const int best = s_best;
@@ -540,7 +604,8 @@ extern "C" int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int
         GFS3D_LAUNCH_CHECK("kpp_pick_kernel");
         if (t == K - 1) break;
 #define KPP_LAUNCH(N_)                                                                                                          \
-    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t, cc, prune, d2, nearest, bsum)
+    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t, cc, prune, d2, nearest, bsum, \
+                       (const unsigned char *)nullptr, (const int *)nullptr)
         if (c4 <= 1) KPP_LAUNCH(1);
         else if (c4 <= 2) KPP_LAUNCH(2);
         else if (c4 <= 3) KPP_LAUNCH(3);
@@ -560,7 +625,8 @@ extern "C" size_t gfs3d_kmeanspp_greedy_workspace_bytes(long long M, int C, int 
     const size_t nblk = (size_t)((M + KPP_BLOCK - 1) / KPP_BLOCK);
     return gfs3d_kmeanspp_workspace_bytes(M, K) + align_up(sizeof(long long) * KPP_TMAX, 256) +
            align_up(sizeof(float) * (size_t)KPP_TMAX * C, 256) + align_up(sizeof(float) * (size_t)KPP_TMAX * K, 256) +
-           align_up(sizeof(float) * (size_t)K, 256) + align_up(sizeof(double) * nblk * KPP_TMAX, 256);
+           align_up(sizeof(float) * (size_t)K, 256) + align_up(sizeof(double) * nblk * KPP_TMAX, 256) + 256 +
+           align_up((size_t)M, 256);
 }
 
 extern "C" int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, int K, long long first, const double *u, int n_trials,
@@ -595,12 +661,17 @@ extern "C" int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, i
     float *ccmin = reinterpret_cast<float *>(ws);
     ws += align_up(sizeof(float) * (size_t)K, 256);
     double *gsum = reinterpret_cast<double *>(ws);
+    ws += align_up(sizeof(double) * (size_t)nblk * KPP_TMAX, 256);
+    int *best = reinterpret_cast<int *>(ws);
+    ws += 256;
+    unsigned char *cmask = reinterpret_cast<unsigned char *>(ws);     // [M]: bit j = candidate j moves the point
     const int c4 = (C / 4 + 15) / 16;                          // float4 pieces per lane of the row kernels (<= 4)
     const int cs = (C + 63) / 64;                              // channels per lane of the centre-distance loop (<= 4)
 #define KPP_UPDATE(N_, t_)                                                                                                      \
-    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t_, cc, prune, d2, nearest, bsum)
+    hipLaunchKernelGGL(kpp_update_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, centers, t_, cc, prune, d2, nearest, bsum, \
+                       (t_) > 0 ? cmask : (const unsigned char *)nullptr, best)
 #define KPP_GAIN(N_)                                                                                                            \
-    hipLaunchKernelGGL(kpp_gain_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, n_trials, candrows, ccmin, prune, d2, nearest, gsum)
+    hipLaunchKernelGGL(kpp_gain_kernel<N_>, dim3(nblk), dim3(256), 0, st, pts, M, C, n_trials, candrows, ccmin, prune, d2, nearest, gsum, cmask)
 #define KPP_CAND(N_, t_)                                                                                                        \
     hipLaunchKernelGGL(kpp_cand_kernel<N_>, dim3(1), dim3(KPP_PICK_THREADS), 0, st, pts, M, C, K, t_, n_trials,                  \
                        u + (size_t)(t_ - 1) * n_trials, d2, bsum, nblk, centers, cand, candrows, cct, ccmin)
@@ -619,7 +690,7 @@ extern "C" int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, i
             else if (c4 <= 3) KPP_GAIN(3);
             else KPP_GAIN(4);
             GFS3D_LAUNCH_CHECK("kpp_gain_kernel");
-            hipLaunchKernelGGL(kpp_choose_kernel, dim3(1), dim3(256), 0, st, C, K, t, n_trials, gsum, nblk, cand, candrows, cct, centers, picks, cc);
+            hipLaunchKernelGGL(kpp_choose_kernel, dim3(1), dim3(256), 0, st, C, K, t, n_trials, gsum, nblk, cand, candrows, cct, centers, picks, cc, best);
             GFS3D_LAUNCH_CHECK("kpp_choose_kernel");
         }
         if (t == K - 1) break;
