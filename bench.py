@@ -219,6 +219,10 @@ def build_step(cfg, dev, rank, world, sync_bn, gdist):
     from gfs3d.synthetic import synthetic_blocks    # input recipe; oracle/ is used by cpu_baseline() only
     torch.manual_seed(0)
     x = synthetic_blocks(cfg["B"], NPTS, seed=rank).to(dev)
+    if os.environ.get("GFS3D_BENCH_MORTON") == "1":          # experiment: the same blocks, their points delivered in Morton order
+        from gfs3d.morton import morton_order
+        order, _ = morton_order(x[:, 0:3])
+        x = torch.gather(x, 2, order[:, None, :].expand(-1, x.shape[1], -1)).contiguous()
     if cfg["model"] == "dgcnn":
         from model.dgcnn import DGCNN
         net = DGCNN([[64, 64]] * 3, [512, 256], CIN, k=KNN, return_edgeconvs=True).to(dev).train()

@@ -137,7 +137,8 @@ ec_stats1_kernel(const float *__restrict__ P, const float *__restrict__ Q, const
             float pv[ST1_FLIGHT];
 #pragma unroll
             for (int u = 0; u < ST1_FLIGHT; ++u) {
-                const int m = __shfl(myidx, min(j0 + u, k - 1), 64);
+                // (a wave-uniform source lane: v_readlane into a scalar, not a trip through the LDS crossbar as __shfl compiles to)
+                const int m = __builtin_amdgcn_readlane(myidx, min(j0 + u, k - 1));
                 pv[u] = P[((size_t)b * N + m) * EC + lane];
             }
 #pragma unroll
