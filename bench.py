@@ -95,7 +95,7 @@ def hbm_traffic(kernel, tag):
     scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
     import glob
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_hbm_traffic.json")))
-    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r03_g", "r02_e"]:
+    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r04_d", "r03_g", "r02_e"]:
         try:
             with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
                 d = json.load(f)
@@ -118,7 +118,7 @@ def pipe_of(kid, dtype):
     return "16-bit matrix cores, one product per fp32 product (dense 16-bit peak)", PEAK_16BIT_TFLOPS
 
 
-def roofline_of(prof, steps, B, cfg, tag="r04"):
+def roofline_of(prof, steps, B, cfg, tag="r05"):
     """Roofline block of one profiled workload: the library kernel with the largest device time among those with a flop model,
     its role flops / average launch time against (a) the fp32 peak the results are priced at and (b) the pipe it executes on,
     and its HBM bytes per launch from the committed PMC passes."""
@@ -779,7 +779,7 @@ def main():
                         "knn_screen_kernel<20, 4,": 2, "knn_exact_kernel<20, 64>": 2}
             tb, src = 0, None
             for name, n in per_step.items():
-                t_, s_ = hbm_traffic(name, "r04")
+                t_, s_ = hbm_traffic(name, "r05")
                 if t_:
                     tb, src = tb + n * t_, s_
             if tb:

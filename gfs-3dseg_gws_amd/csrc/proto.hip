@@ -221,7 +221,8 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
                                           const int *__restrict__ ridx = nullptr)
 {
     constexpr int NROW = NT * 32;
-    constexpr int NU = NROW * 8 / PX_THREADS;            // float4 units of a prototype chunk per thread (NT / 2)
+    constexpr int NU = (NROW * 8 + PX_THREADS - 1) / PX_THREADS;     // float4 units of a prototype chunk per thread (NT / 2, rounded up)
+    constexpr bool RAGGED = (NROW * 8) % PX_THREADS != 0;            // odd NT: the last unit covers rows past the image for half the threads
     constexpr int NP = Mx<PREC>::NP;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -272,8 +273,10 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
             uint2 pc[NP];
             mm_pieces4<PREC>(v4, pc);
             unsigned char *dst = dst_img + (row0 + 64 * u) * PX_ROW + c4 * 8;
+            if (!RAGGED || row0 + 64 * u < NROW) {
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
+            }
         }
     };
     uint4 bp[2][NP];                                     // this lane's point: pieces of 8 channels per K-step
@@ -333,7 +336,7 @@ __device__ __forceinline__ void x6_scores(const float *__restrict__ pt, size_t c
     for (int u = 0; u < NU; ++u) {
         float v = gsq[u];
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-        if (c4 == 0) gsq_out[row0 + 64 * u] = v;
+        if (c4 == 0 && (!RAGGED || row0 + 64 * u < NROW)) gsq_out[row0 + 64 * u] = v;
     }
     __syncthreads();
 }
@@ -409,6 +412,9 @@ static int dispatch_proto(const float *feat, long long bs, int B, int C, int N, 
     if (x6 && nt >= 2 && C % 32 == 0 && (reinterpret_cast<uintptr_t>(proto) & 15) == 0) {
         if (nt <= 2) return launch_proto_x6<2, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
         if (nt <= 4) return launch_proto_x6<4, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
+        // (K_w = 180 -> 6 row tiles, K_w = 200 -> 7: an eighth / a quarter less matrix, LDS and epilogue work than 8)
+        if (nt <= 6) return launch_proto_x6<6, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
+        if (nt <= 7) return launch_proto_x6<7, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
         return launch_proto_x6<8, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who, prec);
     }
     if (nt <= 1) return launch_proto<1, MODE>(feat, bs, B, C, N, proto, P, K, scale, out, assign, onehot, st, who);
@@ -1852,6 +1858,8 @@ static int km_assign(const float *pts, long long M, int C, const float *cent, in
         if (nt <= 1) return launch_kmeans<1>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
         if (nt <= 2) return launch_kmeans<2>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
         if (nt <= 4) return launch_kmeans<4>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
+        if (nt <= 6) return launch_kmeans<6>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
+        if (nt <= 7) return launch_kmeans<7>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);      // 200 centroids
         return launch_kmeans<8>(pts, M, C, cent, K, label, sums, counts, inertia, st, ws, fast);
     }
     const size_t lds = sizeof(float) * (2 * 64 * (size_t)(C + 1) + 64 + 512);
