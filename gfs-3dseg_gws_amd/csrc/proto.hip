@@ -1714,6 +1714,57 @@ static int launch_km_segsums(const float *pts, long long M, int C, int K, const 
     return GFS3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Lloyd iterations after the first few move only a small share of the points: the centroid sums then follow the labels by a
+// DELTA - every point whose label changed leaves its old centroid's sum and joins the new one's - instead of a second pass
+// over all 4 C M bytes.  The running sums are 64-bit FIXED-POINT integers (value * 2^shift, the shift chosen by the caller
+// from max |x| and M so that no sum can overflow): integer atomic adds are associative, so the result does not depend on the
+// order in which the workgroups arrive - bit-reproducible like the sorted segment sums, at a resolution (2^-shift) far below
+// fp32 rounding.  km_fix_from_f32 turns a full pass's fp32 sums into that representation, km_fix_to_f32 back.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+km_delta_fix_kernel(const float *__restrict__ pts, long long M, int C, const int32_t *__restrict__ lab_old,
+                    const int32_t *__restrict__ lab_new, double scale, long long *__restrict__ sums_fix,
+                    long long *__restrict__ counts_fix, unsigned long long *__restrict__ changed)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long m0 = ((long long)blockIdx.x * 4 + wv) * 64;
+    if (m0 >= M) return;
+    const long long m = m0 + lane;
+    const int lo = m < M ? lab_old[m] : 0, ln = m < M ? lab_new[m] : 0;
+    unsigned long long mask = __ballot(m < M && lo != ln);
+    if (lane == 0 && mask) atomicAdd(changed, (unsigned long long)__builtin_popcountll(mask));
+    while (mask) {                                            // wave-uniform: one moved point per trip, lanes along its channels
+        const int src = (int)__builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int ko = __builtin_amdgcn_readlane(lo, src), kn = __builtin_amdgcn_readlane(ln, src);
+        const float *row = pts + (size_t)(m0 + src) * C;
+        for (int c = lane; c < C; c += 64) {
+            const long long v = __double2ll_rn((double)row[c] * scale);
+            atomicAdd(reinterpret_cast<unsigned long long *>(sums_fix + (size_t)kn * C + c), (unsigned long long)v);
+            atomicAdd(reinterpret_cast<unsigned long long *>(sums_fix + (size_t)ko * C + c), (unsigned long long)(-v));
+        }
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(counts_fix + kn), 1ull);
+            atomicAdd(reinterpret_cast<unsigned long long *>(counts_fix + ko), (unsigned long long)(-1ll));
+        }
+    }
+}
+__global__ void km_fix_from_f32_kernel(const float *__restrict__ sums, const float *__restrict__ counts, int K, int C, double scale,
+                                       long long *__restrict__ sums_fix, long long *__restrict__ counts_fix)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < K * C) sums_fix[e] = __double2ll_rn((double)sums[e] * scale);
+    if (e < K) counts_fix[e] = (long long)counts[e];
+}
+__global__ void km_fix_to_f32_kernel(const long long *__restrict__ sums_fix, const long long *__restrict__ counts_fix, int K, int C,
+                                     double inv_scale, float *__restrict__ sums, float *__restrict__ counts)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < K * C) sums[e] = (float)((double)sums_fix[e] * inv_scale);
+    if (e < K) counts[e] = (float)counts_fix[e];
+}
+
 // relative part of the screen's error bound for C channels (knn.hip derives the terms): dropped piece products 2^-15 (1 + 2^-6) per
 // dot, the screen's 3 C fp32 accumulations at 2^-23, the exact form's 6 C at 2^-24 - doubled for d = |c|^2 - 2 <c, p>
 static inline float km_screen_rel(int C) { return 2.0f * (3.1e-5f + (float)C * (3.0f * 1.1920929e-7f + 6.0f * 5.9604645e-8f)) * 1.05f; }
@@ -1760,6 +1811,7 @@ static int launch_kmeans(const float *pts, long long M, int C, const float *cent
                            pts, M, C, cent, K, label, counts, inertia);
         GFS3D_LAUNCH_CHECK("kmeans_assign_mfma_kernel");
     }
+    if (!sums) return GFS3D_OK;                                                // labels / counts / inertia only (gfs3d_kmeans_delta_fix follows)
     if (ws) return launch_km_segsums(pts, M, C, K, label, sums, ws, st);      // sorted segment sums: no atomics, fixed order
     hipLaunchKernelGGL(kmeans_sums_mfma_kernel, dim3((unsigned)((M + KM_CHUNK - 1) / KM_CHUNK), (C + 31) / 32), dim3(256), 0, st,
                        pts, M, C, K, label, sums);
@@ -1841,7 +1893,7 @@ static int km_assign(const float *pts, long long M, int C, const float *cent, in
                      double *inertia, void *workspace, size_t workspace_bytes, void *stream, bool fast)
 {
     using namespace gfs3d;
-    GFS3D_REQUIRE(pts && cent && label && sums && counts, "gfs3d_kmeans_assign_f32: NULL pointer");
+    GFS3D_REQUIRE(pts && cent && label && counts && (sums || (fast && workspace)), "gfs3d_kmeans_assign_f32: NULL pointer");
     GFS3D_REQUIRE(M >= 1 && C >= 1 && K >= 1 && (K <= 256 || C <= 256), "gfs3d_kmeans_assign_f32: bad shape M=%lld C=%d K=%d", M, C, K);
     if (K <= 256 && (M + 127) / 128 < (1ll << 31)) {           // matrix-pipe path
         hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1959,5 +2011,43 @@ extern "C" int gfs3d_proto_backward_proto_f32(const float *feat, long long feat_
     GFS3D_LAUNCH_CHECK("proto_bwd_proto_kernel");
     hipLaunchKernelGGL(proto_bwd_proto_reduce_kernel, dim3(K, P), dim3(1024), 0, st, part, nchunk, B, P, K, C, proto, dproto);
     GFS3D_LAUNCH_CHECK("proto_bwd_proto_reduce_kernel");
+    return GFS3D_OK;
+}
+
+// ---- Lloyd-loop delta form of the centroid sums (fixed-point, order-independent) ----
+extern "C" int gfs3d_kmeans_fix_from_f32(const float *sums, const float *counts, int K, int C, int shift, long long *sums_fix,
+                                         long long *counts_fix, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(sums && counts && sums_fix && counts_fix, "gfs3d_kmeans_fix_from_f32: NULL pointer");
+    GFS3D_REQUIRE(K >= 1 && C >= 1 && shift >= 0 && shift <= 60, "gfs3d_kmeans_fix_from_f32: bad argument (K=%d C=%d shift=%d)", K, C, shift);
+    hipLaunchKernelGGL(km_fix_from_f32_kernel, dim3((unsigned)((K * C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sums, counts,
+                       K, C, ldexp(1.0, shift), sums_fix, counts_fix);
+    GFS3D_LAUNCH_CHECK("km_fix_from_f32_kernel");
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_kmeans_fix_to_f32(const long long *sums_fix, const long long *counts_fix, int K, int C, int shift, float *sums,
+                                       float *counts, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(sums && counts && sums_fix && counts_fix, "gfs3d_kmeans_fix_to_f32: NULL pointer");
+    GFS3D_REQUIRE(K >= 1 && C >= 1 && shift >= 0 && shift <= 60, "gfs3d_kmeans_fix_to_f32: bad argument (K=%d C=%d shift=%d)", K, C, shift);
+    hipLaunchKernelGGL(km_fix_to_f32_kernel, dim3((unsigned)((K * C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sums_fix,
+                       counts_fix, K, C, ldexp(1.0, -shift), sums, counts);
+    GFS3D_LAUNCH_CHECK("km_fix_to_f32_kernel");
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_kmeans_delta_fix(const float *pts, long long M, int C, int K, const int32_t *label_old, const int32_t *label_new,
+                                      int shift, long long *sums_fix, long long *counts_fix, unsigned long long *changed, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(pts && label_old && label_new && sums_fix && counts_fix && changed, "gfs3d_kmeans_delta_fix: NULL pointer");
+    GFS3D_REQUIRE(M >= 1 && M < (1ll << 38) && C >= 1 && K >= 1 && shift >= 0 && shift <= 60,
+                  "gfs3d_kmeans_delta_fix: bad argument (M=%lld C=%d K=%d shift=%d)", M, C, K, shift);
+    hipLaunchKernelGGL(km_delta_fix_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pts, M, C,
+                       label_old, label_new, ldexp(1.0, shift), sums_fix, counts_fix, changed);
+    GFS3D_LAUNCH_CHECK("km_delta_fix_kernel");
     return GFS3D_OK;
 }

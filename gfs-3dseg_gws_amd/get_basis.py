@@ -189,6 +189,9 @@ def _relocate_empty_clusters(points, cent_old, label, sums, counts, sharded):
     return sums, counts
 
 
+_DELTA_SHARE = 0.03          # moved points per iteration below which the sums follow the labels (above it a full pass is cheaper)
+
+
 def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
     """Lloyd iterations from `cent` as sklearn's `_kmeans_single_lloyd` runs them (`KMeans.fit`, get_basis.py:210): labels from
     the current centres, member means with empty clusters relocated, stop when the labels repeat (strict convergence) or the
@@ -200,19 +203,39 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
     # inside the loop only labels / sums / counts matter: the screened assignment (same labels at about half the matrix work);
     # the final assignment below is the exact form, whose inertia is the one reported
     loop_fn = (lambda p, c: ops.kmeans_assign(p, c, fast=True)) if assign_fn is ops.kmeans_assign else assign_fn
-    old_label = None
+    K = cent.shape[0]
+    # once few points move per iteration the centroid sums FOLLOW the labels (ops.KMeansDelta: only the moved rows are read,
+    # order-independent fixed-point sums) instead of being rebuilt from all the points
+    delta_ok = assign_fn is ops.kmeans_assign and points.is_cuda and points.shape[1] % 32 == 0 and 33 <= K <= 256
+    delta = None
+    m_glob = float(points.shape[0])
+    if sharded:
+        t = torch.tensor([m_glob], dtype=torch.float64, device=points.device)
+        torch.distributed.all_reduce(t)
+        m_glob = float(t.item())
+    old_label, moved_share = None, 1.0
     for n_iter in range(1, max_iter + 1):
-        label, sums, counts, _ = loop_fn(points, cent)
-        changed = (label != old_label).sum().float().reshape(1) if old_label is not None else torch.ones(1, device=points.device)
+        if delta is not None and old_label is not None and moved_share <= _DELTA_SHARE:
+            label = ops.kmeans_assign(points, cent, fast=True, want_sums=False)[0]
+            changed = delta.move(old_label, label).to(torch.float32)
+            sums, counts = delta.sums_counts()
+        else:
+            label, sums, counts, _ = loop_fn(points, cent)
+            changed = (label != old_label).sum().float().reshape(1) if old_label is not None else \
+                torch.full((1,), float(points.shape[0]), device=points.device)
+            if delta_ok:
+                delta = delta or ops.KMeansDelta(points, K)
+                delta.load(sums, counts)
         if sharded:
-            K, D = sums.shape
+            D = sums.shape[1]
             packed = torch.zeros((K + 1, D + 1), dtype=sums.dtype, device=sums.device)   # sums | counts ; changed: one collective
-            packed[:K, :D], packed[:K, D], packed[K, 0] = sums, counts, changed[0].clamp(max=1.0)
+            packed[:K, :D], packed[:K, D], packed[K, 0] = sums, counts, changed[0]
             torch.distributed.all_reduce(packed)
             sums, counts, changed = packed[:K, :D], packed[:K, D], packed[K, :1]
         new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
         state = torch.cat([((new - cent) ** 2).sum().reshape(1), changed.to(new.dtype), (counts == 0).sum().reshape(1).to(new.dtype)])
         shift, n_changed, n_empty = state.tolist()                                      # the iteration's one host read
+        moved_share = n_changed / m_glob
         if n_empty > 0:
             sums, counts = _relocate_empty_clusters(points, cent, label, sums, counts, sharded)
             new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)

@@ -1116,10 +1116,11 @@ def capl_train_head(feat, main_proto, bg_proto, y, fake, base_num, ignore_index=
     return CaplTrainHeadFunction.apply(feat, main_proto, bg_proto, y, fake, base_num, ignore_index)
 
 
-def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False):
+def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False, want_sums: bool = True):
     """One Lloyd assignment step on device: labels, per-centroid sums/counts and
     inertia (get_basis.py:210 runs sklearn KMeans on the CPU).  fast=True: the screened form of the Lloyd loop
-    (gfs3d_kmeans_assign_fast_f32: same labels / sums / counts, inertia from the screened scores)."""
+    (gfs3d_kmeans_assign_fast_f32: same labels / sums / counts, inertia from the screened scores).  want_sums=False (fast form
+    only): labels, counts and inertia, `sums` is None - the caller moves its running sums with `KMeansDelta`."""
     _need_gpu(pts, "pts")
     _need_gpu(cent, "cent")
     pts, cent = pts.contiguous(), cent.contiguous()
@@ -1127,7 +1128,7 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False):
     K = cent.shape[0]
     dev = pts.device
     label = torch.empty(M, dtype=torch.int32, device=dev)
-    sums = torch.zeros((K, C), dtype=torch.float32, device=dev)
+    sums = torch.zeros((K, C), dtype=torch.float32, device=dev) if want_sums else None
     counts = torch.zeros(K, dtype=torch.float32, device=dev)
     inertia = torch.zeros(1, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
@@ -1135,6 +1136,8 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False):
         nbytes = L.gfs3d_kmeans_workspace_bytes(M, C, K)       # > 0: centroid sums as sorted segment sums (fixed order, no atomics)
         ws = _workspace(dev, nbytes) if nbytes else None
         fn = L.gfs3d_kmeans_assign_fast_f32 if (fast and ws is not None) else L.gfs3d_kmeans_assign_ws_f32
+        if sums is None and fn is not L.gfs3d_kmeans_assign_fast_f32:
+            raise RuntimeError("gfs3d.kmeans_assign: want_sums=False needs the screened form (fast=True, a supported shape)")
         rc = fn(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "gfs3d_kmeans_assign_ws_f32")
     return label, sums, counts, inertia
@@ -1186,3 +1189,51 @@ def kmeanspp_greedy(pts: torch.Tensor, K: int, first: int, u, n_trials: int, pru
                                          1 if prune else 0, _stream())
     _lib.check(rc, "gfs3d_kmeanspp_greedy_f32")
     return centers, picks
+
+
+class KMeansDelta:
+    """Running centroid sums of a Lloyd loop that FOLLOW the labels (gfs3d_kmeans_delta_fix): after a full pass `load(sums,
+    counts)`, then per iteration `changed = move(label_old, label_new)` touches only the points whose label differs, and
+    `sums_counts()` returns the fp32 (sums, counts).  The sums live as 64-bit fixed-point integers whose scale is fixed at
+    construction from max |x| and M (no sum can overflow); integer atomics make them independent of the order of arrival."""
+
+    def __init__(self, pts: torch.Tensor, K: int):
+        _need_gpu(pts, "pts")
+        self.pts = pts.contiguous()
+        self.M, self.C = self.pts.shape
+        self.K = int(K)
+        peak = float(self.pts.abs().max())                             # one read at construction
+        import math
+        bits_x = max(1, math.ceil(math.log2(max(peak, 1e-30))) + 1)
+        self.shift = int(max(0, min(40, 62 - math.ceil(math.log2(max(self.M, 2))) - bits_x)))
+        dev = self.pts.device
+        self.sums_fix = torch.zeros((self.K, self.C), dtype=torch.int64, device=dev)
+        self.counts_fix = torch.zeros(self.K, dtype=torch.int64, device=dev)
+        self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def load(self, sums: torch.Tensor, counts: torch.Tensor):
+        with torch.cuda.device(self.pts.device):
+            rc = _lib.lib().gfs3d_kmeans_fix_from_f32(_p(sums.contiguous()), _p(counts.contiguous()), self.K, self.C, self.shift,
+                                                      _p(self.sums_fix), _p(self.counts_fix), _stream())
+        _lib.check(rc, "gfs3d_kmeans_fix_from_f32")
+
+    def move(self, label_old: torch.Tensor, label_new: torch.Tensor) -> torch.Tensor:
+        """-> device int64[1]: the number of points whose label changed (their rows were moved between the sums)."""
+        if label_old.dtype != torch.int32 or label_new.dtype != torch.int32:
+            raise RuntimeError("gfs3d.KMeansDelta: labels must be int32 device tensors")
+        self.changed.zero_()
+        with torch.cuda.device(self.pts.device):
+            rc = _lib.lib().gfs3d_kmeans_delta_fix(_p(self.pts), self.M, self.C, self.K, _p(label_old), _p(label_new), self.shift,
+                                                   _p(self.sums_fix), _p(self.counts_fix), _p(self.changed), _stream())
+        _lib.check(rc, "gfs3d_kmeans_delta_fix")
+        return self.changed
+
+    def sums_counts(self):
+        dev = self.pts.device
+        sums = torch.empty((self.K, self.C), dtype=torch.float32, device=dev)
+        counts = torch.empty(self.K, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gfs3d_kmeans_fix_to_f32(_p(self.sums_fix), _p(self.counts_fix), self.K, self.C, self.shift, _p(sums), _p(counts),
+                                                    _stream())
+        _lib.check(rc, "gfs3d_kmeans_fix_to_f32")
+        return sums, counts

@@ -445,6 +445,19 @@ int gfs3d_kmeans_assign_fast_f32(const float *pts, long long M, int C, const flo
 int gfs3d_kmeans_assign_ws_f32(const float *pts, long long M, int C, const float *cent, int K,
                                int32_t *label, float *sums, float *counts, double *inertia,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* Centroid sums that FOLLOW the labels (the Lloyd loop of get_basis.py:210 after its first iterations, when a few per cent of the
+ * points move): gfs3d_kmeans_assign_fast_f32 with sums == NULL computes labels / counts / inertia only, and
+ * gfs3d_kmeans_delta_fix moves every point whose label differs between `label_old` and `label_new` from its old centroid's sum
+ * to the new one's, reading only those rows; `changed` (device, += ) counts them - what sklearn's strict-convergence test needs.
+ * The running sums are 64-bit fixed-point integers (value * 2^shift; choose shift <= 62 - ceil(log2(M)) - ceil(log2(max |x|))
+ * so that no sum overflows): integer atomics are associative, the sums do not depend on the order of arrival (bit-reproducible).
+ * gfs3d_kmeans_fix_from_f32 / _to_f32 convert a full pass's fp32 sums and counts to and from that representation. */
+int gfs3d_kmeans_fix_from_f32(const float *sums, const float *counts, int K, int C, int shift, long long *sums_fix,
+                              long long *counts_fix, void *stream);
+int gfs3d_kmeans_fix_to_f32(const long long *sums_fix, const long long *counts_fix, int K, int C, int shift, float *sums,
+                            float *counts, void *stream);
+int gfs3d_kmeans_delta_fix(const float *pts, long long M, int C, int K, const int32_t *label_old, const int32_t *label_new,
+                           int shift, long long *sums_fix, long long *counts_fix, unsigned long long *changed, void *stream);
 /* k-means++ seeding on the device: the `init='k-means++'` half of `KMeans(n_clusters=num_cnt, init='k-means++').fit(point_feat)`,
  * get_basis.py:210 of the reference (sklearn, not vendored; restated as the plain D^2 sampling of Arthur & Vassilvitskii 2007:
  * centre t + 1 is point i with probability d2[i] / sum d2, d2 = squared distance to the nearest of the centres so far).

@@ -284,3 +284,52 @@ def test_bench_c3_end_to_end_line_small(dev):
     assert set(r["stage_ms"]) == {"features", "subsample", "seeding", "lloyd", "means_to_host", "svd_host"}
     assert r["words_shape"] == [16, 192] and 0.0 < r["host_share"] < 1.0
     assert abs(sum(r["stage_ms"].values()) - r["total_ms"]) < 0.25 * r["total_ms"]
+
+
+def test_lloyd_delta_sums_follow_the_labels_exactly(dev):
+    """ops.KMeansDelta (gfs3d_kmeans_delta_fix): after loading a full pass's sums, moving the points whose label changed leaves
+    exactly the sums / counts a full pass over the new labels gives (to the fixed-point resolution, far below fp32 rounding), counts
+    the moved points, and is independent of the order of arrival: two runs are bit-identical."""
+    from gfs3d import ops
+    M, C, K = 50000, 192, 200
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.randn(M, C, generator=g) * 0.7 + 0.3).to(dev)
+    lab0 = torch.randint(0, K, (M,), generator=g, dtype=torch.int32).to(dev)
+    lab1 = lab0.clone()
+    moved = torch.randperm(M, generator=g)[:1500].to(dev)
+    lab1[moved] = ((lab0[moved].long() + 1 + torch.randint(0, K - 1, (1500,), generator=g).to(dev)) % K).int()
+
+    def full(lab):
+        s = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, lab.long(), pts.double())
+        return s, torch.bincount(lab.long(), minlength=K).double()
+
+    s0, c0 = full(lab0)
+    s1, c1 = full(lab1)
+    outs = []
+    for _ in range(2):
+        d = ops.KMeansDelta(pts, K)
+        d.load(s0.float(), c0.float())
+        n = d.move(lab0, lab1)
+        assert int(n) == int((lab0 != lab1).sum()) == 1500
+        sums, counts = d.sums_counts()
+        outs.append((sums, counts, d.sums_fix.clone()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
+    sums, counts, _ = outs[0]
+    assert torch.equal(counts.double(), c1)
+    # the loaded start is s0 rounded to fp32; the MOVE itself is exact: compare the change of the sums
+    assert float(((sums.double() - s0.float().double()) - (s1 - s0)).abs().max()) < 1e-4 * float(s1.abs().max()) * 1e-3 + 1e-5
+
+
+def test_device_kmeans_with_delta_updates_equals_full_recomputation(dev, monkeypatch):
+    """The Lloyd loop with the sums following the labels (moved share <= 3 %) ends where the loop that rebuilds the sums from all
+    points every iteration ends: same iteration count, labels, inertia."""
+    import get_basis
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, "c")
+    pts = torch.from_numpy(X).to(dev)
+    init = pts[torch.from_numpy(g["c_fit_indices"]).to(dev)]
+    a = get_basis.device_kmeans(pts, K, init=init)
+    monkeypatch.setattr(get_basis, "_DELTA_SHARE", -1.0)            # never: full passes only
+    b = get_basis.device_kmeans(pts, K, init=init)
+    assert a[3] == b[3] and abs(a[2] - b[2]) < 1e-6 * b[2]
+    assert float((a[1] == b[1]).float().mean()) > 0.9999
