@@ -62,6 +62,32 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 
+// Cross-lane sums as v_add_f32 with DPP operands instead of __shfl_xor (which compiles to ds_bpermute_b32: a trip through the LDS
+// crossbar, ~100 cycles of latency each - four DEPENDENT ones per value made kpp_gain_kernel and the per-target sums of
+// ec_bwd_segsum_kernel run at that latency).  Every lane of the group receives the group's sum, bit for bit the xor butterfly's
+// value (after each step the exchanged lanes hold the same partial, and a + b == b + a).
+//   quad_perm [1,0,3,2] = xor 1, quad_perm [2,3,0,1] = xor 2, row_half_mirror = lane 7 - i of each 8 (after the quad steps: xor 4),
+//   row_mirror = lane 15 - i of each 16 (after those: xor 8)
+#define GFS3D_DPP_ADD(v, ctrl) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true)))
+__device__ __forceinline__ float group4_sum(float v) { v = GFS3D_DPP_ADD(v, 0xB1); v = GFS3D_DPP_ADD(v, 0x4E); return v; }
+__device__ __forceinline__ float group8_sum(float v) { v = group4_sum(v); v = GFS3D_DPP_ADD(v, 0x141); return v; }
+__device__ __forceinline__ float row16_sum(float v) { v = group8_sum(v); v = GFS3D_DPP_ADD(v, 0x140); return v; }
+// value of lane (lane ^ ST) for ST in {1, 2, 4, 8} as DPP moves (no LDS crossbar), ds_bpermute otherwise:
+//   xor 1 / xor 2 = quad_perm, xor 8 = row_ror:8 (a rotation by half a row is its own inverse), xor 4 = row_half_mirror (lane 7 - i
+//   of each 8) followed by quad_perm [3,2,1,0]: i = 4 a + b -> 7 - i = 4 (1 - a) + (3 - b) -> 4 (1 - a) + b
+#define GFS3D_DPP_MOV(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, true)
+__device__ __forceinline__ int lane_xor_i(int x, int st)
+{
+    switch (st) {
+    case 1: return GFS3D_DPP_MOV(x, 0xB1);
+    case 2: return GFS3D_DPP_MOV(x, 0x4E);
+    case 4: return GFS3D_DPP_MOV(GFS3D_DPP_MOV(x, 0x141), 0x1B);
+    case 8: return GFS3D_DPP_MOV(x, 0x128);
+    default: return __shfl_xor(x, st, 64);
+    }
+}
+__device__ __forceinline__ float lane_xor_f(float x, int st) { return __builtin_bit_cast(float, lane_xor_i(__builtin_bit_cast(int, x), st)); }
+
 // ---- fp32-accurate products on the bf16 matrix cores ("bf16x6", see pointwise.hip) ----
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // x == h + m + l exactly, each piece a bf16 (stored in the high half of a dword): truncation splits of 8 + 8 + 8 bits

@@ -1804,7 +1804,10 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
 {
     if constexpr (HALF) {
         // lane = (row slot sub = lane >> 3, dword quad c4 = lane & 7): one wave instruction reads 8 rows of 128 B; a lane owns
-        // channels 4 c4 .. 4 c4 + 3 (low halves) and 32 + 4 c4 .. (high halves)
+        // channels 4 c4 .. 4 c4 + 3 (low halves) and 32 + 4 c4 .. (high halves).  (Measured, round 5: the row slots on consecutive
+        // lanes with DPP adds instead of these shuffles changes nothing here - 161 vs 163 us at B = 64 - and costs the gather kernels
+        // their access pattern, csr_gather 96 -> 112 us: this form moves half the bytes of the fp32 form with half as many of them
+        // in flight per wave, 4 KB against 8 KB, and runs at half its rate.)
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         __shared__ double red[4][2][EC];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;

@@ -24,19 +24,6 @@ constexpr float KPP_PRUNE_MARGIN = 1.0f + 1e-3f;       // skip only when the bou
 
 typedef float kf4 __attribute__((ext_vector_type(4)));
 
-// sum over the 16 lanes of a DPP row, every lane receiving it: the xor butterfly 1, 2, 4, 8 as four v_add_f32 with DPP operands
-// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror).  Bit for bit the butterfly's value (after each step all
-// lanes of the exchanged groups hold the same partial, and a + b == b + a), without the LDS crossbar: __shfl_xor compiles to
-// ds_bpermute_b32, and four DEPENDENT ones per candidate row made kpp_gain_kernel run at the LDS pipe's latency (491 us per pass).
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    return v;
-}
-
 // 16 lanes per row (float4 each per piece), 4 rows per wave step; the 64 rows of a wave chunk are filtered first and only the
 // rows that can move are visited.
 template <int C4MAX>       // float4 pieces of a row handled per lane: ceil(C / 64)

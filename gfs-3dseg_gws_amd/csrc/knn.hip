@@ -839,7 +839,9 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
     const int nch_mine = (count + 31) / 32;
     const int nch = max(nch_mine, __shfl_xor(nch_mine, 32, 64));
     __builtin_amdgcn_wave_barrier();
-    auto before = [](float a, int ai, float bb, int bi) { return a > bb || (a == bb && ai < bi); };
+    // (bitwise, not short-circuit: the lane masks are combined by scalar and / or - as `||` / `&&` every comparison of the sorting
+    // network became a divergent branch, 87 of them per chunk)
+    auto before = [](float a, int ai, float bb, int bi) { return (a > bb) | ((a == bb) & (ai < bi)); };
     float tv = -__builtin_inff();
     int ti = 0x7fffffff;                                      // sorted best-first across the 32 lanes of the half
     for (int c = 0; c < nch; ++c) {
@@ -866,8 +868,8 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
         for (int sz = 2; sz <= 32; sz <<= 1) {
 #pragma unroll
             for (int st = sz >> 1; st > 0; st >>= 1) {
-                const float ov = __shfl_xor(v, st, 64);
-                const int oi = __shfl_xor(vi, st, 64);
+                const float ov = lane_xor_f(v, st);            // partners 1, 2, 4, 8 lanes away by DPP moves, 16 through the crossbar
+                const int oi = lane_xor_i(vi, st);
                 const bool want_better = (((l & st) == 0) == ((l & sz) == 0));
                 const bool take = want_better ? before(ov, oi, v, vi) : before(v, vi, ov, oi);
                 v = take ? ov : v;
@@ -884,8 +886,8 @@ knn_exact_kernel(const float *__restrict__ xpm, const float *__restrict__ sqg, c
             ti = take ? ri : ti;
 #pragma unroll
             for (int st = 16; st > 0; st >>= 1) {
-                const float ov = __shfl_xor(tv, st, 64);
-                const int oi = __shfl_xor(ti, st, 64);
+                const float ov = lane_xor_f(tv, st);
+                const int oi = lane_xor_i(ti, st);
                 const bool want_better = (l & st) == 0;
                 const bool tk = want_better ? before(ov, oi, tv, ti) : before(tv, ti, ov, oi);
                 tv = tk ? ov : tv;

@@ -10,11 +10,13 @@ conv = conv1d(192, [512, 256]).to(dev).train()
 xs = [torch.randn(32, 2048, 64, device=dev).requires_grad_(True) for _ in range(3)]
 cot = torch.randn(32, 256, 2048, device=dev)
 parts = conv.fused_parts()
+mode = sys.argv[1] if len(sys.argv) > 1 else "f32"          # f32 | f16 | bf16
 def step():
     for p in conv.parameters(): p.grad = None
     for t in xs: t.grad = None
-    y = ops.pointwise_stack(xs, parts, True)
-    y.backward(cot)
+    with ops.compute(mode):
+        y = ops.pointwise_stack(xs, parts, True)
+        y.backward(cot)
 for _ in range(3): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
