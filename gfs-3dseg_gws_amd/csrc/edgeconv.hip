@@ -1803,15 +1803,14 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
                      const float *__restrict__ stats, int BN, float *__restrict__ GP, const BnAcc partial, int rev)
 {
     if constexpr (HALF) {
-        // lane = (row slot sub = lane >> 3, dword quad c4 = lane & 7): one wave instruction reads 8 rows of 128 B; a lane owns
-        // channels 4 c4 .. 4 c4 + 3 (low halves) and 32 + 4 c4 .. (high halves).  (Measured, round 5: the row slots on consecutive
-        // lanes with DPP adds instead of these shuffles changes nothing here - 161 vs 163 us at B = 64 - and costs the gather kernels
-        // their access pattern, csr_gather 96 -> 112 us: this form moves half the bytes of the fp32 form with half as many of them
-        // in flight per wave, 4 KB against 8 KB, and runs at half its rate.)
+        // The two HALVES of a wave take two targets at once: lane = (target slot hw = lane >> 5, row slot sub = (lane >> 3) & 3, dword
+        // quad c4 = lane & 7); one wave instruction reads 4 rows of 128 B per half, 8 of them in flight = 8 KB per wave as in the
+        // fp32-row form (one target per wave with 4 KB in flight ran at half that form's rate for half its bytes: 161 us per launch
+        // at B = 64).  A lane owns channels 4 c4 .. 4 c4 + 3 (low halves of the dwords) and 32 + 4 c4 .. (high halves).
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        __shared__ double red[4][2][EC];
+        __shared__ double red[4][2][2][EC];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int sub = lane >> 3, c4 = lane & 7;
+        const int hw = lane >> 5, sub = (lane >> 3) & 3, c4 = lane & 7;
         const unsigned *rows = reinterpret_cast<const unsigned *>(dyb);
         f32x4 mean1[2], rstd1[2];
 #pragma unroll
@@ -1828,22 +1827,22 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
             const int ch = rev ? nchunk - 1 - c_ : c_;
             const int t0 = ch * SEG_TPW;
             const int myptr = rowptr[min(t0 + min(lane, SEG_TPW), BN)];
-#pragma unroll 2
-            for (int q = 0; q < SEG_TPW; ++q) {
-                const int tm = t0 + q;
-                if (tm >= BN) break;
-                const int p0 = __shfl(myptr, q, 64), p1 = __shfl(myptr, q + 1, 64);
+            for (int q = 0; q < SEG_TPW; q += 2) {
+                const int tq = q + hw, tm = t0 + tq;
+                const bool live = tm < BN;
+                const int p0 = __shfl(myptr, tq, 64), p1 = live ? __shfl(myptr, tq + 1, 64) : p0;
                 float acc[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-                for (int p = p0 + sub; p < p1; p += 32) {          // 32 rows of 128 B in flight per wave and step
-                    uint4 v[4];
+                for (int p = p0 + sub; __any(p < p1); p += 32) {     // 32 rows of 128 B per half in flight per step
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        v[u] = (p + 8 * u < p1) ? *reinterpret_cast<const uint4 *>(rows + (size_t)(p + 8 * u) * 32 + 4 * c4) : make_uint4(0u, 0u, 0u, 0u);
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = (p + 4 * u < p1) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(rows + (size_t)(p + 4 * u) * 32 + 4 * c4)) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned w4[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             acc[e] += __builtin_bit_cast(float, w4[e] << 16);
@@ -1856,10 +1855,9 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
                     float t = acc[e];
                     t += __shfl_xor(t, 8, 64);
                     t += __shfl_xor(t, 16, 64);
-                    t += __shfl_xor(t, 32, 64);
                     acc[e] = t;
                 }
-                if (sub == 0) {
+                if (sub == 0 && live) {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const size_t o = (size_t)tm * EC + 32 * hf + 4 * c4;
@@ -1879,13 +1877,15 @@ ec_bwd_segsum_kernel(const float *__restrict__ dyb, const int *__restrict__ rowp
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { red[wv][0][32 * hf + 4 * c4 + e] = s[4 * hf + e]; red[wv][1][32 * hf + 4 * c4 + e] = sx[4 * hf + e]; }
+                for (int e = 0; e < 4; ++e) { red[wv][hw][0][32 * hf + 4 * c4 + e] = s[4 * hf + e]; red[wv][hw][1][32 * hf + 4 * c4 + e] = sx[4 * hf + e]; }
         }
         __syncthreads();
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6;
-            bn_acc_add(partial, blockIdx.x, which, lane,
-                       red[0][which][lane] + red[1][which][lane] + red[2][which][lane] + red[3][which][lane]);
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[w][0][which][lane] + red[w][1][which][lane];
+            bn_acc_add(partial, blockIdx.x, which, lane, t);
         }
         return;
     } else {
@@ -2383,8 +2383,11 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
         hipLaunchKernelGGL(csr_place_kernel, grid, dim3(CSR_THREADS), lds, rs, a->idx, rangecnt, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
         GFS3D_LAUNCH_CHECK("csr_place_kernel");
         // (512 long-lived workgroups beside the main stream's kernels instead of 2048: c2 step -0.7 %, A/B on one box)
-        static const int cg_env = [] { const char *e = getenv("GFS3D_EC_CSRGATHER_GRID"); return e ? atoi(e) : 512; }();       // A-B only
-        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, cg_env > 0 ? cg_env : 512)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->N, a->SQ, a->indeg);
+        // ... at B = 64 the lane (count + place + gather) outlasts the main stream's forward of the layer and the join waits for it:
+        // there 2048 workgroups (c5 step 8.13 -> 7.95 ms; at B = 32 no difference beyond noise)
+        static const int cg_env = [] { const char *e = getenv("GFS3D_EC_CSRGATHER_GRID"); return e ? atoi(e) : 0; }();       // A-B only
+        const int cg = cg_env > 0 ? cg_env : (BN > 98304 ? 2048 : 512);
+        hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)min((BN + 31) / 32, cg)), dim3(256), 0, rs, a->Q, a->csr_rowptr, csr_src, BN, a->N, a->SQ, a->indeg);
         GFS3D_LAUNCH_CHECK("csr_gather_kernel");
         return GFS3D_OK;
     }
@@ -2601,8 +2604,9 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
         if (csr) {
             // every workgroup ends in 128 same-address fp64 atomics (the BN1-backward sums): few, long-lived workgroups
             // (2048 -> 512 at B = 32: 93 -> 85 us per launch; 256: slower again)
-            static const int sg_env = [] { const char *e = getenv("GFS3D_EC_SEGSUM_GRID"); return e ? atoi(e) : 512; }();       // A-B only
-            const int sg = min((BN + 31) / 32, sg_env > 0 ? sg_env : 512);
+            // (B = 64: 2048 workgroups, c5 step 8.03 -> 7.97 ms)
+            static const int sg_env = [] { const char *e = getenv("GFS3D_EC_SEGSUM_GRID"); return e ? atoi(e) : 0; }();       // A-B only
+            const int sg = min((BN + 31) / 32, sg_env > 0 ? sg_env : (BN > 98304 ? 2048 : 512));
             static const int seg_rev = [] { const char *e = getenv("GFS3D_EC_SEGSUM_REV"); return e ? atoi(e) : 1; }();       // A-B only
             if (prec_of(a->compute, true) != PREC_X6)
                 hipLaunchKernelGGL(ec_bwd_segsum_kernel<true>, dim3((unsigned)sg), dim3(256), 0, st, dyb, a->csr_rowptr, a->P, a->Q, GQ,
