@@ -333,3 +333,52 @@ def test_device_kmeans_with_delta_updates_equals_full_recomputation(dev, monkeyp
     b = get_basis.device_kmeans(pts, K, init=init)
     assert a[3] == b[3] and abs(a[2] - b[2]) < 1e-6 * b[2]
     assert float((a[1] == b[1]).float().mean()) > 0.9999
+
+
+def test_kmeans_full_size_vs_fp64(dev):
+    """configs[2] at its REAL size (7 x 300 000 points x 192, 200 centroids): the screened Lloyd assignment and the
+    exact final assignment against a float64 evaluation of EVERY point (chunked on the device): labels identical wherever the two
+    best centroids are separated by more than fp32 rounding, counts exact, sums and inertia consistent with the kernel's own labels."""
+    from gfs3d import ops
+    M, C, K = 7 * 300000, 192, 200
+    g = torch.Generator().manual_seed(11)
+    cent = (torch.randn(K, C, generator=g) * 0.6).to(dev)
+    pts = torch.empty(M, C, device=dev)
+    for s in range(0, M, 300000):                                  # clustered points, built on the device chunk by chunk
+        n = min(300000, M - s)
+        which = torch.randint(0, K, (n,), generator=g).to(dev)
+        pts[s:s + n] = cent[which] * 0.9 + 0.45 * torch.randn(n, C, generator=g).to(dev)
+    ref_lab = torch.empty(M, dtype=torch.int64, device=dev)
+    clear = torch.empty(M, dtype=torch.bool, device=dev)
+    ref_best = torch.empty(M, dtype=torch.float64, device=dev)
+    c64 = cent.double()
+    for s in range(0, M, 131072):
+        d = torch.cdist(pts[s:s + 131072].double(), c64) ** 2
+        top = torch.topk(d, 2, dim=1, largest=False)
+        ref_lab[s:s + 131072] = top.indices[:, 0]
+        ref_best[s:s + 131072] = top.values[:, 0]
+        clear[s:s + 131072] = (top.values[:, 1] - top.values[:, 0]) > 1e-4 * top.values[:, 1]
+    for fast in (True, False):
+        label, sums, counts, inertia = ops.kmeans_assign(pts, cent, fast=fast)
+        lab = label.long()
+        assert bool((lab[clear] == ref_lab[clear]).all())
+        assert float((lab == ref_lab).float().mean()) > 0.9999
+        assert torch.equal(counts.double(), torch.bincount(lab, minlength=K).double()) and float(counts.sum()) == M
+        exp_sums = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, lab, pts.double())
+        assert float((sums.double() - exp_sums).abs().max()) < 1e-4 * float(exp_sums.abs().max())
+        if not fast:                                               # the exact form's inertia is the reported one
+            own = ((pts.double() - c64[lab]) ** 2).sum(1)
+            assert abs(float(inertia) - float(own.sum())) < 1e-5 * float(own.sum())
+            assert abs(float(inertia) - float(ref_best.sum())) < 1e-5 * float(ref_best.sum())
+
+
+def test_subsample_per_class_skips_labels_outside_the_class_range(dev):
+    """an ignore index (-100), labels >= num_classes and float labels match no `y == c` mask of the reference
+    (get_basis.py:176-181): they are skipped, not an error."""
+    from get_basis import subsample_per_class
+    y = torch.tensor([[1, -100, 2, 7, 1, 0, 2, 2]], dtype=torch.int64)
+    feat = torch.arange(8, dtype=torch.float32)[:, None].repeat(1, 4).to(dev)
+    out = subsample_per_class(feat, y, 3, max_per_class=10).cpu()
+    assert out[:, 0].tolist() == [0.0, 4.0, 2.0, 6.0, 7.0]                      # class 1 rows, then class 2 rows, point order kept
+    out2 = subsample_per_class(feat, y.float(), 3, max_per_class=10).cpu()
+    assert torch.equal(out, out2)
