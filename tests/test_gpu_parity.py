@@ -1484,6 +1484,13 @@ def _rccl_rank(rank, world, port, out):
     dist.broadcast(c, src=0)                                                 # k-means start
     res["bcast"] = bool(torch.equal(c, c0))
     res["max"] = gd.max_over_ranks(3.5, dev)
+    got = [None]
+    dist.all_gather_object(got, ("cuda:0", 1.25))                            # bench.py: rank_devices / rank_values
+    res["objs"] = got
+    rec = torch.arange(12, dtype=torch.float32, device=dev).reshape(3, 4)
+    parts = [torch.empty_like(rec)]
+    dist.all_gather(parts, rec)                                              # k-means: relocation candidates of every rank
+    res["gather"] = bool(torch.equal(parts[0], rec))
     # CPU counters under nccl (evaluate_metric_GFS moved them to the device for the exchange)
     g = np.load(os.path.join(here, "golden", "metric.npz"))
 
@@ -1536,6 +1543,7 @@ def test_rccl_single_rank_exercises_every_collective(dev):
     r = out[0]
     assert r["backend"] == "nccl" and r["f64"] and r["i32max"] == [0, 1, 0, 1] and r["i64"] == sum(range(39))
     assert r["diff"] == [2.0] * 5 and r["bcast"] and r["max"] == 3.5
+    assert r["objs"] == [("cuda:0", 1.25)] and r["gather"]
     assert np.allclose(r["metric"], load_golden("metric")["res"], atol=1e-12)
     assert r["early_plain"] == 0 and r["early_rccl"] == 2 and r["early_rccl_syncbn"] == 0
     ref = r["grads"]["plain"]
