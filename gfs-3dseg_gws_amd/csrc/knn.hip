@@ -640,23 +640,34 @@ knn_screen_kernel(const unsigned char *__restrict__ img, const float *__restrict
     const float E = KNN_SCREEN_REL * sqrtf(sqq * sqmax) + KNN_SCREEN_ABS * (sqq + sqmax);
 
     const int ns = (N + SR - 1) / SR;
+    // STRIDED stages (round 5): local row r of stage st is point r ns + st - a stage's rows are spread over the whole cloud,
+    // ns apart.  The threshold of sweep 0 is the K-th largest BUCKET maximum (a bucket = the 16 rows a lane sees of one tile) and
+    // is tight only if the K nearest points fall into about K different buckets.  With stages of CONSECUTIVE points that held for
+    // randomly ordered clouds only: in a spatially sorted cloud the neighbours share a few buckets, the candidate lists overflowed
+    // and knn_exact_kernel fell back to its exhaustive scan (45 -> 775 us per launch, measured with Morton-ordered blocks).  Spread
+    // rows make the bucket statistics independent of the order the points come in; for random clouds nothing changes.
     // DMA of stage st into ring slot `buf`: piece i = w D + u, lane l fills LDS slot g = 64 i + l = (row r, physical slot p),
-    // which holds the logical slot p ^ f(r) of that row; rows past N re-read row N - 1 (their norms are patched to +inf)
-    // (the image has a zeroed stage of slack behind the last cloud; a stage's rows past N of an earlier cloud are the next cloud's)
-    unsigned soff[D];
+    // which holds the logical slot p ^ f(r) of that row; rows past N read the slack / the next cloud (their norms are patched to
+    // +inf): r ns + st < SR ns < N + SR, inside the zeroed stage of slack the image keeps behind the last cloud
+    // ... and the local rows of a stage are ROTATED by 4 st: local row r of stage st is point ((r - 4 st) mod SR) ns + st, so
+    // that consecutive points (stages st, st + 1, ...) alternate between the two lane halves of a query (rows 4 h + {0..3} + 8 g of a
+    // tile).  Without the rotation the ~25 candidates of a query in a sorted cloud - a run of consecutive points - all fell to ONE
+    // half and overflowed its KS_QS slots in one query of a few hundred, each of which then costs a 64-chunk exhaustive scan.
+    static_assert((SR & (SR - 1)) == 0, "stage rows: a power of two");
+    auto point_of = [&](int r, int st) { return ((r - 4 * st) & (SR - 1)) * ns + st; };
+    int srow[D], sslot[D];
 #pragma unroll
     for (int u = 0; u < D; ++u) {
         const int g = (w * D + u) * 64 + lane;
-        const int r = g / SPR, pslot = g % SPR;
-        soff[u] = (unsigned)(r * RB + 16 * (pslot ^ ((r / RPB) & (SPR - 1))));
+        srow[u] = g / SPR;
+        sslot[u] = 16 * ((g % SPR) ^ ((srow[u] / RPB) & (SPR - 1)));
     }
     const int wu = __builtin_amdgcn_readfirstlane(w);
     auto issue = [&](int st, int buf) {
         unsigned char *dst = ring + buf * SB + wu * D * 1024;
-        const unsigned char *src = imgb + (size_t)st * SB;
 #pragma unroll
-        for (int u = 0; u < D; ++u) ks_dma16_off(src, soff[u], dst + u * 1024);
-        if (lane < NQ) ks_dma4_off(sqb, (unsigned)(4 * min(SR * st + wu * NQ + lane, N - 1)), tsq + buf * SR + wu * NQ);
+        for (int u = 0; u < D; ++u) ks_dma16_off(imgb, (unsigned)(point_of(srow[u], st) * RB + sslot[u]), dst + u * 1024);
+        if (lane < NQ) ks_dma4_off(sqb, (unsigned)(4 * min(point_of(wu * NQ + lane, st), N - 1)), tsq + buf * SR + wu * NQ);
     };
     // Software pipeline inside a wave: the MFMA chains of stage st are issued together with the selection work on the scores
     // of stage st - 1 (held in tv), so a wave fills its own MFMA gaps; tv of stage st is formed when its chains have finished.
@@ -741,14 +752,14 @@ knn_screen_kernel(const unsigned char *__restrict__ img, const float *__restrict
     auto extract1 = [&](int st, const unsigned (&bits)[KS_NT]) {
 #pragma unroll
         for (int sp = 0; sp < KS_NT; sp += 2) {
-            const int cbase = SR * st + 32 * sp + 4 * h;
+            const int lbase = 32 * sp + 4 * h;                  // local row of the stage -> point_of(local row, st)
             unsigned bt = qvalid ? ((bits[sp] << 16) | bits[sp + 1]) : 0u;
             while (__any(bt != 0)) {
                 if (bt != 0) {
                     const int lz = __builtin_clz(bt);
                     bt &= ~(0x80000000u >> lz);
                     const int r = lz & 15;
-                    if (cnt < KS_QS) myc[cstep * cnt] = cbase + 2 * (lz & 16) + (r & 3) + 8 * (r >> 2);
+                    if (cnt < KS_QS) myc[cstep * cnt] = point_of(lbase + 2 * (lz & 16) + (r & 3) + 8 * (r >> 2), st);
                     ++cnt;
                 }
             }
@@ -769,8 +780,8 @@ knn_screen_kernel(const unsigned char *__restrict__ img, const float *__restrict
             // the candidate stores of sweep 1 only make the wait conservative)
             if (st + 1 < ns) ks_wait_vm<(KS_RING - 2) * (D + 1)>(); else ks_wait_vm<0>();
             __syncthreads();                               // ... for every wave, and ring slot (st - 1) % RING is free
-            if (st == ns - 1 && (N % SR) != 0) {           // ragged last stage: rows past N score -inf
-                if (tid < SR && SR * st + tid >= N) tsq[buf * SR + tid] = __builtin_inff();
+            if ((SR - 1) * ns + st >= N) {                 // a stage whose last rows lie past N: they score -inf (block-uniform test)
+                if (tid < SR && point_of(tid, st) >= N) tsq[buf * SR + tid] = __builtin_inff();
                 __syncthreads();
             }
             if (st + KS_RING - 1 < ns) issue(st + KS_RING - 1, buf == 0 ? KS_RING - 1 : buf - 1);

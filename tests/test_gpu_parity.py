@@ -56,6 +56,8 @@ def relerr(a, b):
     (3, 64, 68, 20, "randn"), (2, 16, 132, 20, "offset"), (9, 40, 1996, 20, "relu"), (16, 9, 3972, 20, "blocks"),
     # N of any remainder mod 4 (the round-2 staging needed N % 4 == 0; the image rows do not)
     (2, 64, 131, 20, "randn"), (3, 9, 1001, 20, "blocks"), (1, 33, 2050, 20, "offset"), (2, 64, 66, 32, "twins"),
+    # spatially sorted clouds (neighbours sit at neighbouring indices): the screen's buckets must not depend on the order
+    (2, 9, 2048, 20, "sorted"), (2, 64, 2048, 20, "sorted"), (1, 64, 1001, 20, "sorted"), (9, 32, 2048, 20, "sorted"),
 ])
 def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
     from gfs3d import ops
@@ -77,6 +79,11 @@ def test_knn_bit_exact_vs_oracle(dev, B, C, N, k, kind):
         x = torch.nn.functional.leaky_relu(torch.randn(B, C, N, generator=g) + 0.8, 0.2)
     elif kind == "tiny_spread":
         x = torch.randn(B, C, N, generator=g) * 1e-3 + 50.0
+    elif kind == "sorted":
+        # points along a smooth curve in feature space, stored in curve order, plus a little noise
+        t = torch.linspace(0, 1, N).view(1, 1, N)
+        f = torch.arange(1, C + 1).view(1, C, 1).float()
+        x = torch.sin(6.0 * t * f ** 0.5 + torch.rand(B, C, 1, generator=g)) + 0.01 * torch.randn(B, C, N, generator=g)
     else:
         x = torch.randn(B, C, N, generator=g)
     i64, i32 = ops.knn_topk(x.to(dev), k, want_i64=True, want_i32=True)
