@@ -3,13 +3,13 @@ gathers (its neighbours' projections, the candidates of its kNN, the targets of 
 Measured on the bench's synthetic blocks (scripts/exp_morton_locality.py): 59 % of a point's 20 neighbours lie within 64
 positions of it (11 % in the sampled order), a 64-query tile touches 327 distinct rows instead of 940.
 
-MEASURED NEGATIVE (round 5, DESIGN_HISTORY.md): delivering the c2 blocks in this order leaves the gather kernels where they were
-(their rows are L2-resident per XCD either way: ec_stats1 44 vs 46 us, ec_main_fwd 106 vs 107, ec_main_bwd_pair 224 vs 226,
-csr_gather 93 vs 96) and breaks the screened kNN: its threshold is the K-th largest BUCKET maximum over buckets of consecutive
-points, which is tight only when a query's neighbours fall into different buckets, i.e. for randomly ordered points - in Morton
-order the lists overflow and knn_exact_kernel falls back to the exhaustive scan (45 -> 775 us per launch, c2 step 3.2 -> 5.9 ms).
-Kept as the reproduction knob of that experiment (`GFS3D_BENCH_MORTON=1 python bench.py`, scripts/exp_morton_locality.py); the
-product path keeps the sampled (random) order the reference's loader produces (dataloaders/loader.py:64-82)."""
+MEASURED NEUTRAL (round 5, DESIGN_HISTORY.md): delivering the c2 blocks in this order leaves the gather kernels where they were
+(their rows are L2-resident per XCD either way: ec_stats1 44.5 vs 43.4 us, ec_main_fwd 104.1 vs 103.5, ec_main_bwd_pair 217.6 vs
+213.6, csr_gather 91.4 vs 90.8). The first run of the experiment also broke the screened kNN (its buckets were runs of consecutive
+points, so the neighbours of a sorted cloud shared buckets and the lists overflowed: knn_exact_kernel 45 -> 775 us); csrc/knn.hip
+now strides and rotates its stages over the cloud and is indifferent to the order (42 vs 44 us). Kept as the reproduction knob of
+the experiment (`GFS3D_BENCH_MORTON=1 python bench.py`, scripts/exp_morton_locality.py); the product path keeps the sampled order
+the reference's loader produces (dataloaders/loader.py:64-82)."""
 from __future__ import annotations
 
 import torch
