@@ -43,6 +43,8 @@ constexpr int HD_PTS = 256;          // points per workgroup (4 waves, lane = po
 constexpr int HD_LD = 65;            // row stride of the per-wave LDS tiles (floats): [row][point], conflict-free both ways
 constexpr int HD_FLD = HD_C + 1;     // row stride of the fsum / dfsum tables: [fake class][128 sums | count]
 constexpr float HD_EPS = 1e-12f;
+// per-item state of the refinement kept for the backward: hs[(b KT + k)][8] = {s, w, cos, |pooled|, |refined|, -, -, -}
+constexpr int HD_HS = 8;
 constexpr float HD_SCALE = 10.0f;    // get_pred's `pred * 10`
 constexpr float HD_SHIFT = 10.0f;    // exp(L - 10): the logits are 10 cos in [-10, 10], so no running maximum is needed
 
@@ -216,6 +218,650 @@ __device__ __forceinline__ void hd_reduce_store(const f32x16 (&acc)[RT], float *
     }
 }
 
+// =====================================================================================================================
+// The four point passes on the fp32 matrix cores (round 5).  The lane = point form above spends its time on ~1000 LDS broadcast
+// reads and 4096 fma per lane and pass with ONE wave per SIMD (65 536 points are 1024 waves) and 16 four-byte loads in flight
+// per lane; here every product of the passes is a v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+//   dots         D[class][point]   = sum_c T[class][c] F[c][point]            (A = table, B = features, k = channel)
+//   contractions D[row][channel]   = sum_p A[row][p] F[channel][p]            (A = per-point coefficients, B = features, k = point)
+//   d F          D[channel][point] = sum_slot T[slot][channel] coef[slot][p]  (A = tables, B = coefficients, k = class slot)
+// A wave owns 64 points; lane = 16 g + j.  Point tile t (0..3) has column j <-> point 4 j + t, so ONE 16-byte access per lane
+// covers the four tiles; a 16x16 result tile leaves rows 4 g + r (r = 0..3) of column j in lane (g, j).  The table rows are
+// fed permuted (A row i <-> class 4 (i & 3) + (i >> 2)), so lane (g, j) ends up with the classes k = 16 rt + 4 r + g of its four
+// points: exactly the B operand of K-step (rt, r) of the d F product - the per-point arithmetic (soft-max, cross-entropy,
+// gradient coefficients) runs on those registers with two cross-lane steps (lanes 16 and 32 apart) per class reduction,
+// and nothing goes back through LDS except the coefficient rows of the point contractions.
+// The features travel in slabs of 32 channels x 64 points per wave (16-byte global loads: four channel rows of 256 B per
+// instruction, all 32 of a wave's loads issued up front - 32 KB in flight per wave - and the tile kept in registers for the second
+// sweep of a pass), rows 68 floats apart in LDS: conflict-free for the
+// 16-byte reads along the points (B of the dots, epilogue of d F) and for the reads along the channels (B of the contractions).
+// =====================================================================================================================
+#ifndef HD_ABL
+#define HD_ABL 0                                 // ablation builds only (scripts/build_ablation.sh): 1 no dot MFMAs, 2 no feature loads, 8 no contraction, 16 no d F MFMAs, 32 no d F stores
+#endif
+constexpr int HD_LDT = HD_C + 4;                 // table row stride (floats): 16-byte reads of 16 rows hit 16 different slots
+constexpr int HD_LDS = 68;                       // slab / coefficient-tile row stride (floats)
+constexpr int HD_SLAB_C = 32;                    // channels per slab
+constexpr int HD_SLAB_F = HD_SLAB_C * HD_LDS;    // floats of one wave's slab
+constexpr int HD_NSLAB = HD_C / HD_SLAB_C;
+
+__device__ __forceinline__ float hd_gsum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }   // over g: the 4 lanes of a column
+__device__ __forceinline__ float hd_gmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+__device__ __forceinline__ f32x4 hd_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// rows [0, rows) of a (rows, 128) matrix -> LDS table of KT rows, HD_LDT floats apart (the rest zero); ends with a barrier
+template <int KT>
+__device__ __forceinline__ void hd_mm_load_table(float *dst, const float *src, int rows, int tid)
+{
+    for (int e = tid; e < KT * (HD_C / 4); e += 256) {
+        const int row = e >> 5, c4 = e & 31;
+        const f32x4 v = (src != nullptr && row < rows) ? hd_ldg4(src + (size_t)row * HD_C + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(dst + row * HD_LDT + 4 * c4) = v;
+    }
+    __syncthreads();
+}
+// unit([bg; main]) (bg == NULL: unit(main)) in the same layout; ends with a barrier
+template <int KT>
+__device__ __forceinline__ void hd_mm_load_bgmain_unit(float *dst, const float *bg, const float *main_proto, int K1, int tid)
+{
+    for (int e = tid; e < KT * (HD_C / 4); e += 256) {
+        const int row = e >> 5, c4 = e & 31;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (bg == nullptr) { if (row < K1) v = hd_ldg4(main_proto + (size_t)row * HD_C + 4 * c4); }
+        else if (row == 0) v = hd_ldg4(bg + 4 * c4);
+        else if (row < K1) v = hd_ldg4(main_proto + (size_t)(row - 1) * HD_C + 4 * c4);
+        *reinterpret_cast<f32x4 *>(dst + row * HD_LDT + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    for (int row = w; row < K1; row += 4) {
+        const float a = dst[row * HD_LDT + lane], b = dst[row * HD_LDT + 64 + lane];
+        const float inv = 1.0f / fmaxf(sqrtf(hd_wsum(fmaf(a, a, b * b))), HD_EPS);
+        dst[row * HD_LDT + lane] = a * inv;
+        dst[row * HD_LDT + 64 + lane] = b * inv;
+    }
+    __syncthreads();
+}
+
+// slab s of the wave's 64 points: lane (g, j) holds channels 32 s + 4 i + g (i = 0..7) of the points n0 + 4 j .. + 3.
+// VEC: N % 4 == 0 and 16-byte aligned rows; a group past N reads the last four points (its coefficients are zero).
+template <bool VEC>
+__device__ __forceinline__ void hd_slab_fetch(const float *fb, int N, int n0, int s, int g, int j, f32x4 (&r)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float *row = fb + (size_t)(HD_SLAB_C * s + 4 * i + g) * N;
+        if (HD_ABL & 2) r[i] = f32x4{0.5f, 0.25f, 1.f, 2.f};
+        else if (VEC) r[i] = hd_ldg4(row + min(n0 + 4 * j, N - 4));
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[i][t] = row[min(n0 + 4 * j + t, N - 1)];
+        }
+    }
+}
+__device__ __forceinline__ void hd_slab_put(float *slab, int g, int j, const f32x4 (&r)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(slab + (4 * i + g) * HD_LDS + 4 * j) = r[i];
+}
+
+// acc[tb][rt][t] += T_tb[class][c] F[c][point] over the 32 channels of the slab; sq[t] += this lane's share of |F|^2
+// (K-step (u, e), k = g <-> channel 16 u + 4 g + e of the slab; table rows past KT - 1 repeat the last row: masked by k < K1)
+template <int KT, int NT>
+__device__ __forceinline__ void hd_mm_dots(const float *slab, const float *const (&tab)[NT], int cbase, int g, int j,
+                                           f32x4 (&acc)[NT][(KT + 15) / 16][4], float (&sq)[4])
+{
+    constexpr int RT = (KT + 15) / 16;
+    const int prow = 4 * (j & 3) + (j >> 2);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        f32x4 a[NT][RT];
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                a[tb][rt] = *reinterpret_cast<const f32x4 *>(tab[tb] + min(16 * rt + prow, KT - 1) * HD_LDT + cbase + 16 * u + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(slab + (16 * u + 4 * g + e) * HD_LDS + 4 * j);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sq[t] = fmaf(bv[t], bv[t], sq[t]);
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (!(HD_ABL & 1)) acc[tb][rt][t] = hd_mfma16(a[tb][rt][e], bv[t], acc[tb][rt][t]);
+        }
+    }
+}
+
+// The point contraction of one slab: D[row][channel] = sum over the wave's 64 points of ct[row][p] slab[channel][p] for the
+// 16 RTC rows of the wave's coefficient tile, the four waves' tiles added in wave order and stored:
+// part[rowmap(row)][32 s + c].  Ends with a barrier (the slab and `red` are free again).
+template <int RTC, typename RowMap>
+__device__ __forceinline__ void hd_mm_contract(const float *slab, const float *ct, float *red /* [4][16 RTC][33] */, int s, int tid,
+                                               float *part, RowMap rowmap)
+{
+    const int lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    f32x4 acc[RTC][2];
+#pragma unroll
+    for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[rt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                    // K-step (u, e), k = g <-> point 16 u + 4 g + e
+        f32x4 a[RTC], bm[2];
+#pragma unroll
+        for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(ct + (16 * rt + j) * HD_LDS + 16 * u + 4 * g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) bm[m] = *reinterpret_cast<const f32x4 *>(slab + (16 * m + j) * HD_LDS + 16 * u + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    if (!(HD_ABL & 8)) acc[rt][m] = hd_mfma16(a[rt][e], bm[m][e], acc[rt][m]);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RTC; ++rt)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(w * 16 * RTC + 16 * rt + 4 * g + r) * 33 + 16 * m + j] = acc[rt][m][r];
+    __syncthreads();
+    for (int e = tid; e < 16 * RTC * 32; e += 256) {
+        const int row = e >> 5, c = e & 31;
+        const float v = ((red[row * 33 + c] + red[(16 * RTC + row) * 33 + c]) + red[(32 * RTC + row) * 33 + c]) + red[(48 * RTC + row) * 33 + c];
+        part[(size_t)rowmap(row) * HD_C + 32 * s + c] = v;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pass 1
+template <int KT, bool VEC>
+__global__ void __launch_bounds__(256, 1)
+hd_fwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, const float *__restrict__ main_proto,
+                  const float *__restrict__ bg, int K1, const HeadFake fk, float *__restrict__ part1, float *__restrict__ sums1)
+{
+    constexpr int RT = (KT + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q3 = hd_smem;                                 // [KT][132]
+    float *slabs = q3 + KT * HD_LDT;                     // [4][32][68]
+    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][32][68]   rows k < K1: e;  rows K1 + f: the fake-novel weights
+    float *red = cts + 4 * 32 * HD_LDS;                  // [4][32][33]
+    float *wsums = red + 4 * 32 * 33;                    // [4][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n0 = chunk * HD_PTS + w * 64;
+    const float *fb = feat + (size_t)b * bs;
+    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * 32 * HD_LDS;
+    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
+    for (int e = lane; e < 32 * HD_LDS; e += 64) ct[e] = 0.f;
+    if (lane < 32) wsums[w * 32 + lane] = 0.f;
+    hd_mm_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
+    f32x4 acc[1][RT][4];
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[0][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *const tabs[1] = {q3};
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) {
+        hd_slab_put(slab, g, j, rg[s]);
+        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
+        hd_mm_dots<KT, 1>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float nrm[4], rn[4];
+    bool valid[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        nrm[t] = sqrtf(hd_gsum(sq[t]));
+        rn[t] = 1.0f / fmaxf(nrm[t], HD_EPS);
+        valid[t] = n0 + 4 * j + t < N;
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + 4 * r + g;
+            f32x4 ev;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ev[t] = (valid[t] && k < K1) ? __expf(HD_SCALE * acc[0][rt][t][r] * rn[t] - HD_SHIFT) : 0.f;
+            if (k < K1) *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = ev;
+            const float se = row16_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
+            if (j == 0 && k < K1) wsums[w * 32 + k] = se;
+        }
+    if (fk.n > 0 && b >= fk.half) {                      // (workgroup-uniform)
+        int fi[4];
+        float rn2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long long y = label[(size_t)b * N + min(n0 + 4 * j + t, N - 1)];
+            fi[t] = valid[t] ? hd_fake_index(fk, y) : -1;
+            rn2[t] = 1.0f / (nrm[t] + HD_EPS);           // generate_fake_proto divides by (|f| + 1e-12)
+        }
+        for (int f = g; f < fk.n; f += 4) {
+            f32x4 v;
+            float cnt = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v[t] = fi[t] == f ? rn2[t] : 0.f; cnt += fi[t] == f ? 1.f : 0.f; }
+            *reinterpret_cast<f32x4 *>(ct + (K1 + f) * HD_LDS + 4 * j) = v;
+            cnt = row16_sum(cnt);
+            if (j == 0) wsums[w * 32 + K1 + f] = cnt;
+        }
+    }
+    float *part = part1 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) {
+        hd_slab_put(slab, g, j, rg[s]);
+        __builtin_amdgcn_wave_barrier();
+        hd_mm_contract<2>(slab, ct, red, s, tid, part, [](int row) { return row; });
+    }
+    if (tid < 32) sums1[(size_t)(b * nchunk + chunk) * 32 + tid] = ((wsums[tid] + wsums[32 + tid]) + wsums[64 + tid]) + wsums[96 + tid];
+}
+
+// The per-point soft-max of one head on the class registers of lane (g, j): L[rt][r] (class k = 16 rt + 4 r + g, rows >= K1
+// excluded) -> probabilities in place; returns the log-sum-exp.  Same arithmetic as hd_softmax, the class reductions across
+// the four lanes of the column.
+template <int RT>
+__device__ __forceinline__ float hd_mm_softmax(float (&L)[RT][4], int K1, int g)
+{
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = (16 * rt + 4 * r + g) < K1 ? fmaxf(mx, L[rt][r]) : mx;
+    mx = hd_gmax(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { L[rt][r] = (16 * rt + 4 * r + g) < K1 ? expf(L[rt][r] - mx) : 0.f; s += L[rt][r]; }
+    s = hd_gsum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) L[rt][r] *= inv;
+    return mx + logf(s);
+}
+
+// ------------------------------------------------------------------------------------------------ forward, pass 2
+template <int KT, bool VEC>
+__global__ void __launch_bounds__(256, 1)
+hd_fwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+                  const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, float *__restrict__ part2, long long *__restrict__ pred)
+{
+    constexpr int RT = (KT + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT;
+    float *slabs = q2 + KT * HD_LDT;                     // [4][32][68]
+    float *wred = slabs + 4 * HD_SLAB_F;                 // [4][4]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n0 = chunk * HD_PTS + w * 64;
+    const float *fb = feat + (size_t)b * bs;
+    float *slab = slabs + w * HD_SLAB_F;
+    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
+    hd_mm_load_table<KT>(q1, q1g, K1, tid);
+    hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    f32x4 acc[2][RT][4];
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *const tabs[2] = {q1, q2};
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) {
+        hd_slab_put(slab, g, j, rg[s]);
+        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
+        hd_mm_dots<KT, 2>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float s1 = 0.f, s2 = 0.f, sc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 4 * j + t;
+        const bool valid = n < N;
+        const float rn = HD_SCALE / fmaxf(sqrtf(hd_gsum(sq[t])), HD_EPS);
+        const long long y = label[(size_t)b * N + min(n, N - 1)];
+        const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+        float L1[RT][4], L2[RT][4];
+        float pick1 = 0.f, pick2 = 0.f, best = -__builtin_inff();
+        int bk = 0x7fffffff;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * rt + 4 * r + g;
+                L1[rt][r] = acc[0][rt][t][r] * rn;
+                L2[rt][r] = acc[1][rt][t][r] * rn;
+                pick1 = (long long)k == y ? L1[rt][r] : pick1;
+                pick2 = (long long)k == y ? L2[rt][r] : pick2;
+                if (k < K1 && L2[rt][r] > best) { best = L2[rt][r]; bk = k; }       // (ascending k within the lane)
+            }
+        pick1 = hd_gsum(pick1);                          // (one lane of the column holds class y, the others add 0)
+        pick2 = hd_gsum(pick2);
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {             // arg-max over the column's four lanes: larger value, then smaller class
+            const float ov = __shfl_xor(best, o, 64);
+            const int ok2 = __shfl_xor(bk, o, 64);
+            if (ov > best || (ov == best && ok2 < bk)) { best = ov; bk = ok2; }
+        }
+        bk = bk == 0x7fffffff ? 0 : bk;                  // (every logit NaN: class 0, like the scan of the lane = point form)
+        const float lse1 = hd_mm_softmax<RT>(L1, K1, g), lse2 = hd_mm_softmax<RT>(L2, K1, g);
+        if (valid && g == 0) pred[(size_t)b * N + n] = (long long)bk;
+        if (ok && g == 0) { s1 += lse1 - pick1; s2 += lse2 - pick2; sc += 1.f; }
+    }
+    s1 = hd_wsum(s1); s2 = hd_wsum(s2); sc = hd_wsum(sc);
+    if (lane == 0) { wred[w * 4 + 0] = s1; wred[w * 4 + 1] = s2; wred[w * 4 + 2] = sc; }
+    __syncthreads();
+    if (tid < 3) part2[(size_t)(b * nchunk + chunk) * 4 + tid] = ((wred[tid] + wred[4 + tid]) + wred[8 + tid]) + wred[12 + tid];
+}
+
+// ------------------------------------------------------------------------------------------------ backward, pass 1
+// coefficient rows of the wave tile: head 1 at k, head 2 at KT + k (compact); part3 rows: head 1 at k, head 2 at R2 + k
+template <int KT, bool VEC>
+__global__ void __launch_bounds__(256, 1)
+hd_bwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+                  const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, const float *__restrict__ loss,
+                  const float *__restrict__ dloss, float *__restrict__ part3)
+{
+    constexpr int RT = (KT + 15) / 16, R2 = 2 * KT <= 32 ? KT : 32, NRW = 2 * KT, RTC = NRW / 16;
+    static_assert(NRW % 16 == 0, "coefficient rows in whole tiles");
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT;
+    float *slabs = q2 + KT * HD_LDT;                     // [4][32][68]
+    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][NRW][68]
+    float *red = cts + 4 * NRW * HD_LDS;                 // [4][NRW][33]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n0 = chunk * HD_PTS + w * 64;
+    const float *fb = feat + (size_t)b * bs;
+    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * NRW * HD_LDS;
+    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
+    for (int e = lane; e < NRW * HD_LDS; e += 64) ct[e] = 0.f;
+    hd_mm_load_table<KT>(q1, q1g, K1, tid);
+    hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    f32x4 acc[2][RT][4];
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *const tabs[2] = {q1, q2};
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) {
+        hd_slab_put(slab, g, j, rg[s]);
+        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
+        hd_mm_dots<KT, 2>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float cbase = HD_SCALE * 0.5f * dloss[0] / loss[1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 4 * j + t;
+        const bool valid = n < N;
+        const float rinv = 1.0f / fmaxf(sqrtf(hd_gsum(sq[t])), HD_EPS);
+        const long long y = label[(size_t)b * N + min(n, N - 1)];
+        const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+        const float coef = ok ? cbase : 0.f;
+        float L1[RT][4], L2[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { L1[rt][r] = acc[0][rt][t][r] * (HD_SCALE * rinv); L2[rt][r] = acc[1][rt][t][r] * (HD_SCALE * rinv); }
+        hd_mm_softmax<RT>(L1, K1, g);
+        hd_mm_softmax<RT>(L2, K1, g);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float oh = (long long)(16 * rt + 4 * r + g) == y ? 1.f : 0.f;
+                acc[0][rt][t][r] = coef * (L1[rt][r] - oh) * rinv;       // (in place; Fhat = F / |F|: the 1 / |F| rides in the A operand)
+                acc[1][rt][t][r] = coef * (L2[rt][r] - oh) * rinv;
+            }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + 4 * r + g;
+            if (k < K1) {
+                *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = f32x4{acc[0][rt][0][r], acc[0][rt][1][r], acc[0][rt][2][r], acc[0][rt][3][r]};
+                *reinterpret_cast<f32x4 *>(ct + (KT + k) * HD_LDS + 4 * j) = f32x4{acc[1][rt][0][r], acc[1][rt][1][r], acc[1][rt][2][r], acc[1][rt][3][r]};
+            }
+        }
+    float *part = part3 + (size_t)(b * nchunk + chunk) * 64 * HD_C;
+#pragma unroll
+    for (int s = 0; s < HD_NSLAB; ++s) {
+        hd_slab_put(slab, g, j, rg[s]);
+        __builtin_amdgcn_wave_barrier();
+        hd_mm_contract<RTC>(slab, ct, red, s, tid, part, [](int row) { return row < KT ? row : R2 + (row - KT); });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward, pass 2
+// d F from all four paths, written once; part4 rows k: sum_n gl3[k][n] Fhat[c][n]  (gl3 = the gradient of cos(F, [bg; main]))
+template <int KT, bool VEC>
+__global__ void __launch_bounds__(256, 1)
+hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
+                  const float *__restrict__ q1g, const float *__restrict__ q2g, const float *__restrict__ main_proto, const float *__restrict__ bg,
+                  int K1, const HeadFake fk, const float *__restrict__ loss, const float *__restrict__ dloss, const float *__restrict__ hs,
+                  const float *__restrict__ dpoolg, const float *__restrict__ t3g, const float *__restrict__ dfsum,
+                  float *__restrict__ dfeat, float *__restrict__ part4)
+{
+    constexpr int RT = (KT + 15) / 16, FT = GFS3D_HEAD_MAX_FAKE;
+    constexpr bool HOLD = RT == 1;                       // two row tiles: 288 coefficient / accumulator registers - two slabs in flight, each sweep fetches the tile
+    constexpr int NB = HOLD ? HD_NSLAB : 2;
+    static_assert(FT == 16, "the fake-novel rows are one 16-row tile");
+    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
+    float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT, *q3 = q2 + KT * HD_LDT, *dpl = q3 + KT * HD_LDT;     // four [KT][132] tables
+    float *dfs = dpl + KT * HD_LDT;                      // [16][132]  d fsum rows (support half only)
+    float *slabs = dfs + FT * HD_LDT;                    // [4][32][68]
+    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][16 RT][68]
+    float *red = cts + 4 * 16 * RT * HD_LDS;             // [4][16 RT][33]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int n0 = chunk * HD_PTS + w * 64;
+    const float *fb = feat + (size_t)b * bs;
+    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * 16 * RT * HD_LDS;
+    const bool support = fk.n > 0 && b >= fk.half;       // (workgroup-uniform)
+    f32x4 rg[NB][8];                                     // HOLD: the wave's whole 128 x 64 tile, every load in flight at once, kept for both sweeps
+#pragma unroll
+    for (int s = 0; s < NB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
+    for (int e = lane; e < 16 * RT * HD_LDS; e += 64) ct[e] = 0.f;
+    for (int e = tid; e < FT * (HD_C / 4); e += 256) {   // d fsum rows: [fake class][128 | count] -> [f][132]
+        const int row = e >> 5, c4 = e & 31;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (support && row < fk.n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = dfsum[row * HD_FLD + 4 * c4 + i];
+        }
+        *reinterpret_cast<f32x4 *>(dfs + row * HD_LDT + 4 * c4) = v;
+    }
+    hd_mm_load_table<KT>(q1, q1g, K1, tid);
+    hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
+    hd_mm_load_table<KT>(dpl, dpoolg + (size_t)b * KT * HD_C, K1, tid);
+    hd_mm_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
+    f32x4 acc[4][RT][4], accf[1][1][4];
+    float sq[4] = {0.f, 0.f, 0.f, 0.f}, sqf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[tb][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accf[0][0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *const tabs[4] = {q1, q2, q3, dpl};
+    const float *const tabf[1] = {dfs};
+#pragma unroll 1
+    for (int s2 = 0; s2 < HD_NSLAB / NB; ++s2)
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+        const int s = s2 * NB + h;
+        hd_slab_put(slab, g, j, rg[h]);
+        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
+        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<VEC>(fb, N, n0, s + NB, g, j, rg[h]);
+        hd_mm_dots<KT, 4>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        if (support) hd_mm_dots<16, 1>(slab, tabf, HD_SLAB_C * s, g, j, accf, sqf);       // <F_n, d fsum[f]>
+        __builtin_amdgcn_wave_barrier();
+    }
+    // per point: the coefficient rows of d F (the B operands of its K-steps) take the place of the dot products they are made of -
+    // acc[table][rt][t][r] -, and the scalar of the -F term
+    const float cbase = HD_SCALE * 0.5f * dloss[0] / loss[1];
+    float scl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 4 * j + t;
+        const bool valid = n < N;
+        const float nrm = sqrtf(hd_gsum(sq[t]));
+        const float rinv = 1.0f / fmaxf(nrm, HD_EPS);
+        const long long y = label[(size_t)b * N + min(n, N - 1)];
+        const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
+        const float coef = ok ? cbase : 0.f;
+        float ca[RT][4], cb[RT][4], L1[RT][4], L2[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ca[rt][r] = acc[0][rt][t][r] * rinv; cb[rt][r] = acc[1][rt][t][r] * rinv;
+                L1[rt][r] = ca[rt][r] * HD_SCALE; L2[rt][r] = cb[rt][r] * HD_SCALE;
+            }
+        hd_mm_softmax<RT>(L1, K1, g);
+        hd_mm_softmax<RT>(L2, K1, g);
+        float tsum = 0.f;                                // <Fhat, dFhat> = sum over the three cosine paths of g[k] cos[k]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * rt + 4 * r + g;
+                const float oh = (long long)k == y ? 1.f : 0.f;
+                const float g1 = coef * (L1[rt][r] - oh), g2 = coef * (L2[rt][r] - oh);
+                tsum = fmaf(g1, ca[rt][r], fmaf(g2, cb[rt][r], tsum));
+                const bool in = k >= 1 && k < K1;
+                const float skv = in ? 1.0f / hs[((size_t)b * KT + k) * HD_HS] : 0.f;
+                const float tkv = k < K1 ? t3g[(size_t)b * KT + k] : 0.f;
+                const float c3 = acc[2][rt][t][r] * rinv;
+                const float resp = (valid && in) ? __expf(HD_SCALE * c3 - HD_SHIFT) * skv : 0.f;      // softmax over the points
+                const float gl = HD_SCALE * resp * (acc[3][rt][t][r] - tkv);                         // acc[3] = <dpool[k], F_n> (raw features)
+                tsum = fmaf(gl, c3, tsum);
+                acc[0][rt][t][r] = g1 * rinv;
+                acc[1][rt][t][r] = g2 * rinv;
+                acc[2][rt][t][r] = gl * rinv;
+                acc[3][rt][t][r] = resp;
+            }
+        tsum = hd_gsum(tsum);
+        // the fake-novel mean path: this point contributes F / (|F| + eps) to fsum[fi]
+        float fa1 = 0.f, fa2 = 0.f;
+        int fi = -1;
+        if (support) {                                   // (uniform)
+            fi = valid ? hd_fake_index(fk, y) : -1;
+            float tf = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tf = (4 * r + g) == fi ? accf[0][0][t][r] : tf;
+            tf = hd_gsum(tf);
+            const float re = nrm + HD_EPS;
+            fa1 = fi >= 0 ? 1.0f / re : 0.f;
+            fa2 = fi >= 0 ? tf / (fmaxf(nrm, 1e-30f) * re * re) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accf[0][0][t][r] = (4 * r + g) == fi ? fa1 : 0.f;
+        scl[t] = fmaf(tsum * rinv, rinv, fa2);           // dF = (dFhat - Fhat <Fhat, dFhat>) / |F| + ..., Fhat = F / |F|
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + 4 * r + g;
+            if (k < K1) *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = f32x4{acc[2][rt][0][r], acc[2][rt][1][r], acc[2][rt][2][r], acc[2][rt][3][r]};
+        }
+    if (!HOLD) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);     // (no registers for them during the per-point arithmetic)
+    }
+    float *part = part4 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
+    float *dfb = dfeat + (size_t)b * HD_C * N;
+#pragma unroll 1
+    for (int s2 = 0; s2 < HD_NSLAB / NB; ++s2)
+#pragma unroll
+    for (int h = 0; h < NB; ++h) {
+        const int s = s2 * NB + h;
+        hd_slab_put(slab, g, j, rg[h]);
+        __builtin_amdgcn_wave_barrier();
+        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<VEC>(fb, N, n0, s + NB, g, j, rg[h]);
+        // d F of the slab's channels: tile m (0, 1), row i = 4 g + r of column j <-> channel 32 s + 2 i + m, point 4 j + t
+        f32x4 da[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) da[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {            // K-step: k = g <-> class 16 rt + 4 r + g of table tb
+                    const float *trow = tabs[tb] + min(16 * rt + 4 * r + g, KT - 1) * HD_LDT + HD_SLAB_C * s + 2 * j;
+                    const float a0 = trow[0], a1 = trow[1];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (HD_ABL & 16) continue;
+                        da[0][t] = hd_mfma16(a0, acc[tb][rt][t][r], da[0][t]);
+                        da[1][t] = hd_mfma16(a1, acc[tb][rt][t][r], da[1][t]);
+                    }
+                }
+        if (support) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *trow = dfs + (4 * r + g) * HD_LDT + HD_SLAB_C * s + 2 * j;
+                const float a0 = trow[0], a1 = trow[1];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    da[0][t] = hd_mfma16(a0, accf[0][0][t][r], da[0][t]);
+                    da[1][t] = hd_mfma16(a1, accf[0][0][t][r], da[1][t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int cl = 2 * (4 * g + r) + m;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + cl * HD_LDS + 4 * j);
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = fmaf(-v[t], scl[t], da[m][t][r]);
+                float *dst = dfb + (size_t)(HD_SLAB_C * s + cl) * N + n0 + 4 * j;
+                if (HD_ABL & 32) { if (o[0] == 1.2345f) dst[0] = o[1]; }
+                else if (VEC) { if (n0 + 4 * j < N) *reinterpret_cast<f32x4 *>(dst) = o; }
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (n0 + 4 * j + t < N) dst[t] = o[t];
+                }
+            }
+        hd_mm_contract<RT>(slab, ct, red, s, tid, part, [](int row) { return row; });
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, pass 1
 // part1[(b nchunk + chunk)][32][128]: rows k < K1: sum_n e[k][n] F[c][n]; rows K1 + f: sum_n [support, y_n = fake f] F[c][n] / (|F_n| + eps)
 // sums1[(b nchunk + chunk)][32]:      rows k < K1: sum_n e[k][n];        rows K1 + f: the number of such points
@@ -316,8 +962,6 @@ hd_mid1_kernel(const float *__restrict__ part1, const float *__restrict__ sums1,
     }
 }
 
-// per-item state of the refinement kept for the backward: hs[(b KT + k)][8] = {s, w, cos, |pooled|, |refined|, -, -, -}
-constexpr int HD_HS = 8;
 // grid = (B, ceil(K1 / 4)), 4 waves = 4 rows k; a lane owns channels lane and lane + 64
 template <int KT>
 __global__ void __launch_bounds__(256)
@@ -931,6 +1575,44 @@ int hd_check(const gfs3d_capl_head_args *a, const char *who, HeadFake &fk)
     return GFS3D_OK;
 }
 
+// GFS3D_HEAD_V1=1 selects the lane = point passes of rounds 3-4 (kept for the A/B in DESIGN_HISTORY.md)
+static bool hd_v1()
+{
+    static const bool v = [] { const char *e = getenv("GFS3D_HEAD_V1"); return e && e[0] == '1'; }();
+    return v;
+}
+// 16-byte accesses along the points: whole groups of four inside every channel row
+static bool hd_vec_ok(const void *p, long long bstride, int N)
+{
+    return N % 4 == 0 && bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+constexpr size_t hd_lds_fwd1(int KT) { return sizeof(float) * ((size_t)KT * HD_LDT + 4 * HD_SLAB_F + 4 * 32 * HD_LDS + 4 * 32 * 33 + 128); }
+constexpr size_t hd_lds_fwd2(int KT) { return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HD_SLAB_F + 16); }
+constexpr size_t hd_lds_bwd1(int KT) { return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HD_SLAB_F + 4 * 2 * KT * HD_LDS + 4 * 2 * KT * 33); }
+constexpr size_t hd_lds_bwd2(int KT)
+{
+    return sizeof(float) * ((size_t)(4 * KT + GFS3D_HEAD_MAX_FAKE) * HD_LDT + 4 * HD_SLAB_F + 4 * 16 * ((KT + 15) / 16) * (HD_LDS + 33));
+}
+
+template <int KT>
+int hd_launch_fwd1(const float *feat, long long bs, int N, const long long *label, const float *main_proto, const float *bg, int K1,
+                   const HeadFake &fk, float *part1, float *sums1, dim3 grid, hipStream_t st, const char *who)
+{
+    if (hd_v1()) {
+        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
+        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+    } else if (hd_vec_ok(feat, bs, N)) {
+        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, true>), hd_lds_fwd1(KT), who);
+        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, true>), grid, dim3(256), hd_lds_fwd1(KT), st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+    } else {
+        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, false>), hd_lds_fwd1(KT), who);
+        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, false>), grid, dim3(256), hd_lds_fwd1(KT), st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+    }
+    GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
+    return GFS3D_OK;
+}
+
 template <int KT>
 int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
 {
@@ -942,11 +1624,8 @@ int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, con
     const dim3 grid(p.nchunk, a->B);
     const long long *label = reinterpret_cast<const long long *>(a->label);
     if (phase == 0) {
-        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
-        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, a->main_proto, a->bg_proto, K1,
-                           fk, F(p.off_part), F(p.off_sums1));
-        GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
+        if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, label, a->main_proto, a->bg_proto, K1, fk, F(p.off_part), F(p.off_sums1), grid, st, who))
+            return rc;
         if (fk.n > 0) {
             hipLaunchKernelGGL(hd_mid1_kernel, dim3(fk.n), dim3(1024), 0, st, F(p.off_part), F(p.off_sums1), a->B, p.nchunk, K1, fk.half, a->fsum);
             GFS3D_LAUNCH_CHECK("hd_mid1_kernel");
@@ -957,10 +1636,20 @@ int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, con
     hipLaunchKernelGGL((hd_mid2_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk, a->main_proto, a->bg_proto, K1,
                        a->base_num, fk, a->fsum, F(p.off_q1), F(p.off_q2), F(p.off_ori), F(p.off_onrm), F(p.off_pooled), F(p.off_hs));
     GFS3D_LAUNCH_CHECK("hd_mid2_kernel");
-    const size_t lds = sizeof(float) * (2 * KT * HD_C + 16);
-    GFS3D_ENSURE_LDS((hd_fwd2_kernel<KT>), lds, who);
-    hipLaunchKernelGGL((hd_fwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
-                       F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+    if (hd_v1()) {
+        const size_t lds = sizeof(float) * (2 * KT * HD_C + 16);
+        GFS3D_ENSURE_LDS((hd_fwd2_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_fwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
+                           F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+    } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
+        GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, true>), hd_lds_fwd2(KT), who);
+        hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, true>), grid, dim3(256), hd_lds_fwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
+                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+    } else {
+        GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, false>), hd_lds_fwd2(KT), who);
+        hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, false>), grid, dim3(256), hd_lds_fwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
+                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+    }
     GFS3D_LAUNCH_CHECK("hd_fwd2_kernel");
     hipLaunchKernelGGL(hd_loss_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * p.nchunk, a->loss);
     GFS3D_LAUNCH_CHECK("hd_loss_kernel");
@@ -980,10 +1669,20 @@ int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, co
     const long long *label = reinterpret_cast<const long long *>(a->label);
     GFS3D_REQUIRE(a->dloss && a->dfsum && a->dfeat && a->dmain && a->dbg, "%s: NULL gradient buffer", who);
     if (phase == 0) {
-        const size_t lds = sizeof(float) * (2 * KT * HD_C + 4 * (RT + 1) * 32 * HD_LD);
-        GFS3D_ENSURE_LDS((hd_bwd1_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_bwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index,
-                           F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+        if (hd_v1()) {
+            const size_t lds = sizeof(float) * (2 * KT * HD_C + 4 * (RT + 1) * 32 * HD_LD);
+            GFS3D_ENSURE_LDS((hd_bwd1_kernel<KT>), lds, who);
+            hipLaunchKernelGGL((hd_bwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index,
+                               F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+        } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
+            GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, true>), hd_lds_bwd1(KT), who);
+            hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, true>), grid, dim3(256), hd_lds_bwd1(KT), st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+        } else {
+            GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, false>), hd_lds_bwd1(KT), who);
+            hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, false>), grid, dim3(256), hd_lds_bwd1(KT), st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+        }
         GFS3D_LAUNCH_CHECK("hd_bwd1_kernel");
         hipLaunchKernelGGL((hd_bwdm1_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), p.nchunk, a->main_proto, a->bg_proto, K1, a->base_num,
                            F(p.off_q2), F(p.off_pooled), F(p.off_hs), F(p.off_dbgp), F(p.off_dorip), F(p.off_dPp), F(p.off_dpool), F(p.off_t3));
@@ -993,11 +1692,23 @@ int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, co
         GFS3D_LAUNCH_CHECK("hd_bwdm2_kernel");
         return GFS3D_OK;
     }
-    const size_t lds = sizeof(float) * (4 * KT * HD_C + 8 * 32 * HD_LD + GFS3D_HEAD_MAX_FAKE * HD_FLD + 2 * KT);
-    GFS3D_ENSURE_LDS((hd_bwd2_kernel<KT>), lds, who);
-    hipLaunchKernelGGL((hd_bwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
-                       F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs), F(p.off_dpool), F(p.off_t3), a->dfsum,
-                       a->dfeat, F(p.off_part));
+    if (hd_v1()) {
+        const size_t lds = sizeof(float) * (4 * KT * HD_C + 8 * 32 * HD_LD + GFS3D_HEAD_MAX_FAKE * HD_FLD + 2 * KT);
+        GFS3D_ENSURE_LDS((hd_bwd2_kernel<KT>), lds, who);
+        hipLaunchKernelGGL((hd_bwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
+                           F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs), F(p.off_dpool), F(p.off_t3), a->dfsum,
+                           a->dfeat, F(p.off_part));
+    } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N) && hd_vec_ok(a->dfeat, 0, a->N)) {
+        GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, true>), hd_lds_bwd2(KT), who);
+        hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, true>), grid, dim3(256), hd_lds_bwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
+                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
+                           F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
+    } else {
+        GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, false>), hd_lds_bwd2(KT), who);
+        hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, false>), grid, dim3(256), hd_lds_bwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
+                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
+                           F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
+    }
     GFS3D_LAUNCH_CHECK("hd_bwd2_kernel");
     hipLaunchKernelGGL(hd_bwdfin_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B * p.nchunk, a->main_proto, a->bg_proto, F(p.off_dbga),
                        F(p.off_dmaina), a->dbg, a->dmain);
@@ -1063,13 +1774,8 @@ static int hd_eval(const gfs3d_capl_eval_args *a, const char *who)
     const dim3 grid(p.nchunk, a->B);
     HeadFake fk{};
     fk.n = 0; fk.half = a->B;
-    {
-        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
-        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, (const long long *)nullptr,
-                           a->main_proto, (const float *)nullptr, K1, fk, F(p.off_part), F(p.off_sums1));
-        GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
-    }
+    if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, nullptr, a->main_proto, nullptr, K1, fk, F(p.off_part), F(p.off_sums1), grid, st, who))
+        return rc;
     hipLaunchKernelGGL((hd_mid2_eval_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk,
                        a->main_proto, a->gened_proto, K1, a->base_num, F(p.off_q2));
     GFS3D_LAUNCH_CHECK("hd_mid2_eval_kernel");
