@@ -225,25 +225,51 @@ __device__ __forceinline__ void hd_reduce_store(const f32x16 (&acc)[RT], float *
 //   dots         D[class][point]   = sum_c T[class][c] F[c][point]            (A = table, B = features, k = channel)
 //   contractions D[row][channel]   = sum_p A[row][p] F[channel][p]            (A = per-point coefficients, B = features, k = point)
 //   d F          D[channel][point] = sum_slot T[slot][channel] coef[slot][p]  (A = tables, B = coefficients, k = class slot)
-// A wave owns 64 points; lane = 16 g + j.  Point tile t (0..3) has column j <-> point 4 j + t, so ONE 16-byte access per lane
-// covers the four tiles; a 16x16 result tile leaves rows 4 g + r (r = 0..3) of column j in lane (g, j).  The table rows are
-// fed permuted (A row i <-> class 4 (i & 3) + (i >> 2)), so lane (g, j) ends up with the classes k = 16 rt + 4 r + g of its four
-// points: exactly the B operand of K-step (rt, r) of the d F product - the per-point arithmetic (soft-max, cross-entropy,
-// gradient coefficients) runs on those registers with two cross-lane steps (lanes 16 and 32 apart) per class reduction,
-// and nothing goes back through LDS except the coefficient rows of the point contractions.
-// The features travel in slabs of 32 channels x 64 points per wave (16-byte global loads: four channel rows of 256 B per
-// instruction, all 32 of a wave's loads issued up front - 32 KB in flight per wave - and the tile kept in registers for the second
-// sweep of a pass), rows 68 floats apart in LDS: conflict-free for the
-// 16-byte reads along the points (B of the dots, epilogue of d F) and for the reads along the channels (B of the contractions).
+// A wave owns 16 NTL points (NTL = 2 or 4 point tiles); lane = 16 g + j.  Point tile t has column j <-> point NTL j + t, so ONE
+// access per lane covers all tiles; a 16x16 result tile leaves rows 4 g + r (r = 0..3) of column j in lane (g, j).  The table
+// rows are fed permuted (A row i <-> class 4 (i & 3) + (i >> 2)), so lane (g, j) ends up with the classes k = 16 rt + 4 r + g of
+// its points: exactly the B operand of K-step (rt, r) of the d F product - the per-point arithmetic (soft-max, cross-entropy,
+// gradient coefficients) runs on those registers, IN PLACE, with two cross-lane steps (lanes 16 and 32 apart) per class
+// reduction, and nothing goes back through LDS except the coefficient rows of the point contractions.
+// The features travel in slabs of 32 channels per wave (16-byte global loads, all of a wave's loads issued up front and the tile
+// kept in registers for the second sweep of a pass), rows 16 NTL + 4 floats apart in LDS: conflict-free for the reads along the
+// points (B of the dots, epilogue of d F) and for the 16-byte reads along the channels' points (B of the contractions).
+// NTL = 2 wherever two workgroups then fit a CU (LDS): the phases of a pass (loads, dot MFMAs, per-point arithmetic, d F MFMAs,
+// stores) do not overlap inside a wave - measured, they add - so a second wave per SIMD is what overlaps them.
 // =====================================================================================================================
 #ifndef HD_ABL
 #define HD_ABL 0                                 // ablation builds only (scripts/build_ablation.sh): 1 no dot MFMAs, 2 no feature loads, 8 no contraction, 16 no d F MFMAs, 32 no d F stores
 #endif
 constexpr int HD_LDT = HD_C + 4;                 // table row stride (floats): 16-byte reads of 16 rows hit 16 different slots
-constexpr int HD_LDS = 68;                       // slab / coefficient-tile row stride (floats)
 constexpr int HD_SLAB_C = 32;                    // channels per slab
-constexpr int HD_SLAB_F = HD_SLAB_C * HD_LDS;    // floats of one wave's slab
 constexpr int HD_NSLAB = HD_C / HD_SLAB_C;
+template <int NTL> struct HdT {
+    static_assert(NTL == 2 || NTL == 4, "two or four point tiles per wave");
+    typedef float V __attribute__((ext_vector_type(NTL)));      // one value per point tile of a lane
+    static constexpr int PW = 16 * NTL;          // points per wave
+    static constexpr int PTS = 4 * PW;           // points per workgroup
+    static constexpr int LD = PW + 4;            // slab / coefficient-tile row stride (floats)
+    static constexpr int SLAB = HD_SLAB_C * LD;  // floats of one wave's slab
+    static constexpr int LPR = PW / 4;           // lanes per channel row of a 16-byte fetch
+    static constexpr int RPI = 64 / LPR;         // channel rows per fetch instruction
+    static constexpr int NF = HD_SLAB_C / RPI;   // fetches per slab and lane
+};
+
+template <int KT, int NTL> constexpr size_t hd_lds_fwd1()
+{
+    return sizeof(float) * ((size_t)KT * HD_LDT + 4 * HdT<NTL>::SLAB + 4 * 32 * HdT<NTL>::LD + 4 * 32 * 33 + 128);
+}
+template <int KT, int NTL> constexpr size_t hd_lds_fwd2() { return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HdT<NTL>::SLAB + 16); }
+template <int KT, int NTL> constexpr size_t hd_lds_bwd1()
+{
+    return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HdT<NTL>::SLAB + 4 * 2 * KT * HdT<NTL>::LD + 4 * 2 * KT * 33);
+}
+template <int KT, int NTL> constexpr size_t hd_lds_bwd2()
+{
+    return sizeof(float) * ((size_t)(4 * KT + GFS3D_HEAD_MAX_FAKE) * HD_LDT + 4 * HdT<NTL>::SLAB + 4 * 16 * ((KT + 15) / 16) * (HdT<NTL>::LD + 33));
+}
+// workgroups per CU the LDS allows (the register budget of __launch_bounds__ follows it)
+constexpr int hd_occ(size_t lds) { return 2 * lds <= 160 * 1024 ? 2 : 1; }
 
 __device__ __forceinline__ float hd_gsum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }   // over g: the 4 lanes of a column
 __device__ __forceinline__ float hd_gmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
@@ -283,34 +309,40 @@ __device__ __forceinline__ void hd_mm_load_bgmain_unit(float *dst, const float *
     __syncthreads();
 }
 
-// slab s of the wave's 64 points: lane (g, j) holds channels 32 s + 4 i + g (i = 0..7) of the points n0 + 4 j .. + 3.
-// VEC: N % 4 == 0 and 16-byte aligned rows; a group past N reads the last four points (its coefficients are zero).
-template <bool VEC>
-__device__ __forceinline__ void hd_slab_fetch(const float *fb, int N, int n0, int s, int g, int j, f32x4 (&r)[8])
+// slab s of the wave's points: fetch i of lane (rr = lane / LPR, q = lane % LPR) holds channel 32 s + RPI i + rr, points
+// n0 + 4 q .. + 3.  VEC: N % 4 == 0 and 16-byte aligned rows; a group past N reads the last four points (its coefficients are zero).
+template <int NTL, bool VEC>
+__device__ __forceinline__ void hd_slab_fetch(const float *fb, int N, int n0, int s, int lane, f32x4 (&r)[HdT<NTL>::NF])
 {
+    typedef HdT<NTL> T;
+    const int q = lane % T::LPR, rr = lane / T::LPR;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float *row = fb + (size_t)(HD_SLAB_C * s + 4 * i + g) * N;
+    for (int i = 0; i < T::NF; ++i) {
+        const float *row = fb + (size_t)(HD_SLAB_C * s + T::RPI * i + rr) * N;
         if (HD_ABL & 2) r[i] = f32x4{0.5f, 0.25f, 1.f, 2.f};
-        else if (VEC) r[i] = hd_ldg4(row + min(n0 + 4 * j, N - 4));
+        else if (VEC) r[i] = hd_ldg4(row + min(n0 + 4 * q, N - 4));
         else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) r[i][t] = row[min(n0 + 4 * j + t, N - 1)];
+            for (int e = 0; e < 4; ++e) r[i][e] = row[min(n0 + 4 * q + e, N - 1)];
         }
     }
 }
-__device__ __forceinline__ void hd_slab_put(float *slab, int g, int j, const f32x4 (&r)[8])
+template <int NTL>
+__device__ __forceinline__ void hd_slab_put(float *slab, int lane, const f32x4 (&r)[HdT<NTL>::NF])
 {
+    typedef HdT<NTL> T;
+    const int q = lane % T::LPR, rr = lane / T::LPR;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(slab + (4 * i + g) * HD_LDS + 4 * j) = r[i];
+    for (int i = 0; i < T::NF; ++i) *reinterpret_cast<f32x4 *>(slab + (T::RPI * i + rr) * T::LD + 4 * q) = r[i];
 }
 
 // acc[tb][rt][t] += T_tb[class][c] F[c][point] over the 32 channels of the slab; sq[t] += this lane's share of |F|^2
 // (K-step (u, e), k = g <-> channel 16 u + 4 g + e of the slab; table rows past KT - 1 repeat the last row: masked by k < K1)
-template <int KT, int NT>
+template <int KT, int NT, int NTL>
 __device__ __forceinline__ void hd_mm_dots(const float *slab, const float *const (&tab)[NT], int cbase, int g, int j,
-                                           f32x4 (&acc)[NT][(KT + 15) / 16][4], float (&sq)[4])
+                                           f32x4 (&acc)[NT][(KT + 15) / 16][NTL], float (&sq)[NTL])
 {
+    typedef HdT<NTL> T;
     constexpr int RT = (KT + 15) / 16;
     const int prow = 4 * (j & 3) + (j >> 2);
 #pragma unroll
@@ -323,27 +355,28 @@ __device__ __forceinline__ void hd_mm_dots(const float *slab, const float *const
                 a[tb][rt] = *reinterpret_cast<const f32x4 *>(tab[tb] + min(16 * rt + prow, KT - 1) * HD_LDT + cbase + 16 * u + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(slab + (16 * u + 4 * g + e) * HD_LDS + 4 * j);
+            const typename T::V bv = *reinterpret_cast<const typename T::V *>(slab + (16 * u + 4 * g + e) * T::LD + NTL * j);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) sq[t] = fmaf(bv[t], bv[t], sq[t]);
+            for (int t = 0; t < NTL; ++t) sq[t] = fmaf(bv[t], bv[t], sq[t]);
 #pragma unroll
             for (int tb = 0; tb < NT; ++tb)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < NTL; ++t)
                         if (!(HD_ABL & 1)) acc[tb][rt][t] = hd_mfma16(a[tb][rt][e], bv[t], acc[tb][rt][t]);
         }
     }
 }
 
-// The point contraction of one slab: D[row][channel] = sum over the wave's 64 points of ct[row][p] slab[channel][p] for the
+// The point contraction of one slab: D[row][channel] = sum over the wave's points of ct[row][p] slab[channel][p] for the
 // 16 RTC rows of the wave's coefficient tile, the four waves' tiles added in wave order and stored:
 // part[rowmap(row)][32 s + c].  Ends with a barrier (the slab and `red` are free again).
-template <int RTC, typename RowMap>
+template <int RTC, int NTL, typename RowMap>
 __device__ __forceinline__ void hd_mm_contract(const float *slab, const float *ct, float *red /* [4][16 RTC][33] */, int s, int tid,
                                                float *part, RowMap rowmap)
 {
+    typedef HdT<NTL> T;
     const int lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     f32x4 acc[RTC][2];
 #pragma unroll
@@ -351,12 +384,12 @@ __device__ __forceinline__ void hd_mm_contract(const float *slab, const float *c
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[rt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                    // K-step (u, e), k = g <-> point 16 u + 4 g + e
+    for (int u = 0; u < NTL; ++u) {                  // K-step (u, e), k = g <-> point 16 u + 4 g + e of the wave
         f32x4 a[RTC], bm[2];
 #pragma unroll
-        for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(ct + (16 * rt + j) * HD_LDS + 16 * u + 4 * g);
+        for (int rt = 0; rt < RTC; ++rt) a[rt] = *reinterpret_cast<const f32x4 *>(ct + (16 * rt + j) * T::LD + 16 * u + 4 * g);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) bm[m] = *reinterpret_cast<const f32x4 *>(slab + (16 * m + j) * HD_LDS + 16 * u + 4 * g);
+        for (int m = 0; m < 2; ++m) bm[m] = *reinterpret_cast<const f32x4 *>(slab + (16 * m + j) * T::LD + 16 * u + 4 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -380,79 +413,97 @@ __device__ __forceinline__ void hd_mm_contract(const float *slab, const float *c
     __syncthreads();
 }
 
+// one value per point tile -> the lane's part of a coefficient row
+template <int NTL, int RT>
+__device__ __forceinline__ typename HdT<NTL>::V hd_row_of(const f32x4 (&a)[RT][NTL], int rt, int r)
+{
+    typename HdT<NTL>::V v;
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) v[t] = a[rt][t][r];
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ forward, pass 1
-template <int KT, bool VEC>
-__global__ void __launch_bounds__(256, 1)
+template <int KT, int NTL, bool VEC>
+__global__ void __launch_bounds__(256, hd_occ(hd_lds_fwd1<KT, NTL>()))
 hd_fwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, const float *__restrict__ main_proto,
                   const float *__restrict__ bg, int K1, const HeadFake fk, float *__restrict__ part1, float *__restrict__ sums1)
 {
+    typedef HdT<NTL> T;
+    typedef typename T::V V;
     constexpr int RT = (KT + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float hd_smem[];
     float *q3 = hd_smem;                                 // [KT][132]
-    float *slabs = q3 + KT * HD_LDT;                     // [4][32][68]
-    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][32][68]   rows k < K1: e;  rows K1 + f: the fake-novel weights
-    float *red = cts + 4 * 32 * HD_LDS;                  // [4][32][33]
+    float *slabs = q3 + KT * HD_LDT;                     // [4][32][LD]
+    float *cts = slabs + 4 * T::SLAB;                    // [4][32][LD]   rows k < K1: e;  rows K1 + f: the fake-novel weights
+    float *red = cts + 4 * 32 * T::LD;                   // [4][32][33]
     float *wsums = red + 4 * 32 * 33;                    // [4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n0 = chunk * HD_PTS + w * 64;
+    const int n0 = chunk * T::PTS + w * T::PW;
     const float *fb = feat + (size_t)b * bs;
-    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * 32 * HD_LDS;
-    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+    float *slab = slabs + w * T::SLAB, *ct = cts + w * 32 * T::LD;
+    f32x4 rg[HD_NSLAB][T::NF];                           // the wave's whole 128-channel tile: every load in flight at once, kept for both sweeps
 #pragma unroll
-    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
-    for (int e = lane; e < 32 * HD_LDS; e += 64) ct[e] = 0.f;
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<NTL, VEC>(fb, N, n0, s, lane, rg[s]);
+    for (int e = lane; e < 32 * T::LD; e += 64) ct[e] = 0.f;
     if (lane < 32) wsums[w * 32 + lane] = 0.f;
     hd_mm_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
-    f32x4 acc[1][RT][4];
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[1][RT][NTL];
+    float sq[NTL];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int t = 0; t < NTL; ++t) {
+        sq[t] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[0][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) acc[0][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float *const tabs[1] = {q3};
 #pragma unroll
     for (int s = 0; s < HD_NSLAB; ++s) {
-        hd_slab_put(slab, g, j, rg[s]);
+        hd_slab_put<NTL>(slab, lane, rg[s]);
         __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
-        hd_mm_dots<KT, 1>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        hd_mm_dots<KT, 1, NTL>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
         __builtin_amdgcn_wave_barrier();
     }
-    float nrm[4], rn[4];
-    bool valid[4];
+    float nrm[NTL], rn[NTL];
+    bool valid[NTL];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTL; ++t) {
         nrm[t] = sqrtf(hd_gsum(sq[t]));
         rn[t] = 1.0f / fmaxf(nrm[t], HD_EPS);
-        valid[t] = n0 + 4 * j + t < N;
+        valid[t] = n0 + NTL * j + t < N;
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * rt + 4 * r + g;
-            f32x4 ev;
+            V ev;
+            float se = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ev[t] = (valid[t] && k < K1) ? __expf(HD_SCALE * acc[0][rt][t][r] * rn[t] - HD_SHIFT) : 0.f;
-            if (k < K1) *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = ev;
-            const float se = row16_sum((ev[0] + ev[1]) + (ev[2] + ev[3]));
+            for (int t = 0; t < NTL; ++t) {
+                ev[t] = (valid[t] && k < K1) ? __expf(HD_SCALE * acc[0][rt][t][r] * rn[t] - HD_SHIFT) : 0.f;
+                se += ev[t];
+            }
+            if (k < K1) *reinterpret_cast<V *>(ct + k * T::LD + NTL * j) = ev;
+            se = row16_sum(se);
             if (j == 0 && k < K1) wsums[w * 32 + k] = se;
         }
     if (fk.n > 0 && b >= fk.half) {                      // (workgroup-uniform)
-        int fi[4];
-        float rn2[4];
+        int fi[NTL];
+        float rn2[NTL];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const long long y = label[(size_t)b * N + min(n0 + 4 * j + t, N - 1)];
+        for (int t = 0; t < NTL; ++t) {
+            const long long y = label[(size_t)b * N + min(n0 + NTL * j + t, N - 1)];
             fi[t] = valid[t] ? hd_fake_index(fk, y) : -1;
             rn2[t] = 1.0f / (nrm[t] + HD_EPS);           // generate_fake_proto divides by (|f| + 1e-12)
         }
         for (int f = g; f < fk.n; f += 4) {
-            f32x4 v;
+            V v;
             float cnt = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { v[t] = fi[t] == f ? rn2[t] : 0.f; cnt += fi[t] == f ? 1.f : 0.f; }
-            *reinterpret_cast<f32x4 *>(ct + (K1 + f) * HD_LDS + 4 * j) = v;
+            for (int t = 0; t < NTL; ++t) { v[t] = fi[t] == f ? rn2[t] : 0.f; cnt += fi[t] == f ? 1.f : 0.f; }
+            *reinterpret_cast<V *>(ct + (K1 + f) * T::LD + NTL * j) = v;
             cnt = row16_sum(cnt);
             if (j == 0) wsums[w * 32 + K1 + f] = cnt;
         }
@@ -460,9 +511,9 @@ hd_fwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
     float *part = part1 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
 #pragma unroll
     for (int s = 0; s < HD_NSLAB; ++s) {
-        hd_slab_put(slab, g, j, rg[s]);
+        hd_slab_put<NTL>(slab, lane, rg[s]);
         __builtin_amdgcn_wave_barrier();
-        hd_mm_contract<2>(slab, ct, red, s, tid, part, [](int row) { return row; });
+        hd_mm_contract<2, NTL>(slab, ct, red, s, tid, part, [](int row) { return row; });
     }
     if (tid < 32) sums1[(size_t)(b * nchunk + chunk) * 32 + tid] = ((wsums[tid] + wsums[32 + tid]) + wsums[64 + tid]) + wsums[96 + tid];
 }
@@ -494,46 +545,49 @@ __device__ __forceinline__ float hd_mm_softmax(float (&L)[RT][4], int K1, int g)
 }
 
 // ------------------------------------------------------------------------------------------------ forward, pass 2
-template <int KT, bool VEC>
-__global__ void __launch_bounds__(256, 1)
+template <int KT, int NTL, bool VEC>
+__global__ void __launch_bounds__(256, hd_occ(hd_lds_fwd2<KT, NTL>()))
 hd_fwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
                   const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, float *__restrict__ part2, long long *__restrict__ pred)
 {
+    typedef HdT<NTL> T;
     constexpr int RT = (KT + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float hd_smem[];
     float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT;
-    float *slabs = q2 + KT * HD_LDT;                     // [4][32][68]
-    float *wred = slabs + 4 * HD_SLAB_F;                 // [4][4]
+    float *slabs = q2 + KT * HD_LDT;                     // [4][32][LD]
+    float *wred = slabs + 4 * T::SLAB;                   // [4][4]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n0 = chunk * HD_PTS + w * 64;
+    const int n0 = chunk * T::PTS + w * T::PW;
     const float *fb = feat + (size_t)b * bs;
-    float *slab = slabs + w * HD_SLAB_F;
-    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+    float *slab = slabs + w * T::SLAB;
+    f32x4 rg[HD_NSLAB][T::NF];
 #pragma unroll
-    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<NTL, VEC>(fb, N, n0, s, lane, rg[s]);
     hd_mm_load_table<KT>(q1, q1g, K1, tid);
     hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
-    f32x4 acc[2][RT][4];
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][RT][NTL];
+    float sq[NTL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int t = 0; t < NTL; ++t) {
+        sq[t] = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float *const tabs[2] = {q1, q2};
 #pragma unroll
     for (int s = 0; s < HD_NSLAB; ++s) {
-        hd_slab_put(slab, g, j, rg[s]);
-        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
-        hd_mm_dots<KT, 2>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        hd_slab_put<NTL>(slab, lane, rg[s]);
+        __builtin_amdgcn_wave_barrier();
+        hd_mm_dots<KT, 2, NTL>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
         __builtin_amdgcn_wave_barrier();
     }
     float s1 = 0.f, s2 = 0.f, sc = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 4 * j + t;
+    for (int t = 0; t < NTL; ++t) {
+        const int n = n0 + NTL * j + t;
         const bool valid = n < N;
         const float rn = HD_SCALE / fmaxf(sqrtf(hd_gsum(sq[t])), HD_EPS);
         const long long y = label[(size_t)b * N + min(n, N - 1)];
@@ -573,50 +627,54 @@ hd_fwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 
 // ------------------------------------------------------------------------------------------------ backward, pass 1
 // coefficient rows of the wave tile: head 1 at k, head 2 at KT + k (compact); part3 rows: head 1 at k, head 2 at R2 + k
-template <int KT, bool VEC>
-__global__ void __launch_bounds__(256, 1)
+template <int KT, int NTL, bool VEC>
+__global__ void __launch_bounds__(256, hd_occ(hd_lds_bwd1<KT, NTL>()))
 hd_bwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
                   const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, const float *__restrict__ loss,
                   const float *__restrict__ dloss, float *__restrict__ part3)
 {
+    typedef HdT<NTL> T;
+    typedef typename T::V V;
     constexpr int RT = (KT + 15) / 16, R2 = 2 * KT <= 32 ? KT : 32, NRW = 2 * KT, RTC = NRW / 16;
     static_assert(NRW % 16 == 0, "coefficient rows in whole tiles");
     extern __shared__ __attribute__((aligned(16))) float hd_smem[];
     float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT;
-    float *slabs = q2 + KT * HD_LDT;                     // [4][32][68]
-    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][NRW][68]
-    float *red = cts + 4 * NRW * HD_LDS;                 // [4][NRW][33]
+    float *slabs = q2 + KT * HD_LDT;                     // [4][32][LD]
+    float *cts = slabs + 4 * T::SLAB;                    // [4][NRW][LD]
+    float *red = cts + 4 * NRW * T::LD;                  // [4][NRW][33]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n0 = chunk * HD_PTS + w * 64;
+    const int n0 = chunk * T::PTS + w * T::PW;
     const float *fb = feat + (size_t)b * bs;
-    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * NRW * HD_LDS;
-    f32x4 rg[HD_NSLAB][8];                               // the wave's whole 128 x 64 tile: every load in flight at once, kept for both sweeps
+    float *slab = slabs + w * T::SLAB, *ct = cts + w * NRW * T::LD;
+    f32x4 rg[HD_NSLAB][T::NF];
 #pragma unroll
-    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
-    for (int e = lane; e < NRW * HD_LDS; e += 64) ct[e] = 0.f;
+    for (int s = 0; s < HD_NSLAB; ++s) hd_slab_fetch<NTL, VEC>(fb, N, n0, s, lane, rg[s]);
+    for (int e = lane; e < NRW * T::LD; e += 64) ct[e] = 0.f;
     hd_mm_load_table<KT>(q1, q1g, K1, tid);
     hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
-    f32x4 acc[2][RT][4];
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][RT][NTL];
+    float sq[NTL];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int t = 0; t < NTL; ++t) {
+        sq[t] = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt) acc[h][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float *const tabs[2] = {q1, q2};
 #pragma unroll
     for (int s = 0; s < HD_NSLAB; ++s) {
-        hd_slab_put(slab, g, j, rg[s]);
-        __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
-        hd_mm_dots<KT, 2>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        hd_slab_put<NTL>(slab, lane, rg[s]);
+        __builtin_amdgcn_wave_barrier();
+        hd_mm_dots<KT, 2, NTL>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
         __builtin_amdgcn_wave_barrier();
     }
     const float cbase = HD_SCALE * 0.5f * dloss[0] / loss[1];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 4 * j + t;
+    for (int t = 0; t < NTL; ++t) {
+        const int n = n0 + NTL * j + t;
         const bool valid = n < N;
         const float rinv = 1.0f / fmaxf(sqrtf(hd_gsum(sq[t])), HD_EPS);
         const long long y = label[(size_t)b * N + min(n, N - 1)];
@@ -644,49 +702,51 @@ hd_bwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * rt + 4 * r + g;
             if (k < K1) {
-                *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = f32x4{acc[0][rt][0][r], acc[0][rt][1][r], acc[0][rt][2][r], acc[0][rt][3][r]};
-                *reinterpret_cast<f32x4 *>(ct + (KT + k) * HD_LDS + 4 * j) = f32x4{acc[1][rt][0][r], acc[1][rt][1][r], acc[1][rt][2][r], acc[1][rt][3][r]};
+                *reinterpret_cast<V *>(ct + k * T::LD + NTL * j) = hd_row_of<NTL, RT>(acc[0], rt, r);
+                *reinterpret_cast<V *>(ct + (KT + k) * T::LD + NTL * j) = hd_row_of<NTL, RT>(acc[1], rt, r);
             }
         }
     float *part = part3 + (size_t)(b * nchunk + chunk) * 64 * HD_C;
 #pragma unroll
     for (int s = 0; s < HD_NSLAB; ++s) {
-        hd_slab_put(slab, g, j, rg[s]);
+        hd_slab_put<NTL>(slab, lane, rg[s]);
         __builtin_amdgcn_wave_barrier();
-        hd_mm_contract<RTC>(slab, ct, red, s, tid, part, [](int row) { return row < KT ? row : R2 + (row - KT); });
+        hd_mm_contract<RTC, NTL>(slab, ct, red, s, tid, part, [](int row) { return row < KT ? row : R2 + (row - KT); });
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward, pass 2
 // d F from all four paths, written once; part4 rows k: sum_n gl3[k][n] Fhat[c][n]  (gl3 = the gradient of cos(F, [bg; main]))
-template <int KT, bool VEC>
-__global__ void __launch_bounds__(256, 1)
+template <int KT, int NTL, bool VEC>
+__global__ void __launch_bounds__(256, hd_occ(hd_lds_bwd2<KT, NTL>()))
 hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
                   const float *__restrict__ q1g, const float *__restrict__ q2g, const float *__restrict__ main_proto, const float *__restrict__ bg,
                   int K1, const HeadFake fk, const float *__restrict__ loss, const float *__restrict__ dloss, const float *__restrict__ hs,
                   const float *__restrict__ dpoolg, const float *__restrict__ t3g, const float *__restrict__ dfsum,
                   float *__restrict__ dfeat, float *__restrict__ part4)
 {
+    typedef HdT<NTL> T;
+    typedef typename T::V V;
     constexpr int RT = (KT + 15) / 16, FT = GFS3D_HEAD_MAX_FAKE;
-    constexpr bool HOLD = RT == 1;                       // two row tiles: 288 coefficient / accumulator registers - two slabs in flight, each sweep fetches the tile
-    constexpr int NB = HOLD ? HD_NSLAB : 2;
     static_assert(FT == 16, "the fake-novel rows are one 16-row tile");
+    constexpr bool HOLD = RT == 1 || NTL == 2;           // two row tiles of four point tiles: 288 coefficient / accumulator registers - one slab ahead, each sweep fetches the tile
+    constexpr int NB = HOLD ? HD_NSLAB : 1;
     extern __shared__ __attribute__((aligned(16))) float hd_smem[];
     float *q1 = hd_smem, *q2 = q1 + KT * HD_LDT, *q3 = q2 + KT * HD_LDT, *dpl = q3 + KT * HD_LDT;     // four [KT][132] tables
     float *dfs = dpl + KT * HD_LDT;                      // [16][132]  d fsum rows (support half only)
-    float *slabs = dfs + FT * HD_LDT;                    // [4][32][68]
-    float *cts = slabs + 4 * HD_SLAB_F;                  // [4][16 RT][68]
-    float *red = cts + 4 * 16 * RT * HD_LDS;             // [4][16 RT][33]
+    float *slabs = dfs + FT * HD_LDT;                    // [4][32][LD]
+    float *cts = slabs + 4 * T::SLAB;                    // [4][16 RT][LD]
+    float *red = cts + 4 * 16 * RT * T::LD;              // [4][16 RT][33]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n0 = chunk * HD_PTS + w * 64;
+    const int n0 = chunk * T::PTS + w * T::PW;
     const float *fb = feat + (size_t)b * bs;
-    float *slab = slabs + w * HD_SLAB_F, *ct = cts + w * 16 * RT * HD_LDS;
+    float *slab = slabs + w * T::SLAB, *ct = cts + w * 16 * RT * T::LD;
     const bool support = fk.n > 0 && b >= fk.half;       // (workgroup-uniform)
-    f32x4 rg[NB][8];                                     // HOLD: the wave's whole 128 x 64 tile, every load in flight at once, kept for both sweeps
+    f32x4 rg[NB][T::NF];                                 // HOLD: the wave's whole 128-channel tile, every load in flight at once, kept for both sweeps
 #pragma unroll
-    for (int s = 0; s < NB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);
-    for (int e = lane; e < 16 * RT * HD_LDS; e += 64) ct[e] = 0.f;
+    for (int s = 0; s < NB; ++s) hd_slab_fetch<NTL, VEC>(fb, N, n0, s, lane, rg[s]);
+    for (int e = lane; e < 16 * RT * T::LD; e += 64) ct[e] = 0.f;
     for (int e = tid; e < FT * (HD_C / 4); e += 256) {   // d fsum rows: [fake class][128 | count] -> [f][132]
         const int row = e >> 5, c4 = e & 31;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -700,16 +760,17 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
     hd_mm_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
     hd_mm_load_table<KT>(dpl, dpoolg + (size_t)b * KT * HD_C, K1, tid);
     hd_mm_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
-    f32x4 acc[4][RT][4], accf[1][1][4];
-    float sq[4] = {0.f, 0.f, 0.f, 0.f}, sqf[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][RT][NTL], accf[1][1][NTL];
+    float sq[NTL], sqf[NTL];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb)
+    for (int t = 0; t < NTL; ++t) {
+        sq[t] = 0.f; sqf[t] = 0.f;
+        accf[0][0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[tb][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) accf[0][0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt) acc[tb][rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float *const tabs[4] = {q1, q2, q3, dpl};
     const float *const tabf[1] = {dfs};
 #pragma unroll 1
@@ -717,20 +778,21 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
         const int s = s2 * NB + h;
-        hd_slab_put(slab, g, j, rg[h]);
+        hd_slab_put<NTL>(slab, lane, rg[h]);
         __builtin_amdgcn_wave_barrier();         // (the slab is the wave's own: LDS operations of one wave complete in order)
-        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<VEC>(fb, N, n0, s + NB, g, j, rg[h]);
-        hd_mm_dots<KT, 4>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
-        if (support) hd_mm_dots<16, 1>(slab, tabf, HD_SLAB_C * s, g, j, accf, sqf);       // <F_n, d fsum[f]>
+        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<NTL, VEC>(fb, N, n0, s + NB, lane, rg[h]);
+        hd_mm_dots<KT, 4, NTL>(slab, tabs, HD_SLAB_C * s, g, j, acc, sq);
+        if (support) hd_mm_dots<16, 1, NTL>(slab, tabf, HD_SLAB_C * s, g, j, accf, sqf);       // <F_n, d fsum[f]>
         __builtin_amdgcn_wave_barrier();
     }
+    if (!HOLD) hd_slab_fetch<NTL, VEC>(fb, N, n0, 0, lane, rg[0]);      // the second sweep's first slab: in flight during the per-point arithmetic
     // per point: the coefficient rows of d F (the B operands of its K-steps) take the place of the dot products they are made of -
     // acc[table][rt][t][r] -, and the scalar of the -F term
     const float cbase = HD_SCALE * 0.5f * dloss[0] / loss[1];
-    float scl[4];
+    float scl[NTL];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 4 * j + t;
+    for (int t = 0; t < NTL; ++t) {
+        const int n = n0 + NTL * j + t;
         const bool valid = n < N;
         const float nrm = sqrtf(hd_gsum(sq[t]));
         const float rinv = 1.0f / fmaxf(nrm, HD_EPS);
@@ -791,12 +853,8 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = 16 * rt + 4 * r + g;
-            if (k < K1) *reinterpret_cast<f32x4 *>(ct + k * HD_LDS + 4 * j) = f32x4{acc[2][rt][0][r], acc[2][rt][1][r], acc[2][rt][2][r], acc[2][rt][3][r]};
+            if (k < K1) *reinterpret_cast<V *>(ct + k * T::LD + NTL * j) = hd_row_of<NTL, RT>(acc[2], rt, r);
         }
-    if (!HOLD) {
-#pragma unroll
-        for (int s = 0; s < NB; ++s) hd_slab_fetch<VEC>(fb, N, n0, s, g, j, rg[s]);     // (no registers for them during the per-point arithmetic)
-    }
     float *part = part4 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
     float *dfb = dfeat + (size_t)b * HD_C * N;
 #pragma unroll 1
@@ -804,15 +862,15 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 #pragma unroll
     for (int h = 0; h < NB; ++h) {
         const int s = s2 * NB + h;
-        hd_slab_put(slab, g, j, rg[h]);
+        hd_slab_put<NTL>(slab, lane, rg[h]);
         __builtin_amdgcn_wave_barrier();
-        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<VEC>(fb, N, n0, s + NB, g, j, rg[h]);
-        // d F of the slab's channels: tile m (0, 1), row i = 4 g + r of column j <-> channel 32 s + 2 i + m, point 4 j + t
-        f32x4 da[2][4];
+        if (!HOLD && s + NB < HD_NSLAB) hd_slab_fetch<NTL, VEC>(fb, N, n0, s + NB, lane, rg[h]);
+        // d F of the slab's channels: tile m (0, 1), row i = 4 g + r of column j <-> channel 32 s + 2 i + m, point NTL j + t
+        f32x4 da[2][NTL];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) da[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NTL; ++t) da[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -822,7 +880,7 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
                     const float *trow = tabs[tb] + min(16 * rt + 4 * r + g, KT - 1) * HD_LDT + HD_SLAB_C * s + 2 * j;
                     const float a0 = trow[0], a1 = trow[1];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < NTL; ++t) {
                         if (HD_ABL & 16) continue;
                         da[0][t] = hd_mfma16(a0, acc[tb][rt][t][r], da[0][t]);
                         da[1][t] = hd_mfma16(a1, acc[tb][rt][t][r], da[1][t]);
@@ -834,7 +892,7 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
                 const float *trow = dfs + (4 * r + g) * HD_LDT + HD_SLAB_C * s + 2 * j;
                 const float a0 = trow[0], a1 = trow[1];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < NTL; ++t) {
                     da[0][t] = hd_mfma16(a0, accf[0][0][t][r], da[0][t]);
                     da[1][t] = hd_mfma16(a1, accf[0][0][t][r], da[1][t]);
                 }
@@ -845,20 +903,20 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int cl = 2 * (4 * g + r) + m;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + cl * HD_LDS + 4 * j);
-                f32x4 o;
+                const V v = *reinterpret_cast<const V *>(slab + cl * T::LD + NTL * j);
+                V o;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = fmaf(-v[t], scl[t], da[m][t][r]);
-                float *dst = dfb + (size_t)(HD_SLAB_C * s + cl) * N + n0 + 4 * j;
+                for (int t = 0; t < NTL; ++t) o[t] = fmaf(-v[t], scl[t], da[m][t][r]);
+                float *dst = dfb + (size_t)(HD_SLAB_C * s + cl) * N + n0 + NTL * j;
                 if (HD_ABL & 32) { if (o[0] == 1.2345f) dst[0] = o[1]; }
-                else if (VEC) { if (n0 + 4 * j < N) *reinterpret_cast<f32x4 *>(dst) = o; }
+                else if (VEC) { if (n0 + NTL * j < N) *reinterpret_cast<V *>(dst) = o; }
                 else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (n0 + 4 * j + t < N) dst[t] = o[t];
+                    for (int t = 0; t < NTL; ++t)
+                        if (n0 + NTL * j + t < N) dst[t] = o[t];
                 }
             }
-        hd_mm_contract<RT>(slab, ct, red, s, tid, part, [](int row) { return row; });
+        hd_mm_contract<RT, NTL>(slab, ct, red, s, tid, part, [](int row) { return row; });
     }
 }
 
@@ -927,7 +985,7 @@ __device__ __forceinline__ float hd_sum_rows(const float *base, size_t stride, i
 {
     const int c = tid & 127, g = tid >> 7;
     float s = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int p = g; p < count; p += 8) s += base[(size_t)p * stride + c];
     __syncthreads();                                     // (sh may still be read from a previous call)
     sh[g][c] = s;
@@ -985,6 +1043,7 @@ hd_mid2_kernel(const float *__restrict__ part1, const float *__restrict__ sums1,
         const int j = k - 1;
         const float P0 = main_proto[(size_t)j * HD_C + lane], P1 = main_proto[(size_t)j * HD_C + 64 + lane];
         float u0 = 0.f, u1 = 0.f, s = 0.f;
+#pragma unroll 8
         for (int ch = 0; ch < nchunk; ++ch) {
             const size_t p = (size_t)b * nchunk + ch;
             u0 += part1[(p * 32 + k) * HD_C + lane];
@@ -1146,6 +1205,7 @@ hd_bwdm1_kernel(const float *__restrict__ part3, int nchunk, const float *__rest
         const int k = blockIdx.y * 4 + w;                // one wave per row
         if (k >= K1) return;
         float g0 = 0.f, g1 = 0.f;                        // d loss / d q2[b][k]
+#pragma unroll 8
         for (int ch = 0; ch < nchunk; ++ch) {
             const float *pr = part3 + (((size_t)b * nchunk + ch) * 64 + R2 + k) * HD_C;
             g0 += pr[lane]; g1 += pr[64 + lane];
@@ -1433,6 +1493,7 @@ hd_mid2_eval_kernel(const float *__restrict__ part1, const float *__restrict__ s
     if (k >= K1) return;
     const float P0 = main_proto[(size_t)k * HD_C + lane], P1 = main_proto[(size_t)k * HD_C + 64 + lane];
     float u0 = 0.f, u1 = 0.f, s = 0.f;
+#pragma unroll 8
     for (int ch = 0; ch < nchunk; ++ch) {
         const size_t p = (size_t)b * nchunk + ch;
         u0 += part1[(p * 32 + k) * HD_C + lane];
@@ -1532,7 +1593,7 @@ HeadPlan hd_plan(int B, int N, int classes)
     HeadPlan p{};
     const int K1 = classes + 1;
     p.KT = K1 <= 16 ? 16 : 24;
-    p.nchunk = (N + HD_PTS - 1) / HD_PTS;
+    p.nchunk = (N + 127) / 128;                         // sized for the finest chunking of the passes (128-point workgroups)
     size_t o = 0;
     auto take = [&](size_t floats) { const size_t at = o; o += align_up(floats * sizeof(float), 256); return at; };
     p.off_part = take((size_t)B * p.nchunk * 64 * HD_C);           // part1 (32 rows) / part3 (64 rows) / part4 (32 rows), one after the other
@@ -1586,32 +1647,45 @@ static bool hd_vec_ok(const void *p, long long bstride, int N)
 {
     return N % 4 == 0 && bstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
-constexpr size_t hd_lds_fwd1(int KT) { return sizeof(float) * ((size_t)KT * HD_LDT + 4 * HD_SLAB_F + 4 * 32 * HD_LDS + 4 * 32 * 33 + 128); }
-constexpr size_t hd_lds_fwd2(int KT) { return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HD_SLAB_F + 16); }
-constexpr size_t hd_lds_bwd1(int KT) { return sizeof(float) * ((size_t)2 * KT * HD_LDT + 4 * HD_SLAB_F + 4 * 2 * KT * HD_LDS + 4 * 2 * KT * 33); }
-constexpr size_t hd_lds_bwd2(int KT)
-{
-    return sizeof(float) * ((size_t)(4 * KT + GFS3D_HEAD_MAX_FAKE) * HD_LDT + 4 * HD_SLAB_F + 4 * 16 * ((KT + 15) / 16) * (HD_LDS + 33));
-}
+// Point tiles per wave of each matrix-core pass: 2 (128-point workgroups, two per CU) wherever the LDS of two workgroups fits a CU
+template <int KT> struct HdCfg {
+    static constexpr int F1 = 2, F2 = 2, B1 = KT <= 16 ? 2 : 4, B2 = KT <= 16 ? 2 : 4;     // (24-row tables: one workgroup per CU either way; measured)
+};
+static int hd_chunks(int N, int pts) { return (N + pts - 1) / pts; }
+static_assert(2 * hd_lds_fwd1<16, 2>() <= 160 * 1024 && 2 * hd_lds_bwd1<16, 2>() <= 160 * 1024 && 2 * hd_lds_bwd2<16, 2>() <= 160 * 1024 &&
+              2 * hd_lds_fwd1<24, 2>() <= 160 * 1024 && hd_lds_bwd1<24, 4>() <= 160 * 1024 && hd_lds_bwd2<24, 4>() <= 160 * 1024,
+              "LDS of the matrix-core passes");
 
+// forward pass 1 (also the soft pooling of the testing path); *nchunk_out = the chunk count of part1 / sums1
 template <int KT>
-int hd_launch_fwd1(const float *feat, long long bs, int N, const long long *label, const float *main_proto, const float *bg, int K1,
-                   const HeadFake &fk, float *part1, float *sums1, dim3 grid, hipStream_t st, const char *who)
+int hd_launch_fwd1(const float *feat, long long bs, int N, int B, const long long *label, const float *main_proto, const float *bg, int K1,
+                   const HeadFake &fk, float *part1, float *sums1, hipStream_t st, const char *who, int *nchunk_out)
 {
+    constexpr int NTL = HdCfg<KT>::F1;
     if (hd_v1()) {
+        const dim3 grid(hd_chunks(N, HD_PTS), B);
         const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
         GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
         hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
-    } else if (hd_vec_ok(feat, bs, N)) {
-        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, true>), hd_lds_fwd1(KT), who);
-        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, true>), grid, dim3(256), hd_lds_fwd1(KT), st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+        *nchunk_out = grid.x;
     } else {
-        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, false>), hd_lds_fwd1(KT), who);
-        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, false>), grid, dim3(256), hd_lds_fwd1(KT), st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+        const dim3 grid(hd_chunks(N, HdT<NTL>::PTS), B);
+        constexpr size_t lds = hd_lds_fwd1<KT, NTL>();
+        if (hd_vec_ok(feat, bs, N)) {
+            GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, true>), lds, who);
+            hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+        } else {
+            GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, false>), lds, who);
+            hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
+        }
+        *nchunk_out = grid.x;
     }
     GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
     return GFS3D_OK;
 }
+// the chunk count hd_launch_fwd1 used (phase 1 of the forward runs in a later call)
+template <int KT> int hd_fwd1_chunks(int N) { return hd_chunks(N, hd_v1() ? HD_PTS : HdT<HdCfg<KT>::F1>::PTS); }
+template <int KT> int hd_bwd1_chunks(int N) { return hd_chunks(N, hd_v1() ? HD_PTS : HdT<HdCfg<KT>::B1>::PTS); }
 
 template <int KT>
 int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
@@ -1621,37 +1695,46 @@ int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, con
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const int K1 = a->classes + 1;
-    const dim3 grid(p.nchunk, a->B);
     const long long *label = reinterpret_cast<const long long *>(a->label);
     if (phase == 0) {
-        if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, label, a->main_proto, a->bg_proto, K1, fk, F(p.off_part), F(p.off_sums1), grid, st, who))
+        int nch = 0;
+        if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, a->B, label, a->main_proto, a->bg_proto, K1, fk, F(p.off_part), F(p.off_sums1), st, who, &nch))
             return rc;
         if (fk.n > 0) {
-            hipLaunchKernelGGL(hd_mid1_kernel, dim3(fk.n), dim3(1024), 0, st, F(p.off_part), F(p.off_sums1), a->B, p.nchunk, K1, fk.half, a->fsum);
+            hipLaunchKernelGGL(hd_mid1_kernel, dim3(fk.n), dim3(1024), 0, st, F(p.off_part), F(p.off_sums1), a->B, nch, K1, fk.half, a->fsum);
             GFS3D_LAUNCH_CHECK("hd_mid1_kernel");
         }
         return GFS3D_OK;
     }
     GFS3D_REQUIRE(a->pred != nullptr, "%s: NULL pred", who);
-    hipLaunchKernelGGL((hd_mid2_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk, a->main_proto, a->bg_proto, K1,
-                       a->base_num, fk, a->fsum, F(p.off_q1), F(p.off_q2), F(p.off_ori), F(p.off_onrm), F(p.off_pooled), F(p.off_hs));
+    hipLaunchKernelGGL((hd_mid2_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), hd_fwd1_chunks<KT>(a->N), a->main_proto,
+                       a->bg_proto, K1, a->base_num, fk, a->fsum, F(p.off_q1), F(p.off_q2), F(p.off_ori), F(p.off_onrm), F(p.off_pooled), F(p.off_hs));
     GFS3D_LAUNCH_CHECK("hd_mid2_kernel");
+    int nch2;
     if (hd_v1()) {
+        const dim3 grid(hd_chunks(a->N, HD_PTS), a->B);
+        nch2 = grid.x;
         const size_t lds = sizeof(float) * (2 * KT * HD_C + 16);
         GFS3D_ENSURE_LDS((hd_fwd2_kernel<KT>), lds, who);
         hipLaunchKernelGGL((hd_fwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
                            F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
-    } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
-        GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, true>), hd_lds_fwd2(KT), who);
-        hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, true>), grid, dim3(256), hd_lds_fwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
-                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
     } else {
-        GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, false>), hd_lds_fwd2(KT), who);
-        hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, false>), grid, dim3(256), hd_lds_fwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
-                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+        constexpr int NTL = HdCfg<KT>::F2;
+        constexpr size_t lds = hd_lds_fwd2<KT, NTL>();
+        const dim3 grid(hd_chunks(a->N, HdT<NTL>::PTS), a->B);
+        nch2 = grid.x;
+        if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
+            GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, NTL, true>), lds, who);
+            hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+        } else {
+            GFS3D_ENSURE_LDS((hd_fwd2_mm_kernel<KT, NTL, false>), lds, who);
+            hipLaunchKernelGGL((hd_fwd2_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
+        }
     }
     GFS3D_LAUNCH_CHECK("hd_fwd2_kernel");
-    hipLaunchKernelGGL(hd_loss_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * p.nchunk, a->loss);
+    hipLaunchKernelGGL(hd_loss_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * nch2, a->loss);
     GFS3D_LAUNCH_CHECK("hd_loss_kernel");
     return GFS3D_OK;
 }
@@ -1665,52 +1748,66 @@ int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, co
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const int K1 = a->classes + 1;
-    const dim3 grid(p.nchunk, a->B);
     const long long *label = reinterpret_cast<const long long *>(a->label);
     GFS3D_REQUIRE(a->dloss && a->dfsum && a->dfeat && a->dmain && a->dbg, "%s: NULL gradient buffer", who);
     if (phase == 0) {
+        const int nch = hd_bwd1_chunks<KT>(a->N);
+        const dim3 grid(nch, a->B);
         if (hd_v1()) {
             const size_t lds = sizeof(float) * (2 * KT * HD_C + 4 * (RT + 1) * 32 * HD_LD);
             GFS3D_ENSURE_LDS((hd_bwd1_kernel<KT>), lds, who);
             hipLaunchKernelGGL((hd_bwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index,
                                F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
-        } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
-            GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, true>), hd_lds_bwd1(KT), who);
-            hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, true>), grid, dim3(256), hd_lds_bwd1(KT), st, a->feat, a->feat_bstride, a->N, label,
-                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
         } else {
-            GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, false>), hd_lds_bwd1(KT), who);
-            hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, false>), grid, dim3(256), hd_lds_bwd1(KT), st, a->feat, a->feat_bstride, a->N, label,
-                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+            constexpr int NTL = HdCfg<KT>::B1;
+            constexpr size_t lds = hd_lds_bwd1<KT, NTL>();
+            if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
+                GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, NTL, true>), lds, who);
+                hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                                   (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+            } else {
+                GFS3D_ENSURE_LDS((hd_bwd1_mm_kernel<KT, NTL, false>), lds, who);
+                hipLaunchKernelGGL((hd_bwd1_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                                   (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
+            }
         }
         GFS3D_LAUNCH_CHECK("hd_bwd1_kernel");
-        hipLaunchKernelGGL((hd_bwdm1_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), p.nchunk, a->main_proto, a->bg_proto, K1, a->base_num,
+        hipLaunchKernelGGL((hd_bwdm1_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), nch, a->main_proto, a->bg_proto, K1, a->base_num,
                            F(p.off_q2), F(p.off_pooled), F(p.off_hs), F(p.off_dbgp), F(p.off_dorip), F(p.off_dPp), F(p.off_dpool), F(p.off_t3));
         GFS3D_LAUNCH_CHECK("hd_bwdm1_kernel");
-        hipLaunchKernelGGL(hd_bwdm2_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B, p.nchunk, a->main_proto, a->bg_proto, fk, a->fsum,
+        hipLaunchKernelGGL(hd_bwdm2_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B, nch, a->main_proto, a->bg_proto, fk, a->fsum,
                            F(p.off_ori), F(p.off_onrm), F(p.off_dbgp), F(p.off_dorip), F(p.off_dPp), F(p.off_dbga), F(p.off_dmaina), a->dfsum);
         GFS3D_LAUNCH_CHECK("hd_bwdm2_kernel");
         return GFS3D_OK;
     }
+    int nch;
     if (hd_v1()) {
+        const dim3 grid(hd_chunks(a->N, HD_PTS), a->B);
+        nch = grid.x;
         const size_t lds = sizeof(float) * (4 * KT * HD_C + 8 * 32 * HD_LD + GFS3D_HEAD_MAX_FAKE * HD_FLD + 2 * KT);
         GFS3D_ENSURE_LDS((hd_bwd2_kernel<KT>), lds, who);
         hipLaunchKernelGGL((hd_bwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
                            F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs), F(p.off_dpool), F(p.off_t3), a->dfsum,
                            a->dfeat, F(p.off_part));
-    } else if (hd_vec_ok(a->feat, a->feat_bstride, a->N) && hd_vec_ok(a->dfeat, 0, a->N)) {
-        GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, true>), hd_lds_bwd2(KT), who);
-        hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, true>), grid, dim3(256), hd_lds_bwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
-                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
-                           F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
     } else {
-        GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, false>), hd_lds_bwd2(KT), who);
-        hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, false>), grid, dim3(256), hd_lds_bwd2(KT), st, a->feat, a->feat_bstride, a->N, label,
-                           (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
-                           F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
+        constexpr int NTL = HdCfg<KT>::B2;
+        constexpr size_t lds = hd_lds_bwd2<KT, NTL>();
+        const dim3 grid(hd_chunks(a->N, HdT<NTL>::PTS), a->B);
+        nch = grid.x;
+        if (hd_vec_ok(a->feat, a->feat_bstride, a->N) && hd_vec_ok(a->dfeat, 0, a->N)) {
+            GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, NTL, true>), lds, who);
+            hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
+                               F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
+        } else {
+            GFS3D_ENSURE_LDS((hd_bwd2_mm_kernel<KT, NTL, false>), lds, who);
+            hipLaunchKernelGGL((hd_bwd2_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label,
+                               (long long)a->ignore_index, F(p.off_q1), F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs),
+                               F(p.off_dpool), F(p.off_t3), a->dfsum, a->dfeat, F(p.off_part));
+        }
     }
     GFS3D_LAUNCH_CHECK("hd_bwd2_kernel");
-    hipLaunchKernelGGL(hd_bwdfin_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B * p.nchunk, a->main_proto, a->bg_proto, F(p.off_dbga),
+    hipLaunchKernelGGL(hd_bwdfin_kernel, dim3(K1), dim3(1024), 0, st, F(p.off_part), a->B * nch, a->main_proto, a->bg_proto, F(p.off_dbga),
                        F(p.off_dmaina), a->dbg, a->dmain);
     GFS3D_LAUNCH_CHECK("hd_bwdfin_kernel");
     return GFS3D_OK;
@@ -1771,20 +1868,21 @@ static int hd_eval(const gfs3d_capl_eval_args *a, const char *who)
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
     hipStream_t st = static_cast<hipStream_t>(a->stream);
     const int K1 = a->classes;                           // no bg row on the testing path
-    const dim3 grid(p.nchunk, a->B);
     HeadFake fk{};
     fk.n = 0; fk.half = a->B;
-    if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, nullptr, a->main_proto, nullptr, K1, fk, F(p.off_part), F(p.off_sums1), grid, st, who))
+    int nch1 = 0;
+    if (int rc = hd_launch_fwd1<KT>(a->feat, a->feat_bstride, a->N, a->B, nullptr, a->main_proto, nullptr, K1, fk, F(p.off_part), F(p.off_sums1), st, who, &nch1))
         return rc;
-    hipLaunchKernelGGL((hd_mid2_eval_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), p.nchunk,
+    hipLaunchKernelGGL((hd_mid2_eval_kernel<KT>), dim3(a->B, (K1 + 3) / 4), dim3(256), 0, st, F(p.off_part), F(p.off_sums1), nch1,
                        a->main_proto, a->gened_proto, K1, a->base_num, F(p.off_q2));
     GFS3D_LAUNCH_CHECK("hd_mid2_eval_kernel");
+    const dim3 grid(hd_chunks(a->N, HD_PTS), a->B);       // (the lane = point logits pass: 256-point workgroups)
     const size_t lds = sizeof(float) * (KT * HD_C + 16 + (size_t)K1 * a->Kw);
     GFS3D_ENSURE_LDS((hd_fwd2_eval_kernel<KT>), lds, who);
     hipLaunchKernelGGL((hd_fwd2_eval_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, F(p.off_q2), K1, a->word, a->coding,
                        a->Kw, a->th, reinterpret_cast<const long long *>(a->label), a->base_num, a->logits, F(p.off_part2));
     GFS3D_LAUNCH_CHECK("hd_fwd2_eval_kernel");
-    hipLaunchKernelGGL(hd_evalstat_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * p.nchunk, (double)a->B * a->N, a->stats);
+    hipLaunchKernelGGL(hd_evalstat_kernel, dim3(1), dim3(64), 0, st, F(p.off_part2), a->B * (int)grid.x, (double)a->B * a->N, a->stats);
     GFS3D_LAUNCH_CHECK("hd_evalstat_kernel");
     return GFS3D_OK;
 }
