@@ -35,6 +35,31 @@ def shard_range(n_items: int, rank: Optional[int] = None, world_size: Optional[i
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x, differentiable: dx = sum over ranks of dy (every rank's y depends on every rank's x)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.contiguous().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = dy.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def all_reduce_sum_diff(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Differentiable SUM all-reduce (generate_fake_proto's (feature sum, count) under block-sharded DP).  The same
+    arithmetic as torch.distributed.nn.functional.all_reduce - which is NOT used: importing torch.distributed.nn pulls in
+    torch.distributed.rpc, and with torch 2.10 a process that imported it aborts at interpreter exit every other run
+    ("terminate called without an active exception": bisected in the 8-rank gloo rehearsal of bench.py, round 5)."""
+    return _AllReduceSum.apply(x, group)
+
+
 class FlatGradBucket:
     """Data-parallel gradient exchange over ONE flat fp32 buffer: after backward the parameter gradients are
     packed by a single multi-tensor copy, summed over the ranks, and handed back to the parameters as views of

@@ -264,7 +264,7 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
             num = torch.matmul(feat, m.transpose(1, 2)).sum(0).t()             # (F, C)
             den = m.sum((0, 2))                                                # (F,)
             if dp:   # masked mean over the GLOBAL support half: differentiable SUM all-reduce of (sum, count)
-                from torch.distributed.nn.functional import all_reduce as _ar
+                from gfs3d.dist import all_reduce_sum_diff as _ar
                 packed = _ar(torch.cat([num, den.unsqueeze(1)], dim=1))
                 num, den = packed[:, :-1], packed[:, -1]
             mean = num / (den + _EPS).unsqueeze(1)

@@ -1482,7 +1482,7 @@ def _rccl_rank(rank, world, port, out):
     cnt = torch.arange(39, dtype=torch.int64, device=dev).reshape(3, 13)
     gd.all_reduce_counts(cnt)                                                # int64 SUM (mIoU counters)
     res["i64"] = int(cnt.sum())
-    from torch.distributed.nn.functional import all_reduce as ar
+    from gfs3d.dist import all_reduce_sum_diff as ar
     w = torch.ones(5, device=dev, requires_grad=True)
     ar(w * 2).sum().backward()                                               # differentiable all-reduce (fake prototypes)
     res["diff"] = w.grad.tolist()
