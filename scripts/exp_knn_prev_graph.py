@@ -47,7 +47,6 @@ def run(label, x):
         prev = idx
 
 
-sys.argv = sys.argv[:1]
-from exp_morton_locality import structured          # noqa: E402  (its module body also prints its own tables)
+from _clouds import structured          # noqa: E402
 run("synthetic (bench recipe)", synthetic_blocks(B, N, seed=0))
 run("structured (box faces, colour per face)", structured(B, N, 1))
