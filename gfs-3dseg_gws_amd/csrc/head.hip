@@ -25,10 +25,10 @@
 //   hd_bwd2   per point: d F from all four paths (both heads, the soft pooling, the fake-novel means), written once;
 //             contraction sum_n dL3[k][n] Fhat[c][n]
 //   hd_bwdfin per class: gradient through the normalisation of [bg; main], final d main / d bg
-// Layout of the point passes: lane = ONE point, a wave = 64 points, a workgroup = 256 points of one batch item; the class
-// tables live in LDS and are read as 16-byte broadcasts (every lane the same address); the few products whose contraction
-// index is the POINT (a cross-lane sum) go through v_mfma_f32_32x32x2_f32 with both operands transposed through small
-// per-wave LDS tiles.  Everything is an exact fp32 fma chain: no operand splitting needed at <= 24 classes.
+// Layout of the point passes (round 5): every product runs on v_mfma_f32_16x16x4_f32 (exact fp32 products) - see "The four point
+// passes on the fp32 matrix cores" below: a wave owns 32 or 64 points, the class tables live in LDS as A operands, the features
+// travel in 32-channel slabs, the per-point arithmetic runs in place on the accumulator registers.  (The logits pass of the testing
+// path, hd_fwd2_eval_kernel, keeps the lane = point form of rounds 3-4: hd_dots.)
 // No atomics anywhere: every cross-workgroup sum is a partial tile added in a fixed order (bit-reproducible).
 #include "common.h"
 
@@ -40,7 +40,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD_C = 128;            // feature channels (main_dim of capl.py:46)
 constexpr int HD_PTS = 256;          // points per workgroup (4 waves, lane = point)
-constexpr int HD_LD = 65;            // row stride of the per-wave LDS tiles (floats): [row][point], conflict-free both ways
 constexpr int HD_FLD = HD_C + 1;     // row stride of the fsum / dfsum tables: [fake class][128 sums | count]
 constexpr float HD_EPS = 1e-12f;
 // per-item state of the refinement kept for the backward: hs[(b KT + k)][8] = {s, w, cos, |pooled|, |refined|, -, -, -}
@@ -159,69 +158,14 @@ __device__ __forceinline__ void hd_dots(const float *col, size_t N, const float 
     }
 }
 
-// log-sum-exp and probabilities of KT logits (rows >= K1 excluded), in place: L -> p
-template <int KT>
-__device__ __forceinline__ float hd_softmax(float (&L)[KT], int K1)
-{
-    float mx = -__builtin_inff();
-#pragma unroll
-    for (int k = 0; k < KT; ++k) mx = k < K1 ? fmaxf(mx, L[k]) : mx;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) { L[k] = k < K1 ? expf(L[k] - mx) : 0.f; s += L[k]; }
-    const float inv = 1.0f / s;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) L[k] *= inv;
-    return mx + logf(s);
-}
 
-// One 32-channel tile of the point contraction  D[row][c] += sum over the wave's 64 points of A[row][n] F[c][n]:
-// the lane (= point) re-reads its 32 channel values (L2: the dots pass has just streamed them), the wave transposes them
-// through its LDS tile and issues 32 MFMA steps of two points each per row tile.
-template <int RT>
-__device__ __forceinline__ void hd_contract_tile(const float *col, size_t N, int ct, bool valid, const float *at, float *bt, int lane,
-                                                 f32x16 (&acc)[RT])
-{
-    const int j = lane & 31, h = lane >> 5;
-    float v[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) v[r] = col[(size_t)(32 * ct + r) * N];
-    __syncthreads();                                     // (the previous tile's reads are done)
-#pragma unroll
-    for (int r = 0; r < 32; ++r) bt[r * HD_LD + lane] = valid ? v[r] : 0.f;
-    __syncthreads();
-#pragma unroll 8
-    for (int s = 0; s < 32; ++s) {
-        const float bv = bt[j * HD_LD + 2 * s + h];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[(rt * 32 + j) * HD_LD + 2 * s + h], bv, acc[rt], 0, 0, 0);
-    }
-}
 
-// the four waves' result tiles of channel tile ct added in wave order and stored: part[(rt 32 + row)][32 ct + c]
-template <int RT>
-__device__ __forceinline__ void hd_reduce_store(const f32x16 (&acc)[RT], float *red /* [4][32][33] */, int ct, int tid, float *part)
-{
-    const int lane = tid & 63, w = tid >> 6, j = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[(w * 32 + hd_acc_row(r, h)) * 33 + j] = acc[rt][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = tid + 256 * i, row = e >> 5, c = e & 31;
-            const float s = ((red[row * 33 + c] + red[(32 + row) * 33 + c]) + red[(64 + row) * 33 + c]) + red[(96 + row) * 33 + c];
-            part[(size_t)(rt * 32 + row) * HD_C + 32 * ct + c] = s;
-        }
-    }
-}
 
 // =====================================================================================================================
-// The four point passes on the fp32 matrix cores (round 5).  The lane = point form above spends its time on ~1000 LDS broadcast
-// reads and 4096 fma per lane and pass with ONE wave per SIMD (65 536 points are 1024 waves) and 16 four-byte loads in flight
-// per lane; here every product of the passes is a v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+// The four point passes on the fp32 matrix cores (round 5).  The lane = point form of rounds 3-4 (hd_dots, still used by the
+// testing path's logits pass) spent its time on ~1000 LDS broadcast reads and 4096 fma per lane and pass with ONE wave per SIMD
+// (65 536 points are 1024 waves) and 16 four-byte loads in flight per lane; here every product of the passes is a
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
 //   dots         D[class][point]   = sum_c T[class][c] F[c][point]            (A = table, B = features, k = channel)
 //   contractions D[row][channel]   = sum_p A[row][p] F[channel][p]            (A = per-point coefficients, B = features, k = point)
 //   d F          D[channel][point] = sum_slot T[slot][channel] coef[slot][p]  (A = tables, B = coefficients, k = class slot)
@@ -424,6 +368,9 @@ __device__ __forceinline__ typename HdT<NTL>::V hd_row_of(const f32x4 (&a)[RT][N
 }
 
 // ------------------------------------------------------------------------------------------------ forward, pass 1
+// part1[(b nchunk + chunk)][32][128]: rows k < K1: sum_n e[k][n] F[c][n], e = exp(10 cos(F_n, unit([bg; main])[k]) - 10) (soft pooling);
+//                                     rows K1 + f: sum_n [support half, y_n = fake class f] F[c][n] / (|F_n| + eps)
+// sums1[(b nchunk + chunk)][32]:      rows k < K1: sum_n e[k][n];  rows K1 + f: the number of such points
 template <int KT, int NTL, bool VEC>
 __global__ void __launch_bounds__(256, hd_occ(hd_lds_fwd1<KT, NTL>()))
 hd_fwd1_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, const float *__restrict__ main_proto,
@@ -545,6 +492,7 @@ __device__ __forceinline__ float hd_mm_softmax(float (&L)[RT][4], int K1, int g)
 }
 
 // ------------------------------------------------------------------------------------------------ forward, pass 2
+// loss partials part2[(b nchunk + chunk)][4] = {sum nll_1, sum nll_2, counted points, -}; pred (B, N) int64
 template <int KT, int NTL, bool VEC>
 __global__ void __launch_bounds__(256, hd_occ(hd_lds_fwd2<KT, NTL>()))
 hd_fwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
@@ -626,6 +574,7 @@ hd_fwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
 }
 
 // ------------------------------------------------------------------------------------------------ backward, pass 1
+// g_t[k][n] = d loss / d (cos_t[k][n]) = 10 . 0.5 . dloss / count . (softmax_t - onehot); part3 rows sum_n g_t[k][n] Fhat[c][n]
 // coefficient rows of the wave tile: head 1 at k, head 2 at KT + k (compact); part3 rows: head 1 at k, head 2 at R2 + k
 template <int KT, int NTL, bool VEC>
 __global__ void __launch_bounds__(256, hd_occ(hd_lds_bwd1<KT, NTL>()))
@@ -920,63 +869,6 @@ hd_bwd2_mm_kernel(const float *__restrict__ feat, long long bs, int N, const lon
     }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, pass 1
-// part1[(b nchunk + chunk)][32][128]: rows k < K1: sum_n e[k][n] F[c][n]; rows K1 + f: sum_n [support, y_n = fake f] F[c][n] / (|F_n| + eps)
-// sums1[(b nchunk + chunk)][32]:      rows k < K1: sum_n e[k][n];        rows K1 + f: the number of such points
-template <int KT>
-__global__ void __launch_bounds__(256, 1)
-hd_fwd1_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, const float *__restrict__ main_proto,
-               const float *__restrict__ bg, int K1, const HeadFake fk, float *__restrict__ part1, float *__restrict__ sums1)
-{
-    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
-    float *q3 = hd_smem;                                 // [KT][128]
-    float *atile = q3 + KT * HD_C;                       // [4][32][65]
-    float *btile = atile + 4 * 32 * HD_LD;               // [4][32][65]   (later: the reduction buffer)
-    float *wsums = btile + 4 * 32 * HD_LD;               // [4][32]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n = chunk * HD_PTS + w * 64 + lane;
-    const bool valid = n < N;
-    const float *col = feat + (size_t)b * bs + min(n, N - 1);
-    hd_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
-    float d[1][KT], sq;
-    const float *const tabs[1] = {q3};
-    hd_dots<KT, 1>(col, (size_t)N, tabs, d, sq);
-    const float nrm = sqrtf(sq);
-    const float rn = 1.0f / fmaxf(nrm, HD_EPS);
-    float *at = atile + w * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) at[r * HD_LD + lane] = 0.f;
-    if (lane < 32) wsums[w * 32 + lane] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const float e = (valid && k < K1) ? __expf(HD_SCALE * d[0][k] * rn - HD_SHIFT) : 0.f;
-        if (k < K1) at[k * HD_LD + lane] = e;
-        const float se = hd_wsum(e);
-        if (lane == 0 && k < K1) wsums[w * 32 + k] = se;
-    }
-    if (fk.n > 0 && b >= fk.half) {                      // (workgroup-uniform)
-        const long long y = label[(size_t)b * N + min(n, N - 1)];
-        const int fi = valid ? hd_fake_index(fk, y) : -1;
-        const float rn2 = 1.0f / (nrm + HD_EPS);         // generate_fake_proto divides by (|f| + 1e-12)
-        for (int f = 0; f < fk.n; ++f) {
-            at[(K1 + f) * HD_LD + lane] = fi == f ? rn2 : 0.f;
-            const float cnt = hd_wsum(fi == f ? 1.f : 0.f);
-            if (lane == 0) wsums[w * 32 + K1 + f] = cnt;
-        }
-    }
-    f32x16 acc[4][1];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][0][r] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) hd_contract_tile<1>(col, (size_t)N, ct, valid, at, bt, lane, acc[ct]);
-    float *part = part1 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) hd_reduce_store<1>(acc[ct], btile, ct, tid, part);
-    if (tid < 32) sums1[(size_t)(b * nchunk + chunk) * 32 + tid] = ((wsums[tid] + wsums[32 + tid]) + wsums[64 + tid]) + wsums[96 + tid];
-}
 
 // Fixed-order sum of `count` partial rows, `stride` floats apart, by a block of 1024 threads: thread (g, c) adds the rows
 // p = g, g + 8, ... of channel c (independent loads, eight in flight), the eight group sums are then added in group order.
@@ -1084,45 +976,6 @@ hd_mid2_kernel(const float *__restrict__ part1, const float *__restrict__ sums1,
     }
 }
 
-// ------------------------------------------------------------------------------------------------ forward, pass 2
-// loss partials part2[(b nchunk + chunk)][4] = {sum nll_1, sum nll_2, counted points, -}; pred (B, N) int64
-template <int KT>
-__global__ void __launch_bounds__(256, 1)
-hd_fwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
-               const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, float *__restrict__ part2, long long *__restrict__ pred)
-{
-    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
-    float *q1 = hd_smem, *q2 = q1 + KT * HD_C;
-    float *wred = q2 + KT * HD_C;                        // [4][4]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n = chunk * HD_PTS + w * 64 + lane;
-    const bool valid = n < N;
-    const float *col = feat + (size_t)b * bs + min(n, N - 1);
-    hd_load_table<KT>(q1, q1g, K1, tid);
-    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
-    float d[2][KT], sq;
-    const float *const tabs[2] = {q1, q2};
-    hd_dots<KT, 2>(col, (size_t)N, tabs, d, sq);
-    const float rn = HD_SCALE / fmaxf(sqrtf(sq), HD_EPS);
-    const long long y = label[(size_t)b * N + min(n, N - 1)];
-    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
-    float pick1 = 0.f, pick2 = 0.f, best = -__builtin_inff();
-    int bk = 0;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        d[0][k] *= rn; d[1][k] *= rn;
-        pick1 = (long long)k == y ? d[0][k] : pick1;
-        pick2 = (long long)k == y ? d[1][k] : pick2;
-        if (k < K1 && d[1][k] > best) { best = d[1][k]; bk = k; }
-    }
-    const float lse1 = hd_softmax<KT>(d[0], K1), lse2 = hd_softmax<KT>(d[1], K1);
-    if (valid) pred[(size_t)b * N + n] = (long long)bk;
-    const float s1 = hd_wsum(ok ? lse1 - pick1 : 0.f), s2 = hd_wsum(ok ? lse2 - pick2 : 0.f), sc = hd_wsum(ok ? 1.f : 0.f);
-    if (lane == 0) { wred[w * 4 + 0] = s1; wred[w * 4 + 1] = s2; wred[w * 4 + 2] = sc; }
-    __syncthreads();
-    if (tid < 3) part2[(size_t)(b * nchunk + chunk) * 4 + tid] = ((wred[tid] + wred[4 + tid]) + wred[8 + tid]) + wred[12 + tid];
-}
 
 // loss[0] = (mean nll_1 + mean nll_2) / 2 over the counted points, loss[1] = their number   (one wave)
 __global__ void __launch_bounds__(64)
@@ -1135,60 +988,6 @@ hd_loss_kernel(const float *__restrict__ part2, int nparts, float *__restrict__ 
     if (threadIdx.x == 0) { loss[0] = (float)(0.5 * (s1 + s2) / sc); loss[1] = (float)sc; }
 }
 
-// ------------------------------------------------------------------------------------------------ backward, pass 1
-// g_t[k][n] = d loss / d (cos_t[k][n]) = 10 . 0.5 . dloss / count . (softmax_t - onehot);  part3 rows: head 1 at k, head 2 at
-// R2 + k (R2 = 16 for KT = 16, else 32): sum_n g_t[k][n] Fhat[c][n]
-template <int KT>
-__global__ void __launch_bounds__(256, 1)
-hd_bwd1_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
-               const float *__restrict__ q1g, const float *__restrict__ q2g, int K1, const float *__restrict__ loss,
-               const float *__restrict__ dloss, float *__restrict__ part3)
-{
-    constexpr int RT = 2 * KT <= 32 ? 1 : 2, R2 = 2 * KT <= 32 ? KT : 32;
-    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
-    float *q1 = hd_smem, *q2 = q1 + KT * HD_C;
-    float *atile = q2 + KT * HD_C;                       // [4][RT 32][65]
-    float *btile = atile + 4 * RT * 32 * HD_LD;          // [4][32][65]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n = chunk * HD_PTS + w * 64 + lane;
-    const bool valid = n < N;
-    const float *col = feat + (size_t)b * bs + min(n, N - 1);
-    hd_load_table<KT>(q1, q1g, K1, tid);
-    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
-    float d[2][KT], sq;
-    const float *const tabs[2] = {q1, q2};
-    hd_dots<KT, 2>(col, (size_t)N, tabs, d, sq);
-    const float rinv = 1.0f / fmaxf(sqrtf(sq), HD_EPS);
-    const long long y = label[(size_t)b * N + min(n, N - 1)];
-    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
-    const float coef = ok ? HD_SCALE * 0.5f * dloss[0] / loss[1] : 0.f;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) { d[0][k] *= HD_SCALE * rinv; d[1][k] *= HD_SCALE * rinv; }
-    hd_softmax<KT>(d[0], K1);
-    hd_softmax<KT>(d[1], K1);
-    float *at = atile + w * RT * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
-#pragma unroll
-    for (int r = 0; r < RT * 32; ++r) at[r * HD_LD + lane] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const float oh = (long long)k == y ? 1.f : 0.f;
-        at[k * HD_LD + lane] = coef * (d[0][k] - oh) * rinv;            // (Fhat = F / |F|: the 1 / |F| rides in the A operand)
-        at[(R2 + k) * HD_LD + lane] = coef * (d[1][k] - oh) * rinv;
-    }
-    f32x16 acc[4][RT];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][rt][r] = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) hd_contract_tile<RT>(col, (size_t)N, ct, valid, at, bt, lane, acc[ct]);
-    float *part = part3 + (size_t)(b * nchunk + chunk) * 64 * HD_C;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) hd_reduce_store<RT>(acc[ct], btile, ct, tid, part);
-}
 
 // grid = (B, ceil(K1 / 4)); wave per row k.  Back through q2 = unit([bg; refined_b]) and the refinement, per batch item:
 //   dbg_part[b], dori_part[b][j], dP_part[b][j], dpool[b][k] (the gradient of pooled, row 0 zero), t3[b][k] = <dpool, pooled>
@@ -1301,156 +1100,6 @@ hd_bwdm2_kernel(const float *__restrict__ part3, int B, int nchunk, const float 
     dmain_a[(size_t)j * HD_C + 64 + lane] = m1;
 }
 
-// ------------------------------------------------------------------------------------------------ backward, pass 2
-// d F from all four paths, written once; part4 rows k: sum_n gl3[k][n] Fhat[c][n]  (gl3 = the gradient of cos(F, [bg; main]))
-template <int KT>
-__global__ void __launch_bounds__(256, 1)
-hd_bwd2_kernel(const float *__restrict__ feat, long long bs, int N, const long long *__restrict__ label, long long ignore_index,
-               const float *__restrict__ q1g, const float *__restrict__ q2g, const float *__restrict__ main_proto, const float *__restrict__ bg,
-               int K1, const HeadFake fk, const float *__restrict__ loss, const float *__restrict__ dloss, const float *__restrict__ hs,
-               const float *__restrict__ dpoolg, const float *__restrict__ t3g, const float *__restrict__ dfsum,
-               float *__restrict__ dfeat, float *__restrict__ part4)
-{
-    extern __shared__ __attribute__((aligned(16))) float hd_smem[];
-    float *q1 = hd_smem, *q2 = q1 + KT * HD_C, *q3 = q2 + KT * HD_C, *dpl = q3 + KT * HD_C;     // four [KT][128] tables
-    float *atile = dpl + KT * HD_C;                      // [4][32][65]
-    float *btile = atile + 4 * 32 * HD_LD;               // [4][32][65]
-    float *dfs = btile + 4 * 32 * HD_LD;                 // [MAX_FAKE][129]
-    float *sk = dfs + GFS3D_HEAD_MAX_FAKE * HD_FLD;      // [KT] 1 / s[b][k]
-    float *tk = sk + KT;                                 // [KT] t3[b][k]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-    const int n = chunk * HD_PTS + w * 64 + lane;
-    const bool valid = n < N;
-    const float *col = feat + (size_t)b * bs + min(n, N - 1);
-    const bool support = fk.n > 0 && b >= fk.half;       // (workgroup-uniform)
-    if (tid < KT) {
-        sk[tid] = (tid >= 1 && tid < K1) ? 1.0f / hs[((size_t)b * KT + tid) * HD_HS] : 0.f;
-        tk[tid] = tid < K1 ? t3g[(size_t)b * KT + tid] : 0.f;
-    }
-    for (int e = tid; e < max(fk.n, 1) * HD_FLD; e += 256) dfs[e] = support ? dfsum[e] : 0.f;
-    hd_load_table<KT>(q1, q1g, K1, tid);
-    hd_load_table<KT>(q2, q2g + (size_t)b * KT * HD_C, K1, tid);
-    hd_load_table<KT>(dpl, dpoolg + (size_t)b * KT * HD_C, K1, tid);
-    hd_load_bgmain_unit<KT>(q3, bg, main_proto, K1, tid);
-    float d[4][KT], sq;
-    const float *const tabs[4] = {q1, q2, q3, dpl};
-    hd_dots<KT, 4>(col, (size_t)N, tabs, d, sq);
-    const float nrm = sqrtf(sq);
-    const float rinv = 1.0f / fmaxf(nrm, HD_EPS);
-    const long long y = label[(size_t)b * N + min(n, N - 1)];
-    const bool ok = valid && y != ignore_index && y >= 0 && y < (long long)K1;
-    const float coef = ok ? HD_SCALE * 0.5f * dloss[0] / loss[1] : 0.f;
-    // coefficient rows: d[0], d[1] <- g1, g2 (gradients of the cosines of the two heads); d[2] <- gl3; d[3] <- resp
-    float tsum = 0.f;                                    // <Fhat, dFhat> = sum over the three cosine paths of g[k] cos[k]
-    {
-        float c1[KT], c2[KT];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) { c1[k] = d[0][k] * rinv; c2[k] = d[1][k] * rinv; d[0][k] = c1[k] * HD_SCALE; d[1][k] = c2[k] * HD_SCALE; }
-        hd_softmax<KT>(d[0], K1);
-        hd_softmax<KT>(d[1], K1);
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const float oh = (long long)k == y ? 1.f : 0.f;
-            d[0][k] = coef * (d[0][k] - oh);
-            d[1][k] = coef * (d[1][k] - oh);
-            tsum = fmaf(d[0][k], c1[k], fmaf(d[1][k], c2[k], tsum));
-        }
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const float c3 = d[2][k] * rinv;
-            const float resp = (valid && k >= 1 && k < K1) ? __expf(HD_SCALE * c3 - HD_SHIFT) * sk[k] : 0.f;     // softmax over the points
-            const float gl = HD_SCALE * resp * (d[3][k] - tk[k]);        // d[3][k] = <dpool[k], F_n> (raw features)
-            d[2][k] = gl;
-            d[3][k] = resp;
-            tsum = fmaf(gl, c3, tsum);
-        }
-    }
-    // the fake-novel mean path: this point contributes F / (|F| + eps) to fsum[fi]
-    const int fi = (support && valid) ? hd_fake_index(fk, y) : -1;
-    float fa1 = 0.f, fa2 = 0.f;
-    if (support) {                                       // (uniform)
-        const float *dr = dfs + max(fi, 0) * HD_FLD;
-        float tf = 0.f;
-#pragma unroll 1
-        for (int c0 = 0; c0 < HD_C; c0 += HD_G) {       // sixteen (L2-resident) channel values in flight
-            float v[HD_G];
-#pragma unroll
-            for (int e = 0; e < HD_G; ++e) v[e] = col[(size_t)(c0 + e) * N];
-#pragma unroll
-            for (int e = 0; e < HD_G; ++e) tf = fmaf(v[e], dr[c0 + e], tf);
-        }
-        const float re = nrm + HD_EPS;
-        fa1 = fi >= 0 ? 1.0f / re : 0.f;
-        fa2 = fi >= 0 ? tf / (fmaxf(nrm, 1e-30f) * re * re) : 0.f;
-    }
-    float *at = atile + w * 32 * HD_LD, *bt = btile + w * 32 * HD_LD;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) at[r * HD_LD + lane] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KT; ++k) at[k * HD_LD + lane] = d[2][k] * rinv;
-    const float tn = tsum * rinv;                        // dF = (dFhat - Fhat <Fhat, dFhat>) / |F|, Fhat = F / |F|
-    const float *drow = dfs + max(fi, 0) * HD_FLD;
-    const int j = lane & 31, h = lane >> 5;
-    f32x16 acc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-    const __amdgpu_buffer_rsrc_t rs_df = __builtin_amdgcn_make_buffer_rsrc(dfeat + (size_t)b * HD_C * N, 0, HD_C * N * 4, 0x00020000);
-    const int voff = valid ? n * 4 : 0x7fffffff;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        __syncthreads();
-        float nv[4];                                     // the next group's channel values, requested one group ahead (L2)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) nv[e] = col[(size_t)(32 * ct + e) * N];
-#pragma unroll 1
-        for (int g4 = 0; g4 < 8; ++g4) {
-            const int c0 = 32 * ct + 4 * g4;
-            float v[4], o[4], dd[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = nv[e]; o[e] = 0.f; dd[e] = 0.f; }
-            if (g4 + 1 < 8) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) nv[e] = col[(size_t)(c0 + 4 + e) * N];
-            }
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const f32x4 a1 = *reinterpret_cast<const f32x4 *>(q1 + k * HD_C + c0), a2 = *reinterpret_cast<const f32x4 *>(q2 + k * HD_C + c0);
-                const f32x4 a3 = *reinterpret_cast<const f32x4 *>(q3 + k * HD_C + c0), a4 = *reinterpret_cast<const f32x4 *>(dpl + k * HD_C + c0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o[e] = fmaf(d[2][k], a3[e], fmaf(d[1][k], a2[e], fmaf(d[0][k], a1[e], o[e])));
-                    dd[e] = fmaf(d[3][k], a4[e], dd[e]);
-                }
-                if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-            // (branch-free, stores included - a lane past N stores through an offset the buffer's range check drops: with a
-            // branch in here the compiler sank the fma chains into the guarded block, left the 4 KT table reads of the group
-            // in front of it and kept all their results alive - 512 registers and spills)
-            float r[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                r[e] = fmaf(rinv, o[e] - v[e] * tn, dd[e]) + (fa1 * drow[c0 + e] - fa2 * v[e]);     // (fa1 = fa2 = 0 off the fake path)
-                bt[(4 * g4 + e) * HD_LD + lane] = valid ? v[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r[e]), rs_df, voff, (c0 + e) * N * 4, 0);
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s)
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[j * HD_LD + 2 * s + h], bt[j * HD_LD + 2 * s + h], acc[ct], 0, 0, 0);
-    }
-    float *part = part4 + (size_t)(b * nchunk + chunk) * 32 * HD_C;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        f32x16 one[1] = {acc[ct]};
-        hd_reduce_store<1>(one, btile, ct, tid, part);
-    }
-}
 
 // grid = K1: d unit([bg; main])[k] summed over all partial tiles, back through the normalisation, added to the other paths
 __global__ void __launch_bounds__(1024)
@@ -1636,12 +1285,6 @@ int hd_check(const gfs3d_capl_head_args *a, const char *who, HeadFake &fk)
     return GFS3D_OK;
 }
 
-// GFS3D_HEAD_V1=1 selects the lane = point passes of rounds 3-4 (kept for the A/B in DESIGN_HISTORY.md)
-static bool hd_v1()
-{
-    static const bool v = [] { const char *e = getenv("GFS3D_HEAD_V1"); return e && e[0] == '1'; }();
-    return v;
-}
 // 16-byte accesses along the points: whole groups of four inside every channel row
 static bool hd_vec_ok(const void *p, long long bstride, int N)
 {
@@ -1662,30 +1305,22 @@ int hd_launch_fwd1(const float *feat, long long bs, int N, int B, const long lon
                    const HeadFake &fk, float *part1, float *sums1, hipStream_t st, const char *who, int *nchunk_out)
 {
     constexpr int NTL = HdCfg<KT>::F1;
-    if (hd_v1()) {
-        const dim3 grid(hd_chunks(N, HD_PTS), B);
-        const size_t lds = sizeof(float) * (KT * HD_C + 8 * 32 * HD_LD + 128);
-        GFS3D_ENSURE_LDS((hd_fwd1_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_fwd1_kernel<KT>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
-        *nchunk_out = grid.x;
+    const dim3 grid(hd_chunks(N, HdT<NTL>::PTS), B);
+    constexpr size_t lds = hd_lds_fwd1<KT, NTL>();
+    if (hd_vec_ok(feat, bs, N)) {
+        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, true>), lds, who);
+        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
     } else {
-        const dim3 grid(hd_chunks(N, HdT<NTL>::PTS), B);
-        constexpr size_t lds = hd_lds_fwd1<KT, NTL>();
-        if (hd_vec_ok(feat, bs, N)) {
-            GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, true>), lds, who);
-            hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, true>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
-        } else {
-            GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, false>), lds, who);
-            hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
-        }
-        *nchunk_out = grid.x;
+        GFS3D_ENSURE_LDS((hd_fwd1_mm_kernel<KT, NTL, false>), lds, who);
+        hipLaunchKernelGGL((hd_fwd1_mm_kernel<KT, NTL, false>), grid, dim3(256), lds, st, feat, bs, N, label, main_proto, bg, K1, fk, part1, sums1);
     }
+    *nchunk_out = grid.x;
     GFS3D_LAUNCH_CHECK("hd_fwd1_kernel");
     return GFS3D_OK;
 }
 // the chunk count hd_launch_fwd1 used (phase 1 of the forward runs in a later call)
-template <int KT> int hd_fwd1_chunks(int N) { return hd_chunks(N, hd_v1() ? HD_PTS : HdT<HdCfg<KT>::F1>::PTS); }
-template <int KT> int hd_bwd1_chunks(int N) { return hd_chunks(N, hd_v1() ? HD_PTS : HdT<HdCfg<KT>::B1>::PTS); }
+template <int KT> int hd_fwd1_chunks(int N) { return hd_chunks(N, HdT<HdCfg<KT>::F1>::PTS); }
+template <int KT> int hd_bwd1_chunks(int N) { return hd_chunks(N, HdT<HdCfg<KT>::B1>::PTS); }
 
 template <int KT>
 int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
@@ -1711,14 +1346,7 @@ int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, con
                        a->bg_proto, K1, a->base_num, fk, a->fsum, F(p.off_q1), F(p.off_q2), F(p.off_ori), F(p.off_onrm), F(p.off_pooled), F(p.off_hs));
     GFS3D_LAUNCH_CHECK("hd_mid2_kernel");
     int nch2;
-    if (hd_v1()) {
-        const dim3 grid(hd_chunks(a->N, HD_PTS), a->B);
-        nch2 = grid.x;
-        const size_t lds = sizeof(float) * (2 * KT * HD_C + 16);
-        GFS3D_ENSURE_LDS((hd_fwd2_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_fwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
-                           F(p.off_q2), K1, F(p.off_part2), reinterpret_cast<long long *>(a->pred));
-    } else {
+    {
         constexpr int NTL = HdCfg<KT>::F2;
         constexpr size_t lds = hd_lds_fwd2<KT, NTL>();
         const dim3 grid(hd_chunks(a->N, HdT<NTL>::PTS), a->B);
@@ -1742,7 +1370,6 @@ int hd_forward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, con
 template <int KT>
 int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, const char *who)
 {
-    constexpr int RT = 2 * KT <= 32 ? 1 : 2;
     const HeadPlan p = hd_plan(a->B, a->N, a->classes);
     char *ws = static_cast<char *>(a->workspace);
     auto F = [&](size_t off) { return reinterpret_cast<float *>(ws + off); };
@@ -1753,12 +1380,7 @@ int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, co
     if (phase == 0) {
         const int nch = hd_bwd1_chunks<KT>(a->N);
         const dim3 grid(nch, a->B);
-        if (hd_v1()) {
-            const size_t lds = sizeof(float) * (2 * KT * HD_C + 4 * (RT + 1) * 32 * HD_LD);
-            GFS3D_ENSURE_LDS((hd_bwd1_kernel<KT>), lds, who);
-            hipLaunchKernelGGL((hd_bwd1_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index,
-                               F(p.off_q1), F(p.off_q2), K1, a->loss, a->dloss, F(p.off_part));
-        } else {
+        {
             constexpr int NTL = HdCfg<KT>::B1;
             constexpr size_t lds = hd_lds_bwd1<KT, NTL>();
             if (hd_vec_ok(a->feat, a->feat_bstride, a->N)) {
@@ -1781,15 +1403,7 @@ int hd_backward(const gfs3d_capl_head_args *a, int phase, const HeadFake &fk, co
         return GFS3D_OK;
     }
     int nch;
-    if (hd_v1()) {
-        const dim3 grid(hd_chunks(a->N, HD_PTS), a->B);
-        nch = grid.x;
-        const size_t lds = sizeof(float) * (4 * KT * HD_C + 8 * 32 * HD_LD + GFS3D_HEAD_MAX_FAKE * HD_FLD + 2 * KT);
-        GFS3D_ENSURE_LDS((hd_bwd2_kernel<KT>), lds, who);
-        hipLaunchKernelGGL((hd_bwd2_kernel<KT>), grid, dim3(256), lds, st, a->feat, a->feat_bstride, a->N, label, (long long)a->ignore_index, F(p.off_q1),
-                           F(p.off_q2), a->main_proto, a->bg_proto, K1, fk, a->loss, a->dloss, F(p.off_hs), F(p.off_dpool), F(p.off_t3), a->dfsum,
-                           a->dfeat, F(p.off_part));
-    } else {
+    {
         constexpr int NTL = HdCfg<KT>::B2;
         constexpr size_t lds = hd_lds_bwd2<KT, NTL>();
         const dim3 grid(hd_chunks(a->N, HdT<NTL>::PTS), a->B);
