@@ -54,9 +54,9 @@ class _AllReduceSum(torch.autograd.Function):
 
 def all_reduce_sum_diff(x: torch.Tensor, group=None) -> torch.Tensor:
     """Differentiable SUM all-reduce (generate_fake_proto's (feature sum, count) under block-sharded DP).  The same
-    arithmetic as torch.distributed.nn.functional.all_reduce - which is NOT used: importing torch.distributed.nn pulls in
-    torch.distributed.rpc, and with torch 2.10 a process that imported it aborts at interpreter exit every other run
-    ("terminate called without an active exception": bisected in the 8-rank gloo rehearsal of bench.py, round 5)."""
+    arithmetic as torch.distributed.nn.functional.all_reduce - which is NOT used: with torch 2.10 a process that has imported
+    torch.distributed.nn (the import alone, no call) aborts at interpreter exit every other run ("terminate called without
+    an active exception": bisected in the 8-rank gloo rehearsal of bench.py, round 5)."""
     return _AllReduceSum.apply(x, group)
 
 
