@@ -2328,7 +2328,7 @@ constexpr int ACC_DOUBLES = 8 * EC;
 // atomic path costs that kernel half of what the overlap hides.
 struct SideLane {
     hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr;      // fork: idx is there (graph build); fork2: Q is there (gather)
     bool ok = false;
     bool pending = false;      // forked work the caller's stream has not joined yet
 };
@@ -2348,6 +2348,7 @@ static SideLane *side_lane(hipStream_t caller)
         SideLane l;
         l.ok = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) == hipSuccess &&
                hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&l.fork2, hipEventDisableTiming) == hipSuccess &&
                hipEventCreateWithFlags(&l.join, hipEventDisableTiming) == hipSuccess;
         it = lanes.emplace(std::make_pair(dev, caller), l).first;
     }
@@ -2368,7 +2369,8 @@ static int side_join(hipStream_t st, const char *who)
     return GFS3D_OK;
 }
 
-static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_t rs, const char *who)
+// part 0: the graph itself (needs idx only); part 1: SQ / indeg gathered over it (needs Q)
+static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_t rs, const char *who, int part)
 {
     char *ws = static_cast<char *>(a->workspace);
     const int BN = a->B * a->N;
@@ -2377,11 +2379,14 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
         unsigned short *rangecnt = reinterpret_cast<unsigned short *>(ws + p.off_rangecnt);
         const size_t lds = csr_lds_bytes(a->N, a->k);
         const dim3 grid((unsigned)csr_ranges(a->N), (unsigned)a->B);
+        if (part == 0) {
         GFS3D_ENSURE_LDS(csr_place_kernel, lds, who);
         hipLaunchKernelGGL(csr_count_kernel, grid, dim3(CSR_THREADS), sizeof(unsigned) * (size_t)a->N, rs, a->idx, a->N, a->k, rangecnt);
         GFS3D_LAUNCH_CHECK("csr_count_kernel");
         hipLaunchKernelGGL(csr_place_kernel, grid, dim3(CSR_THREADS), lds, rs, a->idx, rangecnt, a->B, a->N, a->k, a->csr_rowptr, csr_src, a->csr_pos);
         GFS3D_LAUNCH_CHECK("csr_place_kernel");
+        return GFS3D_OK;
+        }
         // (512 long-lived workgroups beside the main stream's kernels instead of 2048: c2 step -0.7 %, A/B on one box)
         // ... at B = 64 the lane (count + place + gather) outlasts the main stream's forward of the layer and the join waits for it:
         // there 2048 workgroups (c5 step 8.13 -> 7.95 ms; at B = 32 no difference beyond noise)
@@ -2395,6 +2400,13 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
     int *slot = reinterpret_cast<int *>(ws + p.off_slot);
     int2 *ovf = reinterpret_cast<int2 *>(ws + p.off_ovf);
     const size_t nedges = (size_t)BN * a->k;
+    if (part == 1) {
+        hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, rs, a->Q, cnt, slot, BN, a->SQ, a->indeg);
+        GFS3D_LAUNCH_CHECK("rev_gather_kernel");
+        hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, rs, a->Q, ovf_cnt, ovf, a->SQ);
+        GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
+        return GFS3D_OK;
+    }
     if (a->N <= 8192) {                    // per-block table in LDS; only the overflow counter needs zeroing
         GFS3D_ENSURE_LDS(rev_block_kernel, RB_LDS, who);
         if (hipMemsetAsync(ovf_cnt, 0, sizeof(int) * 4, rs) != hipSuccess) {
@@ -2413,10 +2425,6 @@ static int reverse_graph(const gfs3d_edgeconv_args *a, const Plan &p, hipStream_
                            cnt, slot, ovf_cnt, ovf);
         GFS3D_LAUNCH_CHECK("rev_slot_kernel");
     }
-    hipLaunchKernelGGL(rev_gather_kernel, dim3(p.g_heavy), dim3(256), 0, rs, a->Q, cnt, slot, BN, a->SQ, a->indeg);
-    GFS3D_LAUNCH_CHECK("rev_gather_kernel");
-    hipLaunchKernelGGL(rev_overflow_kernel, dim3(64), dim3(256), 0, rs, a->Q, ovf_cnt, ovf, a->SQ);
-    GFS3D_LAUNCH_CHECK("rev_overflow_kernel");
     return GFS3D_OK;
 }
 
@@ -2442,6 +2450,22 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
     const bool fold = !a->training;
     if (phase == 0) {
         double *zero_acc = (a->training && !rows) ? acc : nullptr;          // atomics mode: the projection kernel clears the accumulators
+        // SQ / indeg and the reverse graph are the backward's: built on a side stream.  The graph needs idx only, so it is forked
+        // BEFORE the projections (round 5: the lane used to start after them and outlasted the main stream's forward of the layer by
+        // ~12 us, which the join at the end of phase 2 waited for); the gather over it waits for Q (second event).
+        SideLane *lane = a->training ? side_lane(st) : nullptr;
+        hipStream_t rs = st;
+        if (lane) {
+            if (hipEventRecord(lane->fork, st) != hipSuccess || hipStreamWaitEvent(lane->stream, lane->fork, 0) != hipSuccess) {
+                set_error("%s: fork onto the side stream failed", who);
+                return GFS3D_ERR_HIP;
+            }
+            rs = lane->stream;
+            lane->pending = true;                      // joined in phase 2, or by side_join() on any error return
+#ifndef GFS3D_EC_LATE_FORK                             // (ablation builds: the graph build after the projections, as in rounds 1-4)
+            if (int rc = reverse_graph(a, p, rs, who, 0)) return rc;
+#endif
+        }
         if (a->x_pm && a->C % 32 == 0) {
             float *wpq = reinterpret_cast<float *>(ws + p.off_wpart);        // (128, C); the backward's scratch, free here
             float *eab = fold ? reinterpret_cast<float *>(ws + p.off_bpart) : nullptr;       // (4, 64); likewise
@@ -2464,17 +2488,17 @@ static int forward_phase(const gfs3d_edgeconv_args *a, int phase, double *acc_us
             GFS3D_LAUNCH_CHECK("ec_pq_kernel");
         }
         if (a->training) {
-            SideLane *lane = side_lane(st);            // SQ/indeg are the backward's; build them beside the statistics pass
-            hipStream_t rs = st;
-            if (lane) {
-                if (hipEventRecord(lane->fork, st) != hipSuccess || hipStreamWaitEvent(lane->stream, lane->fork, 0) != hipSuccess) {
+            if (lane) {                                // Q is written: the gather may start
+                if (hipEventRecord(lane->fork2, st) != hipSuccess || hipStreamWaitEvent(lane->stream, lane->fork2, 0) != hipSuccess) {
                     set_error("%s: fork onto the side stream failed", who);
                     return GFS3D_ERR_HIP;
                 }
-                rs = lane->stream;
-                lane->pending = true;                  // joined in phase 2, or by side_join() on any error return
-            }
-            if (int rc = reverse_graph(a, p, rs, who)) return rc;
+            } else if (int rc = reverse_graph(a, p, rs, who, 0)) return rc;
+#ifdef GFS3D_EC_LATE_FORK
+            if (lane)
+                if (int rc = reverse_graph(a, p, rs, who, 0)) return rc;
+#endif
+            if (int rc = reverse_graph(a, p, rs, who, 1)) return rc;
             {
                 ProfScope prof(4, st);
                 hipLaunchKernelGGL(ec_stats1_kernel, dim3((p.g_heavy + ST1_GRID_DIV - 1) / ST1_GRID_DIV), dim3(64 * ST1_WAVES), 0, st, a->P, a->Q, a->idx, BN, a->N, a->k,
