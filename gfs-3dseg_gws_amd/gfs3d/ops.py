@@ -598,10 +598,10 @@ def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: boo
     statistics between the ranks of a block-sharded batch (phased C ABI, one all-reduce per layer and pass).  `slopes`: the
     activation after each layer as a LeakyReLU slope (0 = ReLU, 1 = none), default `slope` everywhere.  Convolution biases
     are honoured.  Returns the channel-first result, the point-major one, or (cf, pm)."""
-    if training and track:
-        for _c, bn in parts:
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+    if training and track:                      # nn.BatchNorm bookkeeping of the stack in one multi-tensor add
+        counters = [bn.num_batches_tracked for _c, bn in parts if bn.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)
     bn0 = parts[0][1]
     mom = bn0.momentum if bn0.momentum is not None else 0.1
     par, run_, bias = [], [], []

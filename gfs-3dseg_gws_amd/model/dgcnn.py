@@ -140,10 +140,11 @@ class DGCNN(nn.Module):
                 and parts[0][0].in_channels == ops.PW_SEG_WIDTH * self.n_edgeconv
                 and (self.training or not torch.is_grad_enabled()))
 
-    def edgeconv_features(self, x, with_point_major=False):
+    def edgeconv_features(self, x, with_point_major=False, also_track=()):
         """The n_edgeconv block outputs, each (B,64,N).  HIP path: K1 (kNN) + K2 (EdgeConv).
-        with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4)."""
-        feats, feats_pm, bns = [], [], []
+        with_point_major: also the (B,N,64) copies the kernels keep (input of the point-wise stack, K4).
+        also_track: further BatchNorm modules whose `num_batches_tracked` rides in this call's one multi-tensor add."""
+        feats, feats_pm, bns = [], [], list(also_track)
         x_pm = x_sq = x_img = None
         for li, block in enumerate(self.edge_convs):
             # Shapes outside the fused kernel (reference conv2d accepts any layer_dims, dgcnn.py:45-58; k > 32; a backward pass in
@@ -180,17 +181,25 @@ class DGCNN(nn.Module):
     def forward(self, x, point_major=False):
         """point_major=True (the fused CAPL heads): returns (block outputs, their (B,N,64) copies, level-2 feature as a
         point-major (B,N,C) tensor) - no channel-first copy of the level-2 feature is written."""
-        feats, feats_pm = self.edgeconv_features(x, with_point_major=True)
-        parts = self.conv.fused_parts() if len(feats) <= ops.PW_MAX_SEGS else None
+        parts = self.conv.fused_parts() if self.n_edgeconv <= ops.PW_MAX_SEGS else None
+        # the point-wise stack's BatchNorm counters ride in the EdgeConv blocks' multi-tensor add when the stack will run fused
+        # (decided below from the same `parts`; a stack that turns out not to be fused bumps its own counters as nn.BatchNorm1d)
+        will_fuse = parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * self.n_edgeconv and self.training and x.is_cuda \
+            and self.fully_fused()
+        feats, feats_pm = self.edgeconv_features(x, with_point_major=True, also_track=[bn for _c, bn in parts] if will_fuse else ())
         fused = (parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats) and all(t is not None for t in feats_pm)
                  and (self.training or not (torch.is_grad_enabled() and any(t.requires_grad for t in feats))))
+        if will_fuse and not fused:      # (a block took the general path after all: nn.BatchNorm1d will count this step itself)
+            torch._foreach_sub_([bn.num_batches_tracked for _c, bn in parts if bn.num_batches_tracked is not None], 1)
+            will_fuse = False
         if point_major:
             if not fused:
                 raise NotImplementedError("DGCNN(point_major=True): the point-wise stack is not in the HIP-fusable form")
-            out_pm = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync, want_cf=False, want_pm=True)
+            out_pm = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync, want_cf=False, want_pm=True,
+                                         track=not will_fuse)
             return feats, feats_pm, out_pm
         if fused:
-            out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync)       # K4: no cat, no transposes
+            out = ops.pointwise_stack(feats_pm, parts, self.training, _LRELU, sync=self.bn_sync, track=not will_fuse)       # K4: no cat, no transposes
         else:
             out = self.conv(torch.cat(feats, dim=1))
         if self.return_edgeconvs:
