@@ -96,6 +96,33 @@ def test_fused_train_head_is_bit_reproducible_and_scales_with_the_incoming_gradi
         assert relmax(v, -3.0 * u) < 1e-6
 
 
+def test_fused_train_head_on_a_misaligned_feature_tensor_equals_the_aligned_run(dev):
+    """The matrix-core passes read the features with 16-byte loads when every channel row is 16-byte aligned (N % 4 == 0, aligned
+    base) and fall back to scalar loads otherwise: a contiguous (B,128,N) view that starts 4 bytes into its storage takes the
+    fallback with the SAME N - same arithmetic in the same order, so every result equals the aligned run bit for bit."""
+    from gfs3d import ops
+    B, N, classes = 4, 512, 13
+    g = torch.Generator().manual_seed(11)
+    feat, main, bg = torch.randn(B, 128, N, generator=g), torch.randn(classes, 128, generator=g), torch.randn(1, 128, generator=g)
+    y = torch.randint(0, 8, (B, N), generator=g).to(dev)
+
+    def run(shifted):
+        if shifted:
+            store = torch.empty(B * 128 * N + 1, device=dev)
+            fd = store[1:].view(B, 128, N)
+            fd.copy_(feat)
+            assert fd.data_ptr() % 16 == 4 and fd.is_contiguous()
+            fd.requires_grad_(True)
+        else:
+            fd = feat.to(dev).requires_grad_(True)
+        md, bd = main.to(dev).requires_grad_(True), bg.to(dev).requires_grad_(True)
+        pred, loss = ops.capl_train_head(fd, md, bd, y, [2, 6], 7, 255)
+        loss.backward()
+        return pred, loss.detach(), fd.grad, md.grad, bd.grad
+    for u, v in zip(run(False), run(True)):
+        assert torch.equal(u, v)
+
+
 def test_fused_train_head_full_size_matches_the_unfused_form(dev):
     """BASELINE configs[3] size (B = 32 x 2048, 13 + 1 classes): the fused head against the tensor-library form of the same model
     code on the device (loss 1e-5 relative, gradients 1e-4 of their max), and a second run bit for bit."""
