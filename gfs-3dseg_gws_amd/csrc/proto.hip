@@ -1765,6 +1765,51 @@ __global__ void km_fix_to_f32_kernel(const long long *__restrict__ sums_fix, con
     if (e < K) counts[e] = (float)counts_fix[e];
 }
 
+// The tail of a Lloyd iteration on the running sums, ONE workgroup (K C <= a few 10^4 elements): the fp32 sums / counts, the new
+// centres (member means; an empty cluster keeps its centre) and the iteration's three scalars - what get_basis._lloyd otherwise builds
+// from ~15 element-wise launches of 5 us each: state = {sum of squared centre shifts (fp32 squares, fp64 sum in a fixed order),
+// labels changed, empty clusters}; `changed` is reset to zero once read.
+__global__ void __launch_bounds__(1024)
+km_fix_step_kernel(const long long *__restrict__ sums_fix, const long long *__restrict__ counts_fix, int K, int C, double inv_scale,
+                   const float *__restrict__ cent_old, unsigned long long *__restrict__ changed, float *__restrict__ sums,
+                   float *__restrict__ counts, float *__restrict__ cent_new, float *__restrict__ state)
+{
+    __shared__ double red[1024];
+    __shared__ int redn[1024];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    int nempty = 0;
+    for (int e = tid; e < K * C; e += 1024) {
+        const int k = e / C;
+        const float s = (float)((double)sums_fix[e] * inv_scale);            // (km_fix_to_f32_kernel's conversion)
+        const float cnt = (float)counts_fix[k];
+        const float old = cent_old[e];
+        const float nv = cnt > 0.f ? s / fmaxf(cnt, 1.f) : old;
+        sums[e] = s;
+        cent_new[e] = nv;
+        const float d = nv - old;
+        acc += (double)(d * d);
+    }
+    for (int k = tid; k < K; k += 1024) {
+        const float cnt = (float)counts_fix[k];
+        counts[k] = cnt;
+        nempty += cnt == 0.f ? 1 : 0;
+    }
+    red[tid] = acc;
+    redn[tid] = nempty;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { red[tid] += red[tid + o]; redn[tid] += redn[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        state[0] = (float)red[0];
+        state[1] = (float)changed[0];
+        state[2] = (float)redn[0];
+        changed[0] = 0ull;                               // read and reset: the next gfs3d_kmeans_delta_fix counts from zero
+    }
+}
+
 // relative part of the screen's error bound for C channels (knn.hip derives the terms): dropped piece products 2^-15 (1 + 2^-6) per
 // dot, the screen's 3 C fp32 accumulations at 2^-23, the exact form's 6 C at 2^-24 - doubled for d = |c|^2 - 2 <c, p>
 static inline float km_screen_rel(int C) { return 2.0f * (3.1e-5f + (float)C * (3.0f * 1.1920929e-7f + 6.0f * 5.9604645e-8f)) * 1.05f; }
@@ -2036,6 +2081,19 @@ extern "C" int gfs3d_kmeans_fix_to_f32(const long long *sums_fix, const long lon
     hipLaunchKernelGGL(km_fix_to_f32_kernel, dim3((unsigned)((K * C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), sums_fix,
                        counts_fix, K, C, ldexp(1.0, -shift), sums, counts);
     GFS3D_LAUNCH_CHECK("km_fix_to_f32_kernel");
+    return GFS3D_OK;
+}
+
+extern "C" int gfs3d_kmeans_fix_step(const long long *sums_fix, const long long *counts_fix, int K, int C, int shift, const float *cent_old,
+                                     unsigned long long *changed, float *sums, float *counts, float *cent_new, float *state, void *stream)
+{
+    using namespace gfs3d;
+    GFS3D_REQUIRE(sums_fix && counts_fix && cent_old && changed && sums && counts && cent_new && state, "gfs3d_kmeans_fix_step: NULL pointer");
+    GFS3D_REQUIRE(K >= 1 && C >= 1 && (long long)K * C <= (1 << 22) && shift >= 0 && shift <= 60,
+                  "gfs3d_kmeans_fix_step: bad argument (K=%d C=%d shift=%d)", K, C, shift);
+    hipLaunchKernelGGL(km_fix_step_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), sums_fix, counts_fix, K, C,
+                       ldexp(1.0, -shift), cent_old, changed, sums, counts, cent_new, state);
+    GFS3D_LAUNCH_CHECK("km_fix_step_kernel");
     return GFS3D_OK;
 }
 

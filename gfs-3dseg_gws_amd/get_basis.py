@@ -189,7 +189,51 @@ def _relocate_empty_clusters(points, cent_old, label, sums, counts, sharded):
     return sums, counts
 
 
-_DELTA_SHARE = 0.03          # moved points per iteration below which the sums follow the labels (above it a full pass is cheaper)
+_DELTA_SHARE = 0.03      # moved points per iteration below which the sums follow the labels (above it a full pass is cheaper)
+_RUN_AHEAD = True        # tests switch it off to compare the run-ahead loop with the blocking one
+
+
+def _lloyd_run_ahead(points, cent, old_label, delta, first_iter, max_iter, scale):
+    """The Lloyd iterations from `first_iter` on, once the centroid sums follow the labels (`delta`, single process): the SAME
+    iterations as the loop of `_lloyd`, but the host stays one iteration ahead of its own decisions.  Iteration n + 1 (labels from
+    the centres of n, the moved rows, the fused tail: three launches) is queued BEFORE the three scalars of iteration n are read -
+    read from pinned memory behind an event, so the device never waits for the host (the blocking read cost ~0.1 ms of idle device
+    per iteration, a tenth of it).  If iteration n turns out to be the last one, the queued iteration is simply abandoned (the
+    final assignment recomputes everything from the returned centres); if it relocates empty clusters, the queued move of the
+    running sums is undone - 64-bit integer sums: exactly - and iteration n + 1 is queued again from the relocated centres.
+    Returns (centres, n_iter) as the loop would have left them."""
+    hosts = [torch.empty(3, dtype=torch.float32).pin_memory() for _ in range(3)]
+    events = [torch.cuda.Event() for _ in range(3)]
+    slot = [0]
+
+    def launch(cent_in, prev_label):
+        label = ops.kmeans_assign(points, cent_in, fast=True, want_sums=False)[0]
+        delta.move(prev_label, label)
+        sums, counts, new, state = delta.step(cent_in)
+        k = slot[0] % 3
+        slot[0] += 1
+        hosts[k].copy_(state, non_blocking=True)
+        events[k].record()
+        return dict(label=label, cent_in=cent_in, sums=sums, counts=counts, new=new, k=k)
+
+    n = first_iter
+    cur = launch(cent, old_label)
+    while True:
+        nxt = launch(cur["new"], cur["label"]) if n < max_iter else None       # queued before iteration n is judged
+        events[cur["k"]].synchronize()
+        shift, n_changed, n_empty = hosts[cur["k"]].tolist()
+        new = cur["new"]
+        if n_empty > 0:
+            if nxt is not None:
+                delta.move(nxt["label"], cur["label"])                          # undo the queued move of the running sums
+                nxt = None
+            sums, counts = _relocate_empty_clusters(points, cur["cent_in"], cur["label"], cur["sums"], cur["counts"], False)
+            new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cur["cent_in"]).contiguous()
+            shift = float(((new - cur["cent_in"]) ** 2).sum())
+        if n_changed == 0 or shift <= scale or n >= max_iter:
+            return new, n
+        cur = nxt if nxt is not None else launch(new, cur["label"])
+        n += 1
 
 
 def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
@@ -215,10 +259,18 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
         m_glob = float(t.item())
     old_label, moved_share = None, 1.0
     for n_iter in range(1, max_iter + 1):
+        fused = None
         if delta is not None and old_label is not None and moved_share <= _DELTA_SHARE:
+            if not sharded and _RUN_AHEAD:      # the rest of the loop with the host one iteration ahead of its decisions
+                cent, n_iter = _lloyd_run_ahead(points, cent, old_label, delta, n_iter, max_iter, scale)
+                break
             label = ops.kmeans_assign(points, cent, fast=True, want_sums=False)[0]
-            changed = delta.move(old_label, label).to(torch.float32)
-            sums, counts = delta.sums_counts()
+            if sharded:
+                changed = delta.move(old_label, label).to(torch.float32)
+                sums, counts = delta.sums_counts()
+            else:                        # one launch: sums, counts, the new centres and the iteration's three scalars
+                delta.move(old_label, label)
+                sums, counts, new, fused = delta.step(cent)
         else:
             label, sums, counts, _ = loop_fn(points, cent)
             changed = (label != old_label).sum().float().reshape(1) if old_label is not None else \
@@ -232,8 +284,11 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
             packed[:K, :D], packed[:K, D], packed[K, 0] = sums, counts, changed[0]
             torch.distributed.all_reduce(packed)
             sums, counts, changed = packed[:K, :D], packed[:K, D], packed[K, :1]
-        new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
-        state = torch.cat([((new - cent) ** 2).sum().reshape(1), changed.to(new.dtype), (counts == 0).sum().reshape(1).to(new.dtype)])
+        if fused is not None:
+            state = fused
+        else:
+            new = torch.where(counts[:, None] > 0, sums / counts.clamp_min(1)[:, None], cent)
+            state = torch.cat([((new - cent) ** 2).sum().reshape(1), changed.to(new.dtype), (counts == 0).sum().reshape(1).to(new.dtype)])
         shift, n_changed, n_empty = state.tolist()                                      # the iteration's one host read
         moved_share = n_changed / m_glob
         if n_empty > 0:

@@ -190,6 +190,7 @@ SYMBOLS = {
                                           c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfs3d_kmeans_fix_from_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfs3d_kmeans_fix_to_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gfs3d_kmeans_fix_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_kmeans_delta_fix": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfs3d_kmeanspp_workspace_bytes": (c_size_t, [c_longlong, c_int]),
     "gfs3d_kmeanspp_seed_f32": (c_int, [c_void_p, c_longlong, c_int, c_int, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

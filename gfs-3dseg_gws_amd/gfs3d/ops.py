@@ -1120,7 +1120,7 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False, wan
     """One Lloyd assignment step on device: labels, per-centroid sums/counts and
     inertia (get_basis.py:210 runs sklearn KMeans on the CPU).  fast=True: the screened form of the Lloyd loop
     (gfs3d_kmeans_assign_fast_f32: same labels / sums / counts, inertia from the screened scores).  want_sums=False (fast form
-    only): labels, counts and inertia, `sums` is None - the caller moves its running sums with `KMeansDelta`."""
+    only): the labels alone, (label, None, None, None) - the caller moves its running sums with `KMeansDelta`."""
     _need_gpu(pts, "pts")
     _need_gpu(cent, "cent")
     pts, cent = pts.contiguous(), cent.contiguous()
@@ -1129,8 +1129,9 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False, wan
     dev = pts.device
     label = torch.empty(M, dtype=torch.int32, device=dev)
     sums = torch.zeros((K, C), dtype=torch.float32, device=dev) if want_sums else None
-    counts = torch.zeros(K, dtype=torch.float32, device=dev)
-    inertia = torch.zeros(1, dtype=torch.float64, device=dev)
+    # want_sums=False: the kernel still adds into counts / inertia, nobody reads them - no zero fills (two launches per Lloyd iteration)
+    counts = torch.zeros(K, dtype=torch.float32, device=dev) if want_sums else torch.empty(K, dtype=torch.float32, device=dev)
+    inertia = torch.zeros(1, dtype=torch.float64, device=dev) if want_sums else torch.empty(1, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         L = _lib.lib()
         nbytes = L.gfs3d_kmeans_workspace_bytes(M, C, K)       # > 0: centroid sums as sorted segment sums (fixed order, no atomics)
@@ -1140,6 +1141,8 @@ def kmeans_assign(pts: torch.Tensor, cent: torch.Tensor, fast: bool = False, wan
             raise RuntimeError("gfs3d.kmeans_assign: want_sums=False needs the screened form (fast=True, a supported shape)")
         rc = fn(_p(pts), M, C, _p(cent), K, _p(label), _p(sums), _p(counts), _p(inertia), _p(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "gfs3d_kmeans_assign_ws_f32")
+    if not want_sums:
+        return label, None, None, None
     return label, sums, counts, inertia
 
 
@@ -1210,6 +1213,7 @@ class KMeansDelta:
         self.sums_fix = torch.zeros((self.K, self.C), dtype=torch.int64, device=dev)
         self.counts_fix = torch.zeros(self.K, dtype=torch.int64, device=dev)
         self.changed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._changed_is_zero = True                                   # (step() resets the counter on the device)
 
     def load(self, sums: torch.Tensor, counts: torch.Tensor):
         with torch.cuda.device(self.pts.device):
@@ -1221,12 +1225,31 @@ class KMeansDelta:
         """-> device int64[1]: the number of points whose label changed (their rows were moved between the sums)."""
         if label_old.dtype != torch.int32 or label_new.dtype != torch.int32:
             raise RuntimeError("gfs3d.KMeansDelta: labels must be int32 device tensors")
-        self.changed.zero_()
+        if not self._changed_is_zero:
+            self.changed.zero_()
+        self._changed_is_zero = False
         with torch.cuda.device(self.pts.device):
             rc = _lib.lib().gfs3d_kmeans_delta_fix(_p(self.pts), self.M, self.C, self.K, _p(label_old), _p(label_new), self.shift,
                                                    _p(self.sums_fix), _p(self.counts_fix), _p(self.changed), _stream())
         _lib.check(rc, "gfs3d_kmeans_delta_fix")
         return self.changed
+
+    def step(self, cent_old: torch.Tensor):
+        """The tail of a Lloyd iteration in one launch -> (sums, counts, cent_new, state): the fp32 sums / counts, the new centres
+        (member means, an empty cluster keeps its old centre) and state = float32[3] {squared centre shift, labels changed by the
+        last `move`, empty clusters} on the device (gfs3d_kmeans_fix_step); the changed-label counter is reset by the kernel."""
+        dev = self.pts.device
+        cent_old = cent_old.contiguous()
+        sums = torch.empty((self.K, self.C), dtype=torch.float32, device=dev)
+        counts = torch.empty(self.K, dtype=torch.float32, device=dev)
+        new = torch.empty((self.K, self.C), dtype=torch.float32, device=dev)
+        state = torch.empty(3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().gfs3d_kmeans_fix_step(_p(self.sums_fix), _p(self.counts_fix), self.K, self.C, self.shift, _p(cent_old),
+                                                  _p(self.changed), _p(sums), _p(counts), _p(new), _p(state), _stream())
+        _lib.check(rc, "gfs3d_kmeans_fix_step")
+        self._changed_is_zero = True
+        return sums, counts, new, state
 
     def sums_counts(self):
         dev = self.pts.device

@@ -458,6 +458,13 @@ int gfs3d_kmeans_fix_to_f32(const long long *sums_fix, const long long *counts_f
                             float *counts, void *stream);
 int gfs3d_kmeans_delta_fix(const float *pts, long long M, int C, int K, const int32_t *label_old, const int32_t *label_new,
                            int shift, long long *sums_fix, long long *counts_fix, unsigned long long *changed, void *stream);
+/* The tail of such an iteration in one launch (`_kmeans_single_lloyd`'s centre update and stopping quantities, get_basis.py:210):
+ * sums / counts as fp32 (like gfs3d_kmeans_fix_to_f32), cent_new (K, C) = member means - an empty cluster keeps cent_old's row -
+ * and state[3] = {sum over all elements of (cent_new - cent_old)^2, *changed, number of empty clusters} as floats: the caller's
+ * single host read of the iteration; *changed is reset to 0 once read (the next gfs3d_kmeans_delta_fix counts from zero).
+ * K C <= 2^22. */
+int gfs3d_kmeans_fix_step(const long long *sums_fix, const long long *counts_fix, int K, int C, int shift, const float *cent_old,
+                          unsigned long long *changed, float *sums, float *counts, float *cent_new, float *state, void *stream);
 /* k-means++ seeding on the device: the `init='k-means++'` half of `KMeans(n_clusters=num_cnt, init='k-means++').fit(point_feat)`,
  * get_basis.py:210 of the reference (sklearn, not vendored; restated as the plain D^2 sampling of Arthur & Vassilvitskii 2007:
  * centre t + 1 is point i with probability d2[i] / sum d2, d2 = squared distance to the nearest of the centres so far).

@@ -66,6 +66,9 @@ def round5_cases(L, _lib):
     assert L.gfs3d_kmeanspp_greedy_f32(1, 10, 8, 2, 11, 1, 2, 1, 1, 1, 1 << 30, 1, None) != 0 and b"first" in L.gfs3d_last_error()
     assert L.gfs3d_kmeanspp_greedy_f32(1, 10, 8, 2, 0, 1, 2, 1, 1, 1, 16, 1, None) != 0 and b"workspace" in L.gfs3d_last_error()
     assert L.gfs3d_kmeanspp_seed_f32(1, 10, 8, 2, 0, 1, 1, 1, 1, 16, 1, None) != 0 and b"workspace" in L.gfs3d_last_error()
+    assert L.gfs3d_kmeans_fix_step(1, 1, 200, 192, 30, 1, None, 1, 1, 1, 1, None) != 0 and b"NULL" in L.gfs3d_last_error()
+    assert L.gfs3d_kmeans_fix_step(1, 1, 200, 192, 61, 1, 1, 1, 1, 1, 1, None) != 0 and b"shift=61" in L.gfs3d_last_error()
+    assert L.gfs3d_kmeans_fix_step(1, 1, 1 << 12, 1 << 12, 30, 1, 1, 1, 1, 1, 1, None) != 0 and b"bad argument" in L.gfs3d_last_error()
     a = _lib.EdgeConvArgs()
     a.B, a.C, a.N, a.k, a.training = 2, 9, 256, 20, 1
     assert L.gfs3d_edgeconv_forward_f32(ctypes.byref(a), None) != 0 and b"NULL input" in L.gfs3d_last_error()

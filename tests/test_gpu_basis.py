@@ -320,6 +320,35 @@ def test_lloyd_delta_sums_follow_the_labels_exactly(dev):
     assert float(((sums.double() - s0.float().double()) - (s1 - s0)).abs().max()) < 1e-4 * float(s1.abs().max()) * 1e-3 + 1e-5
 
 
+def test_lloyd_fused_tail_equals_the_elementwise_form(dev):
+    """ops.KMeansDelta.step (gfs3d_kmeans_fix_step, one launch): sums / counts bit for bit those of sums_counts(), the new centres bit
+    for bit `where(counts > 0, sums / counts, old)` - an empty cluster keeps its centre -, and the three scalars: squared centre
+    shift (1e-6 relative of the tensor-library sum), labels changed, empty clusters."""
+    from gfs3d import ops
+    M, C, K = 30000, 192, 200
+    g = torch.Generator().manual_seed(9)
+    pts = (torch.randn(M, C, generator=g) * 0.7 + 0.3).to(dev)
+    lab0 = torch.randint(0, K - 3, (M,), generator=g, dtype=torch.int32).to(dev)          # clusters K-3 .. K-1 stay empty
+    lab1 = lab0.clone()
+    moved = torch.randperm(M, generator=g)[:700].to(dev)
+    lab1[moved] = ((lab0[moved].long() + 1) % (K - 3)).int()
+    s0 = torch.zeros(K, C, dtype=torch.float64, device=dev).index_add_(0, lab0.long(), pts.double())
+    c0 = torch.bincount(lab0.long(), minlength=K).double()
+    old = torch.randn(K, C, generator=g).to(dev)
+    d = ops.KMeansDelta(pts, K)
+    d.load(s0.float(), c0.float())
+    d.move(lab0, lab1)
+    sums_ref, counts_ref = d.sums_counts()
+    sums, counts, new, state = d.step(old)
+    assert torch.equal(sums, sums_ref) and torch.equal(counts, counts_ref)
+    new_ref = torch.where(counts_ref[:, None] > 0, sums_ref / counts_ref.clamp_min(1)[:, None], old)
+    assert torch.equal(new, new_ref) and torch.equal(new[K - 3:], old[K - 3:])
+    shift, changed, empty = state.tolist()
+    ref_shift = float(((new_ref.double() - old.double()) ** 2).sum())
+    assert abs(shift - ref_shift) <= 1e-6 * ref_shift
+    assert changed == float((lab0 != lab1).sum()) == 700.0 and empty == 3.0
+
+
 def test_device_kmeans_with_delta_updates_equals_full_recomputation(dev, monkeypatch):
     """The Lloyd loop with the sums following the labels (moved share <= 3 %) ends where the loop that rebuilds the sums from all
     points every iteration ends: same iteration count, labels, inertia."""
@@ -333,6 +362,57 @@ def test_device_kmeans_with_delta_updates_equals_full_recomputation(dev, monkeyp
     b = get_basis.device_kmeans(pts, K, init=init)
     assert a[3] == b[3] and abs(a[2] - b[2]) < 1e-6 * b[2]
     assert float((a[1] == b[1]).float().mean()) > 0.9999
+
+
+def test_lloyd_run_ahead_equals_the_blocking_loop(dev, monkeypatch):
+    """get_basis._lloyd_run_ahead (iteration n + 1 queued before the scalars of iteration n are read) ends exactly where the loop that
+    reads them every iteration ends: same iteration count, bit-identical centres, same labels and inertia."""
+    import get_basis
+    g = load_golden("kmeanspp")
+    for case in ("c", "f"):
+        X, K, s = _kpp_case(g, case)
+        pts = torch.from_numpy(X).to(dev)
+        init = pts[torch.from_numpy(g[case + "_fit_indices"]).to(dev)]
+        monkeypatch.setattr(get_basis, "_RUN_AHEAD", True)
+        a = get_basis.device_kmeans(pts, K, init=init)
+        monkeypatch.setattr(get_basis, "_RUN_AHEAD", False)
+        b = get_basis.device_kmeans(pts, K, init=init)
+        assert a[3] == b[3] and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_lloyd_run_ahead_undoes_a_queued_iteration(dev, monkeypatch):
+    """When the iteration being judged relocates empty clusters, the iteration queued behind it started from centres that no longer
+    hold: its move of the running sums is undone (integer sums: exactly) and it is queued again.  Forced here: the fused tail reports
+    an empty cluster at its third call, the relocation is the identity - the run must end exactly like the undisturbed one."""
+    import get_basis
+    from gfs3d import ops
+    g = load_golden("kmeanspp")
+    X, K, s = _kpp_case(g, "c")
+    pts = torch.from_numpy(X).to(dev)
+    init = pts[torch.from_numpy(g["c_fit_indices"]).to(dev)]
+    ref = get_basis.device_kmeans(pts, K, init=init)
+    calls, undone = [0], [0]
+    step0, move0 = ops.KMeansDelta.step, ops.KMeansDelta.move
+
+    def step(self, cent_old):
+        sums, counts, new, state = step0(self, cent_old)
+        calls[0] += 1
+        if calls[0] == 3:
+            state = state.clone()
+            state[2] = 1.0
+        return sums, counts, new, state
+
+    def move(self, a, b):
+        out = move0(self, a, b)
+        undone[0] += 1
+        return out
+    monkeypatch.setattr(ops.KMeansDelta, "step", step)
+    monkeypatch.setattr(ops.KMeansDelta, "move", move)
+    monkeypatch.setattr(get_basis, "_relocate_empty_clusters", lambda p, c, l, sums, counts, sh: (sums, counts))
+    got = get_basis.device_kmeans(pts, K, init=init)
+    assert calls[0] >= 4                                            # the loop went on after the forced relocation ...
+    assert undone[0] == calls[0] + 1                                # ... with one extra move: the undo of the queued iteration
+    assert got[3] == ref[3] and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and got[2] == ref[2]
 
 
 def test_kmeans_full_size_vs_fp64(dev):
