@@ -837,6 +837,19 @@ pw_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int n, float 
     *reinterpret_cast<f32x4 *>(dw + e) = s;
 }
 
+// the eval-mode constants of channel c of a C-wide layer: scale (h - (rm - b)) + beta
+__device__ __forceinline__ void pw_bn_eval_one(int c, int C, const float *gamma, const float *beta, const float *rm, const float *rv, const float *bias,
+                                               float eps, float *stats)
+{
+    const double bc = bias ? (double)bias[c] : 0.0;
+    const double mean = (double)rm[c] - bc, var = rv[c];
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    stats[PST_SCALE * C + c] = sc;
+    stats[PST_SHIFT * C + c] = beta[c] - (float)mean * sc;
+    stats[PST_MEAN * C + c] = (float)mean;
+    stats[PST_RSTD * C + c] = rstd;
+}
 // batch statistics -> (scale, shift, mean, rstd) and the running-statistics update of nn.BatchNorm1d
 __global__ void pw_bn_finalize_kernel(const double *__restrict__ acc, int C, double count, const float *__restrict__ gamma,
                                       const float *__restrict__ beta, float *__restrict__ rm, float *__restrict__ rv,
@@ -849,15 +862,7 @@ __global__ void pw_bn_finalize_kernel(const double *__restrict__ acc, int C, dou
         pw_bn_finalize_one(c, C, acc[c], acc[C + c], count, gamma, beta, rm, rv, eps, momentum, bias, stats);
         return;
     }
-    // running statistics: scale (h - (rm - b)) + beta
-    const double bc = bias ? (double)bias[c] : 0.0;
-    const double mean = (double)rm[c] - bc, var = rv[c];
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * rstd;
-    stats[PST_SCALE * C + c] = sc;
-    stats[PST_SHIFT * C + c] = beta[c] - (float)mean * sc;
-    stats[PST_MEAN * C + c] = (float)mean;
-    stats[PST_RSTD * C + c] = rstd;
+    pw_bn_eval_one(c, C, gamma, beta, rm, rv, bias, eps, stats);      // running statistics
 }
 
 // BatchNorm backward coefficients: dh = a g + b + c h; parameter gradients
@@ -985,12 +990,22 @@ struct SplitJob {
     int n;
     double *zero;
     int nzero;
+    // eval forward: the BatchNorm constants of every layer from the running statistics (what pw_bn_finalize_kernel(training = 0) writes),
+    // in the same launch - they depend on nothing the pass computes.  bn_n layers, entry l: C = Nc[l].
+    int bn_n;
+    const float *bn_gamma[PW_MAX_SPLIT], *bn_beta[PW_MAX_SPLIT], *bn_rm[PW_MAX_SPLIT], *bn_rv[PW_MAX_SPLIT], *bn_bias[PW_MAX_SPLIT];
+    float *bn_stats[PW_MAX_SPLIT];
+    float bn_eps;
 };
 template <int PREC>
 __global__ void pw_split_all_kernel(const SplitJob job)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     for (int z = e; z < job.nzero; z += gridDim.x * blockDim.x) job.zero[z] = 0.0;
+    if (job.bn_n > 0 && blockIdx.x == 0)                 // (at most 8 x 1024 channels: one workgroup)
+        for (int l = 0; l < job.bn_n; ++l)
+            for (int c = threadIdx.x; c < job.Nc[l]; c += blockDim.x)
+                pw_bn_eval_one(c, job.Nc[l], job.bn_gamma[l], job.bn_beta[l], job.bn_rm[l], job.bn_rv[l], job.bn_bias[l], job.bn_eps, job.bn_stats[l]);
     if (e >= job.first[job.n]) return;
     int i = 0;
 #pragma unroll
@@ -1162,6 +1177,14 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
             }
             job.zero = a->training ? acc : nullptr;
             job.nzero = a->training ? (acc_user ? 2 * p.maxw * L : (2 * p.maxw + 1) * L) : 0;      // (+ the ticket slots of bn_tail)
+            if (!a->training) {                          // eval: every layer's BatchNorm constants in the same launch
+                job.bn_n = L;
+                job.bn_eps = a->eps;
+                for (int l = 0; l < L; ++l) {
+                    job.bn_gamma[l] = a->bn_w[l]; job.bn_beta[l] = a->bn_b[l]; job.bn_rm[l] = a->bn_rm[l]; job.bn_rv[l] = a->bn_rv[l];
+                    job.bn_bias[l] = a->bias[l]; job.bn_stats[l] = a->stats[l];
+                }
+            }
             if (int rc = split_all(job, st, prec_of(a->compute, false))) return rc;
         } else if (a->training && hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) {
             set_error("%s: hipMemsetAsync failed", who);
@@ -1214,9 +1237,11 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
                 GFS3D_LAUNCH_CHECK("pw_colsum_reduce_kernel");
             }
         } else {
-            hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
-                               a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l], a->bias[l]);
-            GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
+            if (!split_once) {                           // (more layers than one split launch takes: the constants layer by layer)
+                hipLaunchKernelGGL(pw_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc, C, (double)M, a->bn_w[l], a->bn_b[l],
+                                   a->bn_rm[l], a->bn_rv[l], a->eps, a->momentum, 0, a->stats[l], a->bias[l]);
+                GFS3D_LAUNCH_CHECK("pw_bn_finalize_kernel");
+            }
             rg.ea = a->stats[l] + PST_SCALE * C;
             rg.eb = a->stats[l] + PST_SHIFT * C;
             if (l == L - 1 && a->y_pm) {                 // point-major result (+ a transposed copy if both are wanted)

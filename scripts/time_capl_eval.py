@@ -19,7 +19,8 @@ bc, nc = (torch.rand(7, 200, device=dev) > 0.5).float(), (torch.rand(6, 200, dev
 def fwd():
     with torch.no_grad():
         return m(x, y=y, gened_proto=gened, eval_model=True, base_class_coding=bc, novel_class_coding=nc)
-for _ in range(3): fwd()
+for _ in range(50): fwd()                  # (a short run measures the clock ramp of a cold device, not the forward: 6 ms instead of 1.4)
 torch.cuda.synchronize(); t = time.time()
-for _ in range(10): fwd()
-torch.cuda.synchronize(); print(f"CAPL eval forward B={B}: {(time.time() - t) / 10 * 1e3:.3f} ms = {B / ((time.time() - t) / 10):.0f} blocks/s")
+for _ in range(100): fwd()
+torch.cuda.synchronize(); dt = (time.time() - t) / 100
+print(f"CAPL eval forward B={B}: {dt * 1e3:.3f} ms = {B / dt:.0f} blocks/s")

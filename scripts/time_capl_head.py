@@ -13,9 +13,9 @@ for B, classes, base, fake in ((32, 13, 7, [2, 4, 7]), (64, 21, 15, [1, 3, 5, 8,
     def step():
         f.grad = mp.grad = bg.grad = None
         ops.capl_train_head(f, mp, bg, y, fake, base, 255)[1].backward()
-    for _ in range(3): step()
+    for _ in range(50): step()          # (a short run measures the clock ramp of a cold device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(20): step()
+    for _ in range(200): step()
     e1.record(); torch.cuda.synchronize()
-    print(f"train head fwd+bwd B={B} classes={classes}: {e0.elapsed_time(e1) / 20:.4f} ms")
+    print(f"train head fwd+bwd B={B} classes={classes}: {e0.elapsed_time(e1) / 200:.4f} ms")
