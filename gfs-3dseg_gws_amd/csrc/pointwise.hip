@@ -410,6 +410,10 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
 // (odd, so the 16-lane groups of ds_read_b128 hit 16 different slots).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int PW6_ROW = 208;
+#ifndef PW_RG6_OCC
+#define PW_RG6_OCC 2                    // workgroups per CU the row GEMM is compiled for (3 fits the LDS exactly and 168 VGPRs with 4-20
+                                        // spilled: measured SLOWER, 117 -> 123 / 133 -> 144 / 190 -> 251 us, c2 step +0.07 ms: DESIGN_HISTORY)
+#endif
 
 // w3[n][kt][plane][32] = bf16 pieces of w(n, 32 kt + j);  w element (n, k) is read at w[n * sn + k * sk]
 template <int PREC>
@@ -423,7 +427,7 @@ __global__ void pw_split_w_kernel(const float *__restrict__ w, int Nc, int K, lo
 
 // PREC_BF16 / PREC_F16: one rounded 16-bit product per fp32 product - plane 0 of the same images, one MFMA per K-step of 16.
 template <int BN, int PRO, int EPI, bool OUT_CF, int PREC>
-__global__ void __launch_bounds__(256, 2) pw_rowgemm6_kernel(const RowGemm g)
+__global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowGemm g)
 {
     extern __shared__ f32x4 pw_smem4[];
     char *smem = reinterpret_cast<char *>(pw_smem4);
