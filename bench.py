@@ -47,10 +47,6 @@ PEAK_16BIT_TFLOPS = 2500.0     # dense bf16 / f16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 KERNELS = {0: "knn_topk_kernel", 1: "ec_main_fwd_kernel", 2: "ec_main_bwd_pair_kernel", 3: "proto_kernels", 4: "ec_stats1_kernel",
            5: "kmeans_assign_kernel", 6: "pointwise_stack_fwd", 7: "pointwise_stack_bwd", 8: "attention_fwd", 9: "attention_bwd"}
-# kernel names as the PMC summaries (profiles/*_hbm_traffic.json) spell them, by (kernel id, reduced mode)
-# (ids 6-9 bracket GROUPS of kernels: no single PMC figure)
-KERNEL_PMC_NAME = {(2, False): "ec_main_bwd_pair_kernel<0>", (2, True): "ec_main_bwd_pair_kernel<1>", (1, False): "ec_main_fwd_kernel<true, 0>",
-                   (1, True): "ec_main_fwd_kernel<true, 2>"}
 WORKLOADS = {
     "c2": dict(model="dgcnn", B=32, dtype="f32", classes=0, base=0, Kw=0,
                text="configs[1]: S3DIS-shaped blocks, batch=32x2048x9 per GPU, k=20, DGCNN+EdgeConv fwd/bwd (train mode, BN batch stats) "
@@ -89,22 +85,70 @@ def algorithmic_flops(kid, B, cfg=None):
     return 0, 0
 
 
-def hbm_traffic(kernel, tag):
-    """HBM bytes per launch of `kernel` from the committed PMC profile (profiles/<tag>_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note;
-    scripts/collect_profiles.py) - a figure of the committed profile, not of this run."""
+def _traffic_file(tag, workload):
+    """Newest committed PMC summary of `workload`: profiles/<tag>*_<workload>_hbm_traffic.json, else the older per-bench files."""
     import glob
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}*_hbm_traffic.json")))
-    for t in ([os.path.basename(newest[-1])[:-len("_hbm_traffic.json")]] if newest else []) + ["r04_d", "r03_g", "r02_e"]:
-        try:
-            with open(os.path.join(ROOT, "profiles", f"{t}_hbm_traffic.json")) as f:
-                d = json.load(f)
-            for k, v in d.items():
-                if k.startswith(kernel) and isinstance(v, dict):
-                    return v.get("traffic_bytes_per_launch"), f"profiles/{t}_hbm_traffic.json"
-        except OSError:
-            continue
+    for pat in (f"{tag}*_{workload}_hbm_traffic.json", f"{tag}*_hbm_traffic.json", "r05_d_hbm_traffic.json"):
+        got = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        if got:
+            return got[-1]
+    return None
+
+
+def hbm_traffic(kernel, tag, workload="c2"):
+    """HBM bytes per launch of `kernel` from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, FETCH_SIZE doubled per the gfx950 note; scripts/collect_profiles.py) - a figure of the committed profile, not of
+    this run."""
+    path = _traffic_file(tag, workload)
+    if path:
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d.items():
+            if k.startswith(kernel) and isinstance(v, dict):
+                return v.get("traffic_bytes_per_launch"), "profiles/" + os.path.basename(path)
     return None, None
+
+
+# kernels behind each profile bracket (ids of KERNELS), as regular expressions over the PMC summaries' kernel names.  Brackets 6-9
+# cover GROUPS of kernels (a whole stack pass).  Row GEMM template arguments: <BN, PRO, EPI, OUT_CF, ...>; PRO 2 = backward
+# prologue; EPI 3 = plain (channel-first output: the forward q|k|v projections; point-major: their backward)
+BRACKET_KERNELS = {
+    1: [r"^ec_main_fwd_kernel"],
+    2: [r"^ec_main_bwd_pair_kernel", r"^ec_main_bwd_kernel"],
+    6: [r"^pw_rowgemm6_kernel<\d+, [01], [01], ", r"^pw_rowgemm6_kernel<\d+, 0, 3, true", r"^pw_out_kernel", r"^pw_split_all_kernel", r"^pw_bn_finalize_kernel"],
+    7: [r"^pw_bwd_in_kernel", r"^pw_wgrad6_kernel", r"^pw_wgrad_reduce_kernel", r"^pw_rowgemm6_kernel<\d+, 2, ",
+        r"^pw_rowgemm6_kernel<\d+, 0, 3, false", r"^pw_bwd_coef_kernel"],
+    8: [r"^attn_fwd_kernel"],
+    9: [r"^attn_bwd_"],
+}
+
+
+def group_traffic(kid, workload, launches_per_step, tag="r06"):
+    """(HBM bytes per bracketed launch, source file, kernel names) of profile bracket `kid` in `workload`: the PMC bytes of every
+    launch of the bracket's kernels during the profiled run / the run's steps / the bracket's launches per step.  Needs the
+    workload's own PMC summary (its `_steps` field); None without one."""
+    import re
+    path = _traffic_file(tag, workload)
+    pats = BRACKET_KERNELS.get(kid)
+    if not path or not pats or (kid not in (1, 2) and not os.path.basename(path).endswith(f"_{workload}_hbm_traffic.json")):
+        return None, None, None
+    with open(path) as f:
+        d = json.load(f)
+    total, count, names = 0.0, 0, []
+    for k, v in d.items():
+        if isinstance(v, dict) and any(re.search(p, k) for p in pats):
+            total += v["traffic_bytes_per_launch"] * v["launches"]
+            count += v["launches"]
+            names.append(k)
+    if not names:
+        return None, None, None
+    src = "profiles/" + os.path.basename(path)
+    if kid in (1, 2):                             # one kernel launch per bracket: the launch-weighted mean
+        return int(total / count), src, sorted(names)
+    steps = d.get("_steps")
+    if not steps:
+        return None, None, None
+    return int(total / steps / max(launches_per_step, 1e-9)), src, sorted(names)
 
 
 def pipe_of(kid, dtype):
@@ -118,7 +162,7 @@ def pipe_of(kid, dtype):
     return "16-bit matrix cores, one product per fp32 product (dense 16-bit peak)", PEAK_16BIT_TFLOPS
 
 
-def roofline_of(prof, steps, B, cfg, tag="r05"):
+def roofline_of(prof, steps, B, cfg, tag="r06", workload="c2"):
     """Roofline block of one profiled workload: the library kernel with the largest device time among those with a flop model,
     its role flops / average launch time against (a) the fp32 peak the results are priced at and (b) the pipe it executes on,
     and its HBM bytes per launch from the committed PMC passes."""
@@ -135,8 +179,8 @@ def roofline_of(prof, steps, B, cfg, tag="r05"):
     achieved = flops_step / (ms / steps * 1e-3) / 1e12
     pipe_name, pipe_peak = pipe_of(dom, cfg["dtype"])
     name = KERNELS[dom] + ("<1>" if (dom == 2 and cfg["dtype"] != "f32") else "")
-    pmc_name = KERNEL_PMC_NAME.get((dom, cfg["dtype"] != "f32"))
-    traffic, src = hbm_traffic(pmc_name, tag) if pmc_name else (None, None)
+    # HBM bytes per bracketed launch from the committed PMC passes of THIS workload (profiles/<tag>_<workload>_hbm_traffic.json)
+    traffic, src, traffic_kernels = group_traffic(dom, workload, n / steps, tag)
     # `frac` / `peak` follow the arithmetic the results are priced at: the fp32 peak for the fp32-accurate path; for the reduced
     # dtypes (configs[4]) the executed 16-bit pipe - `frac_fp32` and `frac_executed_pipe` stay as the explicit fields
     reduced = cfg["dtype"] != "f32" and pipe_peak
@@ -146,7 +190,7 @@ def roofline_of(prof, steps, B, cfg, tag="r05"):
                  "frac_fp32": round(achieved / PEAK_FP32_TFLOPS, 4), "executed_pipe": pipe_name,
                  "peak_executed_pipe": round(pipe_peak, 1) if pipe_peak else None,
                  "frac_executed_pipe": round(achieved / pipe_peak, 4) if pipe_peak else None,
-                 "traffic": traffic, "traffic_source": src, "avg_launch_ms": round(avg_ms, 4), "launches": n,
+                 "traffic": traffic, "traffic_source": src, "traffic_kernels": traffic_kernels, "avg_launch_ms": round(avg_ms, 4), "launches": n,
                  "launches_per_step": round(n / steps, 2), "role_flops_per_step": int(flops_step)})
     roof["per_kernel"] = {}
     for kid in sorted(prof):
@@ -182,11 +226,12 @@ def cpu_baseline(seconds_budget=60.0):
             t0 = time.time()
             fn()
             times.append(time.time() - t0)
-        return sorted(times)[len(times) // 2], len(times)
+        ts = sorted(times)
+        return ts[len(ts) // 2], len(ts), ts[0], ts[-1]
 
     x1 = R.synthetic_blocks(1, NPTS, seed=0)
     with torch.no_grad():
-        dt1, n1 = median_time(lambda: R.dgcnn_forward(sd, x1, k=KNN, training=False), 3, 10, 10, 0.0)
+        dt1, n1, lo1, hi1 = median_time(lambda: R.dgcnn_forward(sd, x1, k=KNN, training=False), 3, 10, 10, 0.0)
     Bc = 32
     x = R.synthetic_blocks(Bc, NPTS, seed=0)
 
@@ -194,7 +239,7 @@ def cpu_baseline(seconds_budget=60.0):
         p = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
         _, out = R.dgcnn_forward(p, x, k=KNN, training=True, new_stats={})
         out.mean().backward()
-    dt, n = median_time(one, 1, 3, 10, seconds_budget)
+    dt, n, lo, hi = median_time(one, 1, 3, 10, seconds_budget)
     torch.set_num_threads(prev_threads)
     model = ""
     try:
@@ -202,9 +247,11 @@ def cpu_baseline(seconds_budget=60.0):
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": round(Bc / dt, 3), "unit": "blocks/s", "cores": cores, "kind": "port", "cpu": model,
+    return {"value": round(Bc / dt, 3), "value_min_max": [round(Bc / hi, 3), round(Bc / lo, 3)], "unit": "blocks/s", "cores": cores, "kind": "port",
+            "cpu": model,
             "sample": f"median of {n} iterations (1 warm-up) of B={Bc} x {NPTS} x {CIN}, k={KNN}, DGCNN train-mode fwd+bwd (torch CPU oracle)",
-            "b1_eval_forward": {"value": round(1.0 / dt1, 3), "unit": "blocks/s", "ms": round(dt1 * 1e3, 2),
+            "b1_eval_forward": {"value": round(1.0 / dt1, 3), "value_min_max": [round(1.0 / hi1, 3), round(1.0 / lo1, 3)], "unit": "blocks/s",
+                                "ms": round(dt1 * 1e3, 2), "ms_min_max": [round(lo1 * 1e3, 2), round(hi1 * 1e3, 2)],
                                 "sample": f"BASELINE configs[0]: one 2048 x 9 block, DGCNN eval forward, median of {n1} after 3 warm-ups"}}
 
 
@@ -213,8 +260,9 @@ def capl_args():
                                  base_widths=[128, 64], output_dim=64, eval_weight=1.2)
 
 
-def build_step(cfg, dev, rank, world, sync_bn, gdist):
-    """-> (step(), net, bucket, x): one training step of the workload on this rank's shard."""
+def build_step(cfg, dev, rank, world, sync_bn, gdist, force=False):
+    """-> (step(), net, bucket, x): one training step of the workload on this rank's shard.  force: issue every collective of
+    the N > 1 step although this is the only rank (--force-collectives: a 1-rank RCCL group)."""
     from gfs3d import ops
     from gfs3d.synthetic import synthetic_blocks    # input recipe (SURVEY 8d); oracle/ is used by cpu_baseline() only
     torch.manual_seed(0)
@@ -239,11 +287,13 @@ def build_step(cfg, dev, rank, world, sync_bn, gdist):
         edge = {id(p) for p in net.encoder.edge_convs.parameters()}
         early = [p for p in net.parameters() if id(p) not in edge]      # everything that is complete before the EdgeConv backward
         y = torch.randint(0, cfg["base"] + 1, (cfg["B"], NPTS), generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-    if sync_bn and world > 1:
+    multi = world > 1 or force
+    if sync_bn and multi:
         net = gdist.enable_sync_batchnorm(net)
     # the early slice is exchanged under the EdgeConv backward - unless synchronised BatchNorm puts other collectives inside
     # backward (then every rank must issue them in one fixed order)
-    bucket = gdist.FlatGradBucket(net.parameters(), early=early, overlap=not (sync_bn and world > 1))
+    bucket = gdist.FlatGradBucket(net.parameters(), early=early, overlap=not (sync_bn and multi))
+    bucket.force_collectives = bool(force)
     opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
     mode = cfg["dtype"]
 
@@ -277,17 +327,23 @@ def read_profile(L):
     return prof
 
 
-def timed_ms(fn, iters, warm=3):
-    """Device time per call on the current stream (the stream the library launches on)."""
+def timed_ms(fn, iters=50, warm=10, chunks=10):
+    """Device time per call on the current stream (the stream the library launches on): SURVEY 8(d)'s protocol - `warm` untimed
+    calls (a cold device ramps its clocks over the first few milliseconds), then `iters` calls in `chunks` event-bracketed groups;
+    the MEDIAN of the groups' per-call times (one slow group - a clock step, another tenant's burst - does not move it)."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    chunks = max(1, min(chunks, iters))
+    per = max(1, iters // chunks)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    ev[0].record()
+    for c in range(chunks):
+        for _ in range(per):
+            fn()
+        ev[c + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    ts = sorted(ev[c].elapsed_time(ev[c + 1]) / per for c in range(chunks))
+    return ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
 
 
 def c3_end_to_end(dev, n_blocks=1400, num_cnt=200):
@@ -372,14 +428,14 @@ def extras(dev, L, gdist):
         words = torch.randn(200, 192, generator=g).to(dev)
         for mode in ("f32", "f16"):
             with ops.compute(mode):
-                ms = timed_ms(lambda: ops.word_assign_raw(feat, words, 10.0), 20)
+                ms = timed_ms(lambda: ops.word_assign_raw(feat, words, 10.0), 100)
             byts = 4.0 * B * N * (192 + 200 + 200 + 1)              # features in; softmax, one-hot and word id out
             out["word_assign_" + mode] = {"shape": "B=32x2048, C=192, K_w=200", "ms": round(ms, 4), "bound": "hbm",
                                           "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
                                           "algorithmic_TFLOPps": round(2.0 * B * N * 192 * 200 / ms / 1e9, 2)}
         f2 = torch.randn(B, 128, N, generator=g).to(dev)
         pr = torch.randn(14, 128, generator=g).to(dev)
-        ms = timed_ms(lambda: ops.proto_cosine_raw(f2, pr, 10.0), 50)
+        ms = timed_ms(lambda: ops.proto_cosine_raw(f2, pr, 10.0), 100)
         byts = 4.0 * B * N * (128 + 14)
         out["get_pred"] = {"shape": "B=32x2048, C=128, K=13+1", "ms": round(ms, 4), "bound": "hbm",
                            "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4)}
@@ -392,12 +448,12 @@ def extras(dev, L, gdist):
     def head():
         f3.grad = mp.grad = bgp.grad = None
         ops.capl_train_head(f3, mp, bgp, yh, [2, 4, 7], 7, 255)[1].backward()
-    ms = timed_ms(head, 20)
+    ms = timed_ms(head, 100)
     byts = 4.0 * B * N * 128 * 3                                     # features read by the forward and by the backward, gradient written
     head_flops = 2.0 * B * N * 128 * (14 * 11 + 3 * 14)             # 11 class-table products of 14 x 128 per point + the three point contractions
     out["capl_train_head"] = {"shape": "B=32x2048, C=128, 13+1 classes, 3 fake-novel classes; forward + backward", "ms": round(ms, 4),
-                              "bound": "hbm (its bytes are the floor; the passes run at the VALU / LDS-broadcast rate of one wave per SIMD: "
-                                       "65536 points = 1024 waves)",
+                              "bound": "hbm (its bytes are the floor; the four point passes run on the fp32 matrix cores, v_mfma_f32_16x16x4_f32, "
+                                       "at ~2x their matrix floor; the 11 launches are host-latency bound)",
                               "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
                               "executed_TFLOPps_fp32": round(head_flops / ms / 1e9, 2),
                               "note": "generate_fake_proto + 3 x get_pred + post_refine_proto_v2 + 2 x CrossEntropyLoss + arg-max as 11 "
@@ -411,9 +467,10 @@ def extras(dev, L, gdist):
         byts = 4.0 * M * (192 + 1)                                   # every point read once, its label written
         for key, fast, note in (("lloyd_step", True, "the step of the Lloyd loop (get_basis.device_kmeans): SCREENED assignment (hi + mid bf16 operands, three "
                                  "products, error bound; undecided points re-scored at fp32 accuracy from a list: same labels / sums / counts as the exact "
-                                 "form) + centroid sums as sorted segment sums; the points are read twice"),
+                                 "form) + centroid sums as sorted segment sums over the rows (the Lloyd LOOP itself replaces that second pass by delta "
+                                 "sums over the moved rows once < 3 % of the labels change: gfs3d_kmeans_delta_fix)"),
                                 ("lloyd_step_exact", False, "every point scored at fp32 accuracy (bf16x6 GEMM): the final assignment, whose inertia is reported")):
-            ms = timed_ms(lambda: ops.kmeans_assign(pts, cent, fast=fast), 5, warm=2)
+            ms = timed_ms(lambda: ops.kmeans_assign(pts, cent, fast=fast), 50)
             fl = 2.0 * M * 192 * 200
             out[key] = {"shape": "M=2.1e6, C=192, K=200 (configs[2])", "ms": round(ms, 3),
                         "bound": "mfma (bf16x6: the scoring GEMM is 2 K = 400 flop per 4 B read = 100 flop/B, above the fp32 balance; "
@@ -456,25 +513,30 @@ def extras(dev, L, gdist):
     for name in ("c4", "c5"):
         cfg = WORKLOADS[name]
         step, net, bucket, x = build_step(cfg, dev, 0, 1, False, gdist)
-        for _ in range(3):
+        for _ in range(10):
             step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 5
-        for _ in range(n):
-            step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        chunk_ms = []
+        for _ in range(6):                        # wall clock like the headline: 6 groups of 5 steps, the median group
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            chunk_ms.append((time.perf_counter() - t0) / 5 * 1e3)
+        chunk_ms.sort()
+        dt = 0.5 * (chunk_ms[2] + chunk_ms[3]) * 1e-3
+        n_prof = 10
         L.gfs3d_profile_enable(1)
-        for _ in range(3):
+        for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
         L.gfs3d_profile_enable(0)
         prof = read_profile(L)
         out["step_" + name] = {"workload": cfg["text"], "dtype": cfg["dtype"], "ms_per_step": round(dt * 1e3, 3),
+                               "ms_per_step_min_max": [round(chunk_ms[0], 3), round(chunk_ms[-1], 3)],
                                "blocks_per_s": round(cfg["B"] / dt, 1),
-                               "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / 3, 4) for k, v in prof.items()},
-                               "roofline": roofline_of(prof, 3, cfg["B"], cfg)}
+                               "library_kernel_ms_per_step": {KERNELS[k]: round(v[0] / n_prof, 4) for k, v in prof.items()},
+                               "roofline": roofline_of(prof, n_prof, cfg["B"], cfg, workload=name)}
         if name == "c4":       # the testing path of the reference (train.py test loop): capl.forward(eval_model=True), fp32 results
             net.eval()
             ncls = cfg["classes"]
@@ -483,7 +545,7 @@ def extras(dev, L, gdist):
             nc = (torch.rand(ncls - cfg["base"], cfg["Kw"], generator=torch.Generator().manual_seed(5)) > 0.5).float().to(dev)
             yy = torch.randint(0, ncls, (cfg["B"], NPTS), generator=torch.Generator().manual_seed(6)).to(dev)
             with torch.no_grad():
-                ms = timed_ms(lambda: net(x, y=yy, gened_proto=gened, eval_model=True, base_class_coding=bc, novel_class_coding=nc), 10)
+                ms = timed_ms(lambda: net(x, y=yy, gened_proto=gened, eval_model=True, base_class_coding=bc, novel_class_coding=nc), 50)
             out["capl_eval_forward"] = {"workload": "configs[3] shapes, capl.forward(eval_model=True): backbone + heads + prototype "
                                         "refinement + geometric-word re-weighting, B=32x2048", "ms": round(ms, 4),
                                         "blocks_per_s": round(cfg["B"] / (ms * 1e-3), 1)}
@@ -678,6 +740,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements of the other kernels (rank 0, N = 1)")
     ap.add_argument("--sync-bn", action="store_true", help="whole-batch BatchNorm statistics across ranks (N>1)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N = 1 only: run the step's collectives anyway, through a 1-rank RCCL group (the async early slice, the "
+                         "remainder all-reduce and, with --sync-bn, the BatchNorm phase all-reduces go through real RCCL streams "
+                         "inside the timed step) - first-contact rehearsal for the multi-GPU run; not the default measurement")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # no external launcher: this process becomes one (no GPU call before this)
@@ -698,8 +764,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    forced = bool(args.force_collectives and world == 1)
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -711,9 +780,20 @@ def main():
     if args.dtype:
         cfg["dtype"] = args.dtype
     B = cfg["B"]
-    step, net, bucket, x = build_step(cfg, dev, rank, world, args.sync_bn, gdist)
+    step, net, bucket, x = build_step(cfg, dev, rank, world, args.sync_bn, gdist, force=forced)
+    probe = None
+    if forced:
+        # latency of the step's two gradient messages and of one BatchNorm phase message on this rank's RCCL stream (one rank:
+        # no wire - launch + kernel cost, the floor every N pays; DESIGN.md section 5's prediction table starts from it)
+        def _ar(t):
+            return lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t64 = torch.zeros(128, dtype=torch.float64, device=dev)
+        probe = {"early_slice_us": round(timed_ms(_ar(bucket.flat[:max(bucket.n_early, 1)])) * 1e3, 2),
+                 "remainder_us": round(timed_ms(_ar(bucket.flat[bucket.n_early:] if bucket.n_early < bucket.flat.numel() else bucket.flat)) * 1e3, 2),
+                 "bn_phase_128_f64_us": round(timed_ms(_ar(t64)) * 1e3, 2),
+                 "early_bytes": int(4 * bucket.n_early), "remainder_bytes": int(4 * (bucket.flat.numel() - bucket.n_early))}
 
-    if world > 1:          # communicator set-up and the first-use costs of both message sizes stay out of the timed region for any W
+    if world > 1 or forced:          # communicator set-up and the first-use costs of both message sizes stay out of the timed region for any W
         dist.all_reduce(torch.zeros_like(bucket.flat))
         dist.all_reduce(torch.zeros(max(bucket.n_early, 1), device=dev))
     for _ in range(args.warmup):
@@ -753,12 +833,12 @@ def main():
         from gfs3d import ops
         net.eval()
         with torch.no_grad(), ops.compute(cfg["dtype"]):
-            fwd_ms = timed_ms(lambda: net.edgeconv_features(x), 20)
-            c1_ms = timed_ms(lambda: net(x[:1]), 20)          # BASELINE configs[0] on the device: one 2048 x 9 block, DGCNN eval forward
+            fwd_ms = timed_ms(lambda: net.edgeconv_features(x), 50)
+            c1_ms = timed_ms(lambda: net(x[:1]), 50)          # BASELINE configs[0] on the device: one 2048 x 9 block, DGCNN eval forward
         net.train()
 
     if rank == 0:
-        roof = roofline_of(prof, args.steps, B, cfg)
+        roof = roofline_of(prof, args.steps, B, cfg, workload=args.workload)
         if roof["kernel"] and roof["kernel"].startswith("ec_main_bwd_pair_kernel"):
             roof["traffic_note"] = ("ec_main_bwd_pair_kernel: ~67 MB read (P', Q', neighbour ids, winners, gradients) + ~357 MB of plain 256-B row "
                                     "stores, 335 MB of them the per-edge dy1 rows in CSR order that ec_bwd_segsum_kernel reads back once, last-written "
@@ -779,7 +859,7 @@ def main():
                         "knn_screen_kernel<20, 4,": 2, "knn_exact_kernel<20, 64>": 2}
             tb, src = 0, None
             for name, n in per_step.items():
-                t_, s_ = hbm_traffic(name, "r05")
+                t_, s_ = hbm_traffic(name, "r06")
                 if t_:
                     tb, src = tb + n * t_, s_
             if tb:
@@ -809,22 +889,27 @@ def main():
         line = {
             "metric": metric, "value": round(world * B / (elapsed / args.steps), 2),
             "unit": "blocks/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "devices": devices,
-            "backend": backend if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+            "backend": backend if (world > 1 or forced) else None, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "rank_ms_per_step": {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": cfg["text"], "blocks_per_gpu": B, "points": NPTS, "k": KNN,
-                       "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and world > 1 else "")},
+                       "parallelism": f"block-sharded dp{world}" + ("+syncbn" if args.sync_bn and (world > 1 or forced) else "")},
             "roofline": roof,
         }
-        if world == 1 and not args.no_extras and args.workload == "c2":
+        if forced:
+            line["forced_collectives"] = {"early_slice_launches": int(bucket.early_launches), "bucket_overlap": bool(bucket.overlap),
+                                          "sync_bn": bool(args.sync_bn), "rccl_probe": probe,
+                                          "note": "N = 1 with every collective of the N > 1 step issued on a 1-rank RCCL group inside the timed "
+                                                  "region (rehearsal; the default N = 1 line issues none)"}
+        if world == 1 and not args.no_extras and not forced and args.workload == "c2":
             del step, net, bucket
             torch.cuda.empty_cache()
             line["extra"] = extras(dev, L, gdist)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not forced:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

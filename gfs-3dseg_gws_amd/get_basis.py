@@ -141,6 +141,11 @@ def kmeans_plus_plus(points, n_clusters, rng, return_picks=False, n_local_trials
     if not points.is_cuda:
         cent, picks = kmeans_plus_plus_greedy_host(points, n_clusters, rng, T)
         return (cent, picks) if return_picks else cent
+    if not ops.kmeanspp_greedy_supported(points, T):
+        # outside the fused kernel's shapes (C % 4, C <= 256, at most 8 candidates per pick, i.e. K < 1097): the same algorithm
+        # in tensor ops on the device - slower, same picks up to the same rounding ties
+        cent, picks = kmeans_plus_plus_greedy_host(points, n_clusters, rng, T)
+        return (cent, picks) if return_picks else cent
     first, u = _draw_seeding_variates(M, n_clusters, T, rng)
     cent, picks = ops.kmeanspp_greedy(points, n_clusters, first, u, T)
     return (cent, picks) if return_picks else cent
@@ -310,7 +315,7 @@ def _lloyd(points, cent, max_iter, scale, assign_fn, sharded):
 
 
 def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0, n_init=1, assign_fn=None, return_means=False,
-                  timings=None, rng=None, center=True, n_local_trials=None):
+                  timings=None, rng=None, center=True, n_local_trials=None, details=None):
     """`KMeans(n_clusters, init='k-means++').fit(points)` (get_basis.py:210) on the GPU, step for step as sklearn's `fit`:
     centre the data on its mean, greedy k-means++ from `rng` (default `RandomState(seed)`), Lloyd iterations with empty-cluster
     relocation, stop on repeated labels or a centre shift <= tol * mean(var(points, axis=0)), final assignment, centres shifted
@@ -323,7 +328,10 @@ def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0,
     segment sums) - (centroids, labels, inertia, n_iter, means (K,D), counts (K,)).  `timings`: dict receiving the seconds
     spent seeding and in Lloyd's loop.  Sharded points: the start centroids come from rank 0 (k-means++ on rank 0's shard,
     then broadcast), mean and stop threshold from all-reduced moments, so every rank runs the same number of iterations.
-    `assign_fn` replaces gfs3d.ops.kmeans_assign (CPU logic tests only).  center=False: iterate on the data as given."""
+    `assign_fn` replaces gfs3d.ops.kmeans_assign (CPU logic tests only).  center=False: iterate on the data as given;
+    center="inplace": the caller gives `points` up - they are centred in place (no second 1.6 GB copy at configs[2] size; the
+    labels, means and centres returned are the same, the caller's tensor is left centred).  `details`: dict receiving the
+    seeding's `picks` (indices into `points`; rank 0's shard under sharding)."""
     assign_fn = assign_fn or ops.kmeans_assign
     sharded = _dist_on()
     rng = rng if rng is not None else np.random.RandomState(seed)
@@ -338,7 +346,9 @@ def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0,
         var = points.var(dim=0, unbiased=False).mean()
         mean = points.mean(dim=0)
     scale = float(var) * tol
-    if center:
+    if center == "inplace":
+        points.sub_(mean)
+    elif center:
         points = points - mean
     import time
     best = None
@@ -349,7 +359,9 @@ def device_kmeans(points, n_clusters, init=None, max_iter=300, tol=1e-4, seed=0,
             if center:
                 cent = cent - mean
         elif not sharded or torch.distributed.get_rank() == 0:
-            cent = kmeans_plus_plus(points, n_clusters, rng, n_local_trials=n_local_trials)
+            cent, picks = kmeans_plus_plus(points, n_clusters, rng, return_picks=True, n_local_trials=n_local_trials)
+            if details is not None:
+                details["picks"] = picks
         else:
             cent = torch.empty((n_clusters, points.shape[1]), dtype=points.dtype, device=points.device)
         cent = cent.contiguous().float()
@@ -400,12 +412,15 @@ def collect_edgeconv_features(model, blocks, batch=32):
 
 
 @torch.no_grad()
-def subsample_per_class(feat, labels, num_classes, max_per_class=300000, seed=0, sampler="device"):
+def subsample_per_class(feat, labels, num_classes, max_per_class=300000, seed=0, sampler="device", rng=None, details=None):
     """<= max_per_class feature rows per foreground class (reference get_basis.py:187-205: `np.random.choice(..., replace=False)`
     per class, classes concatenated in order).  ONE host synchronisation (the class counts); the class members come from a
     stable sort of the labels (ascending point order inside a class, as the reference's block-order concatenation gives).
-    sampler "device": `torch.randperm` on the device from a seeded generator; "numpy": the host draw
-    `RandomState(seed).choice(arange(n), max, replace=False)` of rounds 1-3 (a full host permutation per class)."""
+    sampler "device": `torch.randperm` on the device from a seeded generator; "numpy": the reference's own host draw
+    `rng.choice(arange(n), max, replace=False)` per over-full class, in class order, from `rng` (default `RandomState(seed)`) -
+    pass the RandomState that `device_kmeans` continues with and the two consume ONE stream, as the reference's
+    `np.random.seed(s)` ... `np.random.choice` ... `KMeans(random_state=None)` does (get_basis.py:310, 198, 210).
+    `details`: dict receiving `sub_idx` = the per-class draws (class -> indices into the class's rows)."""
     y = labels.reshape(-1).to(feat.device).long()
     # labels outside [0, num_classes) - an ignore index such as -100, float labels - match no `y == c` mask of the reference
     # (get_basis.py:176-181): they are skipped, i.e. counted with the background
@@ -413,8 +428,10 @@ def subsample_per_class(feat, labels, num_classes, max_per_class=300000, seed=0,
     counts = torch.bincount(y, minlength=num_classes)[:num_classes].tolist()           # the one sync
     order = torch.argsort(y, stable=True)
     starts = np.concatenate([[0], np.cumsum(counts)])
+    if sampler not in ("device", "numpy"):
+        raise ValueError(f"subsample_per_class: sampler must be 'device' or 'numpy', got {sampler!r}")
     gen = torch.Generator(device=feat.device).manual_seed(seed) if sampler == "device" else None
-    rng = np.random.RandomState(seed)
+    rng = rng if rng is not None else np.random.RandomState(seed)
     picks = []
     for c in range(1, num_classes):
         n = counts[c]
@@ -425,19 +442,27 @@ def subsample_per_class(feat, labels, num_classes, max_per_class=300000, seed=0,
             if sampler == "device":
                 members = members[torch.randperm(n, generator=gen, device=feat.device)[:max_per_class]]
             else:
-                members = members[torch.as_tensor(rng.choice(np.arange(n), max_per_class, replace=False), device=feat.device)]
+                drawn = rng.choice(np.arange(n), max_per_class, replace=False)
+                if details is not None:
+                    details.setdefault("sub_idx", {})[c] = drawn
+                members = members[torch.as_tensor(drawn, device=feat.device)]
         picks.append(members)
     return feat[torch.cat(picks)] if picks else feat[:0]
 
 
 @torch.no_grad()
 def extract_geometric_words(model, blocks, labels, num_classes, num_cnt, max_per_class=300000, batch=32, seed=0,
-                            init=None, max_iter=300, n_init=1, sampler="device", timings=None):
+                            init=None, max_iter=300, n_init=1, sampler="device", timings=None, rng=None, details=None):
     """blocks (M,9,N) float, labels (M,N) int (0 = background).  Returns the (num_cnt,192)
     SVD-reconstructed geometric words (numpy), like the pickle the reference writes (get_basis.py:162-222).
     Device-resident end to end: features -> per-class subsample -> k-means++ -> Lloyd -> per-cluster means (the final
     assignment's own sums / counts, not a host pass over the points) -> 150 KB to the host for the SVD.
-    `timings`: a dict that receives the wall-clock seconds of each stage (each closed by a device synchronisation)."""
+    `timings`: a dict that receives the wall-clock seconds of each stage (each closed by a device synchronisation).
+    `rng`: ONE numpy RandomState for the whole flow - the per-class subsample (sampler "numpy") and the k-means++ seeding draw
+    from it in sequence, which is what the reference does with numpy's global stream after its single `np.random.seed(args.seed)`
+    (get_basis.py:310 -> :198 -> :210).  `rng=np.random.RandomState(s), sampler="numpy"` therefore reproduces the reference's
+    subsample rows and seeding variates for `--seed s` (tests/golden/basis_flow.npz); default: separate streams from `seed`.
+    `details`: dict receiving the subsample draws, the seeding picks, n_iter, inertia, the cluster means."""
     import time
     model.eval()
 
@@ -450,11 +475,14 @@ def extract_geometric_words(model, blocks, labels, num_classes, num_cnt, max_per
     t = time.perf_counter()
     feat = collect_edgeconv_features(model, blocks, batch)
     t = lap("features", t)
-    pts = subsample_per_class(feat, labels, num_classes, max_per_class, seed, sampler).contiguous()
+    pts = subsample_per_class(feat, labels, num_classes, max_per_class, seed, sampler, rng=rng, details=details).contiguous()
     del feat
     t = lap("subsample", t)
-    cent, label, _, n_iter, means, counts = device_kmeans(pts, num_cnt, init=init, max_iter=max_iter, seed=seed, n_init=n_init,
-                                                          return_means=True, timings=timings)
+    cent, label, inertia, n_iter, means, counts = device_kmeans(pts, num_cnt, init=init, max_iter=max_iter, seed=seed, n_init=n_init,
+                                                                return_means=True, timings=timings, rng=rng, details=details,
+                                                                center="inplace")
+    if details is not None:
+        details.update(n_iter=n_iter, inertia=inertia, means=means, counts=counts, rows=int(pts.shape[0]))
     t = time.perf_counter()
     counts_h = counts.cpu().numpy()
     assert (counts_h != 0).all(), "an empty cluster (Kmean2Proto asserts the same, get_basis.py:36)"

@@ -1170,6 +1170,16 @@ def kmeanspp_seed(pts: torch.Tensor, K: int, first: int, u, prune: bool = True):
     return centers, picks
 
 
+KPP_MAX_TRIALS = 8        # KPP_TMAX of csrc/kmeanspp.hip
+
+
+def kmeanspp_greedy_supported(pts: torch.Tensor, n_trials: int) -> bool:
+    """The shapes gfs3d_kmeanspp_greedy_f32 takes: fp32 rows of C = 4 m <= 256 channels, 1..8 candidates per pick
+    (sklearn's 2 + int(log K) reaches 9 at K = 1097)."""
+    C = int(pts.shape[1])
+    return pts.is_cuda and pts.dtype == torch.float32 and C >= 4 and C % 4 == 0 and C <= 256 and 1 <= int(n_trials) <= KPP_MAX_TRIALS
+
+
 def kmeanspp_greedy(pts: torch.Tensor, K: int, first: int, u, n_trials: int, prune: bool = True):
     """sklearn's greedy k-means++ on the device (gfs3d_kmeanspp_greedy_f32; what `KMeans(init='k-means++')` of get_basis.py:210
     runs): pts (M,C) fp32, `first` the first centre's index, `u` (K - 1, n_trials) uniform variates in sklearn's consumption
@@ -1205,7 +1215,8 @@ class KMeansDelta:
         self.pts = pts.contiguous()
         self.M, self.C = self.pts.shape
         self.K = int(K)
-        peak = float(self.pts.abs().max())                             # one read at construction
+        lo, hi = torch.aminmax(self.pts)                               # no full-size |x| temporary (1.6 GB at configs[2] size)
+        peak = float(torch.maximum(-lo, hi))                           # one read at construction
         import math
         bits_x = max(1, math.ceil(math.log2(max(peak, 1e-30))) + 1)
         self.shift = int(max(0, min(40, 62 - math.ceil(math.log2(max(self.M, 2))) - bits_x)))

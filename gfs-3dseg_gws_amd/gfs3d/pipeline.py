@@ -42,6 +42,24 @@ def sample_indices(labels: torch.Tensor, num_point: int, sampled_class: Optional
     return torch.cat([a, b])
 
 
+def _usable_generator(generator: Optional[torch.Generator], device) -> Optional[torch.Generator]:
+    """`generator` if it can drive draws on `device`, None if none was given.  torch.device('cuda') and a CUDA generator's
+    'cuda:0' name the same card when 0 is the current device: the index is normalised before the comparison.  A generator on
+    another device (a CPU generator for device draws) RAISES - silently drawing from the global stream instead made seeded runs
+    irreproducible without an error."""
+    if generator is None:
+        return None
+    dev, gdev = torch.device(device), generator.device
+    if dev.type == gdev.type:
+        if dev.type != "cuda":
+            return generator
+        cur = torch.cuda.current_device()
+        if (dev.index if dev.index is not None else cur) == (gdev.index if gdev.index is not None else cur):
+            return generator
+    raise RuntimeError(f"gfs3d.pipeline: the generator lives on {gdev} but the draws happen on {dev}; pass torch.Generator(device=...) "
+                       "of the sampler's device")
+
+
 def augment_draws(cfg: dict, num_point: int, device, generator: Optional[torch.Generator] = None):
     """The random quantities of augment_pointcloud (loader.py:132-151): a 3x3 matrix (zoom, rotation about z,
     x / y mirrors) and, if cfg['jitter'], clip(0.01 randn, +-0.05) per coordinate."""
@@ -62,14 +80,15 @@ def augment_draws(cfg: dict, num_point: int, device, generator: Optional[torch.G
             m = torch.diag(torch.tensor([1.0, -1.0, 1.0], dtype=torch.float64)) @ m
     jit = None
     if cfg.get("jitter", 0):
-        jit = (0.01 * torch.randn((num_point, 3), device=device, generator=generator if generator is not None and generator.device == torch.device(device) else None)).clamp(-0.05, 0.05).float()
+        jit = (0.01 * torch.randn((num_point, 3), device=device,
+                                  generator=generator if generator is not None and generator.device.type != "cpu" else None)).clamp(-0.05, 0.05).float()
     return m.to(device), jit
 
 
 def augment_draws_batch(cfg: dict, B: int, num_point: int, device, generator: Optional[torch.Generator] = None):
     """augment_draws for a whole batch in tensor ops (no host reads): (B,3,3) float64 matrices
     M = mirror_y mirror_x R_z(angle) zoom(s) (the reference's order of composition, loader.py:134-145) and the (B,n,3) jitter."""
-    gen = generator if generator is not None and generator.device == torch.device(device) else None
+    gen = _usable_generator(generator, device)
     u = torch.rand((B, 4), dtype=torch.float64, device=device, generator=gen)
     one, zero = torch.ones(B, dtype=torch.float64, device=device), torch.zeros(B, dtype=torch.float64, device=device)
     s = one
@@ -165,7 +184,7 @@ class BlockSampler:
                              generator: Optional[torch.Generator] = None) -> torch.Tensor:
         """(B, num_point) row numbers into `self.data`: the point draw of sample_pointcloud for every block of the batch."""
         dev = self.device
-        gen = generator if generator is not None and generator.device == dev else None
+        gen = _usable_generator(generator, dev)
         B, n = len(block_ids), int(num_point)
         sizes = [self.sizes[int(b)] for b in block_ids]
         mmax = max(sizes)

@@ -190,7 +190,9 @@ class DGCNN(nn.Module):
         fused = (parts is not None and parts[0][0].in_channels == ops.PW_SEG_WIDTH * len(feats) and all(t is not None for t in feats_pm)
                  and (self.training or not (torch.is_grad_enabled() and any(t.requires_grad for t in feats))))
         if will_fuse and not fused:      # (a block took the general path after all: nn.BatchNorm1d will count this step itself)
-            torch._foreach_sub_([bn.num_batches_tracked for _c, bn in parts if bn.num_batches_tracked is not None], 1)
+            counters = [bn.num_batches_tracked for _c, bn in parts if bn.num_batches_tracked is not None]
+            if counters:                 # (track_running_stats=False: nothing was bumped)
+                torch._foreach_sub_(counters, 1)
             will_fuse = False
         if point_major:
             if not fused:

@@ -489,6 +489,51 @@ def dgcnnseg_features(p: Params, x: Tensor, k: int = 20, knn_fn=knn) -> Tensor:
     return torch.cat(ecs, dim=1)
 
 
+def basis_flow_inputs(n_blocks: int, n_points: int, block_seed: int, label_seed: int) -> Tuple[Tensor, Tensor]:
+    """Input recipe of tests/golden/basis_flow.npz (inputs are rebuilt, not stored): synthetic blocks in groups of 8 from seeds
+    block_seed, block_seed + 1, ...; labels: class 1 with probability 0.93, classes 2..7 uniformly on the next 6 %,
+    background (0) on the last 1 %."""
+    blocks = torch.cat([synthetic_blocks(8, n_points, seed=block_seed + i) for i in range(n_blocks // 8)])
+    gl = torch.Generator().manual_seed(label_seed)
+    u = torch.rand(n_blocks, n_points, generator=gl)
+    labels = torch.ones(n_blocks, n_points, dtype=torch.int64)
+    labels[u > 0.93] = 2 + (torch.rand(n_blocks, n_points, generator=gl)[u > 0.93] * 6).long().clamp_(max=5)
+    labels[u > 0.99] = 0
+    return blocks, labels
+
+
+def geometric_words_flow(p: Params, blocks: Tensor, labels: Tensor, num_classes: int, num_cnt: int, max_num: int,
+                         rs: np.random.RandomState, k: int = 20) -> Dict[str, np.ndarray]:
+    """`Get_GlobalProto_GlobalKmeans` (get_basis.py:162-222) on ONE numpy stream `rs` (the reference: numpy's global stream
+    after `np.random.seed(args.seed)`, get_basis.py:310): EdgeConv features of every block in loader order (B = 1, eval mode,
+    :164-170), per foreground class the labelled columns in block order (:172-183), `rs.choice(arange(n), MAX_NUM,
+    replace=False)` for a class with more than MAX_NUM rows (:196-199), classes concatenated (:203-205), then
+    `KMeans(num_cnt, init='k-means++').fit` (:210; sklearn centres the data and draws its seeding variates from the SAME
+    stream), `Kmean2Proto` (:212) and `compute_svd` (:215).  Returns the intermediates by name."""
+    feats = []
+    with torch.no_grad():
+        for i in range(blocks.shape[0]):
+            feats.append(dgcnnseg_features(p, blocks[i:i + 1], k=k)[0])           # (192, N)
+    per_class, sub_idx = [], {}
+    for c in range(1, num_classes):
+        cols = [f[:, labels[i] == c] for i, f in enumerate(feats) if bool((labels[i] == c).any())]
+        if not cols:
+            continue
+        cf = torch.cat(cols, dim=1).transpose(0, 1).numpy()
+        if cf.shape[0] > max_num:
+            sub_idx[c] = rs.choice(np.arange(cf.shape[0]), max_num, replace=False)
+            cf = cf[sub_idx[c], :]
+        per_class.append(cf)
+    X = np.concatenate(per_class, axis=0)
+    mean = X.mean(axis=0)
+    Xc = X - mean
+    picks, margins = greedy_kmeans_plusplus(Xc, num_cnt, rs, with_margins=True)
+    cent, lab, inertia, n_iter = sklearn_lloyd(Xc, Xc[picks])
+    proto = kmean2proto(X, lab, num_cnt)
+    return {"X": X, "sub_idx": sub_idx, "picks": picks, "margins": margins, "centers": cent + mean, "labels": lab,
+            "inertia": inertia, "n_iter": n_iter, "proto": proto, "words": svd_reconstruct(proto)}
+
+
 # --------------------------------------------------------------------------
 # runs/eval.py:9-108
 # --------------------------------------------------------------------------

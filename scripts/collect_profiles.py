@@ -1,6 +1,6 @@
 """Turn the rocprofv3 (rocpd sqlite) outputs of `bench.py` into the committed summaries under profiles/.
 
-  python scripts/collect_profiles.py <tag> <kernel_trace.db> <pmc_sq.db> <pmc_fetch.db> <pmc_write.db>
+  python scripts/collect_profiles.py <tag> <kernel_trace.db> <pmc_sq.db> <pmc_fetch.db> <pmc_write.db> [steps of the PMC runs] [what ran]
 
   profiles/<tag>_bench_kernel_stats.csv   per-kernel calls / total / average (== rocprofv3 --kernel-trace --stats)
   profiles/<tag>_hbm_traffic.json         FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE per launch, separate passes
@@ -9,6 +9,8 @@
 import collections, json, os, re, sqlite3, sys
 
 tag, trace_db, sq_db, fetch_db, write_db = sys.argv[1:6]
+pmc_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 0           # training steps the profiled command ran (warm-up + timed + instrumented)
+what = sys.argv[7] if len(sys.argv) > 7 else "bench.py --no-cpu-baseline --steps 3 --warmup 2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 
@@ -40,10 +42,12 @@ with open(os.path.join(out, f"{tag}_bench_kernel_stats.csv"), "w") as f:
 
 fa, fn = counters(fetch_db)
 wa, wn = counters(write_db)
-traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --no-cpu-baseline --steps 3 --warmup 2` "
-                    "(timed workload configs[1] B=32x2048 + the side measurements: K3 / k-means / attention / CAPL steps c4, c5), "
-                    "per-launch averages over ALL launches of a kernel name. Units KB in the tool; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of "
+traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `" + what + "`, "
+                    "per-launch averages over ALL launches of a kernel name; `_steps` = training steps of the profiled run (bench.py divides a "
+                    "kernel group's bytes by it). Units KB in the tool; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of "
                     "coalesced reads). WRITE_SIZE is exact for stores and float atomics."}
+if pmc_steps:
+    traffic["_steps"] = pmc_steps
 for k in fa:
     n = max(fn.get(k, 1), 1)
     fetch_kb = fa[k].get("FETCH_SIZE", 0.0) / n
@@ -55,7 +59,7 @@ json.dump(traffic, open(os.path.join(out, f"{tag}_hbm_traffic.json"), "w"), inde
 sa, sn = counters(sq_db)
 with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as f:
     names = sorted({c for k in sa for c in sa[k]})
-    f.write("rocprofv3 --pmc " + " ".join(names) + "\non `python3 bench.py --no-cpu-baseline --steps 3 --warmup 2` (configs[1] B=32x2048, k=20 + side measurements); per-launch averages\n")
+    f.write("rocprofv3 --pmc " + " ".join(names) + "\non `" + what + "`; per-launch averages\n")
     f.write("kernel".ljust(46) + "".join(n.replace("SQ_", "")[:15].rjust(16) for n in names) + "\n")
     for k in sorted(sa, key=lambda k: -sa[k].get("SQ_WAVE_CYCLES", 0)):
         if sa[k].get("SQ_WAVE_CYCLES", 0) / max(sn[k], 1) < 1e6:

@@ -55,3 +55,24 @@ def test_bench_two_gloo_ranks_run_the_capl_step_and_synchronised_batchnorm(argv,
     d = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", *argv, GFS3D_BENCH_BACKEND="gloo")
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["config"]["parallelism"] == parallelism
     assert d["value"] > 0 and 0.0 < d["rank_ms_per_step"]["min"] <= d["rank_ms_per_step"]["max"] <= d["ms_per_step"] * 1.001
+
+
+@pytest.mark.parametrize("argv", [[], ["--sync-bn"], ["--workload", "c4", "--sync-bn"]])
+def test_bench_single_rank_with_the_steps_collectives_on_real_rccl_streams(argv):
+    """First-contact rehearsal: `--gpus 1 --force-collectives` puts this one GPU into a 1-rank RCCL ("nccl")
+    group and issues, INSIDE the timed step, every collective the N > 1 step issues: the asynchronous early slice of the flat
+    gradient bucket from its post-accumulate hook (under the EdgeConv backward), the remainder all-reduce, and with --sync-bn
+    the fp64 BatchNorm phase all-reduces of the EdgeConv kernels (bucket overlap off, as under N > 1).  The line reports the
+    launches and a latency probe of the three message sizes (DESIGN.md section 5's prediction table starts from it)."""
+    steps, warm = 3, 2
+    d = _bench("--gpus", "1", "--steps", str(steps), "--warmup", str(warm), "--no-extras", "--no-cpu-baseline", "--force-collectives", *argv)
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["backend"] == "nccl" and d["value"] > 0
+    f = d["forced_collectives"]
+    sync = "--sync-bn" in argv
+    assert f["sync_bn"] is sync and f["bucket_overlap"] is (not sync)
+    assert d["config"]["parallelism"] == "block-sharded dp1" + ("+syncbn" if sync else "")
+    if not sync:                  # the hook fired in every step of the run: warm-up, timed and instrumented passes
+        assert f["early_slice_launches"] == warm + 2 * steps
+    pr = f["rccl_probe"]
+    assert 0 < pr["early_slice_us"] < 2000 and 0 < pr["remainder_us"] < 2000 and 0 < pr["bn_phase_128_f64_us"] < 2000
+    assert pr["early_bytes"] + pr["remainder_bytes"] in (4 * 261504, 4 * 404544)

@@ -1380,6 +1380,15 @@ def test_device_pipeline_matches_reference_loader(dev):
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert tuple(xb.shape) == (4, 9, 2048) and bool(torch.isfinite(xb).all())
+    # the constructor's default device is torch.device("cuda") while a CUDA generator reports "cuda:0" - the seeded
+    # generator must still drive the draws (it used to be dropped silently); a generator of another device must raise
+    smp0 = pipeline.BlockSampler(blocks)                            # device="cuda"
+    xa1, ya1, _ = smp0.batch([0, 1, 0], 2048, sampled_classes=classes, pc_augm=True, pc_augm_config=cfg, generator=torch.Generator(device="cuda:0").manual_seed(9))
+    torch.rand(7, device=dev)                                       # the global stream moves in between
+    xa2, ya2, _ = smp0.batch([0, 1, 0], 2048, sampled_classes=classes, pc_augm=True, pc_augm_config=cfg, generator=torch.Generator(device="cuda:0").manual_seed(9))
+    assert torch.equal(xa1, xa2) and torch.equal(ya1, ya2)
+    with pytest.raises(RuntimeError, match="generator lives on"):
+        smp0.batch([0, 1], 2048, sampled_classes=classes, generator=torch.Generator().manual_seed(1))
 
 
 def test_bench_pipeline_throughput_line_small(dev):

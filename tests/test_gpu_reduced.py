@@ -325,3 +325,82 @@ def test_reduced_modes_full_size_step_is_finite(dev):
             out.mean().backward()
         assert bool(torch.isfinite(out).all())
         assert all(bool(torch.isfinite(q.grad).all()) and float(q.grad.abs().max()) > 0 for q in net.parameters())
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_capl_scannet_step_at_the_bench_size(dev, mode):
+    """BASELINE configs[4] at ITS size: the CAPL ScanNet training step bench.py's `extra.step_c5` times - B = 64 x
+    2048 points, 21 + 1 classes (the 24-row head tables, four point tiles per wave), K_w = 180 words - in a reduced mode:
+    (i) finite prediction, loss and gradients, every parameter reached; (ii) in deterministic mode a second run from the same
+    weights repeats predictions, gradients and running statistics bit for bit (the scalar loss: torch's nll reduction, to
+    rounding - see test_whole_model_train_step_bit_reproducible_in_deterministic_mode); (iii) the fused head, which runs in
+    fp32 in every mode, against the float64 chain of the oracle on the SAME (B,128,N) features the step produced, all 64
+    blocks: loss 1e-5 relative, arg-max equal wherever the top-two gap is clear, feature / prototype gradients 1e-4."""
+    import contextlib
+    import copy
+    import io
+    from gfs3d import ops
+    from gfs3d.synthetic import synthetic_blocks
+    from model.capl import mpti_net_Point_GeoAsWeight_v2
+    from test_gpu_capl_head import head_reference
+    B, N, classes, base, Kw = 64, 2048, 21, 15, 180
+    args = types.SimpleNamespace(edgeconv_widths=[[64, 64]] * 3, dgcnn_mlp_widths=[512, 256], pc_in_dim=9, dgcnn_k=20,
+                                 base_widths=[128, 64], output_dim=64, eval_weight=1.2)
+    torch.manual_seed(0)
+    gp = torch.randn(Kw, 192, generator=torch.Generator().manual_seed(2)).to(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mpti_net_Point_GeoAsWeight_v2(classes=classes, args=args, base_num=base, gp=gp, energy=0.9)
+    net = net.to(dev).train()
+    sd = copy.deepcopy(net.state_dict())
+    x = synthetic_blocks(B, N, seed=0).to(dev)
+    y = torch.randint(0, base + 1, (B, N), generator=torch.Generator().manual_seed(1)).to(dev)
+    net.att_learner._forced_keep_mask = None
+    seen = {}
+    orig_head = net.train_head
+
+    def tapped(point_feat, y_, fake_novel):
+        point_feat.retain_grad()
+        seen["feat"], seen["fake"] = point_feat, list(fake_novel)
+        return orig_head(point_feat, y_, fake_novel)
+    net.train_head = tapped
+    runs = []
+    ops.set_deterministic(True)
+    try:
+        for it in range(2):
+            net.load_state_dict(sd)
+            for p in net.parameters():
+                p.grad = None
+            random.seed(0)
+            torch.manual_seed(5)                     # the attention dropout seed is drawn from torch's stream
+            with ops.compute(mode):
+                pred, loss = net(x, y=y)
+                loss.backward()
+            runs.append([loss.detach().clone(), pred.clone()] + [p.grad.clone() for p in net.parameters()]
+                        + [b.clone() for n, b in net.named_buffers() if "running" in n])
+            if it == 0:
+                feat, dfeat, fake = seen["feat"].detach().clone(), seen["feat"].grad.clone(), seen["fake"]
+                dmain, dbg = net.main_proto.grad.clone(), net.bg_proto.grad.clone()
+    finally:
+        ops.set_deterministic(False)
+    # (i)
+    assert bool(torch.isfinite(runs[0][0])) and pred.shape == (B, N) and int(pred.min()) >= 0 and int(pred.max()) <= classes
+    for p_, g_ in zip(net.parameters(), runs[0][2:]):
+        assert bool(torch.isfinite(g_).all())
+    assert sum(float(g_.abs().max()) > 0 for g_ in runs[0][2:2 + len(list(net.parameters()))]) >= 40
+    # (ii)
+    assert abs(float(runs[1][0]) - float(runs[0][0])) <= 1e-6 * abs(float(runs[0][0]))
+    for a_, b_ in zip(runs[0][1:], runs[1][1:]):
+        assert torch.equal(a_, b_)
+    # (iii) the head on the step's own features, float64 on the host (64 x 128 x 2048 doubles = 134 MB)
+    f64 = feat.cpu().double().requires_grad_(True)
+    m64 = sd["main_proto"].cpu().double().requires_grad_(True)
+    b64 = sd["bg_proto"].cpu().double().requires_grad_(True)
+    logits_ref, loss_ref = head_reference(f64, m64, b64, y.cpu(), fake, base, net.criterion.ignore_index)
+    loss_ref.backward()
+    assert abs(float(runs[0][0]) - float(loss_ref.detach())) <= 1e-5 * abs(float(loss_ref.detach()))
+    top2 = logits_ref.detach().topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert float(clear.float().mean()) > 0.99
+    assert bool((runs[0][1].cpu() == logits_ref.argmax(1))[clear].all())
+    assert relmax(dfeat, f64.grad) < 1e-4
+    assert relmax(dmain, m64.grad) < 1e-4 and relmax(dbg, b64.grad) < 1e-4

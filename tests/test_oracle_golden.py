@@ -286,3 +286,45 @@ def test_lloyd_restatement_relocates_empty_clusters_like_sklearn():
     assert np.array_equal(lab, g["g_fit_labels"].astype(np.int64))
     assert abs(inertia - float(g["g_fit_inertia"])) < 1e-6 * inertia
     close(cent + mean, g["g_fit_centers"], 1e-5)
+
+
+def test_kmeanspp_restatement_at_3e5_points_parts_where_recorded():
+    """tests/golden/kmeanspp_large.npz: sklearn.cluster.kmeans_plusplus on 300 000 x 64 points (K = 24, four RandomStates).  At this
+    size sklearn's float32 potential / cdf deviate from an exact evaluation by ~1e-7 of the potential, which is the order of the
+    distance of the closest variate to a cdf step: the float64 restatement reproduces sklearn's sequence entirely on three of the
+    four seeds and parts from it on one, at a pick whose margin is 1.05e-7 (no seed-for-seed parity at configs[2]
+    size - the same algorithm on the same variates).  Two seeds are re-run here (one of each kind)."""
+    g = load_golden("kmeanspp_large")
+    M, C, K, blobs, data_seed = (int(v) for v in g["params"])
+    X = R.clustered_points(M, C, blobs, seed=data_seed)
+    firsts = [int(g[f"s{s}_first_diff"]) for s in range(4)]
+    assert sum(f == K for f in firsts) == 3
+    for s in (0, 1):
+        idx, marg = R.greedy_kmeans_plusplus(X, K, np.random.RandomState(s), with_margins=True)
+        first = firsts[s]
+        assert np.array_equal(idx[:first], g[f"s{s}_indices"][:first])
+        if first < K:
+            assert idx[first] != g[f"s{s}_indices"][first] and marg[first].min() < 1e-6
+
+
+def test_basis_flow_restatement_equals_the_reference_function():
+    """tests/golden/basis_flow.npz = the reference's OWN `Get_GlobalProto_GlobalKmeans` (get_basis.py:112-222) run end to end after
+    one `np.random.seed(s)` on stubbed loaders (oracle/gen_golden.py: g_basis_flow).  oracle.ref_ops.geometric_words_flow on ONE
+    RandomState(s) must make the same subsample draw, the same k-means++ picks (sklearn seeds from the same stream, after the
+    draw), stop after the same number of Lloyd iterations and arrive at the same words."""
+    g = load_golden("basis_flow")
+    NB, N, K, bseed, lseed, s, max_num = (int(v) for v in g["params"])
+    blocks, labels = R.basis_flow_inputs(NB, N, bseed, lseed)
+    sd = {k: v for k, v in state_dict_from(load_golden("dgcnnseg")).items()}
+    out = R.geometric_words_flow(sd, blocks, labels, 8, K, max_num, np.random.RandomState(s))
+    assert list(out["sub_idx"]) == [1] and np.array_equal(out["sub_idx"][1], g["sub_idx"])
+    assert out["X"].shape[0] == int(g["rows"])
+    assert np.allclose(out["X"].astype(np.float64).sum(0), g["row_checksum"], rtol=1e-5, atol=1e-3)
+    assert np.array_equal(out["picks"], g["picks"])
+    assert np.allclose(out["margins"], g["margins"], rtol=1e-3, atol=1e-9)
+    assert abs(out["n_iter"] - int(g["n_iter"])) <= 1
+    assert abs(out["inertia"] - float(g["inertia"])) < 1e-5 * float(g["inertia"])
+    assert np.array_equal(np.sort(np.bincount(out["labels"], minlength=K)), g["sizes"]) or \
+        np.abs(np.sort(np.bincount(out["labels"], minlength=K)) - g["sizes"]).max() <= 3
+    close(out["proto"], g["proto"], 1e-4)
+    close(out["words"], g["words"], 1e-4)
