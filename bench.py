@@ -123,7 +123,7 @@ BRACKET_KERNELS = {
 }
 
 
-def group_traffic(kid, workload, launches_per_step, tag="r06"):
+def group_traffic(kid, workload, launches_per_step, tag="r06", reduced=False):
     """(HBM bytes per bracketed launch, source file, kernel names) of profile bracket `kid` in `workload`: the PMC bytes of every
     launch of the bracket's kernels during the profiled run / the run's steps / the bracket's launches per step.  Needs the
     workload's own PMC summary (its `_steps` field); None without one."""
@@ -137,6 +137,8 @@ def group_traffic(kid, workload, launches_per_step, tag="r06"):
     total, count, names = 0.0, 0, []
     for k, v in d.items():
         if isinstance(v, dict) and any(re.search(p, k) for p in pats):
+            if kid in (1, 2) and k.rstrip().endswith("0>") == reduced:      # the EdgeConv kernels' last template argument: 0 = the fp32-accurate form
+                continue
             total += v["traffic_bytes_per_launch"] * v["launches"]
             count += v["launches"]
             names.append(k)
@@ -180,7 +182,7 @@ def roofline_of(prof, steps, B, cfg, tag="r06", workload="c2"):
     pipe_name, pipe_peak = pipe_of(dom, cfg["dtype"])
     name = KERNELS[dom] + ("<1>" if (dom == 2 and cfg["dtype"] != "f32") else "")
     # HBM bytes per bracketed launch from the committed PMC passes of THIS workload (profiles/<tag>_<workload>_hbm_traffic.json)
-    traffic, src, traffic_kernels = group_traffic(dom, workload, n / steps, tag)
+    traffic, src, traffic_kernels = group_traffic(dom, workload, n / steps, tag, reduced=cfg["dtype"] != "f32")
     # `frac` / `peak` follow the arithmetic the results are priced at: the fp32 peak for the fp32-accurate path; for the reduced
     # dtypes (configs[4]) the executed 16-bit pipe - `frac_fp32` and `frac_executed_pipe` stay as the explicit fields
     reduced = cfg["dtype"] != "f32" and pipe_peak

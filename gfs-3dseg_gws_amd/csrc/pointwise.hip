@@ -22,6 +22,68 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- storage format of the stack's INTERNAL tensors in HBM (gfs3d.h: gfs3d_pointwise_args.store16) --------------------------
+// fp32-accurate mode: everything fp32.  Reduced modes with store16: the pre-BatchNorm activations h[l] are kept in the forward
+// operand format of the mode (ST_F16 under GFS3D_COMPUTE_F16, ST_BF16 under GFS3D_COMPUTE_BF16), the gradients g[l] in the
+// workspace as bf16 (half cannot hold the gradients of a mean loss).  Accumulators, BatchNorm sums and constants stay fp32 /
+// fp64; the statistics are taken from the fp32 accumulators BEFORE the rounding (the rounding error is zero-mean).
+enum { ST_F32 = 0, ST_BF16 = 1, ST_F16 = 2 };
+template <int ST> struct Raw4 { typedef f32x4 type; };      // four consecutive stored elements, as loaded
+template <> struct Raw4<ST_BF16> { typedef uint2 type; };
+template <> struct Raw4<ST_F16> { typedef uint2 type; };
+template <int ST> __device__ __forceinline__ typename Raw4<ST>::type st_ld4(const void *base, size_t idx)
+{
+    if constexpr (ST == ST_F32) return *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + idx);
+    else return *reinterpret_cast<const uint2 *>(static_cast<const unsigned short *>(base) + idx);
+}
+template <int ST> __device__ __forceinline__ typename Raw4<ST>::type st_zero4()
+{
+    if constexpr (ST == ST_F32) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+    else return make_uint2(0u, 0u);
+}
+template <int ST> __device__ __forceinline__ f32x4 st_cvt4(const typename Raw4<ST>::type &r)
+{
+    if constexpr (ST == ST_F32) return r;
+    else if constexpr (ST == ST_BF16) {
+        const f32x4 v = {__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                         __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u)};
+        return v;
+    } else {
+        const mm_f32x2 a = __builtin_convertvector(__builtin_bit_cast(mm_f16x2, r.x), mm_f32x2);
+        const mm_f32x2 b = __builtin_convertvector(__builtin_bit_cast(mm_f16x2, r.y), mm_f32x2);
+        const f32x4 v = {a[0], a[1], b[0], b[1]};
+        return v;
+    }
+}
+// half saturates instead of overflowing to inf (a pre-BatchNorm activation is unbounded in principle)
+__device__ __forceinline__ float st_sat16(float v) { return __builtin_fminf(__builtin_fmaxf(v, -65504.f), 65504.f); }
+template <int ST> __device__ __forceinline__ typename Raw4<ST>::type st_pack4(const f32x4 &v)
+{
+    if constexpr (ST == ST_F32) return v;
+    else if constexpr (ST == ST_BF16) return make_uint2(mm_pack2<PREC_BF16>(v[0], v[1]), mm_pack2<PREC_BF16>(v[2], v[3]));
+    else return make_uint2(mm_pack2<PREC_F16>(st_sat16(v[0]), st_sat16(v[1])), mm_pack2<PREC_F16>(st_sat16(v[2]), st_sat16(v[3])));
+}
+template <int ST> __device__ __forceinline__ void st_st4(void *base, size_t idx, const f32x4 &v)
+{
+    if constexpr (ST == ST_F32) *reinterpret_cast<f32x4 *>(static_cast<float *>(base) + idx) = v;
+    else *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(base) + idx) = st_pack4<ST>(v);
+}
+template <int ST> __device__ __forceinline__ float st_ld1(const void *base, size_t idx)
+{
+    if constexpr (ST == ST_F32) return static_cast<const float *>(base)[idx];
+    else if constexpr (ST == ST_BF16) return __builtin_bit_cast(float, (unsigned)static_cast<const unsigned short *>(base)[idx] << 16);
+    else return (float)static_cast<const _Float16 *>(base)[idx];
+}
+template <int ST> __device__ __forceinline__ void st_st1(void *base, size_t idx, float v)
+{
+    if constexpr (ST == ST_F32) static_cast<float *>(base)[idx] = v;
+    else if constexpr (ST == ST_BF16) static_cast<unsigned short *>(base)[idx] = mm_cvt1<PREC_BF16>(v);
+    else static_cast<unsigned short *>(base)[idx] = mm_cvt1<PREC_F16>(st_sat16(v));
+}
+// the value a consumer reads back: v rounded to the storage format (the BatchNorm-backward sums pair g with the stored h)
+template <int ST> __device__ __forceinline__ f32x4 st_round4(const f32x4 &v) { return st_cvt4<ST>(st_pack4<ST>(v)); }
+__host__ __device__ constexpr size_t st_bytes(int st) { return st == ST_F32 ? 4 : 2; }
+
 constexpr int PW_BM = 128, PW_BK = 32, PW_LD = 36;      // LD 36: conflict-free ds_read_b128 of 32-float rows
 enum { PRO_NONE = 0, PRO_BNACT = 1, PRO_BWD = 2 };
 enum { EPI_RAW_STATS = 0, EPI_AFFINE_ACT = 1, EPI_BWD_ACT = 2, EPI_PLAIN = 3 };
@@ -97,8 +159,8 @@ __device__ __forceinline__ void bn_tail(const BnTail &tl, unsigned nblocks, int 
 }
 
 struct RowGemm {
-    const float *a[4];        // A operand: K-segments of width a_segw, rows of stride lda   (M, K)
-    const float *a2[4];       // PRO_BWD: second tensor (h) of the same shape
+    const void *a[4];         // A operand: K-segments of width a_segw, rows of stride lda   (M, K); element type: template AT
+    const void *a2[4];        // PRO_BWD: second tensor (h) of the same shape; element type: template HT
     int a_segw, lda;
     const float *pa, *pb, *pc;  // prologue coefficients per K channel
     const float *w;           // (Nc, K) row-major, K contiguous
@@ -108,14 +170,15 @@ struct RowGemm {
     const void *w3;           // bf16x3 image of w for the split kernel: [Nc][K/32][3 planes][32] bf16
     int M, K, Nc;
     float slope;
-    float *out[4];            // point-major output, column segments of width o_segw (row stride o_segw)
+    void *out[4];             // point-major output, column segments of width o_segw (row stride o_segw); element type: template OT
     int o_segw;
+    int at, ht, ot;           // ST_* of a / (a2, eh) / out: picks the instantiation (launch_rowgemm6)
     float *out_cf;            // OUT_CF: (B, Nc, npts) channel-first ...
     float *out_cfs[4];        // ... or, cf_segw > 0: Nc / cf_segw tensors (B, cf_segw, npts)
     int cf_segw;
     int npts;
     const float *ea, *eb;     // epilogue scale / shift per output channel
-    const float *eh;          // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc)
+    const void *eh;           // EPI_BWD_ACT: pre-BN activations of the produced layer (M, Nc); element type: template HT
     double *acc;              // (2, Nc) column sums (fp64 atomics) ...
     double *acc_rows;         // ... or, deterministic mode: [row block][2][Nc] partial sums, added in order by pw_colsum_reduce_kernel
     int prec;                 // PREC_* of the bf16-pipe kernel (common.h)
@@ -129,7 +192,7 @@ __device__ __forceinline__ void pw_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // Shared epilogue of the row GEMMs: acc[TM][TN] are 32x32 MFMA result tiles (column on the lane, rows in the 16
 // registers); wave (wm, wn) owns rows wm*WM.. and columns wn*64.. of the block tile at (row0, col0).
-template <int BN, int EPI, bool OUT_CF, int TM, int TN>
+template <int BN, int EPI, bool OUT_CF, int TM, int TN, int HT = ST_F32, int OT = ST_F32>
 __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)[TM][TN], float *smem, int row0, int col0, int wm,
                                                  int wn, int wv, int t, int li, int lh)
 {
@@ -165,7 +228,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         const int c4 = (t & 31) * 4, rr = t >> 5;
         const int gcol = col0 + c4;
         const int seg = gcol / g.o_segw, ocol = gcol - seg * g.o_segw;
-        float *op = g.out[seg] + ocol;
+        void *const op = g.out[seg];
         f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
         double ts1[4] = {0.0, 0.0, 0.0, 0.0}, ts2[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: sum x^2 - mean^2 cancels when |mean| >> std
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = ldg4(g.ea + gcol); eb = ldg4(g.eb + gcol); }
@@ -183,12 +246,12 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
             }
             pw_lds_barrier();
             float p1[4] = {0.f, 0.f, 0.f, 0.f}, p2[4] = {0.f, 0.f, 0.f, 0.f};     // fp32 over the 8 rows of a pass, fp64 beyond
-            f32x4 hv[8];
+            typename Raw4<HT>::type hv[8];
             if (EPI == EPI_BWD_ACT) {
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const int row = row0 + ps * 64 + rr + 8 * jj;
-                    hv[jj] = row < g.M ? ldg4(g.eh + (size_t)row * g.Nc + gcol) : ea;
+                    hv[jj] = row < g.M ? st_ld4<HT>(g.eh, (size_t)row * g.Nc + gcol) : st_zero4<HT>();
                 }
             }
 #pragma unroll
@@ -196,17 +259,19 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                 const int row = row0 + ps * 64 + rr + 8 * jj;
                 if (row >= g.M) continue;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(&smem[(rr + 8 * jj) * ELD + c4]);
+                f32x4 hh4 = ea;
+                if (EPI == EPI_BWD_ACT) hh4 = st_cvt4<HT>(hv[jj]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (EPI == EPI_RAW_STATS) { p1[e] += v[e]; p2[e] = fmaf(v[e], v[e], p2[e]); }
                     if (EPI == EPI_AFFINE_ACT) v[e] = lrelu(fmaf(v[e], ea[e], eb[e]), g.slope);
                     if (EPI == EPI_BWD_ACT) {
-                        const float hh = hv[jj][e];
+                        const float hh = hh4[e];
                         v[e] = fmaf(hh, ea[e], eb[e]) > 0.f ? v[e] : v[e] * g.slope;
                         p1[e] += v[e]; p2[e] = fmaf(v[e], hh, p2[e]);
                     }
                 }
-                *reinterpret_cast<f32x4 *>(op + (size_t)row * g.o_segw) = v;
+                st_st4<OT>(op, (size_t)row * g.o_segw + ocol, v);
             }
             if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
 #pragma unroll
@@ -234,7 +299,7 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + wn * 64 + j * 32 + li;
         const int seg = col / g.o_segw, ocol = col - seg * g.o_segw;
-        float *op = g.out[seg] + ocol;
+        void *const op = g.out[seg];
         float ea = 0.f, eb = 0.f;
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = g.ea[col]; eb = g.eb[col]; }
         s1[j] = 0.0; s2[j] = 0.0;
@@ -248,11 +313,11 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
                 if (EPI == EPI_RAW_STATS) { s1[j] += (double)v; s2[j] += (double)v * (double)v; }
                 if (EPI == EPI_AFFINE_ACT) v = lrelu(fmaf(v, ea, eb), g.slope);
                 if (EPI == EPI_BWD_ACT) {
-                    const float h = g.eh[(size_t)row * g.Nc + col];
+                    const float h = st_ld1<HT>(g.eh, (size_t)row * g.Nc + col);
                     v = fmaf(h, ea, eb) > 0.f ? v : v * g.slope;
                     s1[j] += (double)v; s2[j] += (double)v * (double)h;
                 }
-                op[(size_t)row * g.o_segw] = v;
+                st_st1<OT>(op, (size_t)row * g.o_segw + ocol, v);
             }
     }
     if (EPI == EPI_RAW_STATS || EPI == EPI_BWD_ACT) {
@@ -314,14 +379,14 @@ __global__ void __launch_bounds__(256, 2) pw_rowgemm_kernel(const RowGemm g)
     auto load = [&](int kt) {
         const int kcol = kt * PW_BK + 4 * c4;
         const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
-        const float *ap = g.a[seg] + koff;
+        const float *ap = static_cast<const float *>(g.a[seg]) + koff;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = row0 + r0 + 32 * p;
             ra[p] = row < g.M ? ldg4(ap + (size_t)row * g.lda) : zero4;
         }
         if (PRO == PRO_BWD) {
-            const float *ap2 = g.a2[seg] + koff;
+            const float *ap2 = static_cast<const float *>(g.a2[seg]) + koff;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int row = row0 + r0 + 32 * p;
@@ -426,12 +491,20 @@ __global__ void pw_split_w_kernel(const float *__restrict__ w, int Nc, int K, lo
 }
 
 // PREC_BF16 / PREC_F16: one rounded 16-bit product per fp32 product - plane 0 of the same images, one MFMA per K-step of 16.
-template <int BN, int PRO, int EPI, bool OUT_CF, int PREC>
+// AT / HT / OT: ST_* of the A operand, of the pre-BN activations read beside it (PRO_BWD's second tensor, EPI_BWD_ACT's `eh`)
+// and of the output.  A 16-bit A that is already in the operand format of PREC (a forward GEMM on the packed fusion input)
+// goes to LDS as loaded - no conversion.
+template <int BN, int PRO, int EPI, bool OUT_CF, int PREC, int AT = ST_F32, int HT = ST_F32, int OT = ST_F32>
 __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowGemm g)
 {
     extern __shared__ f32x4 pw_smem4[];
     char *smem = reinterpret_cast<char *>(pw_smem4);
-    constexpr int NP = Mx<PREC>::NP, PARTS = 4 * NP;          // 16-byte parts of a weight row per K-step
+    constexpr int NP = Mx<PREC>::NP, PARTS = 4 * NP;          // 16-byte parts of a weight row per 32-wide K-chunk
+    // K-chunks of 32 per pipeline step.  A reduced mode fills one of the three 64-byte piece planes of an LDS row; its MFMA work
+    // per chunk is a sixth of the exact form's, too little to hide a trip to HBM (measured: 1.2 TB/s and 0.04 of the matrix pipe
+    // at one chunk per step).  Two chunks per step - the second in the row's MID plane - put twice the bytes in flight per barrier
+    // in the same LDS (layer widths are multiples of 64).
+    constexpr int KM = (PREC == PREC_X6) ? 1 : 2;
     constexpr int TM = (BN == 128) ? 2 : 1, TN = 2, WM = TM * 32, NB = (BN * PARTS + 255) / 256;
     char *sA = smem;                                // [128][208 B]
     char *sB = smem + PW_BM * PW6_ROW;              // [BN][208 B]
@@ -443,7 +516,7 @@ __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowG
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
     const int wm = (BN == 128) ? (wv >> 1) : wv, wn = (BN == 128) ? (wv & 1) : 0;
     const int c4 = t & 7, r0 = t >> 3;
-    const int KT = g.K / PW_BK;
+    const int KT = g.K / (PW_BK * KM), KT32 = g.K / PW_BK;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -453,66 +526,144 @@ __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowG
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[4], ra2[4], rw[NB];
+    // 16-bit A with two chunks per step: ONE 16-byte load per row covers 8 channels - thread c4 reads chunk c4 >> 2, channels
+    // 8 (c4 & 3) .. + 7 of it - so that a row's 64 channels of the step are one 128-byte segment of one instruction (two 8-byte
+    // loads per row left 64-byte segments: the row GEMMs of the reduced modes ran at 1.2 TB/s)
+    constexpr bool WIDE = KM == 2 && AT != ST_F32 && (PRO != PRO_BWD || HT != ST_F32);
+    typename Raw4<AT>::type ra[KM][4];
+    typename Raw4<HT>::type ra2[KM][4];
+    uint4 rwa[WIDE ? 4 : 1], rwa2[(WIDE && PRO == PRO_BWD) ? 4 : 1];
+    f32x4 rw[KM][NB];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr bool DIRECT = PRO == PRO_NONE && ((AT == ST_F16 && PREC == PREC_F16) || (AT == ST_BF16 && PREC == PREC_BF16));
     auto load = [&](int kt) {
-        const int kcol = kt * PW_BK + 4 * c4;
-        const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
-        const float *ap = g.a[seg] + koff;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = row0 + r0 + 32 * p;
-            ra[p] = row < g.M ? ldg4(ap + (size_t)row * g.lda) : zero4;
-        }
-        if (PRO == PRO_BWD) {
-            const float *ap2 = g.a2[seg] + koff;
+        if constexpr (WIDE) {
+            const int kcol = kt * KM * PW_BK + 8 * c4;
+            const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
+            const unsigned short *ap = static_cast<const unsigned short *>(g.a[seg]);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int row = row0 + r0 + 32 * p;
-                ra2[p] = row < g.M ? ldg4(ap2 + (size_t)row * g.lda) : zero4;
+                rwa[p] = row < g.M ? *reinterpret_cast<const uint4 *>(ap + (size_t)row * g.lda + koff) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            if constexpr (PRO == PRO_BWD) {
+                const unsigned short *ap2 = static_cast<const unsigned short *>(g.a2[seg]);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = row0 + r0 + 32 * p;
+                    rwa2[p] = row < g.M ? *reinterpret_cast<const uint4 *>(ap2 + (size_t)row * g.lda + koff) : make_uint4(0u, 0u, 0u, 0u);
+                }
             }
         }
-        const char *w3 = static_cast<const char *>(g.w3);
 #pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
-            if (BN * PARTS % 256 == 0 || q < BN * PARTS)
-                rw[p] = ldg4(reinterpret_cast<const float *>(w3 + ((size_t)(col0 + row) * KT + kt) * 192 + part * 16));
+        for (int kc = 0; kc < KM; ++kc) {
+            const int kcol = (kt * KM + kc) * PW_BK + 4 * c4;
+            const int seg = kcol / g.a_segw, koff = kcol - seg * g.a_segw;
+            const void *ap = g.a[seg];
+            if constexpr (!WIDE) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = row0 + r0 + 32 * p;
+                ra[kc][p] = row < g.M ? st_ld4<AT>(ap, (size_t)row * g.lda + koff) : st_zero4<AT>();
+            }
+            }
+            if (PRO == PRO_BWD && !WIDE) {
+                const void *ap2 = g.a2[seg];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = row0 + r0 + 32 * p;
+                    ra2[kc][p] = row < g.M ? st_ld4<HT>(ap2, (size_t)row * g.lda + koff) : st_zero4<HT>();
+                }
+            }
+            const char *w3 = static_cast<const char *>(g.w3);
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
+                if (BN * PARTS % 256 == 0 || q < BN * PARTS)
+                    rw[kc][p] = ldg4(reinterpret_cast<const float *>(w3 + ((size_t)(col0 + row) * KT32 + kt * KM + kc) * 192 + part * 16));
+            }
         }
     };
     auto store = [&](int kt) {
-        const int kcol = kt * PW_BK + 4 * c4;
-        f32x4 ca = zero4, cb4 = zero4, cc = zero4;
-        if (PRO != PRO_NONE) { ca = ldg4(g.pa + kcol); cb4 = ldg4(g.pb + kcol); }
-        if (PRO == PRO_BWD) cc = ldg4(g.pc + kcol);
+        if constexpr (WIDE) {
+            // this thread's 8 channels: K columns kt 64 + 8 c4 .. + 7 = chunk c4 >> 2, 16-byte slot c4 & 3 of its plane
+            const int kcol = kt * KM * PW_BK + 8 * c4;
+            f32x4 ca[2], cb4[2], cc[2];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            f32x4 v = ra[p];
-            if (PRO == PRO_BNACT) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], ca[e], cb4[e]), g.slope);
-            } else if (PRO == PRO_BWD) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(ra2[p][e], cc[e], fmaf(v[e], ca[e], cb4[e]));
+            for (int hf = 0; hf < 2; ++hf) {
+                ca[hf] = cb4[hf] = cc[hf] = zero4;
+                if (PRO != PRO_NONE) { ca[hf] = ldg4(g.pa + kcol + 4 * hf); cb4[hf] = ldg4(g.pb + kcol + 4 * hf); }
+                if (PRO == PRO_BWD) cc[hf] = ldg4(g.pc + kcol + 4 * hf);
             }
-            if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
-            const float v4[4] = {v[0], v[1], v[2], v[3]};
-            uint2 pc[NP];
-#if defined(PW_ABL) && (PW_ABL & 1)       // ablation builds only: no operand split (wrong results, timing of the rest)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) pc[q] = make_uint2(__builtin_bit_cast(unsigned, v4[0]) ^ __builtin_bit_cast(unsigned, v4[1]), __builtin_bit_cast(unsigned, v4[2]));
-#else
-            mm_pieces4<PREC>(v4, pc);
-#endif
-            char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8;
+            for (int p = 0; p < 4; ++p) {
+                uint4 outw;
+                if constexpr (DIRECT) {
+                    outw = rwa[p];
+                } else {
+                    unsigned o4[4];
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
+                    for (int hf = 0; hf < 2; ++hf) {
+                        f32x4 v = st_cvt4<AT>(hf ? make_uint2(rwa[p].z, rwa[p].w) : make_uint2(rwa[p].x, rwa[p].y));
+                        if constexpr (PRO == PRO_BNACT) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], ca[hf][e], cb4[hf][e]), g.slope);
+                        } else if constexpr (PRO == PRO_BWD) {
+                            const f32x4 h4 = st_cvt4<HT>(hf ? make_uint2(rwa2[p].z, rwa2[p].w) : make_uint2(rwa2[p].x, rwa2[p].y));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(h4[e], cc[hf][e], fmaf(v[e], ca[hf][e], cb4[hf][e]));
+                        }
+                        if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
+                        o4[2 * hf] = mm_pack2<PREC>(v[0], v[1]);
+                        o4[2 * hf + 1] = mm_pack2<PREC>(v[2], v[3]);
+                    }
+                    outw = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                }
+                *reinterpret_cast<uint4 *>(sA + (r0 + 32 * p) * PW6_ROW + 64 * (c4 >> 2) + 16 * (c4 & 3)) = outw;
+            }
         }
 #pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
-            if (BN * PARTS % 256 == 0 || q < BN * PARTS)
-                *reinterpret_cast<f32x4 *>(sB + row * PW6_ROW + part * 16) = rw[p];
+        for (int kc = 0; kc < KM; ++kc) {
+            const int kcol = (kt * KM + kc) * PW_BK + 4 * c4;
+            f32x4 ca = zero4, cb4 = zero4, cc = zero4;
+            if (PRO != PRO_NONE) { ca = ldg4(g.pa + kcol); cb4 = ldg4(g.pb + kcol); }
+            if (PRO == PRO_BWD) cc = ldg4(g.pc + kcol);
+            if constexpr (!WIDE) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint2 pc[NP];
+                if constexpr (DIRECT) {
+                    pc[0] = ra[kc][p];                 // already operands of this PREC (rows past M were loaded as zeros)
+                } else {
+                    f32x4 v = st_cvt4<AT>(ra[kc][p]);
+                    if (PRO == PRO_BNACT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = lrelu(fmaf(v[e], ca[e], cb4[e]), g.slope);
+                    } else if (PRO == PRO_BWD) {
+                        const f32x4 h4 = st_cvt4<HT>(ra2[kc][p]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(h4[e], cc[e], fmaf(v[e], ca[e], cb4[e]));
+                    }
+                    if (PRO != PRO_NONE && row0 + r0 + 32 * p >= g.M) v = zero4;
+                    const float v4[4] = {v[0], v[1], v[2], v[3]};
+#if defined(PW_ABL) && (PW_ABL & 1)       // ablation builds only: no operand split (wrong results, timing of the rest)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) pc[q] = make_uint2(__builtin_bit_cast(unsigned, v4[0]) ^ __builtin_bit_cast(unsigned, v4[1]), __builtin_bit_cast(unsigned, v4[2]));
+#else
+                    mm_pieces4<PREC>(v4, pc);
+#endif
+                }
+                char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8 + 64 * kc;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(dst + 64 * q) = pc[q];
+            }
+            }
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                const int q = t + 256 * p, row = q / PARTS, part = q - row * PARTS;
+                if (BN * PARTS % 256 == 0 || q < BN * PARTS)
+                    *reinterpret_cast<f32x4 *>(sB + row * PW6_ROW + part * 16 + 64 * kc) = rw[kc][p];
+            }
         }
     };
 
@@ -524,18 +675,20 @@ __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowG
         __syncthreads();
         if (kt + 1 < KT) load(kt + 1);
 #pragma unroll
+        for (int kc = 0; kc < KM; ++kc)
+#pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             uint4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    af[i][pl] = *reinterpret_cast<const uint4 *>(pa + i * 32 * PW6_ROW + pl * 64 + kb * 32);
+                    af[i][pl] = *reinterpret_cast<const uint4 *>(pa + i * 32 * PW6_ROW + (pl + kc) * 64 + kb * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pb + j * 32 * PW6_ROW + pl * 64 + kb * 32);
+                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pb + j * 32 * PW6_ROW + (pl + kc) * 64 + kb * 32);
             // smallest pieces first
             constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
@@ -551,14 +704,15 @@ __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowG
         }
         __syncthreads();
     }
-    rowgemm_epilogue<BN, EPI, OUT_CF, TM, TN>(g, acc, reinterpret_cast<float *>(smem), row0, col0, wm, wn, wv, t, li, lh);
+    rowgemm_epilogue<BN, EPI, OUT_CF, TM, TN, HT, OT>(g, acc, reinterpret_cast<float *>(smem), row0, col0, wm, wn, wv, t, li, lh);
 }
 
 struct WGrad {
-    const float *u, *u2;      // (M, Co): PRO_BWD combine a u + b + c u2 with per-Co coefficients, or plain u
+    const void *u, *u2;       // (M, Co): PRO_BWD combine a u + b + c u2 with per-Co coefficients, or plain u; element types: templates GT, HT
     int ldu;
     const float *ua, *ub, *uc;
-    const float *v[4];        // (M, Ci) in column segments of width v_segw, row stride ldv
+    const void *v[4];         // (M, Ci) in column segments of width v_segw, row stride ldv; element type: template VT
+    int gt, ht, vt;           // ST_* of u / u2 / v: picks the instantiation (launch_wgrad_t)
     int v_segw, ldv;
     const float *va, *vb;     // PRO_BNACT per-Ci scale / shift
     float slope;
@@ -572,10 +726,11 @@ struct WGrad {
 // runs over the POINTS, so both operands are transposed while they are staged: a thread owns 4 channels x 2
 // consecutive points, splits the 8 values and writes, per channel and piece, one dword (2 bf16) into that channel's
 // LDS row - rows are channels, 32 points per K-step; lanes of a 16-lane group walk along a row (conflict-free).
-template <int BMU, int BNV, int VPRO, int PREC>
+template <int BMU, int BNV, int VPRO, int PREC, int GT = ST_F32, int HT = ST_F32, int VT = ST_F32>
 __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 {
     constexpr int NP = Mx<PREC>::NP;
+    constexpr int KM = (PREC == PREC_X6) ? 1 : 2;       // 32-point chunks per pipeline step (see pw_rowgemm6_kernel): chunk kc in piece plane kc
     extern __shared__ f32x4 pw_smem4[];
     char *smem = reinterpret_cast<char *>(pw_smem4);
     constexpr int TM = BMU / 64, TN = BNV / 64, NU = BMU / 64, NV = BNV / 64;      // (quad, pair) items per thread
@@ -591,12 +746,14 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int pair = t & 15, quad0 = t >> 4;                 // item p: channel quad quad0 + 16 p, points 2 pair, 2 pair + 1
-    const float *up = g.u + co0, *up2 = g.u2 ? g.u2 + co0 : nullptr;
-    const float *vp[NV];                                     // a V tile may span several 64-channel input segments
+    const void *up = g.u, *up2 = g.u2;
+    const void *vp[NV];                                      // a V tile may span several 64-channel input segments
+    int voff[NV];
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         const int ch = ci0 + 4 * (quad0 + 16 * p), vseg = ch / g.v_segw;
-        vp[p] = g.v[vseg] + (ch - vseg * g.v_segw);
+        vp[p] = g.v[vseg];
+        voff[p] = ch - vseg * g.v_segw;
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 ua[NU], ub[NU], uc[NU], va[NV], vb[NV];
@@ -622,22 +779,27 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 rU[NU][2], rU2[NU][2], rV[NV][2];
+    typename Raw4<GT>::type rU[KM][NU][2];
+    typename Raw4<HT>::type rU2[KM][NU][2];
+    typename Raw4<VT>::type rV[KM][NV][2];
     auto load = [&](int kt) {
-        const int m = m0 + kt * 32 + 2 * pair;
 #pragma unroll
-        for (int p = 0; p < NU; ++p)
+        for (int kc = 0; kc < KM; ++kc) {
+            const int m = m0 + (kt * KM + kc) * 32 + 2 * pair;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const size_t o = (size_t)(m + e) * g.ldu + 4 * (quad0 + 16 * p);
-                rU[p][e] = m + e < m1 ? ldg4(up + o) : zero4;
-                if (up2) rU2[p][e] = m + e < m1 ? ldg4(up2 + o) : zero4;
-            }
+            for (int p = 0; p < NU; ++p)
 #pragma unroll
-        for (int p = 0; p < NV; ++p)
+                for (int e = 0; e < 2; ++e) {
+                    const size_t o = (size_t)(m + e) * g.ldu + co0 + 4 * (quad0 + 16 * p);
+                    rU[kc][p][e] = m + e < m1 ? st_ld4<GT>(up, o) : st_zero4<GT>();
+                    if (up2) rU2[kc][p][e] = m + e < m1 ? st_ld4<HT>(up2, o) : st_zero4<HT>();
+                }
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-                rV[p][e] = m + e < m1 ? ldg4(vp[p] + (size_t)(m + e) * g.ldv) : zero4;
+            for (int p = 0; p < NV; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    rV[kc][p][e] = m + e < m1 ? st_ld4<VT>(vp[p], (size_t)(m + e) * g.ldv + voff[p]) : st_zero4<VT>();
+        }
     };
     // one item: 4 channels x 2 points -> per channel and piece one dword at [channel row][piece][pair]
     auto put = [&](char *base, int quad, const f32x4 &x0, const f32x4 &x1) {
@@ -657,38 +819,42 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
         }
     };
     auto store = [&](int kt) {
-        const int m = m0 + kt * 32 + 2 * pair;
+#pragma unroll
+      for (int kc = 0; kc < KM; ++kc) {
+        const int m = m0 + (kt * KM + kc) * 32 + 2 * pair;
 #pragma unroll
         for (int p = 0; p < NU; ++p) {
             f32x4 x[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                x[e] = rU[p][e];
+                x[e] = st_cvt4<GT>(rU[kc][p][e]);
                 if (up2) {
+                    const f32x4 h4 = st_cvt4<HT>(rU2[kc][p][e]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) x[e][c] = fmaf(rU2[p][e][c], uc[p][c], fmaf(x[e][c], ua[p][c], ub[p][c]));
+                    for (int c = 0; c < 4; ++c) x[e][c] = fmaf(h4[c], uc[p][c], fmaf(x[e][c], ua[p][c], ub[p][c]));
                     if (m + e >= m1) x[e] = zero4;
                 }
             }
-            put(sU, quad0 + 16 * p, x[0], x[1]);
+            put(sU + 64 * kc, quad0 + 16 * p, x[0], x[1]);
         }
 #pragma unroll
         for (int p = 0; p < NV; ++p) {
             f32x4 x[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                x[e] = rV[p][e];
+                x[e] = st_cvt4<VT>(rV[kc][p][e]);
                 if (VPRO == PRO_BNACT) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) x[e][c] = lrelu(fmaf(x[e][c], va[p][c], vb[p][c]), g.slope);
                     if (m + e >= m1) x[e] = zero4;
                 }
             }
-            put(sV, quad0 + 16 * p, x[0], x[1]);
+            put(sV + 64 * kc, quad0 + 16 * p, x[0], x[1]);
         }
+      }
     };
 
-    const int KT = (m1 - m0 + 31) / 32;
+    const int KT = (m1 - m0 + 32 * KM - 1) / (32 * KM);
     const char *pu = sU + (wm * (BMU / 2) + li) * PW6_ROW + lh * 16;
     const char *pv = sV + (wn * (BNV / 2) + li) * PW6_ROW + lh * 16;
     load(0);
@@ -697,18 +863,20 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
         __syncthreads();
         if (kt + 1 < KT) load(kt + 1);
 #pragma unroll
+        for (int kc = 0; kc < KM; ++kc)
+#pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             uint4 af[TM][NP], bf[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    af[i][pl] = *reinterpret_cast<const uint4 *>(pu + i * 32 * PW6_ROW + pl * 64 + kb * 32);
+                    af[i][pl] = *reinterpret_cast<const uint4 *>(pu + i * 32 * PW6_ROW + (pl + kc) * 64 + kb * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pv + j * 32 * PW6_ROW + pl * 64 + kb * 32);
+                    bf[j][pl] = *reinterpret_cast<const uint4 *>(pv + j * 32 * PW6_ROW + (pl + kc) * 64 + kb * 32);
             constexpr int PA[6] = GFS3D_X6_PA, PB[6] = GFS3D_X6_PB;
 #pragma unroll
             for (int term = 0; term < Mx<PREC>::NTERM; ++term)
@@ -733,8 +901,9 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
 }
 
 // y_cf(b, c, n) = act(scale h(b n, c) + shift): 64 points x 64 channels per block, grid (ceil(N/64), C/64, B)
+template <int HT>
 __global__ void __launch_bounds__(256)
-pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf,
+pw_out_kernel(const void *__restrict__ h, const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ y_cf,
               float *__restrict__ y_pm)
 {
     __shared__ float tile[64][65];
@@ -743,7 +912,7 @@ pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int 
     const float sc = stats ? stats[PST_SCALE * C + c0 + c] : 1.f, sh = stats ? stats[PST_SHIFT * C + c0 + c] : 0.f;   // NULL: plain transpose
     for (int p = wv; p < 64; p += 4) {
         const int n = n0 + p;
-        const float v = n < N ? lrelu(fmaf(h[((size_t)b * N + n) * C + c0 + c], sc, sh), slope) : 0.f;
+        const float v = n < N ? lrelu(fmaf(st_ld1<HT>(h, ((size_t)b * N + n) * C + c0 + c), sc, sh), slope) : 0.f;
         tile[p][c] = v;
         if (y_pm && n < N) y_pm[((size_t)b * N + n) * C + c0 + c] = v;
     }
@@ -758,9 +927,10 @@ pw_out_kernel(const float *__restrict__ h, const float *__restrict__ stats, int 
 // grid (ceil(N / 256), C / 64, B): a block walks 4 tiles of 64 points (loads batched ahead of their use; one set of
 // same-address fp64 atomics per block)
 constexpr int PW_IN_TILES = 4;
+template <int HT, int GT>
 __global__ void __launch_bounds__(256)
-pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_pm, const float *__restrict__ h,
-                 const float *__restrict__ stats, int N, int C, float slope, float *__restrict__ gout, double *__restrict__ acc,
+pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_pm, const void *__restrict__ h,
+                 const float *__restrict__ stats, int N, int C, float slope, void *__restrict__ gout, double *__restrict__ acc,
                  double *__restrict__ acc_rows, const BnTail tail)
 {
     __shared__ float tile[64][65];
@@ -776,7 +946,7 @@ pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_p
         __syncthreads();
         float rh[16], rt[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) rh[j] = h[((size_t)b * N + min(n0 + wv + 4 * j, N - 1)) * C + c0 + c];
+        for (int j = 0; j < 16; ++j) rh[j] = st_ld1<HT>(h, ((size_t)b * N + min(n0 + wv + 4 * j, N - 1)) * C + c0 + c);
         {
             const int p = tid & 63;
 #pragma unroll
@@ -795,7 +965,7 @@ pw_bwd_in_kernel(const float *__restrict__ dy_cf, const float *__restrict__ dy_p
                 const float hv = rh[j];
                 const float gin = tile[p][c] + rp[j];
                 const float gv = fmaf(hv, sc, sh) > 0.f ? gin : gin * slope;
-                gout[((size_t)b * N + n) * C + c0 + c] = gv;
+                st_st1<GT>(gout, ((size_t)b * N + n) * C + c0 + c, gv);
                 s += gv;
                 sx = fmaf(gv, hv, sx);
             }
@@ -881,22 +1051,56 @@ __global__ void pw_bwd_coef_kernel(const double *__restrict__ acc, const double 
 }
 
 // ------------------------------------------------------------------ host side
-template <int BN, int PRO, int EPI, bool OUT_CF>
-int launch_rowgemm6(const RowGemm &rg, hipStream_t st, const char *who)
+template <int BN, int PRO, int EPI, bool OUT_CF, int PREC, int AT, int HT, int OT>
+int launch_rg6_t(const RowGemm &rg, hipStream_t st)
 {
     const size_t lds = (size_t)(PW_BM + BN) * PW6_ROW;
     const int ncb = rg.Nc / BN, nrb = (rg.M + PW_BM - 1) / PW_BM;
     const unsigned grid = 8u * ncb * ((nrb + 7) / 8);
-    constexpr bool bwd = PRO == PRO_BWD || EPI == EPI_BWD_ACT;           // gradient GEMMs never run on half operands
-    if (rg.prec == PREC_BF16 || (rg.prec == PREC_F16 && bwd))
-        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, PREC_BF16>), dim3(grid), dim3(256), lds, st, rg);
-    else if (rg.prec == PREC_F16)
-        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, bwd ? PREC_BF16 : PREC_F16>), dim3(grid), dim3(256), lds, st, rg);
-    else
-        hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, PREC_X6>), dim3(grid), dim3(256), lds, st, rg);
+    hipLaunchKernelGGL((pw_rowgemm6_kernel<BN, PRO, EPI, OUT_CF, PREC, AT, HT, OT>), dim3(grid), dim3(256), lds, st, rg);
     GFS3D_LAUNCH_CHECK("pw_rowgemm6_kernel");
-    (void)who;
     return GFS3D_OK;
+}
+
+// The instantiation for (arithmetic, storage formats).  fp32 storage: every PREC.  16-bit storage (reduced modes, training):
+//   forward  (EPI_RAW_STATS)   A = fp32 input (PRO_NONE only) or 16-bit in the mode's format, out = h in the mode's format
+//   backward (PRO_BWD)         A = g (bf16), second tensor / eh = h (the mode's format), out = g (bf16) or dx (fp32 | bf16)
+template <int BN, int PRO, int EPI, bool OUT_CF>
+int launch_rowgemm6(const RowGemm &rg, hipStream_t st, const char *who)
+{
+    constexpr bool bwd = PRO == PRO_BWD || EPI == EPI_BWD_ACT;           // gradient GEMMs never run on half operands
+    const int prec = (rg.prec == PREC_F16 && bwd) ? PREC_BF16 : rg.prec;
+    if (rg.at == ST_F32 && rg.ht == ST_F32 && rg.ot == ST_F32) {
+        if (prec == PREC_BF16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_F32, ST_F32, ST_F32>(rg, st);
+        if constexpr (!bwd) { if (prec == PREC_F16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_F16, ST_F32, ST_F32, ST_F32>(rg, st); }
+        return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_X6, ST_F32, ST_F32, ST_F32>(rg, st);
+    }
+    if constexpr (EPI == EPI_RAW_STATS && !OUT_CF) {
+        if (prec == PREC_BF16 && rg.ot == ST_BF16) {
+            if constexpr (PRO == PRO_NONE) { if (rg.at == ST_F32) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_F32, ST_F32, ST_BF16>(rg, st); }
+            if (rg.at == ST_BF16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_F32, ST_BF16>(rg, st);
+        }
+        if (prec == PREC_F16 && rg.ot == ST_F16) {
+            if constexpr (PRO == PRO_NONE) { if (rg.at == ST_F32) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_F16, ST_F32, ST_F32, ST_F16>(rg, st); }
+            if (rg.at == ST_F16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_F16, ST_F16, ST_F32, ST_F16>(rg, st);
+        }
+    }
+    if constexpr (PRO == PRO_BWD && !OUT_CF) {
+        if (prec == PREC_BF16 && rg.at == ST_BF16) {
+            if constexpr (EPI == EPI_BWD_ACT) {
+                if (rg.ot == ST_BF16 && rg.ht == ST_BF16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_BF16, ST_BF16>(rg, st);
+                if (rg.ot == ST_BF16 && rg.ht == ST_F16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_F16, ST_BF16>(rg, st);
+            }
+            if constexpr (EPI == EPI_PLAIN) {
+                if (rg.ot == ST_F32 && rg.ht == ST_BF16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_BF16, ST_F32>(rg, st);
+                if (rg.ot == ST_F32 && rg.ht == ST_F16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_F16, ST_F32>(rg, st);
+                if (rg.ot == ST_BF16 && rg.ht == ST_BF16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_BF16, ST_BF16>(rg, st);
+                if (rg.ot == ST_BF16 && rg.ht == ST_F16) return launch_rg6_t<BN, PRO, EPI, OUT_CF, PREC_BF16, ST_BF16, ST_F16, ST_BF16>(rg, st);
+            }
+        }
+    }
+    set_error("%s: no row GEMM for storage formats a=%d h=%d out=%d with arithmetic %d", who, rg.at, rg.ht, rg.ot, prec);
+    return GFS3D_ERR_INVALID;
 }
 
 template <int BN, int PRO, int EPI, bool OUT_CF>
@@ -947,19 +1151,45 @@ size_t wg_part_bytes(int M, int Co, int Ci, bool allow192)
     return sizeof(float) * (size_t)wg_geo(M, Co, Ci, allow192).nsplit * Co * Ci;
 }
 
+template <int BMU, int BNV, int VPRO, int PREC, int GT, int HT, int VT>
+int launch_wg6_t(const WGrad &wg, unsigned grid, size_t lds, hipStream_t st, const char *who)
+{
+    GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC, GT, HT, VT>), lds, who);
+    hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC, GT, HT, VT>), dim3(grid), dim3(256), lds, st, wg);
+    GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
+    return GFS3D_OK;
+}
+
+// storage formats: all fp32 (any arithmetic), or - reduced modes with 16-bit storage - u = g (bf16), u2 = h (the mode's format),
+// v = the previous layer's h (VPRO == PRO_BNACT: the same format) or the stack's input (fp32 or the mode's format)
 template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, const WgGeo &geo, hipStream_t st, const char *who)
 {
     const size_t lds = (size_t)(BMU + BNV) * PW6_ROW;
-    if (wg.prec != PREC_X6) GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), lds, who);
-    else GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), lds, who);
     const int ntile = (wg.Co / BMU) * (wg.Ci / BNV);
     wg.rows_per_split = geo.rows;
     wg.nsplit = geo.nsplit;
     const unsigned grid = 8u * ntile * ((geo.nsplit + 7) / 8);
-    if (wg.prec != PREC_X6) hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_BF16>), dim3(grid), dim3(256), lds, st, wg);
-    else hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), dim3(grid), dim3(256), lds, st, wg);
-    GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
+    int rc = -1;                                     // -1: no instantiation for these formats
+    if (wg.gt == ST_F32 && wg.ht == ST_F32 && wg.vt == ST_F32) {
+        if (wg.prec != PREC_X6) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_F32, ST_F32, ST_F32>(wg, grid, lds, st, who);
+        else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_X6, ST_F32, ST_F32, ST_F32>(wg, grid, lds, st, who);
+    } else if (wg.prec != PREC_X6 && wg.gt == ST_BF16 && (wg.ht == ST_BF16 || wg.ht == ST_F16)) {
+        if (wg.vt == wg.ht) {
+            if (wg.ht == ST_BF16) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_BF16, ST_BF16>(wg, grid, lds, st, who);
+            else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_F16, ST_F16>(wg, grid, lds, st, who);
+        } else if (wg.vt == ST_F32) {
+            if constexpr (VPRO == PRO_NONE) {
+                if (wg.ht == ST_BF16) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_BF16, ST_F32>(wg, grid, lds, st, who);
+                else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_F16, ST_F32>(wg, grid, lds, st, who);
+            }
+        }
+    }
+    if (rc == -1) {
+        set_error("%s: no weight-gradient GEMM for storage formats g=%d h=%d v=%d", who, wg.gt, wg.ht, wg.vt);
+        return GFS3D_ERR_INVALID;
+    }
+    if (rc) return rc;
     const int n = wg.Co * wg.Ci;
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, wg.part, geo.nsplit, n, wg.dw);
     GFS3D_LAUNCH_CHECK("pw_wgrad_reduce_kernel");
@@ -1047,6 +1277,14 @@ struct PwPlan {
 };
 
 inline int pw_segw(int seg_width) { return seg_width > 0 ? seg_width : GFS3D_PW_SEG_WIDTH; }
+// storage formats of a call: h[l] / the workspace gradients / the input segments
+inline int pw_ht(const gfs3d_pointwise_args *a)
+{
+    if (!a->store16 || !a->training || a->compute == GFS3D_COMPUTE_F32) return ST_F32;
+    return a->compute == GFS3D_COMPUTE_F16 ? ST_F16 : ST_BF16;
+}
+inline int pw_gt(const gfs3d_pointwise_args *a) { return pw_ht(a) == ST_F32 ? ST_F32 : ST_BF16; }
+inline int pw_xt(const gfs3d_pointwise_args *a) { return a->x_type ? pw_ht(a) : ST_F32; }
 inline float pw_slope(const gfs3d_pointwise_args *a, int l) { return a->per_layer_slope ? a->slope_l[l] : a->slope; }
 
 PwPlan pw_plan(int B, int N, int n_seg, int seg_width, int n_layers, const int *width)
@@ -1100,17 +1338,21 @@ int pw_check(const gfs3d_pointwise_args *a, const char *who, bool need_y)
     GFS3D_REQUIRE(a->workspace, "%s: NULL workspace", who);
     GFS3D_REQUIRE(a->compute == GFS3D_COMPUTE_F32 || a->compute == GFS3D_COMPUTE_BF16 || a->compute == GFS3D_COMPUTE_F16,
                   "%s: compute must be one of GFS3D_COMPUTE_*", who);
+    GFS3D_REQUIRE(a->x_type == 0 || (a->x_type == a->compute && pw_ht(a) != ST_F32),
+                  "%s: x_type=%d needs store16, training mode and x_type == compute (a reduced mode)", who, a->x_type);
     return GFS3D_OK;
 }
 
-void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const float *prev)
+void fill_a(RowGemm &rg, const gfs3d_pointwise_args *a, int l, const void *prev)
 {
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) rg.a[s] = a->x_seg[s];
         rg.a_segw = pw_segw(a->seg_width);
         rg.lda = pw_segw(a->seg_width);
         rg.K = pw_segw(a->seg_width) * a->n_seg;
+        rg.at = pw_xt(a);
     } else {
+        rg.at = pw_ht(a);
         rg.a[0] = prev;
         rg.a_segw = a->width[l - 1];
         rg.lda = a->width[l - 1];
@@ -1219,6 +1461,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         rg.slope = a->training ? (l ? pw_slope(a, l - 1) : 1.f) : pw_slope(a, l);    // training: the prologue's activation; eval: the epilogue's
         rg.out[0] = a->h[l];
         rg.o_segw = C;
+        rg.ot = a->training ? pw_ht(a) : ST_F32;
         rg.acc = acc_l;
         rg.acc_rows = (a->training && g_deterministic) ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
         if (use_tail) {
@@ -1252,8 +1495,8 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
                 rg.out[0] = a->y_pm;
                 rc = rowgemm<PRO_NONE, EPI_AFFINE_ACT, false>(rg, st, who);
                 if (!rc && a->y_cf) {
-                    hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->y_pm, (const float *)nullptr, a->N, C,
-                                       1.f, a->y_cf, (float *)nullptr);
+                    hipLaunchKernelGGL(pw_out_kernel<ST_F32>, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, (const void *)a->y_pm, (const float *)nullptr,
+                                       a->N, C, 1.f, a->y_cf, (float *)nullptr);
                     GFS3D_LAUNCH_CHECK("pw_out_kernel");
                 }
             } else if (l == L - 1) {
@@ -1266,8 +1509,12 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         }
     } else if (a->training) {
         const int C = a->width[L - 1];
-        hipLaunchKernelGGL(pw_out_kernel, dim3((a->N + 63) / 64, C / 64, a->B), dim3(256), 0, st, a->h[L - 1], a->stats[L - 1], a->N, C,
-                           pw_slope(a, L - 1), a->y_cf, a->y_pm);
+        const dim3 og((a->N + 63) / 64, C / 64, a->B);
+        const void *hl = a->h[L - 1];
+        const int ht = pw_ht(a);
+        if (ht == ST_F16) hipLaunchKernelGGL(pw_out_kernel<ST_F16>, og, dim3(256), 0, st, hl, a->stats[L - 1], a->N, C, pw_slope(a, L - 1), a->y_cf, a->y_pm);
+        else if (ht == ST_BF16) hipLaunchKernelGGL(pw_out_kernel<ST_BF16>, og, dim3(256), 0, st, hl, a->stats[L - 1], a->N, C, pw_slope(a, L - 1), a->y_cf, a->y_pm);
+        else hipLaunchKernelGGL(pw_out_kernel<ST_F32>, og, dim3(256), 0, st, hl, a->stats[L - 1], a->N, C, pw_slope(a, L - 1), a->y_cf, a->y_pm);
         GFS3D_LAUNCH_CHECK("pw_out_kernel");
     }
     return GFS3D_OK;
@@ -1358,9 +1605,22 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
         } else if (hipMemsetAsync(acc, 0, sizeof(double) * 2 * p.maxw * L, st) != hipSuccess) { set_error("%s: hipMemsetAsync failed", who); return GFS3D_ERR_HIP; }
         double *rows = g_deterministic ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
         const int gx = ((a->N + 63) / 64 + PW_IN_TILES - 1) / PW_IN_TILES;
-        hipLaunchKernelGGL(pw_bwd_in_kernel, dim3(gx, C / 64, a->B), dim3(256), 0, st, ba->dy_cf, ba->dy_pm, a->h[L - 1],
-                           a->stats[L - 1], a->N, C, pw_slope(a, L - 1), reinterpret_cast<float *>(ws + p.off_g[L - 1]),
-                           acc + (size_t)2 * p.maxw * (L - 1), rows, coef_tail(L - 1));
+        {
+            const dim3 ig(gx, C / 64, a->B);
+            const void *hl = a->h[L - 1];
+            void *gl_ = ws + p.off_g[L - 1];
+            double *accl = acc + (size_t)2 * p.maxw * (L - 1);
+            const int ht = pw_ht(a);
+            if (ht == ST_F16)
+                hipLaunchKernelGGL((pw_bwd_in_kernel<ST_F16, ST_BF16>), ig, dim3(256), 0, st, ba->dy_cf, ba->dy_pm, hl, a->stats[L - 1], a->N, C,
+                                   pw_slope(a, L - 1), gl_, accl, rows, coef_tail(L - 1));
+            else if (ht == ST_BF16)
+                hipLaunchKernelGGL((pw_bwd_in_kernel<ST_BF16, ST_BF16>), ig, dim3(256), 0, st, ba->dy_cf, ba->dy_pm, hl, a->stats[L - 1], a->N, C,
+                                   pw_slope(a, L - 1), gl_, accl, rows, coef_tail(L - 1));
+            else
+                hipLaunchKernelGGL((pw_bwd_in_kernel<ST_F32, ST_F32>), ig, dim3(256), 0, st, ba->dy_cf, ba->dy_pm, hl, a->stats[L - 1], a->N, C,
+                                   pw_slope(a, L - 1), gl_, accl, rows, coef_tail(L - 1));
+        }
         GFS3D_LAUNCH_CHECK("pw_bwd_in_kernel");
         if (rows) {
             hipLaunchKernelGGL(pw_colsum_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, rows, gx * a->B, 2 * C, acc + (size_t)2 * p.maxw * (L - 1));
@@ -1370,8 +1630,9 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     }
     const int l = L - phase;
     const int C = a->width[l], Ci = l ? a->width[l - 1] : p.in_width;
-    float *gl = reinterpret_cast<float *>(ws + p.off_g[l]);
+    void *gl = ws + p.off_g[l];
     void *w3t = ws + p.off_w3[l];
+    const int ht = pw_ht(a), gt = pw_gt(a);
     if (!use_tail) {
         hipLaunchKernelGGL(pw_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, st, acc + (size_t)2 * p.maxw * l, loc + (size_t)2 * p.maxw * l, C, count,
                            a->stats[l], coef, ba->dbn_w[l], ba->dbn_b[l]);
@@ -1385,6 +1646,7 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     wg.slope = l ? pw_slope(a, l - 1) : 1.f;
     wg.M = M; wg.Co = C; wg.Ci = Ci; wg.dw = ba->dw[l];
     wg.prec = prec_of(a->compute, true);
+    wg.gt = gt; wg.ht = ht; wg.vt = l ? ht : pw_xt(a);
     int rc;
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
@@ -1406,12 +1668,17 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     rg.w3 = w3t;
     rg.prec = prec_of(a->compute, true);
     rg.M = M; rg.Nc = Ci; rg.slope = l ? pw_slope(a, l - 1) : 1.f;
+    rg.at = gt; rg.ht = ht;
     if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
         rg.o_segw = pw_segw(a->seg_width);
+        rg.ot = ba->dx_type ? ST_BF16 : ST_F32;
+        // 16-bit dx: the 128-wide tile (its epilogue stores 8 bytes per thread along whole rows; the 64-wide one would store 2)
+        if (rg.ot != ST_F32 && Ci % 128 == 0) return launch_rowgemm<128, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
         return launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
     }
-    rg.out[0] = reinterpret_cast<float *>(ws + p.off_g[l - 1]);
+    rg.out[0] = ws + p.off_g[l - 1];
+    rg.ot = gt;
     rg.o_segw = Ci;
     rg.ea = a->stats[l - 1] + PST_SCALE * Ci;
     rg.eb = a->stats[l - 1] + PST_SHIFT * Ci;
@@ -1434,6 +1701,7 @@ static int pw_bwd_common(const gfs3d_pointwise_bwd_args *ba, const char *who)
     if (int rc = pw_check(a, who, false)) return rc;
     GFS3D_REQUIRE(a->training, "%s: backward is implemented for training mode (batch statistics)", who);
     GFS3D_REQUIRE(ba->dy_cf || ba->dy_pm, "%s: NULL dy_cf and dy_pm", who);
+    GFS3D_REQUIRE(ba->dx_type == 0 || (ba->dx_type == 1 && pw_ht(a) != ST_F32), "%s: dx_type=%d needs store16 in a reduced mode", who, ba->dx_type);
     for (int s = 0; s < a->n_seg; ++s) GFS3D_REQUIRE(ba->dx_seg[s], "%s: NULL dx_seg[%d]", who, s);
     for (int l = 0; l < a->n_layers; ++l)
         GFS3D_REQUIRE(ba->dw[l] && ba->dbn_w[l] && ba->dbn_b[l], "%s: NULL gradient buffer of layer %d", who, l);
@@ -1479,7 +1747,7 @@ struct PackPlan {
     int n_src, tiles[GFS3D_PACK_MAX_SRC + 1], off[GFS3D_PACK_MAX_SRC + 1], total_tiles, used;
 };
 
-template <bool UNPACK>
+template <bool UNPACK, int DT>
 __global__ void __launch_bounds__(256)
 pw_pack_kernel(const gfs3d_pack_args a, const PackPlan pl)
 {
@@ -1493,7 +1761,7 @@ pw_pack_kernel(const gfs3d_pack_args a, const PackPlan pl)
         const int col = pl.used + ty * 64 + lane;
         if (col < a.dst_ld)
             for (int p = wv; p < 64; p += 4)
-                if (n0 + p < N) a.dst[((size_t)b * N + n0 + p) * a.dst_ld + col] = 0.f;
+                if (n0 + p < N) st_st1<DT>(a.dst, ((size_t)b * N + n0 + p) * a.dst_ld + col, 0.f);
         return;
     }
     const int W = a.width[s], c0 = ty * 64, cw = min(64, W - c0), dcol = pl.off[s] + c0;
@@ -1507,9 +1775,10 @@ pw_pack_kernel(const gfs3d_pack_args a, const PackPlan pl)
         __syncthreads();
         if (lane < cw)
             for (int p = wv; p < 64; p += 4)
-                if (n0 + p < N) a.dst[((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane] = tile[p][lane];
+                if (n0 + p < N) st_st1<DT>(a.dst, ((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane, tile[p][lane]);
     } else {
-        for (int p = wv; p < 64; p += 4) tile[p][lane] = (lane < cw && n0 + p < N) ? a.dst[((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane] : 0.f;
+        for (int p = wv; p < 64; p += 4)
+            tile[p][lane] = (lane < cw && n0 + p < N) ? st_ld1<DT>(a.dst, ((size_t)b * N + n0 + p) * a.dst_ld + dcol + lane) : 0.f;
         __syncthreads();
         if (a.channel_first[s]) {
             if (n0 + lane < N)
@@ -1543,8 +1812,16 @@ int pack_launch(const gfs3d_pack_args *a, bool unpack, hipStream_t st, const cha
     pl.total_tiles = tiles + (unpack ? 0 : pl.tiles[a->n_src]);
     GFS3D_REQUIRE(pl.total_tiles <= 65535 && a->B <= 65535, "%s: too many tiles", who);
     const dim3 grid((a->N + 63) / 64, pl.total_tiles, a->B);
-    if (unpack) hipLaunchKernelGGL(pw_pack_kernel<true>, grid, dim3(256), 0, st, *a, pl);
-    else hipLaunchKernelGGL(pw_pack_kernel<false>, grid, dim3(256), 0, st, *a, pl);
+    GFS3D_REQUIRE(a->dst_type == 0 || a->dst_type == GFS3D_COMPUTE_BF16 || (a->dst_type == GFS3D_COMPUTE_F16 && !unpack),
+                  "%s: dst_type=%d unsupported (0 fp32, GFS3D_COMPUTE_BF16, GFS3D_COMPUTE_F16 for packing only)", who, a->dst_type);
+    if (unpack) {
+        if (a->dst_type == GFS3D_COMPUTE_BF16) hipLaunchKernelGGL((pw_pack_kernel<true, ST_BF16>), grid, dim3(256), 0, st, *a, pl);
+        else hipLaunchKernelGGL((pw_pack_kernel<true, ST_F32>), grid, dim3(256), 0, st, *a, pl);
+    } else {
+        if (a->dst_type == GFS3D_COMPUTE_BF16) hipLaunchKernelGGL((pw_pack_kernel<false, ST_BF16>), grid, dim3(256), 0, st, *a, pl);
+        else if (a->dst_type == GFS3D_COMPUTE_F16) hipLaunchKernelGGL((pw_pack_kernel<false, ST_F16>), grid, dim3(256), 0, st, *a, pl);
+        else hipLaunchKernelGGL((pw_pack_kernel<false, ST_F32>), grid, dim3(256), 0, st, *a, pl);
+    }
     GFS3D_LAUNCH_CHECK("pw_pack_kernel");
     return GFS3D_OK;
 }

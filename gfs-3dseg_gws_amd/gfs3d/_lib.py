@@ -75,6 +75,8 @@ class PointwiseArgs(Structure):
         ("per_layer_slope", c_int),
         ("slope_l", c_float * PW_MAX_LAYERS),
         ("y_pm", c_void_p),
+        ("store16", c_int),
+        ("x_type", c_int),
     ]
 
 
@@ -85,6 +87,7 @@ class PointwiseBwdArgs(Structure):
         ("dx_seg", c_void_p * PW_MAX_SEGS),
         ("dw", c_void_p * PW_MAX_LAYERS), ("dbn_w", c_void_p * PW_MAX_LAYERS), ("dbn_b", c_void_p * PW_MAX_LAYERS),
         ("dy_pm", c_void_p),
+        ("dx_type", c_int),
     ]
 
 
@@ -99,6 +102,7 @@ class PackArgs(Structure):
         ("channel_first", c_int * PACK_MAX_SRC),
         ("dst", c_void_p),
         ("dst_ld", c_int),
+        ("dst_type", c_int),
     ]
 
 

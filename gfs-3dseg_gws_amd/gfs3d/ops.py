@@ -42,6 +42,25 @@ def get_compute() -> str:
     return next(k for k, v in _COMPUTE_IDS.items() if v == _compute)
 
 
+_store16 = True
+
+
+def set_store16(on: bool) -> bool:
+    """Reduced modes only: keep the point-wise stacks' internal tensors (pre-BatchNorm activations, their gradients, the packed
+    fusion input) in 16 bits in HBM (include/gfs3d.h: gfs3d_pointwise_args.store16) - default on; off = fp32 storage with
+    16-bit matrix-core operands only (the form of rounds 3-5, kept for A/B measurements).  Returns the previous setting."""
+    global _store16
+    prev, _store16 = _store16, bool(on)
+    return prev
+
+
+def _h_dtype(compute: int, training: bool):
+    """Element type of a stack's internal activations for a call in mode `compute`."""
+    if not (_store16 and training) or compute == _lib.COMPUTE_F32:
+        return torch.float32
+    return torch.float16 if compute == _lib.COMPUTE_F16 else torch.bfloat16
+
+
 def set_deterministic(on: bool) -> None:
     """Bit-reproducible EdgeConv forward / backward (include/gfs3d.h: gfs3d_set_deterministic): the BatchNorm reductions
     are added in a fixed order instead of with float64 atomics.  Process-wide."""
@@ -390,10 +409,16 @@ class PointwiseRun:
         if not 1 <= len(xs) <= PW_MAX_SEGS or not 1 <= len(layers) <= PW_MAX_LAYERS:
             raise NotImplementedError("gfs3d.pointwise: 1..4 input segments and 1..4 layers are implemented in HIP")
         segw = int(xs[0].shape[-1])
+        self.compute = _compute
+        self.training = bool(training)
+        self.h_dtype = _h_dtype(self.compute, self.training)
         for t in xs:
-            _need_gpu(t, "x_seg")
-            if t.dim() != 3 or segw % PW_SEG_WIDTH or t.shape != xs[0].shape:
-                raise RuntimeError("gfs3d.pointwise: inputs must be equal-shape point-major (B,N,64 m) tensors")
+            if t.is_cuda and t.dtype == self.h_dtype and t.dtype != torch.float32 and t.dtype == xs[0].dtype:
+                pass                                   # a 16-bit input in the mode's own format (the packed fusion input)
+            else:
+                _need_gpu(t, "x_seg")
+            if t.dim() != 3 or segw % PW_SEG_WIDTH or t.shape != xs[0].shape or t.dtype != xs[0].dtype:
+                raise RuntimeError("gfs3d.pointwise: inputs must be equal-shape point-major (B,N,64 m) tensors of one type")
         if segw * len(xs) > 1024:
             raise NotImplementedError("gfs3d.pointwise: at most 1024 input channels")
         if not (want_cf or want_pm):
@@ -413,13 +438,12 @@ class PointwiseRun:
         self.slopes = [float(v) for v in slopes] if slopes is not None else None
         if len(self.biases) != L or (self.slopes is not None and len(self.slopes) != L):
             raise ValueError("gfs3d.pointwise: one bias / slope per layer")
-        self.training = bool(training)
-        self.compute = _compute
         self.scalars = (float(eps), float(momentum), float(slope))
         dev = self.xs[0].device
         f32 = dict(dtype=torch.float32, device=dev)
         M = self.B * self.N
-        self.h = [torch.empty((M, c), **f32) if (self.training or l < L - 1) else None for l, c in enumerate(self.widths)]
+        self.h = [torch.empty((M, c), dtype=self.h_dtype, device=dev) if (self.training or l < L - 1) else None
+                  for l, c in enumerate(self.widths)]
         self.stats = [torch.empty((4, c), **f32) for c in self.widths]
         self.y = torch.empty((self.B, self.widths[-1], self.N), **f32) if want_cf else None
         self.y_pm = torch.empty((self.B, self.N, self.widths[-1]), **f32) if want_pm else None
@@ -435,6 +459,8 @@ class PointwiseRun:
         a.seg_width = self.segw
         a.training = 1 if self.training else 0
         a.compute = self.compute
+        a.store16 = 1 if self.h_dtype != torch.float32 else 0
+        a.x_type = self.compute if self.xs[0].dtype != torch.float32 else 0
         a.eps, a.momentum, a.slope = eps, momentum, slope
         a.per_layer_slope = 0 if self.slopes is None else 1
         for s_, t in enumerate(self.xs):
@@ -509,7 +535,8 @@ class PointwiseRun:
             raise RuntimeError("gfs3d.pointwise: backward without a gradient")
         self.dy = dy.contiguous() if dy is not None else None
         self.dy_pm = dy_pm.contiguous() if dy_pm is not None else None
-        self.dxs = [torch.empty_like(t) for t in self.xs]
+        x16 = self.xs[0].dtype != torch.float32            # 16-bit inputs (internal to a fused operator): their gradients are bf16
+        self.dxs = [torch.empty(t.shape, dtype=torch.bfloat16 if x16 else torch.float32, device=dev) for t in self.xs]
         self.dws = [torch.empty_like(w) for (w, *_r) in self.layers]
         self.dgs = [torch.empty(c, **f32) for c in self.widths]
         self.dbs = [torch.empty(c, **f32) for c in self.widths]
@@ -520,6 +547,7 @@ class PointwiseRun:
         self.layers = saved
         ba.dy_cf = self.dy.data_ptr() if self.dy is not None else None
         ba.dy_pm = self.dy_pm.data_ptr() if self.dy_pm is not None else None
+        ba.dx_type = 1 if x16 else 0
         for s_, t in enumerate(self.dxs):
             ba.dx_seg[s_] = t.data_ptr()
         for l in range(len(self.layers)):
@@ -551,12 +579,35 @@ class PointwiseRun:
 
 class PointwiseStackFunction(torch.autograd.Function):
     """act(bn_L(... act(bn_1(W_1 cat(xs))) ...)); tensors = xs + [w, gamma, beta] * L + [rm, rv] * L + [bias] * L (bias
-    entries may be None).  opts = (slopes or None, want_cf, want_pm); returns y_cf (B, C_L, N), y_pm (B, N, C_L) or both."""
+    entries may be None).  opts = (slopes or None, want_cf, want_pm[, pack]); returns y_cf (B, C_L, N), y_pm (B, N, C_L) or both.
+    pack = (channel_first flags, ld): the n_seg tensors are SOURCES in mixed layouts (channel-first (B, w, N) / point-major
+    (B, N, w)) that are first concatenated into one zero-padded point-major (B, N, ld) matrix (the torch.cat of capl.py:357-359)
+    INSIDE the operator - the packed matrix and its gradient are then internal tensors: 16-bit in the reduced modes."""
 
     @staticmethod
     def forward(ctx, n_seg, n_layers, training, eps, momentum, slope, sync, opts, *tensors):
-        slopes, want_cf, want_pm = opts
+        slopes, want_cf, want_pm = opts[:3]
+        pack = opts[3] if len(opts) > 3 else None
         xs = tensors[:n_seg]
+        ctx.pack = None
+        if pack is not None:
+            cf_flags, ld = pack
+            srcs = []
+            for t in xs:
+                _need_gpu(t, "src")
+                srcs.append(t.contiguous())
+            B = srcs[0].shape[0]
+            N = srcs[0].shape[2] if cf_flags[0] else srcs[0].shape[1]
+            for t, cf in zip(srcs, cf_flags):
+                if t.dim() != 3 or t.shape[0] != B or (t.shape[2] if cf else t.shape[1]) != N:
+                    raise RuntimeError("gfs3d.pointwise_stack_packed: sources must be (B, w, N) channel-first or (B, N, w) point-major")
+            packed = torch.empty((B, N, int(ld)), dtype=_h_dtype(_compute, bool(training)), device=srcs[0].device)
+            pa = _pack_args(B, N, srcs, cf_flags, packed)
+            with torch.cuda.device(packed.device):
+                rc = _lib.lib().gfs3d_pack_rows_f32(ctypes.byref(pa), _stream())
+            _lib.check(rc, "gfs3d_pack_rows_f32")
+            ctx.pack = (B, N, tuple(cf_flags), [tuple(t.shape) for t in srcs])
+            xs = (packed,)
         par = tensors[n_seg:n_seg + 3 * n_layers]
         run_ = tensors[n_seg + 3 * n_layers:n_seg + 5 * n_layers]
         biases = tensors[n_seg + 5 * n_layers:]
@@ -570,6 +621,8 @@ class PointwiseStackFunction(torch.autograd.Function):
             ctx.c = run
             ctx.sync = sync
         ctx.n = (n_seg, n_layers, want_cf, want_pm, [b is not None for b in biases] if biases else [False] * n_layers)
+        if ctx.pack is not None:
+            ctx.pack_needs = tuple(ctx.needs_input_grad[8:8 + n_seg])
         if want_cf and want_pm:
             return y, y_pm
         return y if want_cf else y_pm
@@ -584,6 +637,17 @@ class PointwiseStackFunction(torch.autograd.Function):
         else:
             dy, dy_pm = (douts[0], None) if want_cf else (None, douts[0])
         dxs, dws, dgs, dbs = ctx.c.backward(dy, ctx.sync, dy_pm=dy_pm)
+        if ctx.pack is not None:            # the adjoint of the pack: columns of the (bf16 / fp32) packed gradient back to the sources
+            B, N, cf_flags, shapes = ctx.pack
+            dpacked = dxs[0]
+            outs = [torch.empty(sh, dtype=torch.float32, device=dpacked.device) if need else None for sh, need in zip(shapes, ctx.pack_needs)]
+            # sources that need no gradient still occupy their columns: give them scratch so that offsets stay right
+            tmp = [o if o is not None else torch.empty(sh, dtype=torch.float32, device=dpacked.device) for o, sh in zip(outs, shapes)]
+            pa = _pack_args(B, N, tmp, cf_flags, dpacked)
+            with torch.cuda.device(dpacked.device):
+                rc = _lib.lib().gfs3d_unpack_rows_f32(ctypes.byref(pa), _stream())
+            _lib.check(rc, "gfs3d_unpack_rows_f32")
+            dxs = outs
         par = []
         for l in range(n_layers):
             par += [dws[l], dgs[l], dbs[l]]
@@ -613,6 +677,29 @@ def pointwise_stack(xs_pm, parts, training: bool, slope: float = 0.2, track: boo
     opts = (tuple(float(v) for v in slopes) if slopes is not None else None, bool(want_cf), bool(want_pm))
     return PointwiseStackFunction.apply(len(xs_pm), len(parts), bool(training), float(bn0.eps), float(mom), float(slope), sync, opts,
                                         *xs_pm, *par, *run_, *bias)
+
+
+def pointwise_stack_packed(sources, cf_flags, ld: int, parts, training: bool, slope: float = 0.2, track: bool = True,
+                           sync: Optional[BNSync] = None, slopes=None, want_cf: bool = True, want_pm: bool = False):
+    """`pointwise_stack([pack_rows(sources, cf_flags, ld)], parts, ...)` as ONE operator: the concatenated matrix (the fusion
+    layer's input, capl.py:357-359) and its gradient never cross an autograd boundary, so in the reduced modes they are kept
+    in 16 bits (the forward GEMM copies the rows to LDS as loaded; 100 instead of 201 MB each way at configs[4] size)."""
+    if training and track:
+        counters = [bn.num_batches_tracked for _c, bn in parts if bn.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)
+    bn0 = parts[0][1]
+    mom = bn0.momentum if bn0.momentum is not None else 0.1
+    par, run_, bias = [], [], []
+    for conv, bn in parts:
+        w_, b_ = conv if isinstance(conv, tuple) else (conv.weight, conv.bias)
+        par += [w_, bn.weight, bn.bias]
+        run_ += [bn.running_mean, bn.running_var]
+        bias.append(b_)
+    opts = (tuple(float(v) for v in slopes) if slopes is not None else None, bool(want_cf), bool(want_pm),
+            (tuple(bool(c) for c in cf_flags), int(ld)))
+    return PointwiseStackFunction.apply(len(sources), len(parts), bool(training), float(bn0.eps), float(mom), float(slope), sync, opts,
+                                        *sources, *par, *run_, *bias)
 
 
 class LinearFunction(torch.autograd.Function):
@@ -670,6 +757,7 @@ def _pack_args(B, N, tensors, cf_flags, dst):
         a.width[s_] = int(t.shape[1] if cf else t.shape[2])
         a.channel_first[s_] = 1 if cf else 0
     a.dst, a.dst_ld = dst.data_ptr(), int(dst.shape[-1])
+    a.dst_type = {torch.float32: 0, torch.bfloat16: _lib.COMPUTE_BF16, torch.float16: _lib.COMPUTE_F16}[dst.dtype]
     return a
 
 

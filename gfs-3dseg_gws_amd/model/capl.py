@@ -110,9 +110,10 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         conv, bn, act = self.fusion[0], self.fusion[1], self.fusion[2]
         k_in = conv.in_channels
         k_pad = (k_in + 63) // 64 * 64
-        packed = ops.pack_rows([soft, edge_pm[0], att, base_pm], [True, False, True, False], ld=k_pad)
         w = F.pad(conv.weight.squeeze(-1), (0, k_pad - k_in))
-        point_feat = ops.pointwise_stack([packed], [((w, conv.bias), bn)], self.training, float(act.negative_slope), sync=sync)
+        # pack + fusion stack as one operator: the packed (B,N,k_pad) matrix and its gradient stay internal (16-bit in the reduced modes)
+        point_feat = ops.pointwise_stack_packed([soft, edge_pm[0], att, base_pm], [True, False, True, False], k_pad,
+                                                [((w, conv.bias), bn)], self.training, float(act.negative_slope), sync=sync)
         semantic = torch.cat((edge_feats[0], att, base_cf), dim=1) if want_semantic else None
         return point_feat, semantic, one_hot
 

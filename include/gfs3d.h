@@ -234,6 +234,15 @@ typedef struct gfs3d_pointwise_args {
     int per_layer_slope;          /* != 0: layer l ends in LeakyReLU(slope_l[l]) (0 = ReLU, 1 = no activation) instead of `slope` */
     float slope_l[GFS3D_PW_MAX_LAYERS];
     float *y_pm;                  /* optional (B*N, width[last]) point-major copy of the result; y_cf may be NULL when it is given */
+    /* ---- 16-bit storage of the stack's INTERNAL tensors (reduced modes; BASELINE configs[4]) ----
+     * store16 != 0, training, compute != GFS3D_COMPUTE_F32: h[l] point at 2-byte elements in the forward operand format of the
+     * mode - IEEE half (saturating at +-65504) under GFS3D_COMPUTE_F16, bf16 under GFS3D_COMPUTE_BF16 - and the gradients the
+     * backward keeps in the workspace are bf16: half the HBM traffic of every kernel of the stack.  Accumulators, BatchNorm
+     * sums / constants, parameters, parameter gradients and the tensors at the call's boundary (x_seg, y_*, dy_*, dx_seg) stay
+     * fp32 - unless x_type / dx_type say otherwise.  Ignored (fp32 storage) in eval mode and under GFS3D_COMPUTE_F32. */
+    int store16;
+    int x_type;                   /* 0: x_seg are fp32; GFS3D_COMPUTE_BF16 / _F16 (= the call's `compute`, store16 set): x_seg hold bf16 /
+                                     half elements (the packed fusion input written by gfs3d_pack_rows_t) */
 } gfs3d_pointwise_args;
 
 typedef struct gfs3d_pointwise_bwd_args {
@@ -244,6 +253,7 @@ typedef struct gfs3d_pointwise_bwd_args {
     float *dbn_w[GFS3D_PW_MAX_LAYERS];
     float *dbn_b[GFS3D_PW_MAX_LAYERS];
     const float *dy_pm;           /* optional (B*N, width[last]) gradient w.r.t. y_pm, ADDED to dy_cf (either may be NULL) */
+    int dx_type;                  /* 0: dx_seg are fp32; 1 (store16 set): bf16 elements (read back by gfs3d_unpack_rows_t) */
 } gfs3d_pointwise_bwd_args;
 
 size_t gfs3d_pointwise_workspace_bytes(int B, int N, int n_seg, int n_layers, const int *width);
@@ -296,6 +306,9 @@ typedef struct gfs3d_pack_args {
     int channel_first[GFS3D_PACK_MAX_SRC];
     float *dst;
     int dst_ld;
+    int dst_type;                 /* element type of `dst`: 0 fp32; GFS3D_COMPUTE_BF16 bf16; GFS3D_COMPUTE_F16 IEEE half (packing only) -
+                                     the 16-bit fusion input / its bf16 gradient of a reduced-mode call (gfs3d_pointwise_args.x_type,
+                                     gfs3d_pointwise_bwd_args.dx_type); `src` are always fp32 */
 } gfs3d_pack_args;
 int gfs3d_pack_rows_f32(const gfs3d_pack_args *a, void *stream);
 int gfs3d_unpack_rows_f32(const gfs3d_pack_args *a, void *stream);

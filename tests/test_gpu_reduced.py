@@ -386,7 +386,7 @@ def test_capl_scannet_step_at_the_bench_size(dev, mode):
     assert bool(torch.isfinite(runs[0][0])) and pred.shape == (B, N) and int(pred.min()) >= 0 and int(pred.max()) <= classes
     for p_, g_ in zip(net.parameters(), runs[0][2:]):
         assert bool(torch.isfinite(g_).all())
-    assert sum(float(g_.abs().max()) > 0 for g_ in runs[0][2:2 + len(list(net.parameters()))]) >= 40
+    assert sum(float(g_.abs().max()) > 0 for g_ in runs[0][2:2 + len(list(net.parameters()))]) >= 30      # (conv biases in front of a BatchNorm: exactly 0)
     # (ii)
     assert abs(float(runs[1][0]) - float(runs[0][0])) <= 1e-6 * abs(float(runs[0][0]))
     for a_, b_ in zip(runs[0][1:], runs[1][1:]):
@@ -404,3 +404,84 @@ def test_capl_scannet_step_at_the_bench_size(dev, mode):
     assert bool((runs[0][1].cpu() == logits_ref.argmax(1))[clear].all())
     assert relmax(dfeat, f64.grad) < 1e-4
     assert relmax(dmain, m64.grad) < 1e-4 and relmax(dbg, b64.grad) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_pointwise_stack_16bit_storage_against_fp32_storage(dev, mode):
+    """Round 6: in the reduced modes the stack keeps its pre-BatchNorm activations (the mode's own 16-bit format) and their
+    gradients (bf16) in 16 bits in HBM (`store16`, default on).  Same call with fp32 storage (`ops.set_store16(False)`, the form
+    of rounds 3-5): the two must agree within the mode's own tolerance - the storage rounding is one more rounding of the size
+    the operands already carry - and the internal tensors must really be 2-byte elements."""
+    from gfs3d import ops
+    from model.dgcnn import conv1d
+    torch.manual_seed(7)
+    conv = conv1d(192, [512, 256]).to(dev).train()
+    B, N = 3, 333
+    xs0 = [torch.randn(B, N, 64, device=dev) for _ in range(3)]
+    cot = torch.randn(B, 256, N, device=dev)
+    res = {}
+    for store in (False, True):
+        prev = ops.set_store16(store)
+        try:
+            conv.zero_grad(set_to_none=True)
+            xs = [t.clone().requires_grad_(True) for t in xs0]
+            with ops.compute(mode):
+                y = ops.pointwise_stack(xs, conv.fused_parts(), True)
+            run = y.grad_fn.c
+            assert all(h.element_size() == (2 if store else 4) for h in run.h)
+            assert run.h[0].dtype == ({"f16": torch.float16, "bf16": torch.bfloat16}[mode] if store else torch.float32)
+            y.backward(cot)
+            res[store] = (y.detach().clone(), [t.grad.clone() for t in xs], [p.grad.clone() for p in conv.parameters()])
+        finally:
+            ops.set_store16(prev)
+    assert relmax(res[True][0], res[False][0]) < FWD_TOL[mode]
+    for a, b in zip(res[True][1], res[False][1]):
+        assert cosine(a, b) > KERNEL_COS[mode]
+    for a, b in zip(res[True][2], res[False][2]):
+        if float(b.abs().max()) > 1e-9:
+            assert cosine(a, b) > KERNEL_COS[mode]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+def test_packed_fusion_operator_equals_pack_then_stack(dev, mode):
+    """`ops.pointwise_stack_packed` (pack + fusion stack as ONE operator, capl.py:357-359 + :64-65): in the fp32-accurate mode it
+    runs the very kernels of `pack_rows` followed by `pointwise_stack` - bit-identical outputs and gradients; in the reduced
+    modes the packed (B,N,448) matrix and its gradient are 16-bit internal tensors (the forward GEMM copies the rows to LDS as
+    loaded) - against the fp32-accurate result within the mode's tolerances."""
+    import torch.nn as nn
+    from gfs3d import ops
+    torch.manual_seed(11)
+    B, N, Kw = 2, 260, 180
+    k_in = Kw + 192
+    k_pad = (k_in + 63) // 64 * 64
+    conv, bn = nn.Conv1d(k_in, 128, 1).to(dev), nn.BatchNorm1d(128).to(dev).train()
+    w = torch.nn.functional.pad(conv.weight.squeeze(-1), (0, k_pad - k_in)).detach().requires_grad_(True)
+    srcs0 = [torch.softmax(torch.randn(B, Kw, N, device=dev), 1), torch.randn(B, N, 64, device=dev), torch.randn(B, 64, N, device=dev),
+             torch.randn(B, N, 64, device=dev)]
+    flags = [True, False, True, False]
+    cot = torch.randn(B, 128, N, device=dev)
+
+    def run(fused, m):
+        srcs = [t.clone().requires_grad_(True) for t in srcs0]
+        w_ = w.detach().clone().requires_grad_(True)
+        bn.zero_grad(set_to_none=True)
+        conv.bias.grad = None
+        with ops.compute(m):
+            if fused:
+                y = ops.pointwise_stack_packed(srcs, flags, k_pad, [((w_, conv.bias), bn)], True, 0.2, track=False)
+            else:
+                y = ops.pointwise_stack([ops.pack_rows(srcs, flags, ld=k_pad)], [((w_, conv.bias), bn)], True, 0.2, track=False)
+            y.backward(cot)
+        return y.detach(), [t.grad for t in srcs], w_.grad, bn.weight.grad.clone()
+
+    base = run(False, "f32")
+    got = run(True, mode)
+    if mode == "f32":
+        assert torch.equal(got[0], base[0]) and torch.equal(got[2], base[2]) and torch.equal(got[3], base[3])
+        for a, b in zip(got[1], base[1]):
+            assert torch.equal(a, b)
+        return
+    assert relmax(got[0], base[0]) < FWD_TOL[mode]
+    for a, b in zip(got[1], base[1]):
+        assert cosine(a, b) > KERNEL_COS[mode]
+    assert cosine(got[2], base[2]) > KERNEL_COS[mode] and cosine(got[3], base[3]) > KERNEL_COS[mode]
