@@ -232,6 +232,19 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
         f32x4 ea = {0.f, 0.f, 0.f, 0.f}, eb = ea;
         double ts1[4] = {0.0, 0.0, 0.0, 0.0}, ts2[4] = {0.0, 0.0, 0.0, 0.0};   // fp64: sum x^2 - mean^2 cancels when |mean| >> std
         if (EPI == EPI_AFFINE_ACT || EPI == EPI_BWD_ACT) { ea = ldg4(g.ea + gcol); eb = ldg4(g.eb + gcol); }
+        // EPI_BWD_ACT with 16-bit activations: BOTH passes' rows of `eh` are requested here, in front of the LDS round trips of the
+        // accumulators (32 registers) - issued inside a pass they were a serial trip to HBM per pass with nothing beside them
+        constexpr bool EH_AHEAD = EPI == EPI_BWD_ACT && HT != ST_F32;
+        typename Raw4<HT>::type hva[EH_AHEAD ? 2 : 1][8];
+        if constexpr (EH_AHEAD) {
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int row = row0 + ps * 64 + rr + 8 * jj;
+                    hva[ps][jj] = row < g.M ? st_ld4<HT>(g.eh, (size_t)row * g.Nc + gcol) : st_zero4<HT>();
+                }
+        }
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             pw_lds_barrier();
@@ -251,7 +264,8 @@ __device__ __forceinline__ void rowgemm_epilogue(const RowGemm &g, f32x16 (&acc)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const int row = row0 + ps * 64 + rr + 8 * jj;
-                    hv[jj] = row < g.M ? st_ld4<HT>(g.eh, (size_t)row * g.Nc + gcol) : st_zero4<HT>();
+                    if constexpr (EH_AHEAD) hv[jj] = hva[ps][jj];
+                    else hv[jj] = row < g.M ? st_ld4<HT>(g.eh, (size_t)row * g.Nc + gcol) : st_zero4<HT>();
                 }
             }
 #pragma unroll
@@ -900,6 +914,200 @@ __global__ void __launch_bounds__(256, 2) pw_wgrad6_kernel(const WGrad g)
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The weight gradient of the REDUCED modes (one bf16 product per fp32 product).  pw_wgrad6_kernel transposes both operands on
+// their way INTO LDS (rows = channels, 4-byte stores of point pairs, 16 per thread and step) from loads that touch 32 bytes of
+// every row they visit: with a sixth of the exact form's matrix work per byte that staging is the whole kernel (round 6: 213 us
+// for 34 GF and 268 MB - 1.2 TB/s, 0.04 of the matrix pipe).  Here the tiles stay in their NATURAL layout - image rows = points,
+// 16-byte loads along the channels (a point's tile slice is one contiguous segment), 16-byte LDS stores - and the transposition
+// happens in the operand fetch: ds_read_b64_tr_b16 delivers, for rows = channels, the 8 points of a K-step half in MFMA
+// operand order (the read K5 and the EdgeConv backward use).  Both operands are fetched that way, so their K order agrees.
+// 64 points per pipeline step; bf16 operands (gradients: no half).  GT / HT / VT: ST_* of u (g) / u2 (h) / v.
+// ---------------------------------------------------------------------------------------------------------
+typedef short pw_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pw_s16x4 pw_lds_s16x4;
+#ifndef PW_WG16_PTS
+#define PW_WG16_PTS 64
+#endif
+#ifndef PW_WG16_OCC
+#define PW_WG16_OCC 2
+#endif
+constexpr int WG16_PTS = PW_WG16_PTS;
+__host__ __device__ constexpr int wg16_prow(int w) { return 2 * w + 16; }          // bytes per point row of a W-channel image
+// A / B operand of K-step `s` (16 points) for channel rows 32 dt + (lane & 31): lanes 4 q + p4 of a 16-lane group address row q,
+// channels 4 p4 .. + 3 of the group's 16; lane c receives its channel's 4 rows (element q = row q).  EXEC all ones.
+template <int PROW>
+__device__ __forceinline__ uint4 wg16_frag(const unsigned char *img, int lane, int dt, int s)
+{
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane >> 2) & 3, p4 = lane & 3;
+    const unsigned char *base = img + (16 * s + 4 * h + q) * PROW + 2 * (32 * dt + 16 * g1 + 4 * p4);
+    const pw_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pw_lds_s16x4 *)base);
+    const pw_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pw_lds_s16x4 *)(base + 8 * PROW));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+// eight consecutive stored channels of one point -> two f32x4
+template <int ST> struct Raw8 { typedef uint4 type; };
+template <> struct Raw8<ST_F32> { struct type { f32x4 a, b; }; };
+template <int ST> __device__ __forceinline__ typename Raw8<ST>::type st_ld8(const void *base, size_t idx, bool ok)
+{
+    typename Raw8<ST>::type r;
+    if constexpr (ST == ST_F32) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r.a = ok ? *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + idx) : z;
+        r.b = ok ? *reinterpret_cast<const f32x4 *>(static_cast<const float *>(base) + idx + 4) : z;
+    } else
+        r = ok ? *reinterpret_cast<const uint4 *>(static_cast<const unsigned short *>(base) + idx) : make_uint4(0u, 0u, 0u, 0u);
+    return r;
+}
+template <int ST> __device__ __forceinline__ void st_cvt8(const typename Raw8<ST>::type &r, f32x4 &lo, f32x4 &hi)
+{
+    if constexpr (ST == ST_F32) { lo = r.a; hi = r.b; }
+    else { lo = st_cvt4<ST>(make_uint2(r.x, r.y)); hi = st_cvt4<ST>(make_uint2(r.z, r.w)); }
+}
+
+template <int BMU, int BNV, int VPRO, int GT, int HT, int VT>
+__global__ void __launch_bounds__(256, PW_WG16_OCC) pw_wgrad16_kernel(const WGrad g)
+{
+    extern __shared__ f32x4 pw_smem4[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(pw_smem4);
+    constexpr int TM = BMU / 64, TN = BNV / 64;
+    constexpr int UROW = wg16_prow(BMU), VROW = wg16_prow(BNV);
+    constexpr int UO = BMU / 8, VO = BNV / 8;                        // channel octets per point
+    constexpr int NUI = WG16_PTS * UO / 256, NVI = WG16_PTS * VO / 256;      // (point, octet) items per thread and step
+    static_assert(WG16_PTS * UO % 256 == 0 && WG16_PTS * VO % 256 == 0, "whole items per thread");
+    static_assert(VPRO == PRO_NONE || 256 % VO == 0, "a thread's V octet must not change between its items when V has coefficients");
+    static_assert(256 % UO == 0, "a thread's U octet must not change between its items");
+    unsigned char *sU = smem;                                        // [64 points][UROW]
+    unsigned char *sV = smem + WG16_PTS * UROW;                      // [64 points][VROW]
+    const int nci = g.Ci / BNV, ntile = (g.Co / BMU) * nci;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int split = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+    if (split >= g.nsplit) return;
+    const int co0 = (tile / nci) * BMU, ci0 = (tile % nci) * BNV;
+    const int m0 = split * g.rows_per_split, m1 = min(g.M, m0 + g.rows_per_split);
+    if (m0 >= m1) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const bool comb = g.u2 != nullptr;                               // BatchNorm-backward combine a u + b + c u2 (per Co channel)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int uoct = t % UO;
+    f32x4 ua[2], ub[2], uc[2], va[2], vb[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        ua[hf] = ub[hf] = uc[hf] = va[hf] = vb[hf] = zero4;
+        if (comb) { const int c = co0 + 8 * uoct + 4 * hf; ua[hf] = ldg4(g.ua + c); ub[hf] = ldg4(g.ub + c); uc[hf] = ldg4(g.uc + c); }
+        if (VPRO == PRO_BNACT) { const int c = ci0 + 8 * (t % VO) + 4 * hf; va[hf] = ldg4(g.va + c); vb[hf] = ldg4(g.vb + c); }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    typename Raw8<GT>::type rU[NUI];
+    typename Raw8<HT>::type rU2[NUI];
+    typename Raw8<VT>::type rV[NVI];
+    auto load = [&](int kt) {
+        const int mb = m0 + kt * WG16_PTS;
+#pragma unroll
+        for (int p = 0; p < NUI; ++p) {
+            const int it = t + 256 * p, pt = it / UO, oc = it - pt * UO;
+            const bool ok = mb + pt < m1;
+            const size_t o = (size_t)(mb + pt) * g.ldu + co0 + 8 * oc;
+            rU[p] = st_ld8<GT>(g.u, o, ok);
+            if (comb) rU2[p] = st_ld8<HT>(g.u2, o, ok);
+        }
+#pragma unroll
+        for (int p = 0; p < NVI; ++p) {
+            const int it = t + 256 * p, pt = it / VO, oc = it - pt * VO;
+            const bool ok = mb + pt < m1;
+            const int ch = ci0 + 8 * oc, vseg = ch / g.v_segw;
+            rV[p] = st_ld8<VT>(g.v[vseg], (size_t)(mb + pt) * g.ldv + (ch - vseg * g.v_segw), ok);
+        }
+    };
+    auto store = [&](int kt) {
+        const int mb = m0 + kt * WG16_PTS;
+#pragma unroll
+        for (int p = 0; p < NUI; ++p) {
+            const int it = t + 256 * p, pt = it / UO, oc = it - pt * UO;
+            uint4 o;
+            if constexpr (GT == ST_BF16) {
+                if (!comb) { o = rU[p]; *reinterpret_cast<uint4 *>(sU + pt * UROW + 16 * oc) = o; continue; }
+            }
+            f32x4 x[2];
+            st_cvt8<GT>(rU[p], x[0], x[1]);
+            if (comb) {
+                f32x4 h[2];
+                st_cvt8<HT>(rU2[p], h[0], h[1]);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) x[hf][c] = fmaf(h[hf][c], uc[hf][c], fmaf(x[hf][c], ua[hf][c], ub[hf][c]));
+                if (mb + pt >= m1) { x[0] = zero4; x[1] = zero4; }
+            }
+            o = make_uint4(mm_pack2<PREC_BF16>(x[0][0], x[0][1]), mm_pack2<PREC_BF16>(x[0][2], x[0][3]),
+                           mm_pack2<PREC_BF16>(x[1][0], x[1][1]), mm_pack2<PREC_BF16>(x[1][2], x[1][3]));
+            *reinterpret_cast<uint4 *>(sU + pt * UROW + 16 * oc) = o;
+        }
+#pragma unroll
+        for (int p = 0; p < NVI; ++p) {
+            const int it = t + 256 * p, pt = it / VO, oc = it - pt * VO;
+            uint4 o;
+            if constexpr (VT == ST_BF16 && VPRO == PRO_NONE) {
+                o = rV[p];
+            } else {
+                f32x4 x[2];
+                st_cvt8<VT>(rV[p], x[0], x[1]);
+                if (VPRO == PRO_BNACT) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x[hf][c] = lrelu(fmaf(x[hf][c], va[hf][c], vb[hf][c]), g.slope);
+                    if (mb + pt >= m1) { x[0] = zero4; x[1] = zero4; }
+                }
+                o = make_uint4(mm_pack2<PREC_BF16>(x[0][0], x[0][1]), mm_pack2<PREC_BF16>(x[0][2], x[0][3]),
+                               mm_pack2<PREC_BF16>(x[1][0], x[1][1]), mm_pack2<PREC_BF16>(x[1][2], x[1][3]));
+            }
+            *reinterpret_cast<uint4 *>(sV + pt * VROW + 16 * oc) = o;
+        }
+    };
+
+    const int KT = (m1 - m0 + WG16_PTS - 1) / WG16_PTS;
+    load(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        store(kt);
+        __syncthreads();
+        if (kt + 1 < KT) load(kt + 1);
+#pragma unroll
+        for (int s = 0; s < WG16_PTS / 16; ++s) {
+            uint4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = wg16_frag<UROW>(sU, lane, wm * TM + i, s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = wg16_frag<VROW>(sV, lane, wn * TN + j, s);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mm_mfma<PREC_BF16>(af[i], bf[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * (BMU / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ci = ci0 + wn * (BNV / 2) + j * 32 + li;
+                g.part[((size_t)split * g.Co + co) * g.Ci + ci] = acc[i][j][r];
+            }
+}
+
 // y_cf(b, c, n) = act(scale h(b n, c) + shift): 64 points x 64 channels per block, grid (ceil(N/64), C/64, B)
 template <int HT>
 __global__ void __launch_bounds__(256)
@@ -1135,10 +1343,12 @@ WgGeo wg_geo(int M, int Co, int Ci, bool allow192)
     WgGeo g{};
     g.bmu = Co % 128 == 0 ? 128 : 64;
     g.bnv = (allow192 && Ci == 192) ? 192 : (Ci % 128 == 0 ? 128 : 64);
-    const size_t lds = (size_t)(g.bmu + g.bnv) * PW6_ROW;
     const int ntile = (Co / g.bmu) * (Ci / g.bnv);
-    // 2-3 blocks per CU; every split ends in a bmu x bnv partial tile, so no more splits than that
-    int nsplit = ((lds > 60 * 1024 ? 512 : 768) + ntile - 1) / ntile;
+    // ONE round of resident blocks: the 128 x 128 (and wider) tiles run two blocks per CU (their 200-odd registers, not the LDS,
+    // decide), so 512 blocks; 768 - sized for the three blocks the LDS would admit - left half the card idle through a second round
+    // (round 6: 752 blocks = 1.47 rounds in the c2 step).  Smaller tiles fit 3 - 4 per CU.
+    const int per_cu = g.bmu * g.bnv >= 128 * 128 ? 2 : (g.bmu * g.bnv >= 128 * 64 ? 3 : 4);
+    int nsplit = (256 * per_cu + ntile - 1) / ntile;
     int rows = (M + nsplit - 1) / nsplit;
     rows = (rows + 31) / 32 * 32;
     if (rows < 256) rows = 256;
@@ -1151,17 +1361,19 @@ size_t wg_part_bytes(int M, int Co, int Ci, bool allow192)
     return sizeof(float) * (size_t)wg_geo(M, Co, Ci, allow192).nsplit * Co * Ci;
 }
 
-template <int BMU, int BNV, int VPRO, int PREC, int GT, int HT, int VT>
-int launch_wg6_t(const WGrad &wg, unsigned grid, size_t lds, hipStream_t st, const char *who)
+template <int BMU, int BNV, int VPRO, int GT, int HT, int VT>
+int launch_wg16_t(const WGrad &wg, unsigned grid, hipStream_t st, const char *who)
 {
-    GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC, GT, HT, VT>), lds, who);
-    hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC, GT, HT, VT>), dim3(grid), dim3(256), lds, st, wg);
-    GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
+    const size_t lds = (size_t)WG16_PTS * (wg16_prow(BMU) + wg16_prow(BNV));
+    GFS3D_ENSURE_LDS((pw_wgrad16_kernel<BMU, BNV, VPRO, GT, HT, VT>), lds, who);
+    hipLaunchKernelGGL((pw_wgrad16_kernel<BMU, BNV, VPRO, GT, HT, VT>), dim3(grid), dim3(256), lds, st, wg);
+    GFS3D_LAUNCH_CHECK("pw_wgrad16_kernel");
     return GFS3D_OK;
 }
 
-// storage formats: all fp32 (any arithmetic), or - reduced modes with 16-bit storage - u = g (bf16), u2 = h (the mode's format),
-// v = the previous layer's h (VPRO == PRO_BNACT: the same format) or the stack's input (fp32 or the mode's format)
+// fp32-accurate mode: pw_wgrad6_kernel (exact bf16 split).  Reduced modes: pw_wgrad16_kernel; storage formats: all fp32, or
+// (16-bit storage) u = g (bf16), u2 = h (the mode's format), v = the previous layer's h (VPRO == PRO_BNACT: the same format) or the
+// stack's input (fp32 or the mode's format)
 template <int BMU, int BNV, int VPRO>
 int launch_wgrad_t(WGrad wg, const WgGeo &geo, hipStream_t st, const char *who)
 {
@@ -1171,17 +1383,23 @@ int launch_wgrad_t(WGrad wg, const WgGeo &geo, hipStream_t st, const char *who)
     wg.nsplit = geo.nsplit;
     const unsigned grid = 8u * ntile * ((geo.nsplit + 7) / 8);
     int rc = -1;                                     // -1: no instantiation for these formats
-    if (wg.gt == ST_F32 && wg.ht == ST_F32 && wg.vt == ST_F32) {
-        if (wg.prec != PREC_X6) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_F32, ST_F32, ST_F32>(wg, grid, lds, st, who);
-        else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_X6, ST_F32, ST_F32, ST_F32>(wg, grid, lds, st, who);
-    } else if (wg.prec != PREC_X6 && wg.gt == ST_BF16 && (wg.ht == ST_BF16 || wg.ht == ST_F16)) {
+    if (wg.prec == PREC_X6) {
+        if (wg.gt == ST_F32 && wg.ht == ST_F32 && wg.vt == ST_F32) {
+            GFS3D_ENSURE_LDS((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), lds, who);
+            hipLaunchKernelGGL((pw_wgrad6_kernel<BMU, BNV, VPRO, PREC_X6>), dim3(grid), dim3(256), lds, st, wg);
+            GFS3D_LAUNCH_CHECK("pw_wgrad6_kernel");
+            rc = GFS3D_OK;
+        }
+    } else if (wg.gt == ST_F32 && wg.ht == ST_F32 && wg.vt == ST_F32) {
+        rc = launch_wg16_t<BMU, BNV, VPRO, ST_F32, ST_F32, ST_F32>(wg, grid, st, who);
+    } else if (wg.gt == ST_BF16 && (wg.ht == ST_BF16 || wg.ht == ST_F16)) {
         if (wg.vt == wg.ht) {
-            if (wg.ht == ST_BF16) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_BF16, ST_BF16>(wg, grid, lds, st, who);
-            else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_F16, ST_F16>(wg, grid, lds, st, who);
+            if (wg.ht == ST_BF16) rc = launch_wg16_t<BMU, BNV, VPRO, ST_BF16, ST_BF16, ST_BF16>(wg, grid, st, who);
+            else rc = launch_wg16_t<BMU, BNV, VPRO, ST_BF16, ST_F16, ST_F16>(wg, grid, st, who);
         } else if (wg.vt == ST_F32) {
             if constexpr (VPRO == PRO_NONE) {
-                if (wg.ht == ST_BF16) rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_BF16, ST_F32>(wg, grid, lds, st, who);
-                else rc = launch_wg6_t<BMU, BNV, VPRO, PREC_BF16, ST_BF16, ST_F16, ST_F32>(wg, grid, lds, st, who);
+                if (wg.ht == ST_BF16) rc = launch_wg16_t<BMU, BNV, VPRO, ST_BF16, ST_BF16, ST_F32>(wg, grid, st, who);
+                else rc = launch_wg16_t<BMU, BNV, VPRO, ST_BF16, ST_F16, ST_F32>(wg, grid, st, who);
             }
         }
     }
@@ -1766,6 +1984,7 @@ pw_pack_kernel(const gfs3d_pack_args a, const PackPlan pl)
     }
     const int W = a.width[s], c0 = ty * 64, cw = min(64, W - c0), dcol = pl.off[s] + c0;
     float *src = a.src[s];
+    if (UNPACK && !src) return;                            // (adjoint only: a source whose gradient the caller forms elsewhere)
     if (!UNPACK) {
         if (a.channel_first[s]) {
             for (int cc = wv; cc < cw; cc += 4) tile[lane][cc] = n0 + lane < N ? src[((size_t)b * W + c0 + cc) * N + n0 + lane] : 0.f;
@@ -1800,7 +2019,7 @@ int pack_launch(const gfs3d_pack_args *a, bool unpack, hipStream_t st, const cha
     pl.n_src = a->n_src;
     int off = 0, tiles = 0;
     for (int s = 0; s < a->n_src; ++s) {
-        GFS3D_REQUIRE(a->src[s] && a->width[s] >= 1, "%s: NULL or empty source %d", who, s);
+        GFS3D_REQUIRE((a->src[s] || unpack) && a->width[s] >= 1, "%s: NULL or empty source %d", who, s);
         pl.off[s] = off;
         pl.tiles[s] = (a->width[s] + 63) / 64;
         off += a->width[s];

@@ -1890,6 +1890,107 @@ extern "C" int gfs3d_word_assign_mixed(const float *feat, long long feat_bstride
                                         static_cast<hipStream_t>(stream), "gfs3d_word_assign_f32", prec_of(compute, false));
 }
 
+// ---------------------------------------------------------------------------
+// Softmax backward of the word assignment in front of the fused word-gradient kernel:  d[b][w][n] = soft (dsoft - <soft, dsoft>_w).
+// `dsoft` arrives as the first Kw columns of the packed fusion gradient (point-major rows of `ld` elements, fp32 or bf16: the
+// adjoint of the pack of capl.py:357-359); `soft` and `d` are channel-first (B, Kw, N).  With `d` in hand the word gradient
+// is a plain logits backward (proto_bwd_x6i_kernel<MODE_LOGITS>): soft and its gradient are read ONCE - the softmax form of that
+// kernel read both twice (its dot pre-pass and its main loop: 391 MB per launch for 160 MB of operands, round 5) and the
+// unpack kernel wrote the channel-first dsoft in between.
+// One workgroup: 64 points x all words.  The 64 packed rows go through an LDS tile (coalesced along the rows); then lane =
+// point, wave v owns words v, v + 4, ...: soft is read once into registers (coalesced along the points).
+// ---------------------------------------------------------------------------
+constexpr int WSB_MAXW = 64;             // words per wave: Kw <= 256
+template <bool BF16>
+__global__ void __launch_bounds__(256)
+word_soft_bwd_rows_kernel(const void *__restrict__ dpacked, int ld, const float *__restrict__ soft, int Kw, int N, float *__restrict__ d)
+{
+    extern __shared__ float wsb_tile[];                    // [64][Kw | 1] dsoft of the tile's points, then [4][64] partial dots
+    const int TLD = Kw | 1;
+    float *red = wsb_tile + 64 * TLD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = blockIdx.y, n0 = blockIdx.x * 64;
+    const int np = min(64, N - n0);
+    // the tile's rows in 16-byte pieces (8 bf16 / 4 fp32 columns; a row starts 16-byte aligned: ld % 8 == 0 is required)
+    constexpr int VW = BF16 ? 8 : 4;
+    const int nch = (Kw + VW - 1) / VW;
+    for (int e = tid; e < 64 * nch; e += 256) {
+        const int p = e / nch, c = e - p * nch;
+        float v[VW];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) v[i] = 0.f;
+        if (p < np) {
+            const size_t o = ((size_t)b * N + n0 + p) * ld + VW * c;
+            if constexpr (BF16) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(static_cast<const unsigned short *>(dpacked) + o);
+                const unsigned rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = __builtin_bit_cast(float, rr[i] << 16);
+                    v[2 * i + 1] = __builtin_bit_cast(float, rr[i] & 0xffff0000u);
+                }
+            } else {
+                const float4 r = *reinterpret_cast<const float4 *>(static_cast<const float *>(dpacked) + o);
+                v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i)
+            if (VW * c + i < Kw) wsb_tile[p * TLD + VW * c + i] = v[i];
+    }
+    __syncthreads();
+    const int n = n0 + min(lane, np - 1);
+    const float *sb = soft + (size_t)b * Kw * N + n;
+    float sv[WSB_MAXW];
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < WSB_MAXW; ++q) {
+        const int w = wv + 4 * q;
+        sv[q] = w < Kw ? sb[(size_t)w * N] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < WSB_MAXW; ++q) {
+        const int w = wv + 4 * q;
+        if (w < Kw) dot = fmaf(sv[q], wsb_tile[lane * TLD + w], dot);
+    }
+    red[wv * 64 + lane] = dot;
+    __syncthreads();
+    dot = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];           // fixed order: bit-reproducible
+    if (lane < np) {
+        float *db = d + (size_t)b * Kw * N + n0 + lane;
+#pragma unroll
+        for (int q = 0; q < WSB_MAXW; ++q) {
+            const int w = wv + 4 * q;
+            if (w < Kw) db[(size_t)w * N] = sv[q] * (wsb_tile[lane * TLD + w] - dot);
+        }
+    }
+}
+
+extern "C" int gfs3d_word_soft_backward_rows(const void *dpacked, int dtype, int ld, const float *soft, int B, int Kw, int N, float *d,
+                                             void *stream)
+{
+    using namespace gfs3d;
+    const char *who = "gfs3d_word_soft_backward_rows";
+    GFS3D_REQUIRE(dpacked && soft && d, "%s: NULL pointer", who);
+    GFS3D_REQUIRE(dtype == 0 || dtype == GFS3D_COMPUTE_BF16, "%s: dtype=%d unsupported (0 fp32, GFS3D_COMPUTE_BF16)", who, dtype);
+    GFS3D_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && Kw >= 1 && Kw <= 4 * WSB_MAXW && ld >= (Kw + 7) / 8 * 8 && ld % 8 == 0,
+                  "%s: bad shape B=%d Kw=%d N=%d ld=%d (ld a multiple of 8, >= Kw rounded up to 8)", who, B, Kw, N, ld);
+    GFS3D_REQUIRE(((size_t)dpacked & 15) == 0, "%s: dpacked must be 16-byte aligned", who);
+    const size_t lds = sizeof(float) * ((size_t)64 * (Kw | 1) + 256);
+    const dim3 grid((N + 63) / 64, B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope prof(3, st);
+    if (dtype) {
+        GFS3D_ENSURE_LDS((word_soft_bwd_rows_kernel<true>), lds, who);
+        hipLaunchKernelGGL((word_soft_bwd_rows_kernel<true>), grid, dim3(256), lds, st, dpacked, ld, soft, Kw, N, d);
+    } else {
+        GFS3D_ENSURE_LDS((word_soft_bwd_rows_kernel<false>), lds, who);
+        hipLaunchKernelGGL((word_soft_bwd_rows_kernel<false>), grid, dim3(256), lds, st, dpacked, ld, soft, Kw, N, d);
+    }
+    GFS3D_LAUNCH_CHECK(who);
+    return GFS3D_OK;
+}
+
 extern "C" int gfs3d_proto_cosine_f32(const float *feat, long long feat_bstride, int B, int C, int N,
                                       const float *proto, int P, int K, float scale, float *out, void *stream)
 {

@@ -212,6 +212,7 @@ SYMBOLS = {
     "gfs3d_capl_head_backward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
     "gfs3d_word_assign_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gfs3d_word_soft_backward_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gfs3d_proto_backward_feat_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
                                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "gfs3d_proto_backward_feat_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -702,6 +702,89 @@ def pointwise_stack_packed(sources, cf_flags, ld: int, parts, training: bool, sl
                                         *sources, *par, *run_, *bias)
 
 
+class WordsFusionFunction(torch.autograd.Function):
+    """The geometric-word branch and the fusion layer of `getFeatures` as ONE operator (model/capl.py:344-359, 64-65):
+        soft = softmax(scale cos(word, edge feature));  word = argmax;  y = act(bn(W [soft | others] + b))
+    Forward: word assignment (K3) -> pack -> fusion stack (K4).  Backward: the stack's input gradient stays packed; its other
+    sources are unpacked, its soft columns go through `gfs3d_word_soft_backward_rows` (d = soft (dsoft - <soft, dsoft>)) and then
+    the word-gradient kernel in its plain logits form - soft and its gradient are read once each, the channel-first dsoft is
+    never written, and `soft`, the packed matrix and its gradient never cross an autograd boundary (16-bit in the reduced modes).
+    tensors = [feat (B,C,N), words (Kw,C)] + others + [w, gamma, beta, rm, rv, bias]; returns (y_cf (B,Cout,N), word (B,N) int32)."""
+
+    @staticmethod
+    def forward(ctx, scale, other_cf, ld, training, eps, momentum, slope, sync, n_other, *tensors):
+        feat, words = tensors[0], tensors[1]
+        others = tensors[2:2 + n_other]
+        w, gamma, beta, rm, rv, bias = tensors[2 + n_other:]
+        _need_gpu(feat, "feat")
+        _need_gpu(words, "words")
+        feat = feat.contiguous()
+        B, C, N = feat.shape
+        Kw = words.shape[0]
+        soft, word, _ = word_assign_raw(feat, words, scale, want_onehot=False)
+        srcs = [soft] + [t.contiguous() for t in others]
+        flags = (True,) + tuple(bool(c) for c in other_cf)
+        for t, cf in zip(srcs, flags):
+            _need_gpu(t, "src")
+            if t.dim() != 3 or t.shape[0] != B or (t.shape[2] if cf else t.shape[1]) != N:
+                raise RuntimeError("gfs3d.words_fusion: sources must be (B, w, N) channel-first or (B, N, w) point-major")
+        packed = torch.empty((B, N, int(ld)), dtype=_h_dtype(_compute, bool(training)), device=feat.device)
+        pa = _pack_args(B, N, srcs, flags, packed)
+        with torch.cuda.device(packed.device):
+            rc = _lib.lib().gfs3d_pack_rows_f32(ctypes.byref(pa), _stream())
+        _lib.check(rc, "gfs3d_pack_rows_f32")
+        run = PointwiseRun([packed], [(w, gamma, beta, rm, rv)], training, eps, momentum, slope, biases=[bias])
+        run.forward(sync)
+        y = run.y
+        run.y = None
+        ctx.mark_non_differentiable(word)
+        if training:
+            ctx.c, ctx.sync = run, sync
+            ctx.save_for_backward(feat, words, soft)
+            ctx.meta = (float(scale), flags, [tuple(t.shape) for t in srcs], _compute, bias is not None, n_other)
+        return y, word
+
+    @staticmethod
+    def backward(ctx, dy, _dword):
+        if not hasattr(ctx, "c"):
+            raise RuntimeError("gfs3d.words_fusion: backward is implemented for training mode (batch statistics) only")
+        feat, words, soft = ctx.saved_tensors
+        scale, flags, shapes, compute, has_bias, n_other = ctx.meta
+        dxs, dws, dgs, dbs = ctx.c.backward(dy, ctx.sync)
+        dpacked = dxs[0]
+        B, Kw, N = soft.shape
+        dev = dpacked.device
+        need = ctx.needs_input_grad[9:]
+        outs = [None] + [torch.empty(sh, dtype=torch.float32, device=dev) if need[2 + i] else None for i, sh in enumerate(shapes[1:])]
+        widths = [sh[1] if cf else sh[2] for sh, cf in zip(shapes, flags)]
+        pa = _pack_args(B, N, outs, flags, dpacked, widths=widths)
+        L = _lib.lib()
+        dfeat = None
+        with torch.cuda.device(dev):
+            if any(o is not None for o in outs):
+                _lib.check(L.gfs3d_unpack_rows_f32(ctypes.byref(pa), _stream()), "gfs3d_unpack_rows_f32")
+            if need[0]:
+                d = torch.empty_like(soft)
+                rc = L.gfs3d_word_soft_backward_rows(_p(dpacked), _lib.COMPUTE_BF16 if dpacked.dtype == torch.bfloat16 else 0,
+                                                     int(dpacked.shape[-1]), _p(soft), B, Kw, N, _p(d), _stream())
+                _lib.check(rc, "gfs3d_word_soft_backward_rows")
+                dfeat = proto_backward_feat(feat, words, scale, d, None, compute=compute)
+        dbias = torch.zeros_like(dgs[0]) if has_bias else None      # a bias in front of a training-mode BatchNorm: exactly zero
+        return (None,) * 9 + (dfeat, None) + tuple(outs[1:]) + (dws[0], dgs[0], dbs[0], None, None, dbias)
+
+
+def words_fusion(feat, words, scale, others, other_cf, ld: int, conv_w, conv_b, bn, training: bool, slope: float = 0.2, track: bool = True,
+                 sync: Optional[BNSync] = None):
+    """-> (point_feat (B, Cout, N), word (B, N) int32): `pointwise_stack_packed([softmax words | others], ...)` with the word
+    assignment inside (see WordsFusionFunction).  `conv_w` (Cout, ld): the fusion convolution's weight, K-padded to `ld`."""
+    if training and track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    return WordsFusionFunction.apply(float(scale), tuple(bool(c) for c in other_cf), int(ld), bool(training), float(bn.eps), float(mom),
+                                     float(slope), sync, len(others), feat, words, *others, conv_w, bn.weight, bn.bias,
+                                     bn.running_mean, bn.running_var, conv_b)
+
+
 class LinearFunction(torch.autograd.Function):
     """y = x W^T for a bias-free 1x1 convolution without BatchNorm on a point-major input: x_pm (B, N, K), w (64 n, K) ->
     n channel-first (B, 64, N) tensors (the q / k / v projections of model/attention.py:39-41 as one GEMM)."""
@@ -749,12 +832,13 @@ def linear_cf(x_pm: torch.Tensor, w: torch.Tensor):
     return LinearFunction.apply(x_pm, w)
 
 
-def _pack_args(B, N, tensors, cf_flags, dst):
+def _pack_args(B, N, tensors, cf_flags, dst, widths=None):
+    """`tensors[s]` may be None in an unpack call (the source's columns are skipped); `widths` then carries its width."""
     a = _lib.PackArgs()
     a.B, a.N, a.n_src = B, N, len(tensors)
     for s_, (t, cf) in enumerate(zip(tensors, cf_flags)):
-        a.src[s_] = t.data_ptr()
-        a.width[s_] = int(t.shape[1] if cf else t.shape[2])
+        a.src[s_] = t.data_ptr() if t is not None else None
+        a.width[s_] = int(widths[s_]) if widths is not None else int(t.shape[1] if cf else t.shape[2])
         a.channel_first[s_] = 1 if cf else 0
     a.dst, a.dst_ld = dst.data_ptr(), int(dst.shape[-1])
     a.dst_type = {torch.float32: 0, torch.bfloat16: _lib.COMPUTE_BF16, torch.float16: _lib.COMPUTE_F16}[dst.dtype]

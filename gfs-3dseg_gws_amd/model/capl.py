@@ -103,17 +103,23 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         att = self.att_learner.forward_pm(level2_pm)                                        # (B,64,N)
         base = self.base_learner.forward_pm(level2_pm, sync=sync, want_cf=want_semantic)
         base_cf, base_pm = base if want_semantic else (None, base)
-        if want_onehot:
-            soft, one_hot, _ = ops.WordAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)
-        else:
-            soft, one_hot = ops.WordSoftAssignFunction.apply(torch.cat(edge_feats, dim=1), words, _COS_SCALE)       # the word index
         conv, bn, act = self.fusion[0], self.fusion[1], self.fusion[2]
         k_in = conv.in_channels
         k_pad = (k_in + 63) // 64 * 64
         w = F.pad(conv.weight.squeeze(-1), (0, k_pad - k_in))
-        # pack + fusion stack as one operator: the packed (B,N,k_pad) matrix and its gradient stay internal (16-bit in the reduced modes)
-        point_feat = ops.pointwise_stack_packed([soft, edge_pm[0], att, base_pm], [True, False, True, False], k_pad,
-                                                [((w, conv.bias), bn)], self.training, float(act.negative_slope), sync=sync)
+        edge_cat = torch.cat(edge_feats, dim=1)
+        if not want_onehot and sync is None and edge_cat.shape[1] <= 192:
+            # words + pack + fusion stack as ONE operator (the training / testing path: only the word index leaves it)
+            point_feat, one_hot = ops.words_fusion(edge_cat, words, _COS_SCALE, [edge_pm[0], att, base_pm], [False, True, False], k_pad,
+                                                   w, conv.bias, bn, self.training, float(act.negative_slope))
+        else:
+            if want_onehot:
+                soft, one_hot, _ = ops.WordAssignFunction.apply(edge_cat, words, _COS_SCALE)
+            else:
+                soft, one_hot = ops.WordSoftAssignFunction.apply(edge_cat, words, _COS_SCALE)       # the word index
+            # pack + fusion stack as one operator: the packed (B,N,k_pad) matrix and its gradient stay internal (16-bit in the reduced modes)
+            point_feat = ops.pointwise_stack_packed([soft, edge_pm[0], att, base_pm], [True, False, True, False], k_pad,
+                                                    [((w, conv.bias), bn)], self.training, float(act.negative_slope), sync=sync)
         semantic = torch.cat((edge_feats[0], att, base_cf), dim=1) if want_semantic else None
         return point_feat, semantic, one_hot
 

@@ -297,7 +297,8 @@ int gfs3d_linear_backward_f32(const float *x_pm, int B, int N, int K, const floa
  * layout change the point-major GEMMs need.
  *   src[s]  width[s] channels, channel-first (B, width[s], N) if channel_first[s] else point-major (B*N, width[s])
  *   dst     (B*N, dst_ld) point-major; columns [sum width, dst_ld) are written as zeros (K padding of the GEMM)
- * gfs3d_unpack_rows_f32 is the adjoint: it scatters the columns of `dst` (read-only there) back into src[s] (written). */
+ * gfs3d_unpack_rows_f32 is the adjoint: it scatters the columns of `dst` (read-only there) back into src[s] (written); a NULL
+ * src[s] skips that source's columns (its gradient is formed elsewhere, e.g. gfs3d_word_soft_backward_rows). */
 #define GFS3D_PACK_MAX_SRC 8
 typedef struct gfs3d_pack_args {
     int B, N, n_src;
@@ -512,6 +513,15 @@ int gfs3d_kmeanspp_greedy_f32(const float *pts, long long M, int C, int K, long 
 int gfs3d_word_assign_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
                             const float *words, int Kw, float scale,
                             float *soft, int32_t *assign, float *onehot, int compute, void *stream);
+/* Softmax backward of the word assignment fed from the PACKED fusion gradient (model/capl.py:344-359: soft = softmax(10 cos) is
+ * concatenated into the fusion layer's input):  d[b][w][n] = soft[b][w][n] (dsoft[b][n][w] - sum_w' soft[b][w'][n] dsoft[b][n][w']).
+ *   dpacked  (B*N, ld) point-major rows whose first Kw columns are dsoft; dtype 0: fp32, GFS3D_COMPUTE_BF16: bf16 elements
+ *            (gfs3d_pointwise_bwd_args.dx_type of a reduced-mode call)
+ *   soft, d  (B, Kw, N) channel-first fp32, Kw <= 256
+ * `d` is then the logits gradient of a plain cosine head: gfs3d_proto_backward_feat_ws(..., soft = NULL, dup = d) finishes the
+ * word gradient reading it once (the softmax form of that kernel reads soft and dsoft twice each).  Fixed summation order. */
+int gfs3d_word_soft_backward_rows(const void *dpacked, int dtype, int ld, const float *soft, int B, int Kw, int N, float *d, void *stream);
+
 int gfs3d_proto_backward_feat_mixed(const float *feat, long long feat_bstride, int B, int C, int N,
                                     const float *proto, int P, int K, float scale,
                                     const float *soft, const float *dup, float *dfeat, int compute, void *stream);
