@@ -296,7 +296,11 @@ def build_step(cfg, dev, rank, world, sync_bn, gdist, force=False):
     # backward (then every rank must issue them in one fixed order)
     bucket = gdist.FlatGradBucket(net.parameters(), early=early, overlap=not (sync_bn and multi))
     bucket.force_collectives = bool(force)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    if os.environ.get("GFS3D_BENCH_TORCH_ADAM") == "1":       # A/B switch (scripts/ab_env.sh): torch's own fused multi-tensor Adam
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    else:
+        from gfs3d.optim import FusedAdam
+        opt = FusedAdam(net.parameters(), lr=1e-3)       # torch.optim.Adam's update, all parameters in one launch (csrc/optim.hip)
     mode = cfg["dtype"]
 
     if cfg["model"] == "dgcnn":

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_lon
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _CSRC = os.path.join(_PKG, "csrc")
 _SO = os.environ.get("GFS3D_LIB") or os.path.join(_PKG, "lib", "libgfs3d_hip.so")   # GFS3D_LIB: ablation builds only
-_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip", "kmeanspp.hip")
+_SOURCES = ("api.hip", "knn.hip", "edgeconv.hip", "proto.hip", "pointwise.hip", "attention.hip", "head.hip", "kmeanspp.hip", "optim.hip")
 _lib = None
 KNN_IMG_SLACK_ROWS = 128      # GFS3D_KNN_IMG_SLACK_ROWS
 
@@ -103,6 +103,22 @@ class PackArgs(Structure):
         ("dst", c_void_p),
         ("dst_ld", c_int),
         ("dst_type", c_int),
+    ]
+
+
+ADAM_MAX_TENSORS = 64
+
+
+class AdamArgs(Structure):
+    _fields_ = [
+        ("n_tensors", c_int),
+        ("param", c_void_p * ADAM_MAX_TENSORS), ("grad", c_void_p * ADAM_MAX_TENSORS),
+        ("exp_avg", c_void_p * ADAM_MAX_TENSORS), ("exp_avg_sq", c_void_p * ADAM_MAX_TENSORS),
+        ("numel", c_longlong * ADAM_MAX_TENSORS),
+        ("lr", c_float * ADAM_MAX_TENSORS), ("weight_decay", c_float * ADAM_MAX_TENSORS),
+        ("first_block", c_int * ADAM_MAX_TENSORS),
+        ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("bias_correction1", c_float), ("bias_correction2", c_float),
+        ("one_minus_beta1", c_float), ("one_minus_beta2", c_float),
     ]
 
 
@@ -212,6 +228,7 @@ SYMBOLS = {
     "gfs3d_capl_head_backward_phase": (c_int, [POINTER(CaplHeadArgs), c_int]),
     "gfs3d_word_assign_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gfs3d_adam_multi_f32": (c_int, [POINTER(AdamArgs), c_void_p]),
     "gfs3d_word_soft_backward_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gfs3d_proto_backward_feat_mixed": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
                                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

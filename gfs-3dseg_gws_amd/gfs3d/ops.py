@@ -42,7 +42,7 @@ def get_compute() -> str:
     return next(k for k, v in _COMPUTE_IDS.items() if v == _compute)
 
 
-_store16 = True
+_store16 = __import__("os").environ.get("GFS3D_STORE16", "1") != "0"      # (GFS3D_STORE16=0: A/B runs, scripts/ab_env.sh)
 
 
 def set_store16(on: bool) -> bool:

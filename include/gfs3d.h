@@ -33,7 +33,11 @@ extern "C" {
 #define GFS3D_ERR_HIP 3          /* a HIP runtime call or launch failed */
 
 /* Arithmetic of the GEMM-shaped kernels (EdgeConv conv2, point-wise stack, word / prototype matching, k-means),
- * chosen per call.  Tensors in HBM are fp32 in every mode; what changes is the matrix-core operand form:
+ * chosen per call.  Every tensor that crosses this ABI is fp32 in every mode (exceptions are explicit fields:
+ * gfs3d_pointwise_args.store16 / x_type, gfs3d_pointwise_bwd_args.dx_type, gfs3d_pack_args.dst_type); what changes is the
+ * matrix-core operand form - and, in the reduced modes, the storage of tensors that live INSIDE an operator between its
+ * forward and its backward: the point-wise stacks' pre-BatchNorm activations (the mode's 16-bit format), their gradients
+ * and the packed fusion input's gradient (bf16), the EdgeConv backward's per-edge dy1 rows (bf16 pairs).
  *   GFS3D_COMPUTE_F32   fp32 accuracy (default): every fp32 operand enters the bf16 matrix cores as the exact sum of
  *                       three bf16 pieces, six piece products per fp32 product - within 1e-4 of the fp32 reference
  *   GFS3D_COMPUTE_BF16  ONE bf16 product per fp32 product (operands rounded to nearest-even), fp32 accumulate:
@@ -534,6 +538,28 @@ int gfs3d_proto_backward_feat_ws(const float *feat, long long feat_bstride, int 
                                  const float *proto, int P, int K, float scale,
                                  const float *soft, const float *dup, float *dfeat, int compute,
                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ optimiser step --
+ * torch.optim.Adam (train.py:425-435: parameter groups with their own learning rates, betas (0.9, 0.999), eps 1e-8, L2
+ * weight_decay, no amsgrad) over up to GFS3D_ADAM_MAX_TENSORS parameter tensors in ONE launch:
+ *     g += weight_decay p;  m += (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g g;
+ *     p -= lr / bias_correction1 * m / (sqrt(v) / sqrt(bias_correction2) + eps)      bias_correction_i = 1 - beta_i^step
+ * param / exp_avg / exp_avg_sq are updated in place; first_block is filled by the call (scratch). */
+#define GFS3D_ADAM_MAX_TENSORS 64
+typedef struct gfs3d_adam_args {
+    int n_tensors;
+    float *param[GFS3D_ADAM_MAX_TENSORS];
+    const float *grad[GFS3D_ADAM_MAX_TENSORS];
+    float *exp_avg[GFS3D_ADAM_MAX_TENSORS];
+    float *exp_avg_sq[GFS3D_ADAM_MAX_TENSORS];
+    long long numel[GFS3D_ADAM_MAX_TENSORS];
+    float lr[GFS3D_ADAM_MAX_TENSORS];
+    float weight_decay[GFS3D_ADAM_MAX_TENSORS];
+    int first_block[GFS3D_ADAM_MAX_TENSORS];
+    float beta1, beta2, eps, bias_correction1, bias_correction2;
+    float one_minus_beta1, one_minus_beta2;   /* (float)(1.0 - (double)beta): 1.0f - 0.999f is 1.3e-5 off 0.001 */
+} gfs3d_adam_args;
+int gfs3d_adam_multi_f32(gfs3d_adam_args *a, void *stream);
 
 #ifdef __cplusplus
 }

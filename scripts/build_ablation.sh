@@ -8,7 +8,7 @@ mkdir -p "$pkg/lib/abl"
 flags="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value"
 /opt/rocm/bin/hipcc $flags "$@" -c "$pkg/csrc/$src" -o "$pkg/lib/abl/$name.o"
 objs=""
-for f in api knn edgeconv proto pointwise attention head kmeanspp; do
+for f in api knn edgeconv proto pointwise attention head kmeanspp optim; do
   if [ "$f.hip" == "$src" ]; then objs="$objs $pkg/lib/abl/$name.o"; else objs="$objs $pkg/lib/obj/$f.hip.o"; fi
 done
 /opt/rocm/bin/hipcc $flags -shared $objs -o "$pkg/lib/abl/lib_$name.so"

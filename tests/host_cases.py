@@ -88,6 +88,41 @@ def round5_cases(L, _lib):
     assert L.gfs3d_edgeconv_backward_f32(ctypes.byref(b), None) != 0
 
 
+def round6_cases(L, _lib):
+    """Round 6: the softmax backward from packed rows, the multi-tensor Adam, the storage-format fields of the point-wise stack."""
+    f = L.gfs3d_word_soft_backward_rows
+    assert f(None, 0, 384, 1, 2, 180, 64, 1, None) != 0 and b"NULL" in L.gfs3d_last_error()
+    assert f(16, 3, 384, 16, 2, 180, 64, 16, None) != 0 and b"dtype" in L.gfs3d_last_error()
+    assert f(16, 0, 100, 16, 2, 180, 64, 16, None) != 0 and b"bad shape" in L.gfs3d_last_error()
+    assert f(16, 0, 388, 16, 2, 180, 64, 16, None) != 0 and b"bad shape" in L.gfs3d_last_error()          # ld % 8
+    assert f(16, 0, 384, 16, 2, 300, 64, 16, None) != 0 and b"bad shape" in L.gfs3d_last_error()          # Kw > 256
+    assert f(20, 1, 384, 16, 2, 180, 64, 16, None) != 0 and b"aligned" in L.gfs3d_last_error()
+    a = _lib.AdamArgs()
+    assert L.gfs3d_adam_multi_f32(None, None) != 0 and b"NULL args" in L.gfs3d_last_error()
+    assert L.gfs3d_adam_multi_f32(ctypes.byref(a), None) != 0 and b"n_tensors" in L.gfs3d_last_error()
+    a.n_tensors = 1
+    assert L.gfs3d_adam_multi_f32(ctypes.byref(a), None) != 0 and b"bias corrections" in L.gfs3d_last_error()
+    a.bias_correction1 = a.bias_correction2 = 0.5
+    assert L.gfs3d_adam_multi_f32(ctypes.byref(a), None) != 0 and b"NULL or empty tensor 0" in L.gfs3d_last_error()
+    a.n_tensors = 65
+    assert L.gfs3d_adam_multi_f32(ctypes.byref(a), None) != 0 and b"n_tensors" in L.gfs3d_last_error()
+    # x_type / dx_type need 16-bit storage in a reduced training call
+    pa = _lib.PointwiseArgs()
+    pa.B, pa.N, pa.n_seg, pa.n_layers, pa.training = 2, 64, 1, 1, 1
+    pa.width[0] = 64
+    for name in ("x_seg", "w", "bn_w", "bn_b", "h", "stats"):
+        getattr(pa, name)[0] = 16
+    pa.y_cf, pa.workspace, pa.workspace_bytes = 16, 16, 1 << 30
+    pa.x_type = _lib.COMPUTE_F16
+    assert L.gfs3d_pointwise_forward_f32(ctypes.byref(pa), None) != 0 and b"x_type" in L.gfs3d_last_error()
+    pk = _lib.PackArgs()
+    pk.B, pk.N, pk.n_src, pk.dst, pk.dst_ld, pk.dst_type = 1, 64, 1, 16, 64, 7
+    pk.src[0], pk.width[0] = 16, 64
+    assert L.gfs3d_pack_rows_f32(ctypes.byref(pk), None) != 0 and b"dst_type" in L.gfs3d_last_error()
+    pk.dst_type = _lib.COMPUTE_F16
+    assert L.gfs3d_unpack_rows_f32(ctypes.byref(pk), None) != 0 and b"dst_type" in L.gfs3d_last_error()        # half: packing only
+
+
 def workspace_sweep(L):
     """Every workspace query over a grid of shapes, odd ones included: the plans are pure host arithmetic (sizes, alignments,
     grid dimensions) - monotone in the batch and never absurd."""

@@ -20,5 +20,6 @@ assert L.gfs3d_version() > 0
 host_cases.round2_cases(L, _lib)
 host_cases.round3_cases(L, _lib)
 host_cases.round5_cases(L, _lib)
+host_cases.round6_cases(L, _lib)
 host_cases.workspace_sweep(L)
 print("SAN_DRIVER_OK")

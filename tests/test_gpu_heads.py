@@ -443,3 +443,39 @@ def test_kmeans_centroid_sums_are_sorted_segment_sums(dev, M, C, K):
         assert abs(float(inertia) - float(d2.min(1)[0].sum())) <= 1e-4 * float(d2.min(1)[0].sum())
     lab2, sums2, cnt2, _ = ops.kmeans_assign(pts, cent)
     assert torch.equal(lab2, lab) and torch.equal(sums2, sums) and torch.equal(cnt2, cnt)
+
+
+def test_fused_adam_equals_torch_adam_over_steps_groups_and_schedules(dev):
+    """gfs3d.optim.FusedAdam (gfs3d_adam_multi_f32: every parameter of the model in one launch) against torch.optim.Adam in the
+    configuration of the reference's train.py:425-435 - parameter groups with their own learning rates, a StepLR schedule, L2
+    weight decay on one group - over 12 steps on the DGCNN's 30 tensors (ragged sizes: 64 ... 131 072 elements): parameters
+    and both moment estimates agree to fp32 rounding (5e-6 of the tensor's scale), and the state dict of one loads into the
+    other."""
+    from gfs3d.optim import FusedAdam
+    from model.dgcnn import DGCNN
+    torch.manual_seed(4)
+    net_a = DGCNN([[64, 64]] * 3, [512, 256], 9, k=20, return_edgeconvs=True).to(dev)
+    net_b = copy.deepcopy(net_a)
+
+    def groups(net):
+        return [{"params": list(net.edge_convs.parameters()), "lr": 1e-4}, {"params": list(net.conv.parameters()), "weight_decay": 1e-2}]
+    oa = FusedAdam(groups(net_a), lr=1e-3)
+    ob = torch.optim.Adam(groups(net_b), lr=1e-3)
+    sa, sb = (torch.optim.lr_scheduler.StepLR(o, step_size=5, gamma=0.5) for o in (oa, ob))
+    g = torch.Generator(device=dev).manual_seed(9)
+    for step in range(12):
+        for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+            gr = torch.randn(pa.shape, device=dev, generator=g) * (10.0 ** (step % 4 - 3))
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for (n, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        scale = float(pb.abs().max()) + 1e-12
+        assert float((pa - pb).abs().max()) < 5e-6 * scale, n
+        assert float((oa.state[pa]["exp_avg"] - ob.state[pb]["exp_avg"]).abs().max()) <= 5e-6 * float(ob.state[pb]["exp_avg"].abs().max()), n
+        assert float((oa.state[pa]["exp_avg_sq"] - ob.state[pb]["exp_avg_sq"]).abs().max()) <= 5e-6 * float(ob.state[pb]["exp_avg_sq"].abs().max()), n
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == 1e-4 * 0.25
+    ob.load_state_dict(oa.state_dict())            # the state layouts are interchangeable
+    cpu_p = torch.nn.Parameter(torch.zeros(4))
+    cpu_p.grad = torch.zeros(4)
+    with pytest.raises(RuntimeError):              # no CPU fallback
+        FusedAdam([cpu_p]).step()

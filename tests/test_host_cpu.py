@@ -77,6 +77,7 @@ def test_entry_points_reject_bad_arguments_before_touching_a_device():
     host_cases.round2_cases(L, _lib)
     host_cases.round3_cases(L, _lib)
     host_cases.round5_cases(L, _lib)
+    host_cases.round6_cases(L, _lib)
     host_cases.workspace_sweep(L)
     assert not ops.capl_head_supported(torch.zeros(2, 64, 16), 13, 2)       # (CPU tensor / wrong width: the model keeps its tensor-library head)
 

@@ -12,7 +12,7 @@ import pytest
 from conftest import PKG, ROOT
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ("api", "knn", "edgeconv", "proto", "pointwise", "attention", "head", "kmeanspp")
+SOURCES = ("api", "knn", "edgeconv", "proto", "pointwise", "attention", "head", "kmeanspp", "optim")
 
 
 def _asan_runtime():
