@@ -173,6 +173,8 @@ struct RowGemm {
     void *out[4];             // point-major output, column segments of width o_segw (row stride o_segw); element type: template OT
     int o_segw;
     int at, ht, ot;           // ST_* of a / (a2, eh) / out: picks the instantiation (launch_rowgemm6)
+    void *a16_out;            // reduced forward on an fp32 A: the operands it forms anyway, written once ((M, K) 16-bit, by the column-block-0
+                              // workgroups) - the backward's weight gradient reads them instead of the fp32 rows
     float *out_cf;            // OUT_CF: (B, Nc, npts) channel-first ...
     float *out_cfs[4];        // ... or, cf_segw > 0: Nc / cf_segw tensors (B, cf_segw, npts)
     int cf_segw;
@@ -666,6 +668,10 @@ __global__ void __launch_bounds__(256, PW_RG6_OCC) pw_rowgemm6_kernel(const RowG
 #else
                     mm_pieces4<PREC>(v4, pc);
 #endif
+                    if constexpr (PRO == PRO_NONE && AT == ST_F32 && PREC != PREC_X6) {
+                        if (g.a16_out && cb == 0 && row0 + r0 + 32 * p < g.M)
+                            *reinterpret_cast<uint2 *>(static_cast<unsigned short *>(g.a16_out) + (size_t)(row0 + r0 + 32 * p) * g.K + kcol) = pc[0];
+                    }
                 }
                 char *dst = sA + (r0 + 32 * p) * PW6_ROW + c4 * 8 + 64 * kc;
 #pragma unroll
@@ -1680,6 +1686,7 @@ static int pw_forward_phase(const gfs3d_pointwise_args *a, int phase, double *ac
         rg.out[0] = a->h[l];
         rg.o_segw = C;
         rg.ot = a->training ? pw_ht(a) : ST_F32;
+        if (l == 0 && a->training && a->x16 && pw_ht(a) != ST_F32 && !a->x_type) rg.a16_out = a->x16;
         rg.acc = acc_l;
         rg.acc_rows = (a->training && g_deterministic) ? reinterpret_cast<double *>(ws + p.off_rows) : nullptr;
         if (use_tail) {
@@ -1866,7 +1873,10 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
     wg.prec = prec_of(a->compute, true);
     wg.gt = gt; wg.ht = ht; wg.vt = l ? ht : pw_xt(a);
     int rc;
-    if (l == 0) {
+    if (l == 0 && a->x16 && ht != ST_F32 && !a->x_type) {        // the forward's 16-bit copy of the fp32 input (one matrix, all segments)
+        wg.v[0] = a->x16; wg.v_segw = p.in_width; wg.ldv = p.in_width; wg.vt = ht;
+        rc = wgrad<PRO_NONE>(wg, true, st, who);
+    } else if (l == 0) {
         for (int s = 0; s < a->n_seg; ++s) wg.v[s] = a->x_seg[s];
         wg.v_segw = pw_segw(a->seg_width); wg.ldv = pw_segw(a->seg_width);
         // all of a 192-channel input in one tile: dH (two tensors + the BN-backward combine) is then read once

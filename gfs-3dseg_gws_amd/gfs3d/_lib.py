@@ -76,6 +76,7 @@ class PointwiseArgs(Structure):
         ("slope_l", c_float * PW_MAX_LAYERS),
         ("y_pm", c_void_p),
         ("store16", c_int),
+        ("x16", c_void_p),
         ("x_type", c_int),
     ]
 

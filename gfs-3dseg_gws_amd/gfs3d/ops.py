@@ -444,6 +444,9 @@ class PointwiseRun:
         M = self.B * self.N
         self.h = [torch.empty((M, c), dtype=self.h_dtype, device=dev) if (self.training or l < L - 1) else None
                   for l, c in enumerate(self.widths)]
+        # reduced training call on fp32 inputs: the first GEMM leaves its 16-bit operands of x behind for the backward's weight gradient
+        self.x16 = (torch.empty((M, segw * len(self.xs)), dtype=self.h_dtype, device=dev)
+                    if (self.h_dtype != torch.float32 and self.xs[0].dtype == torch.float32) else None)
         self.stats = [torch.empty((4, c), **f32) for c in self.widths]
         self.y = torch.empty((self.B, self.widths[-1], self.N), **f32) if want_cf else None
         self.y_pm = torch.empty((self.B, self.N, self.widths[-1]), **f32) if want_pm else None
@@ -461,6 +464,7 @@ class PointwiseRun:
         a.compute = self.compute
         a.store16 = 1 if self.h_dtype != torch.float32 else 0
         a.x_type = self.compute if self.xs[0].dtype != torch.float32 else 0
+        a.x16 = self.x16.data_ptr() if self.x16 is not None else None
         a.eps, a.momentum, a.slope = eps, momentum, slope
         a.per_layer_slope = 0 if self.slopes is None else 1
         for s_, t in enumerate(self.xs):

@@ -245,6 +245,10 @@ typedef struct gfs3d_pointwise_args {
      * sums / constants, parameters, parameter gradients and the tensors at the call's boundary (x_seg, y_*, dy_*, dx_seg) stay
      * fp32 - unless x_type / dx_type say otherwise.  Ignored (fp32 storage) in eval mode and under GFS3D_COMPUTE_F32. */
     int store16;
+    void *x16;                    /* optional, store16 with fp32 x_seg: (B*N, n_seg * seg_width) 2-byte elements.  The forward's first GEMM
+                                     writes the operands it forms from x_seg (the mode's 16-bit format) here; the backward's weight
+                                     gradient of layer 0 reads them instead of the fp32 rows (which it would otherwise fetch once per
+                                     128-channel output tile) */
     int x_type;                   /* 0: x_seg are fp32; GFS3D_COMPUTE_BF16 / _F16 (= the call's `compute`, store16 set): x_seg hold bf16 /
                                      half elements (the packed fusion input written by gfs3d_pack_rows_t) */
 } gfs3d_pointwise_args;
@@ -505,7 +509,11 @@ int gfs3d_kmeanspp_seed_f32(const float *pts, long long M, int C, int K, long lo
  *      per pick): candidate j of pick t is searchsorted(cumsum(d2), u[t - 1][j] * sum(d2)) (side 'left', 0 when no mass is left);
  *   the winner is the first candidate with the smallest potential (numpy's argmin);  potentials are summed in fp64 in a fixed
  *   order (sklearn: a float32 BLAS dot), so the picks are a pure function of the arguments and equal sklearn's except where a
- *   variate lands within rounding of a cdf step or two candidates' potentials tie to ~1e-7.
+ *   variate lands within rounding of a cdf step or two candidates' potentials tie - sklearn's float32 potential is ~1e-7 of the
+ *   potential away from an exact sum.  Measured against sklearn 1.7.2 (tests/golden/kmeanspp*.npz, basis_flow.npz): every pick
+ *   equal on all fixtures up to 50 000 points (K = 200) and on 3 of 4 seeds at 300 000 points (K = 24); at configs[2] size (2.1e6
+ *   points: the mean cdf step is 5e-7 of the potential) most sequences part somewhere - the same algorithm on the same
+ *   variates, statistically equivalent, NOT seed-for-seed.
  *   centers (K, C) out;  picks (K) out.  4 K - 2 launches on `stream`, no host synchronisation.  prune as above (the gain
  *   pass skips a point when no candidate can come closer than its nearest centre). */
 size_t gfs3d_kmeanspp_greedy_workspace_bytes(long long M, int C, int K);
