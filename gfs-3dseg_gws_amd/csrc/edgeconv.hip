@@ -1080,8 +1080,25 @@ constexpr size_t BWD_LDS_BYTES = 2 * EC * BWD_WROW + sizeof(float) * (BWD_WAVES 
 // segment; masked rows go to a per-wave scratch row behind the B N k real ones) and ec_bwd_segsum_kernel sums the
 // segments: plain stores at ~5x the float-atomic rate, a fixed summation order, no memset of G_P.  CSR = false: float
 // atomics into G_P (shapes beyond csr_place_kernel's LDS tables).
+// Geometry of ec_main_bwd_kernel per arithmetic.  The fp32-accurate form: 3 piece planes everywhere, 25 KB of LDS and ~350 registers per
+// wave -> 4 waves per workgroup, one per SIMD.  The reduced forms keep ONE plane (W2 rows 144 B, dH2 pieces 4 KB): 16.7 KB per wave and
+// < 256 registers -> EIGHT waves per workgroup, two independent tile streams per SIMD (152 KB).  Round 6: with a sixth of the matrix work
+// the wave-pair form (ec_main_bwd_pair_kernel, two COUPLED waves per SIMD, two workgroup barriers per tile) and this kernel at one wave
+// per SIMD ran the c5 step in the same time (A/B 7.00 vs 7.03 ms) - neither overlaps a wave's own gather / LDS round trips with anything.
+template <int PREC> struct BwdCfg {
+    static constexpr int NP = Mx<PREC>::NP;
+    static constexpr int WAVES = PREC == PREC_X6 ? 4 : 8;
+    static constexpr int WROW = NP * 2 * EC + 16;                     // bytes per row of a W2 piece image
+    static constexpr int DIMG = NP * EC * 64;                         // bytes: piece planes of the dH2 tile
+    static constexpr int WAVE_LDS = 32 * (EC + 4) + 8 * 32 + 8 * EC + 8 * 32 + DIMG / 4;      // floats per wave
+    static constexpr size_t LDS_BYTES = 2 * EC * WROW + sizeof(float) * (WAVES * WAVE_LDS + 192);
+};
+static_assert(BwdCfg<PREC_X6>::WROW == BWD_WROW && BwdCfg<PREC_X6>::DIMG == BWD_DIMG && BwdCfg<PREC_X6>::WAVE_LDS == BWD_WAVE_LDS &&
+              BwdCfg<PREC_X6>::LDS_BYTES == BWD_LDS_BYTES, "the fp32-accurate geometry is the one the pair kernel shares");
+constexpr int BWD_MAX_WAVES = 8;                                      // trash rows behind dyb per workgroup (edgeconv plan: off_dyb)
+
 template <int PREC, bool CSR>
-__global__ void __launch_bounds__(64 * BWD_WAVES)
+__global__ void __launch_bounds__(64 * BwdCfg<PREC>::WAVES)
 ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, const int32_t *__restrict__ idx,
                    const float *__restrict__ w2, const CoefIn cin,
                    const float *__restrict__ g_pm, const uint8_t *__restrict__ jsel,
@@ -1089,6 +1106,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
                    float *__restrict__ GP, float *__restrict__ GQ, float *__restrict__ partial,
                    const int *__restrict__ pos, float *__restrict__ dyb)
 {
+    typedef BwdCfg<PREC> Cfg;
+    constexpr int BWD_WAVES = Cfg::WAVES, BWD_WROW = Cfg::WROW, BWD_WAVE_LDS = Cfg::WAVE_LDS;      // (shadow the fp32-accurate globals)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char *sW3 = reinterpret_cast<unsigned char *>(smem);        // [co][hi | mid | lo][ci] bf16 pieces of W2
     unsigned char *sW3T = sW3 + EC * BWD_WROW;                           // [ci][hi | mid | lo][co] pieces of W2^T
@@ -1104,7 +1123,7 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     // ds_read_b64_tr_b16 as the A operand of (3): the split of (2) is reused, no fp32 transpose and no second split.
     // Slot s of row co sits at physical slot s ^ ((co >> 1) & 3): conflict-free b128 writes (32 banks) and transposed reads.
     unsigned char *dimg = reinterpret_cast<unsigned char *>(pall + 8 * 32);
-    const int trash_row = BN * k + (int)(blockIdx.x * BWD_WAVES + wv);     // where masked rows are stored (never read)
+    const int trash_row = BN * k + (int)(blockIdx.x * BWD_MAX_WAVES + wv);     // where masked rows are stored (never read)
 
     for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
         const int co = e >> 6, ci = e & 63;
@@ -1170,8 +1189,11 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
         asm volatile("" ::: "memory");
         for (int t = 0; t < T; ++t) {
             // tile 0: everything older (ids, Q', P' gather); later tiles: all but the previous tile's 32 atomics
+            // (the previous tile issued, AFTER this tile's gather: 32 stores / atomics in the fp32-accurate and the atomic forms, 16 in
+            // the reduced CSR form - one dword of two bf16 per row - so vmcnt(32) there would let the gather itself stay in flight)
             if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (GFS3D_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (CSR && PREC != PREC_X6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             const int *mrow = CSR ? pall + t * 32 : mall + t * 32;
             float a[32];
@@ -1366,8 +1388,8 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
             }
         }
     }
-    // block-level sum of the four waves' dW2 accumulators in a FIXED order (one [64][64] image per wave: 64 KB of the
-    // 99 KB this block owns), then one partial per block
+    // block-level sum of the waves' dW2 accumulators in a FIXED order (one [64][64] image per wave: 64 / 128 KB of the
+    // LDS this block owns), then one partial per block
     __syncthreads();
     float *sD = smem + (size_t)wv * EC * EC;
 #pragma unroll
@@ -1380,8 +1402,13 @@ ec_main_bwd_kernel(const float *__restrict__ Pp, const float *__restrict__ Qp, c
     }
     __syncthreads();
     float *out = partial + (size_t)blockIdx.x * BWD_PART;
-    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES)
-        out[e] = ((smem[e] + smem[EC * EC + e]) + smem[2 * EC * EC + e]) + smem[3 * EC * EC + e];
+    static_assert((size_t)BWD_WAVES * EC * EC * sizeof(float) <= Cfg::LDS_BYTES, "the dW2 images reuse the workgroup's LDS");
+    for (int e = tid; e < EC * EC; e += 64 * BWD_WAVES) {
+        float sum = smem[e];
+#pragma unroll
+        for (int w = 1; w < BWD_WAVES; ++w) sum += smem[w * EC * EC + e];
+        out[e] = sum;
+    }
 }
 
 // B3': the same backward (fp32-accurate mode, CSR form) as a PAIR of waves per SIMD.  In ec_main_bwd_kernel a wave's matrix
@@ -1423,7 +1450,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pair = wv & 3;
     const bool front = wv < BP_PAIRS;
-    static_assert(BWD_WAVES == BP_PAIRS, "the trash rows behind dyb are sized by BWD_WAVES per workgroup (edgeconv plan: off_dyb)");
+    static_assert(BP_PAIRS <= BWD_MAX_WAVES, "the trash rows behind dyb are sized by BWD_MAX_WAVES per workgroup (edgeconv plan: off_dyb)");
     const int i = lane & 31, h = lane >> 5;
     unsigned char *pbase = sW3 + EC * BWD_WROW + (size_t)pair * BP_PAIR_LDS;
     unsigned char *aimg = pbase;
@@ -1431,7 +1458,7 @@ ec_main_bwd_pair_kernel(const float *__restrict__ Pp, const float *__restrict__ 
     float *qt = reinterpret_cast<float *>(dimg + BWD_DIMG);             // [8][64] Q' rows of FRONT's super-tile
     int *pall = reinterpret_cast<int *>(qt + 8 * EC);                   // [8][32] CSR row of each row of each tile of BACK's super-tile
     float *sC = reinterpret_cast<float *>(sW3 + EC * BWD_WROW + (size_t)BP_PAIRS * BP_PAIR_LDS);
-    const int trash_row = BN * k + (int)(blockIdx.x * BP_PAIRS + pair);  // where masked rows are stored (never read)
+    const int trash_row = BN * k + (int)(blockIdx.x * BWD_MAX_WAVES + pair);  // where masked rows are stored (never read)
 
     for (int e = tid; e < EC * EC; e += 128 * BP_PAIRS)
         mm_store1<PREC>(w2[e], reinterpret_cast<unsigned short *>(sW3 + (e >> 6) * BWD_WROW) + (e & 63), EC);
@@ -2273,7 +2300,7 @@ static Plan make_plan(int B, int C, int N, int k)
     p.csr_ok = (size_t)N * k < 65536 && csr_lds_bytes(N, k) <= 160 * 1024 && (BN * k + 4096) < (size_t)(1u << 24);
     p.off_csrsrc = take(p.csr_ok ? sizeof(int) * BN * k : 0);
     p.off_rangecnt = take(p.csr_ok ? sizeof(unsigned short) * (size_t)csr_ranges(N) * BN : 0);
-    p.off_dyb = take(p.csr_ok ? sizeof(float) * EC * (BN * k + (size_t)p.g_bwd * BWD_WAVES) : 0);
+    p.off_dyb = take(p.csr_ok ? sizeof(float) * EC * (BN * k + (size_t)p.g_bwd * BWD_MAX_WAVES) : 0);
     p.total = o;
     return p;
 }
@@ -2603,13 +2630,15 @@ static int backward_phase(const gfs3d_edgeconv_bwd_args *ba, int phase, double *
             const bool reduced = prec_of(a->compute, true) != PREC_X6;           // gradients: bf16 operands in both reduced modes
 #define GFS3D_BWD_LAUNCH(PREC_, CSR_)                                                                                              \
             do {                                                                                                                   \
-                GFS3D_ENSURE_LDS((ec_main_bwd_kernel<PREC_, CSR_>), BWD_LDS_BYTES, who);                                           \
+                GFS3D_ENSURE_LDS((ec_main_bwd_kernel<PREC_, CSR_>), BwdCfg<PREC_>::LDS_BYTES, who);                                \
                 ProfScope prof(2, st);                                                                                             \
-                hipLaunchKernelGGL((ec_main_bwd_kernel<PREC_, CSR_>), dim3(p.g_bwd), dim3(64 * BWD_WAVES), BWD_LDS_BYTES, st, Pp, Qp, a->idx, \
+                hipLaunchKernelGGL((ec_main_bwd_kernel<PREC_, CSR_>), dim3(p.g_bwd), dim3(64 * BwdCfg<PREC_>::WAVES), BwdCfg<PREC_>::LDS_BYTES, st, Pp, Qp, a->idx, \
                                    a->w2, cin, g, a->jsel, BN, a->N, a->k, a->slope, GP, GQ, bpart, a->csr_pos, dyb);              \
             } while (0)
-            static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 1; }();       // 0: the one-wave-per-SIMD form (A-B only)
-            if (csr && pair_env) {                       // CSR form as wave pairs (ec_main_bwd_pair_kernel)
+            // GFS3D_EC_BWD_PAIR (A-B only): 0 = never the wave-pair form, 2 = the wave-pair form in the reduced modes too.  Default: pairs for the
+            // fp32-accurate arithmetic, ec_main_bwd_kernel with eight independent waves per workgroup for the reduced ones (round 6)
+            static const int pair_env = [] { const char *e = getenv("GFS3D_EC_BWD_PAIR"); return e ? atoi(e) : 1; }();
+            if (csr && (reduced ? pair_env == 2 : pair_env != 0)) {       // CSR form as wave pairs (ec_main_bwd_pair_kernel)
                 ProfScope prof(2, st);
                 if (reduced) {
                     GFS3D_ENSURE_LDS(ec_main_bwd_pair_kernel<PREC_BF16>, BP_LDS_BYTES, who);
