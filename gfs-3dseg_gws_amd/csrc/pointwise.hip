@@ -1208,21 +1208,29 @@ pw_colsum_reduce_kernel(const double *__restrict__ rows, int nrows, int C2, doub
     acc[e] = s;
 }
 
-// dW[e] = sum over the point splits in split order (a fixed order: the weight gradient is reproducible bit for bit)
+// dW[e] = sum over the point splits in a FIXED order (the weight gradient is reproducible bit for bit): the splits in four
+// consecutive quarters, each summed in split order by its own wave, then ((q0 + q1) + q2) + q3.  (One thread per element walking all
+// 64 - 128 splits was a chain of dependent trips to memory on 128 workgroups: 10 - 20 us per launch, six launches per CAPL step.)
 __global__ void __launch_bounds__(256)
 pw_wgrad_reduce_kernel(const float *__restrict__ part, int nsplit, int n, float *__restrict__ dw)
 {
-    const int e = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (e >= n) return;
+    __shared__ f32x4 quarter[3][64];
+    const int eg = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int e = 4 * (blockIdx.x * 64 + eg);
+    const int per = (nsplit + 3) / 4, q0 = sg * per, q1 = min(nsplit, q0 + per);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int q = 0;
-    for (; q + 4 <= nsplit; q += 4) {                         // four loads in flight, added in order
-        const f32x4 a = ldg4(part + (size_t)q * n + e), b = ldg4(part + (size_t)(q + 1) * n + e);
-        const f32x4 c = ldg4(part + (size_t)(q + 2) * n + e), d = ldg4(part + (size_t)(q + 3) * n + e);
-        s = (((s + a) + b) + c) + d;
+    if (e < n) {
+        int q = q0;
+        for (; q + 4 <= q1; q += 4) {                         // four loads in flight, added in order
+            const f32x4 a = ldg4(part + (size_t)q * n + e), b = ldg4(part + (size_t)(q + 1) * n + e);
+            const f32x4 c = ldg4(part + (size_t)(q + 2) * n + e), d = ldg4(part + (size_t)(q + 3) * n + e);
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; q < q1; ++q) s = s + ldg4(part + (size_t)q * n + e);
     }
-    for (; q < nsplit; ++q) s = s + ldg4(part + (size_t)q * n + e);
-    *reinterpret_cast<f32x4 *>(dw + e) = s;
+    if (sg) quarter[sg - 1][eg] = s;
+    __syncthreads();
+    if (sg == 0 && e < n) *reinterpret_cast<f32x4 *>(dw + e) = ((s + quarter[0][eg]) + quarter[1][eg]) + quarter[2][eg];
 }
 
 // the eval-mode constants of channel c of a C-wide layer: scale (h - (rm - b)) + beta
@@ -1415,7 +1423,7 @@ int launch_wgrad_t(WGrad wg, const WgGeo &geo, hipStream_t st, const char *who)
     }
     if (rc) return rc;
     const int n = wg.Co * wg.Ci;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, st, wg.part, geo.nsplit, n, wg.dw);
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n / 4 + 63) / 64), dim3(256), 0, st, wg.part, geo.nsplit, n, wg.dw);
     GFS3D_LAUNCH_CHECK("pw_wgrad_reduce_kernel");
     return GFS3D_OK;
 }
@@ -1901,8 +1909,9 @@ static int pw_backward_phase(const gfs3d_pointwise_bwd_args *ba, int phase, doub
         for (int s = 0; s < a->n_seg; ++s) rg.out[s] = ba->dx_seg[s];
         rg.o_segw = pw_segw(a->seg_width);
         rg.ot = ba->dx_type ? ST_BF16 : ST_F32;
-        // 16-bit dx: the 128-wide tile (its epilogue stores 8 bytes per thread along whole rows; the 64-wide one would store 2)
-        if (rg.ot != ST_F32 && Ci % 128 == 0) return launch_rowgemm<128, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
+        // the 128-wide tile where the input width allows it: the gradient rows (two tensors) are fetched once per COLUMN block, and its
+        // epilogue stores whole rows 16 / 8 bytes per thread (the 64-wide tile: 4 / 2)
+        if (Ci % 128 == 0) return launch_rowgemm<128, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
         return launch_rowgemm<64, PRO_BWD, EPI_PLAIN, false>(rg, st, who);
     }
     rg.out[0] = ws + p.off_g[l - 1];

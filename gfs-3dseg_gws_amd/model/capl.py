@@ -89,8 +89,8 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
     def _features(self, x, want_semantic, want_onehot=True):
         """capl.py:324-362.  Returns (point_feat, semantic or None, one-hot words - or, want_onehot=False, the (B,N) int32 word
         index).  On the GPU everything between the EdgeConv blocks and `point_feat` stays point-major and on the
-        library's kernels: level-2 stack -> {q|k|v GEMM -> K5 attention, BaseLearner stack} -> one packed (B,N,448) matrix
-        [soft words | edge feature | attention | base feature | zero pad] -> fusion stack (K padded from 392 to 448)."""
+        library's kernels: level-2 stack -> {q|k|v GEMM -> K5 attention, BaseLearner stack} -> one packed (B,N,512) matrix
+        [soft words | edge feature | attention | base feature | zero pad] -> fusion stack (K padded from 392 to 512)."""
         words = self._words_on(x.device)
         if not (x.is_cuda and self._heads_fusable()):
             edge_feats, level2 = self.encoder(x)
@@ -105,7 +105,9 @@ class mpti_net_Point_GeoAsWeight_v2(nn.Module):
         base_cf, base_pm = base if want_semantic else (None, base)
         conv, bn, act = self.fusion[0], self.fusion[1], self.fusion[2]
         k_in = conv.in_channels
-        k_pad = (k_in + 63) // 64 * 64
+        # K padded to a multiple of 128 (392 -> 512 for K_w = 200, 372 -> 384 for 180): the backward's input-gradient GEMM and weight
+        # gradient then run their 128-wide tiles (4 column blocks instead of 7 of 64: the gradient rows are fetched once per column block)
+        k_pad = (k_in + 127) // 128 * 128
         w = F.pad(conv.weight.squeeze(-1), (0, k_pad - k_in))
         edge_cat = torch.cat(edge_feats, dim=1)
         if not want_onehot and sync is None and edge_cat.shape[1] <= 192:
