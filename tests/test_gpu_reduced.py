@@ -485,3 +485,47 @@ def test_packed_fusion_operator_equals_pack_then_stack(dev, mode):
     for a, b in zip(got[1], base[1]):
         assert cosine(a, b) > KERNEL_COS[mode]
     assert cosine(got[2], base[2]) > KERNEL_COS[mode] and cosine(got[3], base[3]) > KERNEL_COS[mode]
+
+
+def _reduced_grads(mode):
+    from gfs3d import ops
+    from test_gpu_parity import _block_params, _make_block
+    d = torch.device("cuda:0")
+    B, C, N, k = 8, 64, 264, 20
+    p = _block_params(C, 31)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, N, generator=g).to(d)
+    cot = torch.randn(B, 64, N, generator=g).to(d)
+    idx = ops.knn_topk(x, k, want_i64=False, want_i32=True)
+    blk = _make_block(p, C, d).train()
+    c1, bn1, c2, bn2 = blk.fused_parts()
+    xg = x.clone().requires_grad_(True)
+    with ops.compute(mode):
+        y = ops.edgeconv_block(xg, idx, c1.weight, bn1, c2.weight, bn2, True)
+        (y * cot).sum().backward()
+    return [t.detach().cpu().numpy() for t in (xg.grad, c1.weight.grad, c2.weight.grad, bn1.weight.grad, bn1.bias.grad)]
+
+
+def _pair_form_reduced(out):
+    """Child process (GFS3D_EC_BWD_PAIR is read once per process): the wave-pair backward in a reduced mode."""
+    import os
+    os.environ["GFS3D_EC_BWD_PAIR"] = "2"
+    out["grads"] = _reduced_grads("bf16")
+
+
+def test_reduced_edgeconv_backward_eight_wave_form_equals_wave_pair_form(dev):
+    """Round 6: in the reduced modes the heavy EdgeConv backward runs as eight independent waves per workgroup
+    (ec_main_bwd_kernel<PREC_BF16, true>, one-plane LDS geometry) instead of four coupled wave pairs.  Against the pair form
+    (GFS3D_EC_BWD_PAIR=2, a child process): the same bf16 operands and the same per-edge arithmetic, only the order in which the
+    weight gradient's tiles are accumulated differs - gradients equal to fp32 rounding of those sums."""
+    import torch.multiprocessing as mp
+    from test_gpu_parity import _join_child
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    pr = ctx.Process(target=_pair_form_reduced, args=(out,))
+    pr.start()
+    _join_child(pr, 300, "pair-form reduced backward")
+    assert "grads" in out, "the child ended without writing its gradients"
+    new = _reduced_grads("bf16")
+    for a, b in zip(new, out["grads"]):
+        assert np.abs(a - b).max() <= 5e-5 * max(np.abs(b).max(), 1e-12)
