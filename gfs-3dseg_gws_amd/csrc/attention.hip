@@ -34,36 +34,12 @@ __device__ __forceinline__ unsigned at_seed(unsigned long long seed, int b)
 {
     return at_hash((unsigned)seed + 0x9e3779b9u * (unsigned)(b + 1)) ^ (unsigned)(seed >> 32);
 }
-// keep decision of attention weight (q, k) of batch item b.  ONE hash serves the two keys 2 i, 2 i + 1 of a query (round 6): the low /
-// high 16 bits of hash(q ceil(N / 2) + i) are compared with a 16-bit threshold (p_drop resolved to 1 / 65536) - in the kernels that
-// hold a query's keys in adjacent registers (forward, dQ) that halves the hashing, which was 40 % of their vector time (32
-// quarter-rate integer multiplies per tile).  A cheaper one-multiply mixer was tried and rejected: its decisions correlate across rows
-// (0.17) and its per-row drop counts vary 22x a binomial's; this two-multiply hash halves: correlations < 2e-3, variance ratio 0.95.
-__device__ __forceinline__ unsigned at_pair_hash(unsigned sb, int q, int k, int N)
-{
-    return at_hash((unsigned)(q * ((N + 1) >> 1) + (k >> 1)) ^ sb);
-}
+// keep decision of attention weight (q, k) of batch item b
 template <bool HAS_MASK>
 __device__ __forceinline__ bool at_keep(const uint8_t *mask, unsigned sb, unsigned thresh, int b, int q, int k, int N)
 {
     if (HAS_MASK) return mask[((size_t)b * N + q) * N + k] != 0;
-    const unsigned hv = at_pair_hash(sb, q, k, N);
-    return ((k & 1) ? hv >> 16 : hv & 0xffffu) >= thresh;
-}
-// the decisions of keys k0 (EVEN) and k0 + 1 of query q from one hash; keys past N - 1 are clamped for the mask read (their
-// probabilities are zero anyway)
-template <bool HAS_MASK>
-__device__ __forceinline__ void at_keep2(const uint8_t *mask, unsigned sb, unsigned thresh, int b, int q, int k0, int N, bool &keep0, bool &keep1)
-{
-    if (HAS_MASK) {
-        const uint8_t *row = mask + ((size_t)b * N + q) * N;
-        keep0 = row[min(k0, N - 1)] != 0;
-        keep1 = row[min(k0 + 1, N - 1)] != 0;
-        return;
-    }
-    const unsigned hv = at_pair_hash(sb, q, k0, N);
-    keep0 = (hv & 0xffffu) >= thresh;
-    keep1 = (hv >> 16) >= thresh;
+    return at_hash((unsigned)(q * N + k) ^ sb) >= thresh;
 }
 
 struct AttnArgs {
@@ -72,7 +48,7 @@ struct AttnArgs {
     const float *dout, *Dq;       // (B, 64, N); (B, N)
     int B, N;
     float scale, inv_keep;
-    unsigned thresh;              // drop if the element's 16-bit hash field < thresh = p_drop 65536  (0: no dropout)
+    unsigned thresh;              // drop if hash < thresh  (0: no dropout)
     unsigned long long seed;
     const uint8_t *mask;          // optional (B, N, N) keep mask
 };
@@ -235,11 +211,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const AttnArgs g, floa
         for (int r = 0; r < 16; ++r) { O0[r] *= sc; O1[r] *= sc; }
         if constexpr (drop) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {          // registers r, r + 1: keys j0 + at_drow(r, h) (even) and the next one
-                bool k0, k1;
-                at_keep2<HAS_MASK>(g.mask, sb, g.thresh, b, qi, j0 + at_drow(r, h), N, k0, k1);
-                pd[r] = k0 ? pd[r] * g.inv_keep : 0.f;
-                pd[r + 1] = k1 ? pd[r + 1] * g.inv_keep : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int key = min(j0 + at_drow(r, h), N - 1);
+                pd[r] = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, key, N) ? pd[r] * g.inv_keep : 0.f;
             }
         }
         // O^T += V^T P: rows = output channels (two tiles of 32), k = keys, B = the probabilities as they sit in the registers
@@ -332,11 +306,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const AttnArgs g, f
         }
         if constexpr (drop) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                bool k0, k1;
-                at_keep2<HAS_MASK>(g.mask, sb, g.thresh, b, qi, j0 + at_drow(r, h), N, k0, k1);
-                ds[r] *= (k0 ? dp[r] * g.inv_keep : 0.f) - Dv;
-                ds[r + 1] *= (k1 ? dp[r + 1] * g.inv_keep : 0.f) - Dv;
+            for (int r = 0; r < 16; ++r) {
+                const bool keep = at_keep<HAS_MASK>(g.mask, sb, g.thresh, b, qi, min(j0 + at_drow(r, h), N - 1), N);
+                ds[r] *= (keep ? dp[r] * g.inv_keep : 0.f) - Dv;
             }
         } else {
 #pragma unroll
@@ -470,9 +442,8 @@ __global__ void __launch_bounds__(256) attn_mask_kernel(int B, int N, unsigned t
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)N * N;
     if (e >= (size_t)B * per) return;
     const int b = (int)(e / per);
-    const size_t qk = e - (size_t)b * per;
-    const int q = (int)(qk / N), k = (int)(qk - (size_t)q * N);
-    mask[e] = at_keep<false>(nullptr, at_seed(seed, b), thresh, b, q, k, N) ? 1 : 0;
+    const unsigned qk = (unsigned)(e - (size_t)b * per);
+    mask[e] = at_hash(qk ^ at_seed(seed, b)) >= thresh ? 1 : 0;
 }
 
 
@@ -486,21 +457,13 @@ int at_check(const char *who, const float *q, const float *k, const float *v, in
     return GFS3D_OK;
 }
 
-// p_drop as a 16-bit threshold: the smallest positive probability still drops (1 / 65536), p < 1 never reaches 65536
-unsigned at_thresh16(float p_drop)
-{
-    if (p_drop <= 0.f) return 0u;
-    const unsigned t = (unsigned)((double)p_drop * 65536.0 + 0.5);
-    return t < 1u ? 1u : (t > 65535u ? 65535u : t);
-}
-
 AttnArgs at_args(const float *q, const float *k, const float *v, int B, int N, float scale, float p_drop, unsigned long long seed,
                  const uint8_t *mask)
 {
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.B = B; a.N = N; a.scale = scale;
     a.inv_keep = (p_drop > 0.f) ? 1.f / (1.f - p_drop) : 1.f;
-    a.thresh = mask ? 0u : at_thresh16(p_drop);
+    a.thresh = mask ? 0u : (unsigned)((double)p_drop * 4294967296.0);
     a.seed = seed;
     a.mask = mask;
     return a;
@@ -603,7 +566,7 @@ extern "C" int gfs3d_attention_dropout_mask(int B, int N, float p_drop, unsigned
     GFS3D_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "%s: dropout probability %g outside [0, 1)", who, (double)p_drop);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t total = (size_t)B * N * N;
-    hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N, at_thresh16(p_drop), seed, mask);
+    hipLaunchKernelGGL(attn_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N, (unsigned)((double)p_drop * 4294967296.0), seed, mask);
     GFS3D_LAUNCH_CHECK("attn_mask_kernel");
     return GFS3D_OK;
 }

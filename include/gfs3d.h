@@ -327,9 +327,8 @@ int gfs3d_unpack_rows_f32(const gfs3d_pack_args *a, void *stream);
  * model/attention.py:39-48:  y = dropout(softmax_k(q^T k * scale)) v^T  without materialising the (B, N, N) scores.
  *   q, k, v (B, 64, N) channel-first; scale = 1 / sqrt(64) in the reference; out (B, 64, N); lse (B, N) = log-sum-exp
  *   of every query's scores (kept for the backward).
- *   Dropout (p_drop > 0): weight (q, k) of item b is kept iff the 16-bit field (k & 1) of hash(seed, b, q ceil(N / 2) + k / 2) is
- *   >= round(p_drop 65536) - one 32-bit hash serves a query's keys 2 i and 2 i + 1 - and scaled by 1 / (1 - p_drop); the backward
- *   regenerates the same decisions from (seed, p_drop).  keep_mask, if not NULL, is an
+ *   Dropout (p_drop > 0): weight (q, k) of item b is kept iff hash(seed, b, q N + k) >= p_drop 2^32 and scaled by
+ *   1 / (1 - p_drop); the backward regenerates the same decisions from (seed, p_drop).  keep_mask, if not NULL, is an
  *   explicit (B, N, N) byte mask used instead (tests; p_drop then only sets the scale).
  *   gfs3d_attention_dropout_mask writes the decisions of (seed, p_drop) as such a mask.
  * Backward: dout (B, 64, N) -> dq, dk, dv (B, 64, N); workspace: B*N floats. */

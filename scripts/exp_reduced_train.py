@@ -51,4 +51,7 @@ if __name__ == "__main__":
     r = np.array(ref)
     for name, c in (("f32 again", ref2), ("f16", h), ("bf16", b)):
         c = np.array(c)
-        print(f"{name}: max |dloss| / loss = {np.max(np.abs(c - r) / r):.4f}; last-10 mean {c[-10:].mean():.5f} vs {r[-10:].mean():.5f}")
+        d = np.abs(c - r) / r
+        top = np.argsort(-d)[:4]
+        print(f"{name}: max |dloss| / loss = {d.max():.4f} (step {int(d.argmax())}; next {[(int(t), round(float(d[t]), 4)) for t in top[1:]]}; "
+              f"95th pct {np.percentile(d, 95):.4f}); last-10 mean {c[-10:].mean():.5f} vs {r[-10:].mean():.5f}")
