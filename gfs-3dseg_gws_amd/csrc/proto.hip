@@ -17,6 +17,8 @@
 // (row stride 68 floats => conflict-free ds_read_b128 A-fragments), the point
 // chunk is read straight from the channel-first input (128-B coalesced rows).
 // Norms are accumulated on the fly and applied to the fp32 accumulators.
+#include <type_traits>
+
 #include "common.h"
 
 namespace gfs3d {
@@ -1427,6 +1429,252 @@ kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The SCREEN as a persistent, software-pipelined kernel (round 6).  kmeans_assign_x6_kernel<NT, PREC_X3, false> ran one 256-point
+// tile per workgroup at one workgroup per CU: every tile paid the latency of its first loads with nothing in flight, re-read and
+// re-split the centroid chunks (half of the vector work of its main loop), requested point rows ONE 32-channel step (~1 us of
+// MFMAs) ahead of their use - 32 KB in flight per CU against the ~64 KB that 8 TB/s x 2 us need - and ran the 112-score epilogue
+// of its eight waves with no load outstanding: 717 us for 1.61 GB, 2.3 TB/s, neither roof.  Here
+//   * km_cent_image_kernel writes, once per call, the centroids' operand image [chunk][NROW rows][hi 64 B | mid 64 B | pad 16 B]
+//     (144-B rows: 9 sixteen-byte slots, odd => conflict-free ds_read_b128) and |c_k|^2; a step's image chunk travels
+//     global (L2) -> LDS by LDS-DMA (global_load_lds: no registers, no vector instructions);
+//   * a workgroup walks tiles blockIdx.x, + gridDim.x, ...: the chunk steps of consecutive tiles form ONE pipeline - at step g the
+//     image of step g + 1 and the point rows of step g + 2 are requested (the DMA first: loads return in order, so the wait for the
+//     image leaves exactly the newest four row loads outstanding), and the epilogue of a tile runs under the first loads of the next;
+//   * per-centroid counts stay in LDS for all of a workgroup's tiles (K global adds per workgroup, not per tile), the inertia
+//     in a register; undecided points are appended to the list with one atomic per wave.
+// Same scores, same error bound, same decisions as the one-tile form (|c_k|^2 is summed in a different order: inside eabs).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KI_ROWB = 144;            // hi | mid | pad
+template <int PREC>
+__global__ void __launch_bounds__(256)
+km_cent_image_kernel(const float *__restrict__ cent, int K, int C, int nrow, unsigned char *__restrict__ gimg, float *__restrict__ gcn)
+{
+    static_assert(Mx<PREC>::NP * 64 + 16 == KI_ROWB, "image rows: the pieces of 32 channels + one pad slot");
+    constexpr int NP = Mx<PREC>::NP;
+    const int nchunk = C / 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nchunk * nrow * 8) {
+        const int c4 = e & 7, w = (e >> 3) % nrow, ch = (e >> 3) / nrow;
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < K) {
+            const float4 v = *reinterpret_cast<const float4 *>(cent + (size_t)w * C + ch * 32 + 4 * c4);
+            v4[0] = v.x; v4[1] = v.y; v4[2] = v.z; v4[3] = v.w;
+        }
+        uint2 pc[NP];
+        mm_pieces4<PREC>(v4, pc);
+        unsigned char *row = gimg + ((size_t)ch * nrow + w) * KI_ROWB;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(row + 64 * q + 8 * c4) = pc[q];
+        if (c4 < 2) *reinterpret_cast<uint2 *>(row + 64 * NP + 8 * c4) = make_uint2(0u, 0u);
+    }
+    // |c_w|^2: one wave per row (the blocks after the image's; a lane's channels in ascending order, then the wave's sum)
+    const int nimg = (nchunk * nrow * 8 + 255) / 256;
+    if ((int)blockIdx.x >= nimg) {
+        const int w = ((int)blockIdx.x - nimg) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (w < nrow) {
+            float sq = 0.f;
+            if (w < K)
+                for (int c = lane; c < C; c += 64) sq = fmaf(cent[(size_t)w * C + c], cent[(size_t)w * C + c], sq);
+            sq = wave_sum(sq);
+            if (lane == 0) gcn[w] = sq;
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(PX_THREADS)
+kmeans_screen_img_kernel(const float *__restrict__ pts, long long M, int C, int K, const unsigned char *__restrict__ gimg,
+                         const float *__restrict__ gcn, int32_t *__restrict__ label, float *__restrict__ counts,
+                         double *__restrict__ inertia, const KmFast fa)
+{
+    constexpr int PREC = PREC_X3, NP = Mx<PREC>::NP, NROW = NT * 32, IMGB = NROW * KI_ROWB;
+    constexpr int NWAVE = PX_THREADS / 64, NPIECE = (IMGB + 1023) / 1024, ND = (NPIECE + NWAVE - 1) / NWAVE;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [2][IMGB]
+    float *cn = reinterpret_cast<float *>(img + 2 * IMGB);                    // [NROW] |c_k|^2
+    int *hist = reinterpret_cast<int *>(cn + NROW);                           // [NROW] members of this workgroup per centroid
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float *wtile = reinterpret_cast<float *>(hist + NROW) + wv * 32 * XS_LD;  // wave-private [32][XS_LD]
+    const long long ntile = (M + 255) / 256;
+    const int nchunk = C / 32;                                                // even (the launcher checks)
+    // (rows past K: +inf, their image rows are zero - no per-row `w < K` test in the epilogue, which the compiler would hoist out of the
+    // tile loop as 16 NT wave masks)
+    for (int w = tid; w < NROW; w += PX_THREADS) { cn[w] = w < K ? gcn[w] : __builtin_inff(); hist[w] = 0; }
+
+    // image chunk -> LDS: 1-KB pieces, lane l of piece i moves image bytes 1024 i + 16 l .. + 15 (global layout == LDS layout)
+    unsigned doff[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) doff[u] = (unsigned)(((wv * ND + u) * 64 + lane) * 16);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    auto dma = [&](int chunk) {
+        const unsigned char *src = gimg + (size_t)chunk * IMGB;
+        unsigned char *dst = img + (chunk & 1) * IMGB;
+#pragma unroll
+        for (int u = 0; u < ND; ++u)
+            if (doff[u] < (unsigned)IMGB) px_dma16_off(src, doff[u], dst + (wvu * ND + u) * 1024);
+    };
+    // the wave's 32 rows x 32 channels of a step as 128-B row pieces: rows (lane >> 3) + 8 i, 16 B at column 4 (lane & 7)
+    auto loadp = [&](const float *base, int nrows, int c0, float (&f)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min((lane >> 3) + 8 * i, nrows - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(base + (size_t)row * C + c0 + 4 * (lane & 7));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * i + e] = v[e];
+        }
+    };
+    auto wave_rows = [&](long long blk, const float *&base, int &nrows) {
+        const long long m0 = blk * 256 + wv * 32, mb = m0 < M ? m0 : M - 1;     // (a wave past the end re-reads the last point, stores nothing)
+        nrows = (int)min((long long)32, M - mb);
+        base = pts + (size_t)mb * C;
+    };
+    uint4 bp[2][NP];                                     // this lane's point: pieces of 8 channels per K-step
+    float fsq = 0.f;
+    auto split_point = [&](float (&f)[16]) {             // row pieces -> tile -> this lane's 16 channels of point j -> pieces
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4 *>(wtile + ((lane >> 3) + 8 * i) * XS_LD + 4 * (lane & 7)) = f32x4{f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]};
+        __builtin_amdgcn_wave_barrier();
+        float g[16];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wtile + j * XS_LD + 16 * s + 8 * h + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[8 * s + 4 * q + e] = v[e];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fsq = fmaf(g[8 * s + e], g[8 * s + e], fsq);
+            mm_pieces8<PREC>(g + 8 * s, bp[s]);
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    double contrib = 0.0;
+    float cmx = 0.f;
+
+    auto epilogue = [&](const long long blk) {
+        const long long m0 = blk * 256 + wv * 32;
+        const float psq = fsq + __shfl_xor(fsq, 32, 64);
+        const bool live = h == 0 && m0 + j < M;
+        const long long m = m0 + j;
+        float best = __builtin_inff(), second = __builtin_inff();
+        int bk = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int w = t * 32 + acc_row(r, h);               // increasing within a lane: '<' keeps the lowest index of a tie
+                const float d = cn[w] - 2.f * acc[t][r];             // + |p|^2, constant per point; +inf for w >= K
+                const bool lt = d < best;
+                second = fminf(second, lt ? best : d);
+                bk = lt ? w : bk;
+                best = lt ? d : best;
+            }
+        {
+            const float ob = __shfl_xor(best, 32, 64);
+            const int ok = __shfl_xor(bk, 32, 64);
+            second = fminf(fminf(second, __shfl_xor(second, 32, 64)), fmaxf(best, ob));
+            if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        const float E = fa.erel * sqrtf(psq * cmx) + fa.eabs * (psq + cmx);
+        const bool decided = second - best > 2.0f * E;               // (K == 1: second = +inf)
+        const bool undecided = live && !decided;
+        const unsigned long long um = __ballot(undecided);
+        if (um) {                                                     // one list atomic per wave (order of the list: irrelevant)
+            const int first = __builtin_ctzll(um);
+            int base = 0;
+            if (lane == first) base = atomicAdd(fa.fcount, __builtin_popcountll(um));
+            base = __shfl(base, first, 64);
+            if (undecided) fa.flist[base + __builtin_popcountll(um & ((1ull << lane) - 1ull))] = (int)m;
+        }
+        if (live && decided) {
+            label[m] = bk;
+            atomicAdd(&hist[bk], 1);
+            contrib += (double)fmaxf(best + psq, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        fsq = 0.f;
+    };
+
+    float fr[2][16];
+    long long blk = blockIdx.x;
+    const float *cb, *nb;
+    int cr, nr;
+    wave_rows(blk, cb, cr);
+    dma(0);
+    loadp(cb, cr, 0, fr[0]);
+    loadp(cb, cr, 32, fr[1]);
+    split_point(fr[0]);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // image chunk 0 has landed (this wave's pieces); outstanding: the rows of chunk 1
+    __syncthreads();                                     // ... everyone's; cn, hist
+    for (int w = lane; w < NROW; w += 64) cmx = fmaxf(cmx, w < K ? cn[w] : 0.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o, 64));
+
+    auto step = [&](int c, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        const bool last = P == 1 && c + 1 == nchunk;     // (an even number of chunks: a tile ends on an odd step)
+        dma(last ? 0 : c + 1);                           // into image P ^ 1: last read a barrier ago
+        const int c2 = c + 2;
+        if (c2 < nchunk) loadp(cb, cr, 32 * c2, fr[P]);  // fr[P]: split into bp during the previous step
+        else             loadp(nb, nr, 32 * (c2 - nchunk), fr[P]);
+        const unsigned char *pa = img + P * IMGB + j * KI_ROWB + h * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int wt = 0; wt < NT; ++wt) {
+                uint4 af[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) af[pl] = *reinterpret_cast<const uint4 *>(pa + wt * 32 * KI_ROWB + pl * 64 + s * 32);
+                mm_mac<PREC>(af, bp[s], acc[wt]);
+            }
+        if (last) {
+            epilogue(blk);
+            cb = nb; cr = nr;
+        }
+        split_point(fr[P ^ 1]);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();
+    };
+    for (; blk < ntile; blk += gridDim.x) {
+        const long long nblk = blk + gridDim.x < ntile ? blk + gridDim.x : ntile - 1;   // (past the end: the last tile again, never scored)
+        wave_rows(nblk, nb, nr);
+        for (int c = 0; c < nchunk; c += 2) {
+            step(c, std::integral_constant<int, 0>{});
+            step(c + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    // counts: one global float add per workgroup and non-empty centroid; inertia: one fp64 atomic per workgroup
+    if (tid < K && hist[tid] != 0) atomicAdd(&counts[tid], (float)hist[tid]);
+    if (inertia) {
+        contrib = wave_sum(contrib);
+        double *red = reinterpret_cast<double *>(cn);    // (every wave is past its last read of cn: the barrier of the last step)
+        if (lane == 0) red[wv] = contrib;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) tot += red[w];
+            atomicAdd(inertia, tot);
+        }
+    }
+}
+
 constexpr int KM_CHUNK = 2048;     // points per workgroup of the sums kernel
 // S[k][c] = sum_m [label_m == k] p_m[c] as a one-hot GEMM on the bf16 matrix cores: the one-hot operand is exact in
 // bf16, the point values go in as their three bf16 pieces (hi + mid + lo == the fp32 value), so the three MFMAs per
@@ -1504,7 +1752,7 @@ kmeans_sums_mfma_kernel(const float *__restrict__ pts, long long M, int C, int K
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KS_SORT_CHUNK = 1024;       // points per (one-wave) block of the histogram / placement kernels
 constexpr int KS_SEG = 256;               // rows per partial sum
-struct KmWs { size_t off_flist, off_fcnt, off_perm, off_bh, off_tot, off_off, off_cb, off_part, total; int nblk, nchmax; };
+struct KmWs { size_t off_flist, off_fcnt, off_perm, off_bh, off_tot, off_off, off_cb, off_part, off_img, off_cn, total; int nblk, nchmax; };
 static KmWs km_ws(long long M, int C, int K)
 {
     KmWs w{};
@@ -1520,6 +1768,8 @@ static KmWs km_ws(long long M, int C, int K)
     w.off_off = take(sizeof(int) * (size_t)(K + 1));
     w.off_cb = take(sizeof(int) * (size_t)(K + 1));
     w.off_part = take(sizeof(float) * (size_t)w.nchmax * C);
+    w.off_img = take((size_t)((C + 31) / 32) * 256 * KI_ROWB);   // the screen's operand image of the centroids (K <= 256 rows per chunk)
+    w.off_cn = take(sizeof(float) * 256);
     w.total = o;
     return w;
 }
@@ -1832,10 +2082,23 @@ static int launch_kmeans(const float *pts, long long M, int C, const float *cent
                     set_error("gfs3d_kmeans_assign_fast_f32: hipMemsetAsync failed");
                     return GFS3D_ERR_HIP;
                 }
-                GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X3, false>), lds, "gfs3d_kmeans_assign_fast_f32");
-                hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X3, false>), grid, dim3(PX_THREADS), lds, st, pts, M, C, cent, K, label, counts,
-                                   inertia, fa);
-                GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel (screen)");
+                static const bool img_off = [] { const char *e = getenv("GFS3D_KM_IMG"); return e && atoi(e) == 0; }();       // A-B only
+                if (C % 64 == 0 && !img_off) {            // persistent, pipelined screen on a per-call operand image (an even number of chunks)
+                    unsigned char *gimg = reinterpret_cast<unsigned char *>(ws + w.off_img);
+                    float *gcn = reinterpret_cast<float *>(ws + w.off_cn);
+                    hipLaunchKernelGGL(km_cent_image_kernel<PREC_X3>, dim3(((C / 32) * NT * 32 * 8 + 255) / 256 + (NT * 32 + 3) / 4), dim3(256), 0, st, cent, K, C, NT * 32, gimg, gcn);
+                    GFS3D_LAUNCH_CHECK("km_cent_image_kernel");
+                    const size_t ilds = (size_t)2 * NT * 32 * KI_ROWB + sizeof(float) * (2 * NT * 32 + 8 * 32 * XS_LD);
+                    GFS3D_ENSURE_LDS((kmeans_screen_img_kernel<NT>), ilds, "gfs3d_kmeans_assign_fast_f32");
+                    hipLaunchKernelGGL((kmeans_screen_img_kernel<NT>), dim3(min(grid.x, 256u)), dim3(PX_THREADS), ilds, st, pts, M, C, K, gimg, gcn, label,
+                                       counts, inertia, fa);
+                    GFS3D_LAUNCH_CHECK("kmeans_screen_img_kernel");
+                } else {
+                    GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X3, false>), lds, "gfs3d_kmeans_assign_fast_f32");
+                    hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X3, false>), grid, dim3(PX_THREADS), lds, st, pts, M, C, cent, K, label, counts,
+                                       inertia, fa);
+                    GFS3D_LAUNCH_CHECK("kmeans_assign_x6_kernel (screen)");
+                }
                 GFS3D_ENSURE_LDS((kmeans_assign_x6_kernel<NT, PREC_X6, true>), lds, "gfs3d_kmeans_assign_fast_f32");
                 hipLaunchKernelGGL((kmeans_assign_x6_kernel<NT, PREC_X6, true>), dim3(min(grid.x, 512u)), dim3(PX_THREADS), lds, st, pts, M, C, cent, K,
                                    label, counts, inertia, fa);
