@@ -1446,6 +1446,7 @@ kmeans_assign_x6_kernel(const float *__restrict__ pts, long long M, int C, const
 // Same scores, same error bound, same decisions as the one-tile form (|c_k|^2 is summed in a different order: inside eabs).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int KI_ROWB = 144;            // hi | mid | pad
+static inline int ki_rows(int K) { return (K + 15) / 16 * 16; }
 template <int PREC>
 __global__ void __launch_bounds__(256)
 km_cent_image_kernel(const float *__restrict__ cent, int K, int C, int nrow, unsigned char *__restrict__ gimg, float *__restrict__ gcn)
@@ -1664,6 +1665,253 @@ kmeans_screen_img_kernel(const float *__restrict__ pts, long long M, int C, int 
     if (inertia) {
         contrib = wave_sum(contrib);
         double *red = reinterpret_cast<double *>(cn);    // (every wave is past its last read of cn: the barrier of the last step)
+        if (lane == 0) red[wv] = contrib;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) tot += red[w];
+            atomicAdd(inertia, tot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The screen with the WHOLE operand image resident in LDS (C = 192, K <= 208: 6 chunks x 208 rows x 128 B = 156 KB): no staging
+// step, hence no workgroup barrier after the first - the eight waves of a workgroup (one per CU, persistent) walk their own 32-point
+// tiles independently.  The pipelined form above keeps its waves in lock step (a barrier per 32-channel step): the two waves of a SIMD
+// issue their MFMAs together and their vector work (operand split, epilogue) together, so the matrix pipe idles under every vector
+// phase - its time did not change when the points came from the memory-side cache (300 k points: 20.6 us per tile and workgroup;
+// 2.1 M from HBM: 17.8).  Here a wave's vector phases fall under the other wave's MFMAs.
+//   * image rows are 128 B (hi | mid, no pad); the 16-byte units of a row are XOR-swizzled with (row >> 1) & 7 instead, which keeps
+//     ds_read_b128 conflict-free for 16 consecutive rows; the lanes of the last row tile whose rows lie past the image read its last
+//     (zero) row, and cn = +inf masks them;
+//   * a lane loads ITS point's channels directly (row j, 32 B per K-step half): no transposition tile in LDS; rows two steps ahead;
+//   * the compiler counts the outstanding loads itself (no LDS-DMA inside the loop).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int KR_ROWB = 128;
+static inline size_t kr_lds_bytes(int NT, int C, int K) { return (size_t)(C / 32) * ki_rows(K) * KR_ROWB + sizeof(float) * 2 * NT * 32; }
+__global__ void __launch_bounds__(256)
+km_cent_image_swz_kernel(const float *__restrict__ cent, int K, int C, int imgr, int nrow, unsigned char *__restrict__ gimg, float *__restrict__ gcn)
+{
+    const int nchunk = C / 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int nimg = (nchunk * imgr * 8 + 255) / 256;
+    if (e < nchunk * imgr * 8) {
+        const int c4 = e & 7, w = (e >> 3) % imgr, ch = (e >> 3) / imgr;
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (w < K) {
+            const float4 v = *reinterpret_cast<const float4 *>(cent + (size_t)w * C + ch * 32 + 4 * c4);
+            v4[0] = v.x; v4[1] = v.y; v4[2] = v.z; v4[3] = v.w;
+        }
+        uint2 pc[2];
+        mm_pieces4<PREC_X3>(v4, pc);
+        const int key = (w >> 1) & 7;
+        unsigned char *row = gimg + ((size_t)ch * imgr + w) * KR_ROWB + 8 * (c4 & 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<uint2 *>(row + 16 * ((4 * q + (c4 >> 1)) ^ key)) = pc[q];
+    }
+    if ((int)blockIdx.x >= nimg) {                      // |c_w|^2: one wave per row
+        const int w = ((int)blockIdx.x - nimg) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (w < nrow) {
+            float sq = 0.f;
+            if (w < K)
+                for (int c = lane; c < C; c += 64) sq = fmaf(cent[(size_t)w * C + c], cent[(size_t)w * C + c], sq);
+            sq = wave_sum(sq);
+            if (lane == 0) gcn[w] = sq;
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(PX_THREADS)
+kmeans_screen_res_kernel(const float *__restrict__ pts, long long M, int C, int K, const unsigned char *__restrict__ gimg,
+                         const float *__restrict__ gcn, int32_t *__restrict__ label, float *__restrict__ counts,
+                         double *__restrict__ inertia, const KmFast fa)
+{
+    constexpr int PREC = PREC_X3, NP = Mx<PREC>::NP, NROW = NT * 32, NWAVE = PX_THREADS / 64;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nchunk = C / 32;                                                // even (the launcher checks)
+    const int imgr = (K + 15) / 16 * 16, chunkb = imgr * KR_ROWB, imgb = nchunk * chunkb;     // (a multiple of 1024)
+    unsigned char *img = reinterpret_cast<unsigned char *>(smem);            // [nchunk][imgr][128]
+    float *cn = reinterpret_cast<float *>(img + imgb);                        // [NROW] -|c_k|^2 / 2 (-inf past K): the accumulators START there
+    int *hist = reinterpret_cast<int *>(cn + NROW);                           // [NROW] members of this workgroup per centroid
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    for (int w = tid; w < NROW; w += PX_THREADS) { cn[w] = w < K ? -0.5f * gcn[w] : -__builtin_inff(); hist[w] = 0; }
+    {   // the image, once: 1-KB pieces by LDS-DMA (global layout == LDS layout), wave v moves pieces v, v + 8, ...
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        for (int p = wvu; p < imgb / 1024; p += NWAVE) px_dma16_off(gimg, (unsigned)(p * 1024 + lane * 16), img + p * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    float cmx = 0.f;
+    for (int w = lane; w < NROW; w += 64) cmx = fmaxf(cmx, w < K ? gcn[w] : 0.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmx = fmaxf(cmx, __shfl_xor(cmx, o, 64));
+
+    // A-operand byte offsets of this lane inside a chunk: row tile wt at + 4096 wt; [pl][s] = piece, K-step
+    unsigned aoff[NP][2], aoff_last[NP][2];
+    {
+        const int jl = min((NT - 1) * 32 + j, imgr - 1);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int u = 4 * pl + 2 * s + h;
+                aoff[pl][s] = (unsigned)(j * KR_ROWB + 16 * (u ^ ((j >> 1) & 7)));
+                aoff_last[pl][s] = (unsigned)(jl * KR_ROWB + 16 * (u ^ ((jl >> 1) & 7)));
+            }
+    }
+    const long long nwt = (M + 31) / 32;                 // 32-point wave tiles
+    const long long gw = (long long)blockIdx.x * NWAVE + wv, GW = (long long)gridDim.x * NWAVE;
+    // lane (j, h) reads row j of the wave tile: channels 16 s + 8 h .. + 7 of a chunk = 32 bytes at 64 s + 32 h
+    auto rows_of = [&](long long t, const float *&base, unsigned &vo) {
+        const long long m0 = t * 32;
+        const int nrows = (int)min((long long)32, M - m0);
+        base = pts + (size_t)m0 * C;
+        vo = (unsigned)(min(j, nrows - 1) * C + 8 * h) * 4u;
+    };
+    auto loadp = [&](const float *base, unsigned vo, int c, float (&f)[16]) {
+        const char *sb = reinterpret_cast<const char *>(base + 32 * c) + vo;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sb + 64 * s + 16 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[8 * s + 4 * q + e] = v[e];
+            }
+    };
+    uint4 bp[2][NP];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 fsq2 = {0.f, 0.f};                             // |p|^2 of this lane's channels, even / odd positions (v_pk_fma_f32)
+    auto split_point = [&](const float (&f)[16]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {f[8 * s + e], f[8 * s + e + 1]};
+                fsq2 = __builtin_elementwise_fma(v, v, fsq2);
+            }
+            mm_pieces8<PREC>(f + 8 * s, bp[s]);
+        }
+    };
+    // score of (point, centroid w) = <c_w, p> - |c_w|^2 / 2 = -d / 2: the accumulators start at -|c_w|^2 / 2 (one ds_read_b128 per
+    // four rows, no vector instruction), so the epilogue compares them as they are - no zeroing pass, no fma per score
+    f32x16 acc[NT];
+    auto acc_init = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = cn[t * 32 + acc_row(r, h)];
+    };
+    acc_init();
+    double contrib = 0.0;
+
+    auto epilogue = [&](const long long t) {
+        const long long m = t * 32 + j;
+        const float fsq = fsq2[0] + fsq2[1];
+        const float psq = fsq + __shfl_xor(fsq, 32, 64);
+        const bool live = h == 0 && m < M;
+        // four instructions per score s (larger = nearer): second = med3(best, second, s) (best >= second always: the median is
+        // max(second, min(best, s))), the row index as a literal select (+ 4 h at the end), best = max(best, s)
+        float best = -__builtin_inff(), second = -__builtin_inff();
+        int bk = 0x7ffffff0;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = acc[tt][r];
+                second = __builtin_amdgcn_fmed3f(best, second, sc);
+                const bool gt = sc > best;                         // (one compare, two selects: fmaxf adds a canonicalising v_max per call)
+                bk = gt ? tt * 32 + acc_row(r, 0) : bk;            // increasing within a lane: '>' keeps the lowest index of a tie
+                best = gt ? sc : best;
+            }
+        bk += 4 * h;
+        {
+            const float ob = __shfl_xor(best, 32, 64);
+            const int ok = __shfl_xor(bk, 32, 64);
+            second = fmaxf(fmaxf(second, __shfl_xor(second, 32, 64)), fminf(best, ob));
+            if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        best *= -2.f;                                    // d = |c|^2 - 2 <c, p>  (+ |p|^2, constant per point)
+        second *= -2.f;
+        const float E = fa.erel * sqrtf(psq * cmx) + fa.eabs * (psq + cmx);
+        const bool decided = second - best > 2.0f * E;               // (K == 1: second = +inf)
+        const bool undecided = live && !decided;
+        const unsigned long long um = __ballot(undecided);
+        if (um) {                                                     // one list atomic per wave (order of the list: irrelevant)
+            const int first = __builtin_ctzll(um);
+            int base = 0;
+            if (lane == first) base = atomicAdd(fa.fcount, __builtin_popcountll(um));
+            base = __shfl(base, first, 64);
+            if (undecided) fa.flist[base + __builtin_popcountll(um & ((1ull << lane) - 1ull))] = (int)m;
+        }
+        if (live && decided) {
+            label[m] = bk;
+            atomicAdd(&hist[bk], 1);
+            contrib += (double)fmaxf(best + psq, 0.f);
+        }
+        acc_init();
+        fsq2 = f32x2{0.f, 0.f};
+    };
+
+    if (gw < nwt) {
+        float fr[2][16];
+        long long t = gw;
+        const float *cb, *nb;
+        unsigned vo, nvo;
+        rows_of(t, cb, vo);
+        loadp(cb, vo, 0, fr[0]);
+        loadp(cb, vo, 1, fr[1]);
+        split_point(fr[0]);
+        auto step = [&](int c, auto parity) {
+            constexpr int P = decltype(parity)::value;
+            const bool last = P == 1 && c + 1 == nchunk;     // (an even number of chunks: a tile ends on an odd step)
+            const int c2 = c + 2;
+            if (c2 < nchunk) loadp(cb, vo, c2, fr[P]);      // fr[P]: split into bp during the previous step
+            else             loadp(nb, nvo, c2 - nchunk, fr[P]);
+            const unsigned char *pc = img + c * chunkb;
+            // the A fragments of group g + 1 are requested before the MFMAs of group g are issued: a wave alone on its SIMD (the other
+            // one in its epilogue) keeps the matrix pipe fed
+            uint4 af[2][NP];
+            auto fetch = [&](int g, uint4 (&a)[NP]) {
+                const int s = g / NT, wt = g % NT;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    a[pl] = *reinterpret_cast<const uint4 *>(pc + (wt == NT - 1 ? aoff_last[pl][s] : aoff[pl][s] + wt * 32 * KR_ROWB));
+            };
+            fetch(0, af[0]);
+#pragma unroll
+            for (int g = 0; g < 2 * NT; ++g) {
+                if (g + 1 < 2 * NT) fetch(g + 1, af[(g + 1) & 1]);
+                mm_mac<PREC>(af[g & 1], bp[g / NT], acc[g % NT]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (last) {
+                epilogue(t);
+                cb = nb;
+                vo = nvo;
+            }
+            split_point(fr[P ^ 1]);
+        };
+        for (; t < nwt; t += GW) {
+            const long long tn = t + GW < nwt ? t + GW : nwt - 1;       // (past the end: the last tile again, never scored)
+            rows_of(tn, nb, nvo);
+            for (int c = 0; c < nchunk; c += 2) {
+                step(c, std::integral_constant<int, 0>{});
+                step(c + 1, std::integral_constant<int, 1>{});
+            }
+        }
+    }
+    __syncthreads();                                     // every wave's LDS counts
+    // counts: one global float add per workgroup and non-empty centroid; inertia: one fp64 atomic per workgroup
+    if (tid < K && hist[tid] != 0) atomicAdd(&counts[tid], (float)hist[tid]);
+    if (inertia) {
+        contrib = wave_sum(contrib);
+        double *red = reinterpret_cast<double *>(cn);    // (every wave is past its last read of cn)
         if (lane == 0) red[wv] = contrib;
         __syncthreads();
         if (tid == 0) {
@@ -2083,9 +2331,21 @@ static int launch_kmeans(const float *pts, long long M, int C, const float *cent
                     return GFS3D_ERR_HIP;
                 }
                 static const bool img_off = [] { const char *e = getenv("GFS3D_KM_IMG"); return e && atoi(e) == 0; }();       // A-B only
-                if (C % 64 == 0 && !img_off) {            // persistent, pipelined screen on a per-call operand image (an even number of chunks)
-                    unsigned char *gimg = reinterpret_cast<unsigned char *>(ws + w.off_img);
-                    float *gcn = reinterpret_cast<float *>(ws + w.off_cn);
+                static const int img_mode = [] { const char *e = getenv("GFS3D_KM_IMG"); return e ? atoi(e) : 2; }();            // A-B only
+                unsigned char *gimg = reinterpret_cast<unsigned char *>(ws + w.off_img);
+                float *gcn = reinterpret_cast<float *>(ws + w.off_cn);
+                if (C % 64 == 0 && img_mode == 2 && kr_lds_bytes(NT, C, K) <= 160 * 1024 - 1024) {
+                    // the whole operand image resident in LDS, independent waves (C = 192: K <= 208)
+                    const int imgr = ki_rows(K);
+                    hipLaunchKernelGGL(km_cent_image_swz_kernel, dim3(((C / 32) * imgr * 8 + 255) / 256 + (NT * 32 + 3) / 4), dim3(256), 0, st, cent, K, C,
+                                       imgr, NT * 32, gimg, gcn);
+                    GFS3D_LAUNCH_CHECK("km_cent_image_swz_kernel");
+                    const size_t rlds = kr_lds_bytes(NT, C, K);
+                    GFS3D_ENSURE_LDS((kmeans_screen_res_kernel<NT>), rlds, "gfs3d_kmeans_assign_fast_f32");
+                    hipLaunchKernelGGL((kmeans_screen_res_kernel<NT>), dim3(min(grid.x, 256u)), dim3(PX_THREADS), rlds, st, pts, M, C, K, gimg, gcn, label,
+                                       counts, inertia, fa);
+                    GFS3D_LAUNCH_CHECK("kmeans_screen_res_kernel");
+                } else if (C % 64 == 0 && !img_off) {     // persistent, pipelined screen on a per-call operand image (an even number of chunks)
                     hipLaunchKernelGGL(km_cent_image_kernel<PREC_X3>, dim3(((C / 32) * NT * 32 * 8 + 255) / 256 + (NT * 32 + 3) / 4), dim3(256), 0, st, cent, K, C, NT * 32, gimg, gcn);
                     GFS3D_LAUNCH_CHECK("km_cent_image_kernel");
                     const size_t ilds = (size_t)2 * NT * 32 * KI_ROWB + sizeof(float) * (2 * NT * 32 + 8 * 32 * XS_LD);

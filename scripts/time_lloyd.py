@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "gfs-3dseg_gws_amd"))
 from gfs3d import ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(5)
-M = 7 * 300000
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 7 * 300000           # (300000: the points fit the 256-MB memory-side cache)
 pts = torch.randn(M, 192, generator=g).to(dev)
 cent = pts[torch.randperm(M, generator=g)[:200].to(dev)].contiguous()
 for fast in (False, True):
