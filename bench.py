@@ -472,7 +472,7 @@ def extras(dev, L, gdist):
         cent = pts[torch.randperm(M, generator=g)[:200].to(dev)].contiguous()
         byts = 4.0 * M * (192 + 1)                                   # every point read once, its label written
         for key, fast, note in (("lloyd_step", True, "the step of the Lloyd loop (get_basis.device_kmeans): SCREENED assignment (hi + mid bf16 operands, three "
-                                 "products, error bound; undecided points re-scored at fp32 accuracy from a list: same labels / sums / counts as the exact "
+                                 "products, error bound, the whole operand image of the centroids resident in LDS; undecided points re-scored at fp32 accuracy from a list: same labels / sums / counts as the exact "
                                  "form) + centroid sums as sorted segment sums over the rows (the Lloyd LOOP itself replaces that second pass by delta "
                                  "sums over the moved rows once < 3 % of the labels change: gfs3d_kmeans_delta_fix)"),
                                 ("lloyd_step_exact", False, "every point scored at fp32 accuracy (bf16x6 GEMM): the final assignment, whose inertia is reported")):
