@@ -365,7 +365,10 @@ def c3_end_to_end(dev, n_blocks=1400, num_cnt=200):
     seg = DGCNNSeg(a, num_classes=8).to(dev).eval()
     blocks = torch.cat([synthetic_blocks(100, NPTS, seed=100 + i) for i in range(n_blocks // 100)]).to(dev)   # resident: no PCIe in the flow
     labels = torch.randint(0, 8, (blocks.shape[0], NPTS), generator=torch.Generator().manual_seed(1)).to(dev)
-    extract_geometric_words(seg, blocks[:64], labels[:64], 8, 16, max_per_class=2000, max_iter=3)                # warm-up (first-use costs)
+    # warm-up (first-use costs) through the SAME code paths as the timed flow: 40 centroids (>= 33: the Lloyd loop builds its running
+    # sums - ops.KMeansDelta, whose torch.aminmax is the first tensor-library reduction of the process: 166 ms of module loading in the
+    # first process on a box, scripts/c3_first_call.py - and enters the run-ahead loop)
+    extract_geometric_words(seg, blocks[:64], labels[:64], 8, 40, max_per_class=2000, max_iter=12)
     torch.cuda.synchronize()
     tm = {}
     t0 = time.perf_counter()
