@@ -1758,14 +1758,15 @@ def test_dgcnn_general_shapes_run_through_the_hip_graph_and_match_the_oracle(dev
 @pytest.mark.parametrize("M,C,K,kind", [(5000, 192, 200, "clusters"), (70000, 192, 256, "clusters"), (4097, 64, 33, "clusters"),
                                         (3000, 192, 200, "offset"), (2049, 96, 129, "twins"), (1000, 192, 200, "relu"),
                                         (600011, 192, 200, "clusters"), (70, 192, 208, "clusters"), (4100, 192, 197, "twins"),
-                                        (33, 128, 40, "clusters"), (300007, 256, 200, "clusters"), (31, 192, 33, "clusters")])
+                                        (33, 128, 40, "clusters"), (300007, 256, 200, "clusters"), (31, 192, 33, "clusters"),
+                                        (5003, 256, 100, "clusters"), (9001, 64, 256, "twins"), (40007, 128, 224, "offset")])
 def test_kmeans_assign_fast_equals_the_exact_form(dev, M, C, K, kind):
     """The screened Lloyd step (gfs3d_kmeans_assign_fast_f32: hi + mid bf16 screen with an error bound, exact re-scoring of
     the undecided points from a list) returns the labels, counts and sums of the fp32-accurate form - on well separated
     clusters (nothing on the list), on features whose norms dwarf their distances (a loose bound: most points re-scored), on
     duplicated centroids (exact ties: the list pass must pick the lower index) and on ReLU-ed features; inertia within 1e-3.
     The shapes reach all three screens: the whole operand image resident in LDS with independent persistent waves (C = 192 with
-    K <= 208, C = 64 / 128; 600 011 points = nine tiles per wave and a ragged last one; K = 208 / 197 / 33: the clamped rows of the
+    K <= 208, C = 64 / 128 / 256 with fewer centroids (eight chunks; eight row tiles); 600 011 points = nine tiles per wave and a ragged last one; K = 208 / 197 / 33: the clamped rows of the
     last row tile), the pipelined form with a ring of image chunks (K = 256 or C = 256: the image does not fit; 300 007 points =
     several tiles per workgroup) and the one-tile form (C = 96: an odd number of 32-channel chunks)."""
     from gfs3d import ops
