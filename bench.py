@@ -458,9 +458,27 @@ def extras(dev, L, gdist):
         f3.grad = mp.grad = bgp.grad = None
         ops.capl_train_head(f3, mp, bgp, yh, [2, 4, 7], 7, 255)[1].backward()
     ms = timed_ms(head, 100)
+    # the same forward + backward replayed as ONE hipGraph: the figure a host that cannot queue 11 launches in 0.13 ms does not move
+    graph_ms, graph_note = None, None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                head()
+        torch.cuda.current_stream().wait_stream(side)
+        gph = torch.cuda.CUDAGraph()
+        f3.grad = mp.grad = bgp.grad = None
+        with torch.cuda.graph(gph):
+            ops.capl_train_head(f3, mp, bgp, yh, [2, 4, 7], 7, 255)[1].backward()
+        graph_ms = round(timed_ms(gph.replay, 100), 4)
+        del gph
+    except Exception as exc:                                          # a capture failure must not take the bench line with it
+        graph_note = f"graph capture failed: {type(exc).__name__}: {exc}"[:200]
     byts = 4.0 * B * N * 128 * 3                                     # features read by the forward and by the backward, gradient written
     head_flops = 2.0 * B * N * 128 * (14 * 11 + 3 * 14)             # 11 class-table products of 14 x 128 per point + the three point contractions
     out["capl_train_head"] = {"shape": "B=32x2048, C=128, 13+1 classes, 3 fake-novel classes; forward + backward", "ms": round(ms, 4),
+                              "graph_replay_ms": graph_ms, **({"graph_note": graph_note} if graph_note else {}),
                               "bound": "hbm (its bytes are the floor; the four point passes run on the fp32 matrix cores, v_mfma_f32_16x16x4_f32, "
                                        "at ~2x their matrix floor; the 11 launches are host-latency bound)",
                               "algorithmic_GBps": round(byts / ms / 1e6, 1), "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4),
